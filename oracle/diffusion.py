@@ -1,0 +1,243 @@
+"""ORACLE (test infrastructure only — never imported by the product path).
+
+CPU restatement of the reference's reverse-diffusion sampler:
+schedule tables (models/decompdiff.py:95-131, models/transitions.py:12-62,98-120),
+categorical transitions (transitions.py:65-161), drift guidance
+(utils/guidance_funcs.py:24-78) and the 1000-step loop
+(models/decompdiff.py:552-703).  Pinned by tests/golden (generated from the reference
+itself by oracle/make_golden.py).
+
+Noise: by default the loop draws from torch's global generator in the reference order
+(rand_like → rand_like → randn_like per step), so with the same seed on CPU it is
+bit-identical with the reference.  ``noise=dict(u_v,u_b,eps)`` injects pre-drawn tensors
+instead (decompdiff_amd.synth.draw_step_noise) — that is how the HIP path and the oracle
+are made to consume the same random numbers.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import model as M
+from . import ops
+
+
+# ---------------------------------------------------------------------------- schedules
+def cosine_alphas(timesteps, s):
+    """cosine_beta_schedule (transitions.py:12-28) — returns sqrt-alphas."""
+    steps = timesteps + 1
+    x = np.linspace(0, steps, steps)
+    ac = np.cos(((x / steps) + s) / (1 + s) * np.pi * 0.5) ** 2
+    ac = ac / ac[0]
+    alphas = np.clip(ac[1:] / ac[:-1], a_min=0.001, a_max=1.0)
+    return np.sqrt(alphas)
+
+
+def sigmoid_betas(beta_start, beta_end, n):
+    """get_beta_schedule('sigmoid') (transitions.py:55-57)."""
+    b = np.linspace(-6, 6, n)
+    return 1.0 / (np.exp(-b) + 1.0) * (beta_end - beta_start) + beta_start
+
+
+def f32(a):
+    return torch.from_numpy(np.asarray(a)).float()
+
+
+def position_tables(cfg):
+    """Gaussian-chain tables of DecompScorePosNet3D.__init__ (decompdiff.py:95-131), fp32."""
+    assert cfg.beta_schedule == "sigmoid"
+    betas = sigmoid_betas(cfg.beta_start, cfg.beta_end, cfg.num_diffusion_timesteps)
+    alphas = 1.0 - betas
+    ac = np.cumprod(alphas, axis=0)
+    ac_prev = np.append(1.0, ac[:-1])
+    post_var = betas * (1.0 - ac_prev) / (1.0 - ac)
+    t = dict(
+        betas=f32(betas), alphas_cumprod=f32(ac), alphas_cumprod_prev=f32(ac_prev),
+        sqrt_alphas_cumprod=f32(np.sqrt(ac)), sqrt_one_minus_alphas_cumprod=f32(np.sqrt(1.0 - ac)),
+        sqrt_recip_alphas_cumprod=f32(np.sqrt(1.0 / ac)), sqrt_recipm1_alphas_cumprod=f32(np.sqrt(1.0 / ac - 1)),
+        posterior_mean_c0_coef=f32(betas * np.sqrt(ac_prev) / (1.0 - ac)),
+        posterior_mean_ct_coef=f32((1.0 - ac_prev) * np.sqrt(alphas) / (1.0 - ac)),
+        posterior_var=f32(post_var),
+        pos_score_coef=f32(betas / np.sqrt(alphas)),
+    )
+    # decompdiff.py:130 — the log is taken of the *fp32* tensor with entry 0 := entry 1
+    pv = t["posterior_var"].numpy()
+    t["posterior_logvar"] = f32(np.log(np.append(pv[1], pv[1:])))
+    return t
+
+
+def categorical_tables(cfg, num_classes):
+    """DiscreteTransition.__init__ (transitions.py:98-120), uniform prior."""
+    assert cfg.v_beta_schedule == "cosine"
+    la = np.log(cosine_alphas(cfg.num_diffusion_timesteps, cfg.v_beta_s))
+    lca = np.cumsum(la)
+    l1m = lambda a: np.log(1 - np.exp(a) + 1e-40)                     # transitions.py:87
+    return dict(log_alphas_v=f32(la), log_one_minus_alphas_v=f32(l1m(la)),
+                log_alphas_cumprod_v=f32(lca), log_one_minus_alphas_cumprod_v=f32(l1m(lca)),
+                prior_probs=f32(-np.log(num_classes).repeat(num_classes)[None, :]))
+
+
+# -------------------------------------------------------------------------- transitions
+def index_to_log_onehot(x, num_classes):
+    return torch.log(F.one_hot(x, num_classes).float().clamp(min=1e-30))   # transitions.py:65-71
+
+
+def log_add_exp(a, b):
+    m = torch.max(a, b)
+    return m + torch.log(torch.exp(a - m) + torch.exp(b - m))              # transitions.py:91-93
+
+
+def q_v_pred(tab, log_v0, t, batch):
+    return log_add_exp(log_v0 + tab["log_alphas_cumprod_v"][t][batch].unsqueeze(-1),
+                       tab["log_one_minus_alphas_cumprod_v"][t][batch].unsqueeze(-1) + tab["prior_probs"])
+
+
+def q_v_pred_one_timestep(tab, log_vt_1, t, batch):
+    return log_add_exp(log_vt_1 + tab["log_alphas_v"][t][batch].unsqueeze(-1),
+                       tab["log_one_minus_alphas_v"][t][batch].unsqueeze(-1) + tab["prior_probs"])
+
+
+def q_v_posterior(tab, log_v0, log_vt, t, batch):
+    """transitions.py:153-161."""
+    tm1 = torch.where(t - 1 < 0, torch.zeros_like(t), t - 1)
+    un = q_v_pred(tab, log_v0, tm1, batch) + q_v_pred_one_timestep(tab, log_vt, t, batch)
+    return un - torch.logsumexp(un, dim=-1, keepdim=True)
+
+
+def gumbel_argmax(logits, uniform=None):
+    """log_sample_categorical (transitions.py:78-84)."""
+    if uniform is None:
+        uniform = torch.rand_like(logits)
+    g = -torch.log(-torch.log(uniform + 1e-30) + 1e-30)
+    return (g + logits).argmax(dim=-1)
+
+
+# ----------------------------------------------------------------------------- guidance
+def clash_loss(protein_pos, ligand_pos, batch_protein, batch_ligand, sigma, surface_ct):
+    """compute_batch_clash_loss + G_fn (guidance_funcs.py:24-42): summed over samples."""
+    total = torch.tensor(0.0)
+    for i in range(int(batch_ligand.max().item()) + 1):
+        p, l = protein_pos[batch_protein == i], ligand_pos[batch_ligand == i]
+        e = torch.exp(-torch.sum((p.view(1, -1, 3) - l.view(-1, 1, 3)) ** 2, dim=2) / float(sigma))
+        g = -sigma * torch.log(1e-3 + e.sum(dim=1))
+        total = total + torch.mean(torch.clamp(surface_ct - g, min=0))
+    return total
+
+
+def armsca_prox_loss(ligand_pos, batch_ligand, decomp_index, min_d, max_d):
+    """compute_batch_armsca_prox_loss / compute_armsca_prox_loss (guidance_funcs.py:50-78)."""
+    total = torch.tensor(0.0)
+    num_graphs = int(batch_ligand.max().item()) + 1
+    n_valid = 0
+    for i in range(num_graphs):
+        pos = ligand_pos[batch_ligand == i]
+        mask = decomp_index[batch_ligand == i]
+        arm = mask != -1
+        arm_pos, sca_pos = pos[arm], pos[~arm]
+        if len(arm_pos) > 0 and len(sca_pos) > 0:
+            pd = torch.norm(arm_pos.unsqueeze(1) - sca_pos.unsqueeze(0), p=2, dim=-1)
+            min_all, _ = ops.scatter_min(pd, mask[arm], dim=0)
+            md, _ = min_all.min(-1)
+            total = total + torch.mean(torch.clamp(min_d - md, min=0) + torch.clamp(md - max_d, min=0))
+            n_valid += 1
+    return total / num_graphs, n_valid
+
+
+# -------------------------------------------------------------------------- sample loop
+def sample_diffusion(sd, cfg, *, protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v,
+                     ligand_v_aux, batch_ligand, prior_stds, ligand_decomp_batch, ligand_decomp_index,
+                     ligand_fc_bond_index, init_ligand_fc_bond_type, batch_ligand_bond,
+                     num_steps=None, center_pos_mode="protein", energy_drift_opt=None,
+                     full_protein_pos=None, full_batch_protein=None, ligand_atom_mask=None,
+                     num_classes=8, noise=None, keep_traj=True, step_hook=None, t_start=None, **unused):
+    """DecompScorePosNet3D.sample_diffusion for model_mean_type='C0' (decompdiff.py:552-703).
+
+    Extra keyword arguments of the reference signature that the shipped path never reads
+    (``*_group_idx``, ``prior_centers`` without center_prox drift, ``prior_num_atoms``,
+    ``batch_prior``) are accepted and ignored via ``**unused``.  ``t_start`` starts the chain at
+    an arbitrary t (the reference does the same when its ``num_timesteps`` attribute is
+    lowered: time_seq = reversed(range(num_timesteps - num_steps, num_timesteps)), :575).
+    """
+    assert cfg.model_mean_type == "C0"
+    pt = position_tables(cfg)
+    vt = categorical_tables(cfg, num_classes)
+    bt = categorical_tables(cfg, cfg.num_bond_classes)
+    T = cfg.num_diffusion_timesteps
+    if num_steps is None:
+        num_steps = T
+    num_graphs = int(batch_protein.max().item()) + 1
+    assert center_pos_mode == "protein"
+    offset = ops.scatter_mean(protein_pos, batch_protein, dim=0)          # decompdiff.py:20-32
+    protein_pos = protein_pos - offset[batch_protein]
+    ligand_pos = init_ligand_pos - offset[batch_ligand]
+    ligand_v, ligand_bond = init_ligand_v, init_ligand_fc_bond_type
+
+    traj = dict(pos_traj=[], v_traj=[], bond_traj=[], v0_traj=[], vt_traj=[], bt_traj=[])
+    if t_start is not None:
+        T = t_start + 1
+    for step, i in enumerate(reversed(range(T - num_steps, T))):
+        t = torch.full((num_graphs,), i, dtype=torch.long)
+        with torch.no_grad():
+            preds = M.forward(sd, cfg, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, ligand_v_aux,
+                              batch_ligand, ligand_fc_bond_index, ligand_bond, ligand_atom_mask, num_classes)
+            pos0 = preds["pred_ligand_pos"]
+            mean = pt["posterior_mean_c0_coef"][t][batch_ligand].unsqueeze(-1) * pos0 + \
+                pt["posterior_mean_ct_coef"][t][batch_ligand].unsqueeze(-1) * ligand_pos
+            logvar = pt["posterior_logvar"][t][batch_ligand].unsqueeze(-1)
+            nonzero = (1 - (t == 0).float())[batch_ligand].unsqueeze(-1)
+
+            log_v_recon = F.log_softmax(preds["pred_ligand_v"], dim=-1)
+            log_v = index_to_log_onehot(ligand_v, num_classes)
+            log_v_prob = q_v_posterior(vt, log_v_recon, log_v, t, batch_ligand)
+            v_next = gumbel_argmax(log_v_prob, None if noise is None else noise["u_v"][step])
+            if ligand_atom_mask is not None:
+                v_next[ligand_atom_mask == 0] = ligand_v[ligand_atom_mask == 0]
+
+            log_b_recon = F.log_softmax(preds["pred_bond"], dim=-1)
+            log_b = index_to_log_onehot(ligand_bond, cfg.num_bond_classes)
+            log_b_prob = q_v_posterior(bt, log_b_recon, log_b, t, batch_ligand_bond)
+            b_next = gumbel_argmax(log_b_prob, None if noise is None else noise["u_b"][step])
+
+        if energy_drift_opt is not None:
+            grad_all = 0.0
+            for drift in energy_drift_opt:
+                xt = ligand_pos.detach().clone().requires_grad_(True)
+                g = 0.0
+                if drift["type"] == "armsca_prox":
+                    e, n_valid = armsca_prox_loss(xt, batch_ligand, ligand_decomp_index,
+                                                  drift["min_d"], drift["max_d"])
+                    if n_valid > 0:
+                        g = torch.autograd.grad(e, xt)[0]
+                        if drift.get("scale", False):
+                            g = g * pt["pos_score_coef"][t][batch_ligand].unsqueeze(-1)
+                elif drift["type"] == "clash":
+                    e = clash_loss(full_protein_pos, xt + offset[batch_ligand], full_batch_protein, batch_ligand,
+                                   drift["sigma"], drift["gamma"])
+                    g = torch.autograd.grad(e, xt)[0]
+                    if drift.get("scale", False):
+                        g = g * pt["pos_score_coef"][t][batch_ligand].unsqueeze(-1)
+                else:
+                    raise ValueError(drift["type"])
+                grad_all = grad_all + g
+            mean = mean - grad_all
+
+        with torch.no_grad():
+            eps = torch.randn_like(ligand_pos) if noise is None else noise["eps"][step]
+            pos_next = mean + nonzero * (0.5 * logvar).exp() * eps * prior_stds[ligand_decomp_batch]
+            if ligand_atom_mask is not None:
+                pos_next[ligand_atom_mask == 0] = ligand_pos[ligand_atom_mask == 0]
+            ligand_pos, ligand_v, ligand_bond = pos_next.detach(), v_next, b_next
+            if keep_traj:
+                traj["v0_traj"].append(log_v_recon.clone())
+                traj["vt_traj"].append(log_v_prob.clone())
+                traj["bt_traj"].append(log_b_prob.clone())
+                traj["bond_traj"].append(ligand_bond.clone())
+                traj["pos_traj"].append((ligand_pos + offset[batch_ligand]).clone())
+                traj["v_traj"].append(ligand_v.clone())
+            if step_hook is not None:
+                step_hook(step, i, ligand_pos, ligand_v, ligand_bond, preds)
+
+    out = dict(pos=ligand_pos + offset[batch_ligand], v=ligand_v, bond=ligand_bond)
+    out.update(traj)
+    return out

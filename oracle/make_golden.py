@@ -1,0 +1,262 @@
+"""ORACLE TOOLING (survey container only): generate tests/golden/* from the REFERENCE itself.
+
+    python -m oracle.make_golden [--skip-long]
+
+Imports /root/reference through oracle/ref_shims.py, loads the deterministic synthetic
+weights (decompdiff_amd.synth.synthetic_state_dict), runs the reference's own
+``DecompScorePosNet3D.forward`` / ``.sample_diffusion`` on synthetic pockets and writes
+small fixtures (inputs + expected outputs) that travel to the GPU box.  The reference's
+Python never leaves this container; only data does.
+
+Every fixture is also replayed through the oracle here and the maximum deviation is
+printed (and stored under ``oracle_vs_reference_maxabs``) so a regression of the
+restatement is caught at generation time as well as by tests/test_oracle_golden.py.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from decompdiff_amd import synth                      # noqa: E402
+from decompdiff_amd.config import shipped_config      # noqa: E402
+from oracle import diffusion as OD                    # noqa: E402
+from oracle import model as OM                        # noqa: E402
+from oracle import ref_shims                          # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+FWD_KEYS = ["protein_pos", "protein_v", "batch_protein", "protein_group_idx", "init_ligand_pos", "init_ligand_v",
+            "batch_ligand", "ligand_group_idx", "prior_centers", "prior_stds", "batch_prior", "prior_group_idx",
+            "ligand_fc_bond_index", "init_ligand_fc_bond_type"]
+DRIFT = [dict(type="armsca_prox", min_d=1.2, max_d=1.9), dict(type="clash", sigma=2, gamma=4)]  # sampling_drift.yml:31-37
+
+
+def np_inputs(batch):
+    out = {}
+    for k, v in batch.items():
+        if v is None:
+            continue
+        a = v.numpy()
+        if k == "protein_v":
+            a = a.astype(np.uint8)
+        out["in_" + k] = a
+    return out
+
+
+def ref_forward(ref, batch):
+    kw = {k: batch[k] for k in FWD_KEYS}
+    kw["init_ligand_v_aux"] = batch["ligand_v_aux"]
+    with torch.no_grad():
+        return ref(**kw)
+
+
+def oracle_forward(sd, cfg, batch, trace=None):
+    with torch.no_grad():
+        return OM.forward(sd, cfg, batch["protein_pos"], batch["protein_v"], batch["batch_protein"],
+                          batch["init_ligand_pos"], batch["init_ligand_v"], batch["ligand_v_aux"],
+                          batch["batch_ligand"], batch["ligand_fc_bond_index"], batch["init_ligand_fc_bond_type"],
+                          trace=trace)
+
+
+def maxabs(a, b):
+    return float((a.double() - b.double()).abs().max()) if a.numel() else 0.0
+
+
+def gen_spec_and_schedules(ref, cfg):
+    spec = {k: dict(shape=list(v.shape), dtype=str(v.dtype).replace("torch.", "")) for k, v in ref.state_dict().items()}
+    trainable = {n for n, p in ref.named_parameters() if p.requires_grad}
+    for k in spec:
+        spec[k]["trainable"] = k in trainable
+    with open(os.path.join(GOLDEN, "state_dict_spec.json"), "w") as f:
+        json.dump(spec, f, indent=0, sort_keys=True)
+    tabs = {}
+    for k, v in ref.state_dict().items():
+        if (v.dim() == 1 and v.numel() == cfg.num_diffusion_timesteps) or k.endswith("prior_probs") \
+                or k.endswith("offset") or k.endswith("freq_bands"):
+            if k.startswith("refine_net.base_block.") and not k.startswith("refine_net.base_block.0."):
+                continue
+            tabs[k.replace(".", "__")] = v.numpy()
+    np.savez_compressed(os.path.join(GOLDEN, "schedules.npz"), **tabs)
+    # oracle check
+    pt, vt, bt = OD.position_tables(cfg), OD.categorical_tables(cfg, 8), OD.categorical_tables(cfg, cfg.num_bond_classes)
+    worst = 0.0
+    for k, v in pt.items():
+        worst = max(worst, maxabs(v, ref.state_dict()[k]))
+    for k, v in vt.items():
+        worst = max(worst, maxabs(v, ref.state_dict()["atom_type_trans." + k]))
+    for k, v in bt.items():
+        worst = max(worst, maxabs(v, ref.state_dict()["bond_type_trans." + k]))
+    print(f"[schedules] {len(tabs)} tables, oracle maxabs diff = {worst:g}")
+
+
+def gen_forward_tiny():
+    """Reduced-size network with per-layer intermediates (SURVEY.md §8c fixture 3)."""
+    cfg = shipped_config(hidden_dim=32, n_heads=4, num_layers=2, knn=8)
+    sd = synth.synthetic_state_dict(cfg, seed=3)
+    ref = ref_shims.load_reference_model(cfg.to_dict(), sd)
+    pocket = synth.make_pocket_tiny(seed=5)
+    torch.manual_seed(11)
+    batch = synth.build_sampling_batch(pocket, 2)
+    layers = []
+    hooks = [blk.register_forward_hook(lambda m, i, o: layers.append([t.detach().clone() for t in o]))
+             for blk in ref.refine_net.base_block]
+    pr = ref_forward(ref, batch)
+    for h in hooks:
+        h.remove()
+    trace = []
+    po = oracle_forward(sd, cfg, batch, trace)
+    worst = max(maxabs(pr[k], po[k]) for k in pr)
+    for l, (h, hb, x) in enumerate(layers):
+        worst = max(worst, maxabs(h, trace[1 + l]["h"]), maxabs(hb, trace[1 + l]["h_bond"]), maxabs(x, trace[1 + l]["x"]))
+    out = np_inputs(batch)
+    out.update({"out_" + k: v.numpy() for k, v in pr.items()})
+    for l, (h, hb, x) in enumerate(layers):
+        out[f"layer{l}_h"], out[f"layer{l}_h_bond"], out[f"layer{l}_x"] = h.numpy(), hb.numpy(), x.numpy()
+    out["cfg_json"] = np.array(json.dumps(dict(hidden_dim=32, n_heads=4, num_layers=2, knn=8)))
+    out["weight_seed"] = np.array(3)
+    out["oracle_vs_reference_maxabs"] = np.array(worst)
+    np.savez_compressed(os.path.join(GOLDEN, "forward_tiny.npz"), **out)
+    print(f"[forward_tiny] oracle maxabs diff = {worst:g}")
+
+
+def gen_forward_small(ref, sd, cfg):
+    pocket = synth.make_pocket_small(seed=0)
+    torch.manual_seed(2021)
+    batch = synth.build_sampling_batch(pocket, 2)
+    pr = ref_forward(ref, batch)
+    po = oracle_forward(sd, cfg, batch)
+    worst = max(maxabs(pr[k], po[k]) for k in pr)
+    out = np_inputs(batch)
+    out.update({"out_" + k: v.numpy() for k, v in pr.items()})
+    out["weight_seed"] = np.array(0)
+    out["oracle_vs_reference_maxabs"] = np.array(worst)
+    np.savez_compressed(os.path.join(GOLDEN, "forward_small.npz"), **out)
+    print(f"[forward_small] oracle maxabs diff = {worst:g}")
+
+
+def run_ref_sampling(ref, batch, num_steps, drift, t_start=None):
+    """Run the reference loop.  ``t_start`` (single step at an arbitrary t) is realised by
+    temporarily shrinking ``num_timesteps`` so that time_seq == [t_start] (decompdiff.py:575)."""
+    kw = {k: v for k, v in batch.items()}
+    T = ref.num_timesteps
+    try:
+        if t_start is not None:
+            ref.num_timesteps = t_start + 1
+        r = ref.sample_diffusion(num_steps=num_steps, center_pos_mode="protein", energy_drift_opt=drift, **kw)
+    finally:
+        ref.num_timesteps = T
+    return r
+
+
+def run_oracle_sampling(sd, cfg, batch, num_steps, drift, noise, t_start=None):
+    return OD.sample_diffusion(sd, cfg, num_steps=num_steps, energy_drift_opt=drift, noise=noise,
+                               t_start=t_start, **batch)
+
+
+def traj_arrays(r, every=1):
+    sel = lambda xs: xs[every - 1::every] if every > 1 else xs
+    return dict(
+        out_pos=r["pos"].numpy(), out_v=r["v"].numpy(), out_bond=r["bond"].numpy(),
+        traj_pos=torch.stack(sel(r["pos_traj"])).numpy(), traj_v=torch.stack(sel(r["v_traj"])).numpy().astype(np.int8),
+        traj_bond=torch.stack(sel(r["bond_traj"])).numpy().astype(np.int8),
+    )
+
+
+def gen_steps(ref, sd, cfg):
+    """Single reverse steps with injected noise at t in {999,500,1,0}, drift off/on (fixture 4)."""
+    pocket = synth.make_pocket_small(seed=1)
+    out = {}
+    worst = 0.0
+    for t_start in (999, 500, 1, 0):
+        for tag, drift in (("plain", None), ("drift", DRIFT)):
+            seed = 100 + t_start
+            torch.manual_seed(seed)
+            batch = synth.build_sampling_batch(pocket, 2, per_sample_std_scale=[1.0, 0.8] if drift else None)
+            state = torch.get_rng_state()
+            r = run_ref_sampling(ref, batch, 1, drift, t_start)
+            torch.set_rng_state(state)
+            noise = synth.draw_step_noise(1, batch["init_ligand_pos"].size(0), batch["init_ligand_fc_bond_type"].size(0))
+            ro = run_oracle_sampling(sd, cfg, batch, 1, drift, noise, t_start)
+            w = max(maxabs(r["pos"], ro["pos"]), maxabs(r["v"], ro["v"]), maxabs(r["bond"], ro["bond"]),
+                    maxabs(r["vt_traj"][0], ro["vt_traj"][0]), maxabs(r["bt_traj"][0], ro["bt_traj"][0]))
+            worst = max(worst, w)
+            p = f"t{t_start}_{tag}_"
+            if t_start == 999 and tag == "plain":
+                out.update(np_inputs(batch))          # pocket-level inputs shared by all cases
+            out[p + "seed"] = np.array(seed)
+            for k in ("init_ligand_pos", "init_ligand_v", "init_ligand_fc_bond_type", "prior_stds"):
+                out[p + "in_" + k] = batch[k].numpy()
+            out[p + "pos"], out[p + "v"], out[p + "bond"] = r["pos"].numpy(), r["v"].numpy(), r["bond"].numpy()
+            out[p + "log_v_recon"] = r["v0_traj"][0].numpy()
+            out[p + "log_v_prob"] = r["vt_traj"][0].numpy()
+            out[p + "log_b_prob"] = r["bt_traj"][0].numpy()
+            out[p + "noise_checksum"] = np.array([float(noise["u_v"].double().sum()), float(noise["u_b"].double().sum()),
+                                                  float(noise["eps"].double().sum())])
+    out["weight_seed"] = np.array(0)
+    out["oracle_vs_reference_maxabs"] = np.array(worst)
+    np.savez_compressed(os.path.join(GOLDEN, "steps.npz"), **out)
+    print(f"[steps] oracle maxabs diff = {worst:g}")
+
+
+def gen_traj(ref, sd, cfg, name, pocket, n_data, num_steps, drift, seed, every=1, std_scale=None):
+    torch.manual_seed(seed)
+    batch = synth.build_sampling_batch(pocket, n_data, per_sample_std_scale=std_scale)
+    state = torch.get_rng_state()
+    t0 = time.time()
+    r = run_ref_sampling(ref, batch, num_steps, drift)
+    t_ref = time.time() - t0
+    torch.set_rng_state(state)
+    noise = synth.draw_step_noise(num_steps, batch["init_ligand_pos"].size(0), batch["init_ligand_fc_bond_type"].size(0))
+    t0 = time.time()
+    ro = run_oracle_sampling(sd, cfg, batch, num_steps, drift, noise)
+    t_or = time.time() - t0
+    w = max(maxabs(r["pos"], ro["pos"]), maxabs(r["v"], ro["v"]), maxabs(r["bond"], ro["bond"]))
+    out = np_inputs(batch)
+    out.update(traj_arrays(r, every))
+    out["seed"], out["num_steps"], out["every"] = np.array(seed), np.array(num_steps), np.array(every)
+    out["drift"] = np.array(json.dumps(drift))
+    out["noise_checksum"] = np.array([float(noise["u_v"].double().sum()), float(noise["u_b"].double().sum()),
+                                      float(noise["eps"].double().sum())])
+    out["weight_seed"] = np.array(0)
+    out["oracle_vs_reference_maxabs"] = np.array(w)
+    out["ref_seconds"], out["oracle_seconds"] = np.array(t_ref), np.array(t_or)
+    np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **out)
+    print(f"[{name}] {num_steps} steps: reference {t_ref:.1f}s, oracle {t_or:.1f}s, oracle maxabs diff = {w:g}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-long", action="store_true", help="skip the 1000-step trajectory (~10 min)")
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    os.makedirs(GOLDEN, exist_ok=True)
+    torch.set_num_threads(os.cpu_count())
+    cfg = shipped_config()
+    sd = synth.synthetic_state_dict(cfg, seed=0)
+    ref = ref_shims.load_reference_model(cfg.to_dict(), sd)
+    want = lambda n: args.only is None or args.only == n
+    if want("spec"):
+        gen_spec_and_schedules(ref, cfg)
+    if want("forward_tiny"):
+        gen_forward_tiny()
+    if want("forward_small"):
+        gen_forward_small(ref, sd, cfg)
+    if want("steps"):
+        gen_steps(ref, sd, cfg)
+    if want("traj20"):
+        gen_traj(ref, sd, cfg, "traj20_plain", synth.make_pocket_small(2), 2, 20, None, 2021)
+        gen_traj(ref, sd, cfg, "traj20_drift", synth.make_pocket_small(2), 2, 20, DRIFT, 2022, std_scale=[1.0, 0.85])
+    if want("traj1000") and not args.skip_long:
+        gen_traj(ref, sd, cfg, "traj1000_plain", synth.make_pocket_small(3), 1, 1000, None, 2021, every=50)
+
+
+if __name__ == "__main__":
+    main()
