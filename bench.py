@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""bench.py — denoising steps/sec of the reverse-diffusion sampling hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 1000 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): one synthetic pocket (300 protein + 30 ligand atoms, ref_prior)
+per rank, batch of 8 samples, K steps of the 1000-step reverse chain, no drift, device Philox noise,
+all six trajectories recorded and copied to the host inside the timed region (what the reference's
+`sample_diffusion` returns).  A "step" is one denoising step of the whole batch.  Multi-GPU: every
+rank samples its own pocket (independent units, weak scaling); RCCL is used for init, the two
+barriers and one all-reduce(MAX) of the wall time.  `value` = N * K / max-over-ranks seconds.
+
+The JSON line also carries
+  roofline     — the dominant kernel (bond-layer triplet attention), its mean launch duration measured
+                 live with HIP events on the launch stream, against the fp32 peak (157.3 TFLOP/s vector =
+                 matrix on CDNA4) with the algorithmic FLOP count of DESIGN.md §kernels;
+  cpu_baseline — the oracle (CPU restatement of the reference, torch fp32, all host threads) timed on a
+                 bounded sample of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from decompdiff_amd import DecompScorePosNet3D, hip_lib, shipped_config, synth  # noqa: E402
+
+FP32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 vector == matrix peak
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=8, help="samples per pocket batch (BASELINE configs[1]: 8)")
+    ap.add_argument("--workload", default="small", choices=["small", "large"])
+    ap.add_argument("--drift", action="store_true", help="BASELINE configs[2]: armsca_prox + clash guidance")
+    ap.add_argument("--eager", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    return ap.parse_args()
+
+
+def algorithmic_flops_bond_layer(B, NL):
+    """FLOPs of one bond_layer attention launch, factored count (SURVEY.md §8d / DESIGN.md):
+    per triplet, two MLPs x (13-wide angle contraction + 128x128 second Linear), 2 FLOP per MAC."""
+    e3 = NL * (NL - 1) * (NL - 2)
+    return 2.0 * B * e3 * 2 * (13 * 128 + 128 * 128)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl")          # RCCL on ROCm
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    cfg = shipped_config()
+    model = DecompScorePosNet3D(cfg, 29, 10, 8)
+    sd = model.state_dict()
+    sd.update(synth.synthetic_state_dict(cfg, seed=0))
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+
+    pocket = synth.make_pocket_small(seed=rank) if args.workload == "small" else synth.make_pocket_large(seed=rank)
+    torch.manual_seed(2021 + rank)
+    batch_cpu = synth.build_sampling_batch(pocket, args.batch, per_sample_std_scale=[1.0] * args.batch)
+    batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch_cpu.items()}
+    drift = [dict(type="armsca_prox", min_d=1.2, max_d=1.9), dict(type="clash", sigma=2, gamma=4)] if args.drift else None
+    NP, NL = pocket.num_protein_atoms, pocket.num_ligand_atoms
+
+    def run(n_steps, seed):
+        return model.sample_diffusion(num_steps=n_steps, center_pos_mode="protein", energy_drift_opt=drift,
+                                      seed=seed, keep_traj=True, use_graph=not args.eager, **batch)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    if args.warmup > 0:
+        run(args.warmup, seed=1)
+    barrier()
+    t0 = time.perf_counter()
+    out = run(args.steps, seed=2)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out["pos"]).all()
+    assert len(out["pos_traj"]) == args.steps
+
+    result = None
+    if rank == 0:
+        steps_per_s = world * args.steps / elapsed
+        # ---- per-kernel-class timing with HIP events on the launch stream (live, this process)
+        s, bufs = model._last
+        cats = (ctypes.c_float * len(hip_lib.PROF_CATS))()
+        # profile on a fresh short run so the step counter / trajectory indices stay in range
+        model.sample_diffusion(num_steps=1, center_pos_mode="protein", energy_drift_opt=drift, seed=3, keep_traj=False,
+                               use_graph=False, **batch)
+        s2, bufs2 = model._last
+        bufs2["step_counter"].zero_()
+        n_prof = 10
+        hip_lib.check(hip_lib.load().dd_profile_step(ctypes.byref(s2), n_prof, cats, hip_lib.stream_ptr(dev)),
+                      "dd_profile_step")
+        per_cat = {k: float(cats[i]) for i, k in enumerate(hip_lib.PROF_CATS)}
+        dom = max((k for k in per_cat if k.startswith("attn")), key=lambda k: per_cat[k])
+        n_layers = cfg.num_layers
+        launch_ms = per_cat["attn_BL"] / n_layers
+        flops = algorithmic_flops_bond_layer(args.batch, NL)
+        achieved = flops / (launch_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "k_attn<BL> (bond_layer triplet attention)", "achieved": round(achieved, 3),
+                    "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4),
+                    "traffic": None, "launch_ms": round(launch_ms, 4),
+                    "note": "fp32 FLOP roofline (CDNA4 fp32 vector peak == fp32 MFMA peak); algorithmic FLOPs = factored "
+                            "count, DESIGN.md; the kernel is fused so q/k/v never touch HBM (SURVEY.md 8d)",
+                    "ms_per_step_by_kernel_class": {k: round(v, 4) for k, v in per_cat.items()},
+                    "dominant_attention_class": dom}
+        cpu = None
+        if not args.no_cpu_baseline:
+            from oracle import diffusion as OD          # the checker, timed as the CPU baseline only
+            weights = synth.synthetic_state_dict(cfg, seed=0)
+            n_cpu = max(1, args.cpu_steps)
+            torch.manual_seed(7)
+            OD.sample_diffusion(weights, cfg, num_steps=1, energy_drift_opt=drift, keep_traj=False, **batch_cpu)   # warm-up
+            t1 = time.perf_counter()
+            OD.sample_diffusion(weights, cfg, num_steps=n_cpu, energy_drift_opt=drift, keep_traj=True, **batch_cpu)
+            cpu_s = time.perf_counter() - t1
+            cpu = {"value": round(n_cpu / cpu_s, 4), "unit": "denoising steps/s", "cores": torch.get_num_threads(),
+                   "kind": "port", "sample": f"{n_cpu} steps after 1 warm-up step, same pocket batch (B={args.batch}), "
+                   f"oracle = CPU restatement of the reference (torch fp32); host has {os.cpu_count()} logical CPUs"}
+        result = {
+            "metric": "denoising steps/sec (1000-step reverse) per pocket", "value": round(steps_per_s, 3),
+            "unit": "denoising steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: single pocket ref_prior, {NP} protein + {NL} ligand atoms, batch={args.batch} "
+                                   f"per GPU, {'drift guidance, ' if args.drift else ''}trajectories recorded and copied to host",
+                       "batch_per_gpu": args.batch, "sample_steps_per_s": round(steps_per_s * args.batch, 2),
+                       "parallelism": f"{world} independent pocket batches (no data-path collective)",
+                       "launch": "eager" if args.eager else "hipGraph replay", "noise": "device Philox"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        if cpu:
+            result["config"]["speedup_vs_cpu_baseline"] = round(steps_per_s / cpu["value"], 1)
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,373 @@
+// C ABI orchestration: workspace carving, the score-network forward (launch sequence of
+// models/decompdiff.py:213-351 + uni_transformer_edge.py:259-287,394-443) and the reverse loop
+// (decompdiff.py:575-689), eager or as a replayed hipGraph.
+#include <string.h>
+
+#include "dd_kernels.hpp"
+
+namespace dd {
+
+// ---- workspace --------------------------------------------------------------------------------
+struct Workspace {
+  float *xa, *xb, *h, *hb, *ew, *P, *PL, *PB, *Ek, *Ev, *q1bl, *qn, *ql, *qb, *A, *dxe, *ga, *gc;
+  int32_t* nbr;
+  size_t total;
+};
+
+static inline size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }
+
+static Workspace carve(float* base, int B, int NP, int NL, int K) {
+  Workspace w;
+  const size_t N = (size_t)NP + NL, Eb = (size_t)NL * (NL > 0 ? NL - 1 : 0);
+  size_t off = 0;
+  auto take = [&](size_t n) { float* p = base ? base + off : nullptr; off += align64(n); return p; };
+  w.xa = take(B * N * 3);
+  w.xb = take(B * N * 3);
+  w.h = take(B * N * 128);
+  w.hb = take(B * Eb * 128);
+  w.nbr = reinterpret_cast<int32_t*>(take(B * N * K));
+  w.ew = take(B * N * K);
+  w.P = take(B * N * 640);
+  w.PL = take((size_t)B * NL * 1280);
+  w.PB = take(B * Eb * 640);
+  w.Ek = take(B * Eb * 128);
+  w.Ev = take(B * Eb * 128);
+  w.q1bl = take(B * Eb * 128);
+  w.qn = take(B * N * 128);
+  w.ql = take((size_t)B * NL * 128);
+  w.qb = take(B * Eb * 128);
+  w.A = take(B * N * 128);
+  w.dxe = take((size_t)B * NL * 3);
+  w.ga = take((size_t)B * NL * 3);
+  w.gc = take((size_t)B * NL * 3);
+  w.total = off;
+  return w;
+}
+
+static int check_shapes(const dd_sampler* s) {
+  if (!s || !s->weights || !s->slot_off || !s->workspace) return DD_ERR_BAD_ARG;
+  if (s->B <= 0 || s->NP < 0 || s->NL < 2 || s->K <= 0) return DD_ERR_BAD_ARG;
+  const int N = s->NP + s->NL;
+  if (s->NL > DD_NL_MAX || N > DD_N_MAX || s->K > DD_KNN_MAX || s->K > N - 1) return DD_ERR_UNSUPPORTED_SHAPE;
+  if (s->workspace_floats < dd_workspace_floats(s->B, s->NP, s->NL, s->K)) return DD_ERR_WORKSPACE_TOO_SMALL;
+  return DD_OK;
+}
+
+// ---- optional per-category HIP-event profiler (dd_profile_forward) --------------------------------
+struct Profiler {
+  static constexpr int MAXEV = 512;
+  hipEvent_t start[MAXEV], stop[MAXEV];
+  int cat[MAXEV];
+  int n = 0, created = 0;
+};
+static Profiler* g_prof = nullptr;
+
+struct ProfScope {
+  hipStream_t st; int idx;
+  ProfScope(int cat, hipStream_t s) : st(s), idx(-1) {
+    if (g_prof && g_prof->n < Profiler::MAXEV) {
+      idx = g_prof->n++;
+      g_prof->cat[idx] = cat;
+      (void)hipEventRecord(g_prof->start[idx], st);
+    }
+  }
+  ~ProfScope() { if (idx >= 0) (void)hipEventRecord(g_prof->stop[idx], st); }
+};
+#define DD_TRYP(cat, expr)               \
+  do {                                  \
+    ProfScope prof_scope__(cat, st);    \
+    int rc__ = (expr);                  \
+    if (rc__ != DD_OK) return rc__;     \
+  } while (0)
+
+#define DD_TRY(expr)            \
+  do {                          \
+    int rc__ = (expr);          \
+    if (rc__ != DD_OK) return rc__; \
+  } while (0)
+
+static int forward_impl(const dd_sampler* s, hipStream_t st) {
+  DD_TRY(check_shapes(s));
+  const int B = s->B, NP = s->NP, NL = s->NL, K = s->K, N = NP + NL;
+  const long Eb = (long)NL * (NL - 1);
+  Workspace w = carve(s->workspace, B, NP, NL, K);
+  const float* W = s->weights;
+  const int64_t* off = s->slot_off;
+  auto LW = [&](int l, int slot) { return W + off[(long)l * DD_NUM_LAYER_SLOTS + slot]; };
+  auto GW = [&](int slot) { return W + off[(long)s->num_layers * DD_NUM_LAYER_SLOTS + slot]; };
+
+  // embeddings + context (decompdiff.py:219-297)
+  DD_TRYP(DD_PROF_MISC, launch_embed_nodes(s->protein_h, s->protein_pos, s->lig_pos, s->lig_v, s->lig_aux, GW(DD_G_W_lemb),
+                            GW(DD_G_b_lemb), B, NP, NL, w.h, w.xa, w.xb, st));
+  DD_TRYP(DD_PROF_MISC, launch_embed_bonds(s->lig_bond, (long)B * Eb, GW(DD_G_W_bemb), GW(DD_G_b_bemb), w.hb, st));
+  // graph (uni_transformer_edge.py:404-427)
+  DD_TRYP(DD_PROF_MISC, launch_knn(w.xa, B, N, K, w.nbr, st));
+  DD_TRYP(DD_PROF_MISC, launch_edge_weights(w.xa, w.nbr, B, N, K, GW(DD_G_EW_W1T), GW(DD_G_EW_b1), GW(DD_G_EW_ln), GW(DD_G_EW_w2),
+                             GW(DD_G_EW_b2), w.ew, st));
+
+  float* xcur = w.xa;
+  float* xnext = w.xb;
+  const long hN = (long)N * 128;
+  for (int l = 0; l < s->num_layers; ++l) {
+    // ---- projections of the old h / h_bond
+    DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.h, B * N, 0, 128, B * N, LW(l, DD_W_n1), LW(l, DD_b_n1), nullptr, w.P, B * N, 0, 640, 640, 0}, st));
+    DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(l, DD_W_l1), LW(l, DD_b_l1), nullptr, w.PL,
+                           B * NL, 0, 1280, 1280, 0}, st));
+    DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.hb, (int)(B * Eb), 0, 128, (int)(B * Eb), LW(l, DD_W_b1), LW(l, DD_b_b1), nullptr, w.PB,
+                           (int)(B * Eb), 0, 640, 640, 0}, st));
+    DD_TRYP(DD_PROF_ASSEMBLE, launch_bl_assemble(xcur, w.PB, w.PL, LW(l, DD_BL_Wg1k), LW(l, DD_BL_Wg1v), B, NP, NL, w.Ek, w.Ev, w.q1bl, st));
+    // ---- queries: second Linear of the q MLPs (LayerNorm+ReLU prologue)
+    DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.P + 512, B * N, 0, 640, B * N, LW(l, DD_NE_W2q), LW(l, DD_NE_b2q), LW(l, DD_NE_lnq), w.qn,
+                           B * N, 0, 128, 128, 0}, st));
+    DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.PL + 512, B * NL, 0, 1280, B * NL, LW(l, DD_NB_W2q), LW(l, DD_NB_b2q), LW(l, DD_NB_lnq), w.ql,
+                           B * NL, 0, 128, 128, 0}, st));
+    DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.q1bl, (int)(B * Eb), 0, 128, (int)(B * Eb), LW(l, DD_BL_W2q), LW(l, DD_BL_b2q),
+                           LW(l, DD_BL_lnq), w.qb, (int)(B * Eb), 0, 128, 128, 0}, st));
+    // ---- node_layer_with_edge
+    AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.NP = NP; a.NL = NL; a.K = K; a.x = xcur; a.nbr = w.nbr; a.ew = w.ew;
+    a.kd = w.P; a.ks = w.P + 128; a.vd = w.P + 256; a.vs = w.P + 384; a.ld_kd = a.ld_ks = a.ld_vd = a.ld_vs = 640;
+    a.q = w.qn; a.Ak = LW(l, DD_NE_Ak); a.Av = LW(l, DD_NE_Av); a.lnk = LW(l, DD_NE_lnk); a.lnv = LW(l, DD_NE_lnv);
+    a.W2k = LW(l, DD_NE_W2k); a.W2vT = LW(l, DD_NE_W2vT); a.b2v = LW(l, DD_NE_b2v); a.out = w.A;
+    DD_TRYP(DD_PROF_ATTN_NE, launch_attn(M_NE, a, st));
+    // ---- node_layer_with_bond (adds into the ligand rows of A)
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.NP = NP; a.NL = NL; a.K = K; a.x = xcur;
+    a.kd = w.PL; a.ks = w.PL + 128; a.vd = w.PL + 256; a.vs = w.PL + 384; a.ld_kd = a.ld_ks = a.ld_vd = a.ld_vs = 1280;
+    a.ke = w.PB; a.ve = w.PB + 128; a.ld_ke = a.ld_ve = 640;
+    a.q = w.ql; a.lnk = LW(l, DD_NB_lnk); a.lnv = LW(l, DD_NB_lnv);
+    a.W2k = LW(l, DD_NB_W2k); a.W2vT = LW(l, DD_NB_W2vT); a.b2v = LW(l, DD_NB_b2v); a.out = w.A;
+    DD_TRYP(DD_PROF_ATTN_NB, launch_attn(M_NB, a, st));
+    // ---- bond_layer (residual add into h_bond)
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.NP = NP; a.NL = NL; a.K = K; a.x = xcur;
+    a.ke = w.Ek; a.ve = w.Ev; a.ld_ke = a.ld_ve = 128;
+    a.q = w.qb; a.Wg2k = LW(l, DD_BL_Wg2k); a.Wg2v = LW(l, DD_BL_Wg2v); a.Wak = LW(l, DD_BL_Wak); a.Wav = LW(l, DD_BL_Wav);
+    a.lnk = LW(l, DD_BL_lnk); a.lnv = LW(l, DD_BL_lnv);
+    a.W2k = LW(l, DD_BL_W2k); a.W2vT = LW(l, DD_BL_W2vT); a.b2v = LW(l, DD_BL_b2v); a.out = w.hb;
+    DD_TRYP(DD_PROF_ATTN_BL, launch_attn(M_BL, a, st));
+    // ---- h += lin_node(A)
+    DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.A, B * N, 0, 128, B * N, LW(l, DD_W_lin), LW(l, DD_b_lin), nullptr, w.h, B * N, 0, 128, 128, 1}, st));
+    // ---- projections of the new h / h_bond
+    DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.h, B * N, 0, 128, B * N, LW(l, DD_W_n2), LW(l, DD_b_n2), nullptr, w.P, B * N, 0, 256, 256, 0}, st));
+    DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(l, DD_W_l2), LW(l, DD_b_l2), nullptr, w.PL,
+                           B * NL, 0, 1024, 1024, 0}, st));
+    DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.hb, (int)(B * Eb), 0, 128, (int)(B * Eb), LW(l, DD_W_b2), LW(l, DD_b_b2), nullptr, w.PB,
+                           (int)(B * Eb), 0, 256, 256, 0}, st));
+    // ---- pos_layer_with_edge
+    DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.PL + 256, B * NL, 0, 1024, B * NL, LW(l, DD_PE_W2q), LW(l, DD_PE_b2q), LW(l, DD_PE_lnq), w.ql,
+                           B * NL, 0, 128, 128, 0}, st));
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.NP = NP; a.NL = NL; a.K = K; a.x = xcur; a.nbr = w.nbr; a.ew = w.ew;
+    a.kd = w.PL; a.vd = w.PL + 128; a.ld_kd = a.ld_vd = 1024; a.ks = w.P; a.vs = w.P + 128; a.ld_ks = a.ld_vs = 256;
+    a.q = w.ql; a.Ak = LW(l, DD_PE_Ak); a.Av = LW(l, DD_PE_Av); a.lnk = LW(l, DD_PE_lnk); a.lnv = LW(l, DD_PE_lnv);
+    a.W2k = LW(l, DD_PE_W2k); a.W2v16 = LW(l, DD_PE_W2v); a.b2v16 = LW(l, DD_PE_b2v); a.out = w.dxe;
+    DD_TRYP(DD_PROF_ATTN_PE, launch_attn(M_PE, a, st));
+    // ---- pos_layer_with_bond + coordinate update (ligand rows only: mask_ligand_atom)
+    DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.PL + 896, B * NL, 0, 1024, B * NL, LW(l, DD_PB_W2q), LW(l, DD_PB_b2q), LW(l, DD_PB_lnq), w.ql,
+                           B * NL, 0, 128, 128, 0}, st));
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.NP = NP; a.NL = NL; a.K = K; a.x = xcur;
+    a.kd = w.PL + 384; a.ks = w.PL + 512; a.vd = w.PL + 640; a.vs = w.PL + 768; a.ld_kd = a.ld_ks = a.ld_vd = a.ld_vs = 1024;
+    a.ke = w.PB; a.ve = w.PB + 128; a.ld_ke = a.ld_ve = 256;
+    a.q = w.ql; a.lnk = LW(l, DD_PB_lnk); a.lnv = LW(l, DD_PB_lnv);
+    a.W2k = LW(l, DD_PB_W2k); a.W2v16 = LW(l, DD_PB_W2v); a.b2v16 = LW(l, DD_PB_b2v); a.dxe = w.dxe; a.x_next = xnext;
+    DD_TRYP(DD_PROF_ATTN_PB, launch_attn(M_PB, a, st));
+    float* t = xcur; xcur = xnext; xnext = t;
+  }
+  // heads, first Linear (decompdiff.py:194-211): v head on ligand rows of h, bond head on h_bond
+  DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.h + (long)NP * 128, NL, hN, 128, B * NL, GW(DD_G_VH_W1), GW(DD_G_VH_b1), nullptr, w.ql, B * NL, 0,
+                         128, 128, 0}, st));
+  DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.hb, (int)(B * Eb), 0, 128, (int)(B * Eb), GW(DD_G_BH_W1), GW(DD_G_BH_b1), nullptr, w.qb,
+                         (int)(B * Eb), 0, 128, 128, 0}, st));
+  // x0-hat = ligand rows of the final x
+  if (!s->pred_pos) return DD_ERR_BAD_ARG;
+  DD_TRYP(DD_PROF_MISC, launch_extract_ligand(xcur, B, NP, NL, s->pred_pos, st));
+  return DD_OK;
+}
+
+static int heads_and_step(const dd_sampler* s, hipStream_t st) {
+  const int B = s->B, NL = s->NL;
+  const long Eb = (long)NL * (NL - 1);
+  Workspace w = carve(s->workspace, B, s->NP, NL, s->K);
+  const float* W = s->weights;
+  const int64_t* off = s->slot_off;
+  auto GW = [&](int slot) { return W + off[(long)s->num_layers * DD_NUM_LAYER_SLOTS + slot]; };
+  StepRowsArgs r;
+  memset(&r, 0, sizeof(r));
+  r.hid = w.ql; r.W2 = GW(DD_G_VH_W2); r.b2 = GW(DD_G_VH_b2); r.rows = B * NL; r.NC = DD_NUM_V; r.rows_per_sample = NL;
+  r.tab = s->tab_v; r.T = s->T; r.t_start = s->t_start; r.step_counter = s->step_counter;
+  r.state = s->lig_v; r.uniforms = s->u_v; r.seed = s->seed; r.stream_id = 1;
+  r.logits_out = s->pred_v; r.traj_recon = s->traj_v0; r.traj_prob = s->traj_vt; r.traj_state = s->traj_v;
+  StepRowsArgs rb = r;
+  rb.hid = w.qb; rb.W2 = GW(DD_G_BH_W2); rb.b2 = GW(DD_G_BH_b2); rb.rows = (int)(B * Eb); rb.NC = DD_NUM_B;
+  rb.rows_per_sample = (int)Eb; rb.tab = s->tab_b; rb.state = s->lig_bond; rb.uniforms = s->u_b; rb.stream_id = 2;
+  rb.logits_out = s->pred_bond; rb.traj_recon = nullptr; rb.traj_prob = s->traj_bt; rb.traj_state = s->traj_bond;
+  // drift gradients are evaluated at x_t BEFORE the position update (decompdiff.py:638-677)
+  const float* ga = nullptr;
+  const float* gc = nullptr;
+  if (s->drift_armsca) {
+    if (!s->decomp_index) return DD_ERR_BAD_ARG;
+    DD_TRYP(DD_PROF_STEP, dd_drift_armsca(s->lig_pos, s->decomp_index, B, NL, s->armsca_min_d, s->armsca_max_d, w.ga, 0, st));
+    ga = w.ga;
+  }
+  if (s->drift_clash) {
+    if (!s->full_protein_pos || s->NF <= 0) return DD_ERR_BAD_ARG;
+    DD_TRYP(DD_PROF_STEP, dd_drift_clash(s->lig_pos, s->offset, s->full_protein_pos, B, NL, s->NF, s->clash_sigma, s->clash_gamma, w.gc, 0, st));
+    gc = w.gc;
+  }
+  DD_TRYP(DD_PROF_STEP, launch_step_rows(r, st));
+  DD_TRYP(DD_PROF_STEP, launch_step_rows(rb, st));
+  StepPosArgs p;
+  memset(&p, 0, sizeof(p));
+  p.B = B; p.NL = NL; p.T = s->T; p.t_start = s->t_start; p.step_counter = s->step_counter;
+  p.x0 = s->pred_pos; p.xt = s->lig_pos; p.tab_pos = s->tab_pos; p.tab_score = s->tab_score;
+  p.atom_std = s->atom_std; p.offset = s->offset; p.grad_a = ga; p.scale_a = s->armsca_scale; p.grad_c = gc;
+  p.scale_c = s->clash_scale; p.eps = s->eps; p.seed = s->seed; p.traj_pos = s->traj_pos;
+  DD_TRYP(DD_PROF_STEP, launch_step_pos(p, st));
+  DD_TRYP(DD_PROF_STEP, launch_advance(s->step_counter, st));
+  return DD_OK;
+}
+
+// forward-only head evaluation: logits without sampling (state untouched)
+__global__ __launch_bounds__(256) void k_head_logits(const float* __restrict__ hid, const float* __restrict__ W2,
+                                                     const float* __restrict__ b2, int rows, int NC,
+                                                     float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float2 hv = *reinterpret_cast<const float2*>(hid + row * 128 + 2 * lane);
+  hv.x = (hv.x > 20.f ? hv.x : log1pf(expf(hv.x))) - 0.6931471805599453f;
+  hv.y = (hv.y > 20.f ? hv.y : log1pf(expf(hv.y))) - 0.6931471805599453f;
+  for (int c = 0; c < NC; ++c) {
+    const float2 w = *reinterpret_cast<const float2*>(W2 + c * 128 + 2 * lane);
+    float v = wave_sum(fmaf(hv.y, w.y, hv.x * w.x)) + b2[c];
+    if (lane == 0) out[row * NC + c] = v;
+  }
+}
+
+}  // namespace dd
+
+extern "C" const char* dd_status_string(int status) {
+  switch (status) {
+    case DD_OK: return "ok";
+    case DD_ERR_BAD_ARG: return "bad argument (null pointer or non-positive size)";
+    case DD_ERR_UNSUPPORTED_SHAPE: return "unsupported shape (NL > 64, N > 1024, K > 32 or K > N-1)";
+    case DD_ERR_WORKSPACE_TOO_SMALL: return "workspace too small (see dd_workspace_floats)";
+    case DD_ERR_HIP: return "HIP launch/runtime error";
+  }
+  return "unknown status";
+}
+
+extern "C" int dd_abi_version(void) { return 1; }
+
+extern "C" size_t dd_workspace_floats(int B, int NP, int NL, int K) {
+  if (B <= 0 || NP < 0 || NL <= 0 || K <= 0) return 0;
+  return dd::carve(nullptr, B, NP, NL, K).total;
+}
+
+extern "C" int dd_workspace_view(const dd_sampler* s, dd_ws_view* out) {
+  if (!s || !out || !s->workspace) return DD_ERR_BAD_ARG;
+  dd::Workspace w = dd::carve(s->workspace, s->B, s->NP, s->NL, s->K);
+  out->x = (s->num_layers & 1) ? w.xb : w.xa;
+  out->h = w.h; out->hb = w.hb; out->ew = w.ew; out->A = w.A; out->nbr = w.nbr;
+  return DD_OK;
+}
+
+extern "C" int dd_forward(const dd_sampler* s, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  int rc = dd::forward_impl(s, st);
+  if (rc != DD_OK) return rc;
+  if (!s->pred_pos || !s->pred_v || !s->pred_bond) return DD_ERR_BAD_ARG;
+  dd::Workspace w = dd::carve(s->workspace, s->B, s->NP, s->NL, s->K);
+  const float* W = s->weights;
+  const int64_t* off = s->slot_off;
+  auto GW = [&](int slot) { return W + off[(long)s->num_layers * DD_NUM_LAYER_SLOTS + slot]; };
+  const int rows_v = s->B * s->NL;
+  const long rows_b = (long)s->B * s->NL * (s->NL - 1);
+  hipLaunchKernelGGL(dd::k_head_logits, dim3((rows_v + 3) / 4), dim3(256), 0, st, w.ql, GW(DD_G_VH_W2), GW(DD_G_VH_b2),
+                     rows_v, DD_NUM_V, s->pred_v);
+  hipLaunchKernelGGL(dd::k_head_logits, dim3((unsigned)((rows_b + 3) / 4)), dim3(256), 0, st, w.qb, GW(DD_G_BH_W2),
+                     GW(DD_G_BH_b2), (int)rows_b, DD_NUM_B, s->pred_bond);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
+static int one_step(const dd_sampler* s, hipStream_t st) {
+  int rc = dd::forward_impl(s, st);
+  if (rc != DD_OK) return rc;
+  return dd::heads_and_step(s, st);
+}
+
+extern "C" int dd_sample_steps(const dd_sampler* s, int n_steps, void* stream) {
+  if (!s || n_steps < 0 || !s->step_counter || !s->tab_pos || !s->tab_v || !s->tab_b || !s->atom_std || !s->offset ||
+      !s->pred_pos)
+    return DD_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  for (int i = 0; i < n_steps; ++i) {
+    int rc = one_step(s, st);
+    if (rc != DD_OK) return rc;
+  }
+  return DD_OK;
+}
+
+extern "C" int dd_sample_steps_graph(const dd_sampler* s, int n_steps, void* stream) {
+  if (!s || n_steps < 0 || !s->step_counter || !s->tab_pos || !s->tab_v || !s->tab_b || !s->atom_std || !s->offset ||
+      !s->pred_pos)
+    return DD_ERR_BAD_ARG;
+  if (n_steps == 0) return DD_OK;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = dd::check_shapes(s);
+  if (rc != DD_OK) return rc;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) return DD_ERR_HIP;
+  rc = one_step(s, st);
+  hipError_t e = hipStreamEndCapture(st, &graph);
+  if (rc != DD_OK || e != hipSuccess || !graph) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc != DD_OK ? rc : DD_ERR_HIP;
+  }
+  if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+    (void)hipGraphDestroy(graph);
+    return DD_ERR_HIP;
+  }
+  rc = DD_OK;
+  for (int i = 0; i < n_steps; ++i) {
+    if (hipGraphLaunch(exec, st) != hipSuccess) { rc = DD_ERR_HIP; break; }
+  }
+  // the exec object must outlive its launches: wait for this stream only, then release
+  if (hipStreamSynchronize(st) != hipSuccess) rc = DD_ERR_HIP;
+  (void)hipGraphExecDestroy(exec);
+  (void)hipGraphDestroy(graph);
+  return rc;
+}
+
+extern "C" int dd_profile_step(const dd_sampler* s, int n_iters, float* ms_per_category, void* stream) {
+  if (!s || !ms_per_category || n_iters <= 0) return DD_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  static dd::Profiler prof;
+  if (!prof.created) {
+    for (int i = 0; i < dd::Profiler::MAXEV; ++i) {
+      if (hipEventCreate(&prof.start[i]) != hipSuccess || hipEventCreate(&prof.stop[i]) != hipSuccess) return DD_ERR_HIP;
+    }
+    prof.created = 1;
+  }
+  for (int c = 0; c < DD_NUM_PROF_CATS; ++c) ms_per_category[c] = 0.f;
+  int rc = DD_OK;
+  for (int it = 0; it < n_iters && rc == DD_OK; ++it) {
+    prof.n = 0;
+    dd::g_prof = &prof;
+    rc = one_step(s, st);
+    dd::g_prof = nullptr;
+    if (hipStreamSynchronize(st) != hipSuccess) return DD_ERR_HIP;
+    for (int i = 0; i < prof.n; ++i) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, prof.start[i], prof.stop[i]) != hipSuccess) return DD_ERR_HIP;
+      ms_per_category[prof.cat[i]] += ms;
+    }
+  }
+  for (int c = 0; c < DD_NUM_PROF_CATS; ++c) ms_per_category[c] /= (float)n_iters;
+  return rc;
+}

@@ -1,0 +1,110 @@
+// fp32 projection GEMM, K = 128:  Y[r, c] (+)= op(X[r, :]) . W[c, :] + bias[c]
+//
+// Replaces the ATen addmm call sites behind every nn.Linear of the reference's MLPs
+// (models/common.py:85-105) after the first-Linear factorisation (packing.py).  Exact fp32
+// on the matrix cores: v_mfma_f32_32x32x2_f32 is bitwise a k-ordered fmaf chain
+// (cdna_hip_programming.md §3), so results do not depend on scheduling.
+//
+// Tile: 64 rows x 64 cols per 256-thread workgroup, whole K=128 staged in LDS once
+// (2 x 64 x 130 floats = 66.6 KB -> 2 workgroups/CU); 4 waves as 2x2, one 32x32
+// accumulator each, 64 MFMAs per wave.  LDS row pitch 130 floats makes the per-lane
+// ds_read_b64 operand fetch (row = lane&31) conflict-free: bank = (2*row + const) mod 64.
+#include "dd_kernels.hpp"
+
+namespace dd {
+
+constexpr int GT = 64;        // tile rows / cols
+constexpr int GP = 130;       // LDS row pitch (floats)
+
+
+__global__ __launch_bounds__(256) void k_gemm128(GemmArgs a) {
+  __shared__ float Xs[GT * GP];
+  __shared__ float Ws[GT * GP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * GT, col0 = blockIdx.y * GT;
+
+  // ---- stage X tile (64 rows x 128) and W tile (64 cols x 128): float4 global loads,
+  //      two ds_write_b64 each (pitch 130 is only 8-byte aligned)
+  for (int i = tid; i < GT * 32; i += 256) {
+    int r = i >> 5, c4 = (i & 31) * 4;
+    int gr = row0 + r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gr < a.rows) {
+      const float* src = a.X + (long)(gr / a.x_rows_per_b) * a.x_stride_b + (long)(gr % a.x_rows_per_b) * a.ldx + c4;
+      v = *reinterpret_cast<const float4*>(src);
+    }
+    float2* d = reinterpret_cast<float2*>(&Xs[r * GP + c4]);
+    d[0] = make_float2(v.x, v.y);
+    d[1] = make_float2(v.z, v.w);
+    int gc = col0 + r;
+    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gc < a.ncols) w = *reinterpret_cast<const float4*>(a.W + (long)gc * 128 + c4);
+    float2* e = reinterpret_cast<float2*>(&Ws[r * GP + c4]);
+    e[0] = make_float2(w.x, w.y);
+    e[1] = make_float2(w.z, w.w);
+  }
+  __syncthreads();
+
+  // ---- optional LayerNorm+ReLU prologue on the X rows (MLP hidden activation)
+  if (a.ln != nullptr) {
+    float g0 = a.ln[2 * lane], g1 = a.ln[2 * lane + 1];
+    float b0 = a.ln[128 + 2 * lane], b1 = a.ln[128 + 2 * lane + 1];
+    for (int r = wave; r < GT; r += 4) {
+      float2 v = *reinterpret_cast<float2*>(&Xs[r * GP + 2 * lane]);
+      ln_relu2(v.x, v.y, g0, g1, b0, b1);
+      *reinterpret_cast<float2*>(&Xs[r * GP + 2 * lane]) = v;
+    }
+    __syncthreads();
+  }
+
+  // ---- MFMA: wave (wr, wc) computes rows wr*32.., cols wc*32..
+  const int wr = wave >> 1, wc = wave & 1;
+  const int li = lane & 31, hh = lane >> 5;
+  const float* xa = &Xs[(wr * 32 + li) * GP + 2 * hh];
+  const float* wb = &Ws[(wc * 32 + li) * GP + 2 * hh];
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll 8
+  for (int kk = 0; kk < 32; ++kk) {
+    float2 av = *reinterpret_cast<const float2*>(xa + 4 * kk);
+    float2 bv = *reinterpret_cast<const float2*>(wb + 4 * kk);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+  }
+
+  // ---- epilogue: C/D map  col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const int gc = col0 + wc * 32 + li;
+  if (gc < a.ncols) {
+    const float bias = a.bias ? a.bias[gc] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      int gr = row0 + wr * 32 + row;
+      if (gr < a.rows) {
+        float* dst = a.Y + (long)(gr / a.y_rows_per_b) * a.y_stride_b + (long)(gr % a.y_rows_per_b) * a.ldy + gc;
+        float v = acc[r] + bias;
+        if (a.accumulate) v += *dst;
+        *dst = v;
+      }
+    }
+  }
+}
+
+int launch_gemm128(const GemmArgs& a, hipStream_t st) {
+  if (a.rows <= 0 || a.ncols <= 0) return DD_OK;
+  dim3 grid((a.rows + GT - 1) / GT, (a.ncols + GT - 1) / GT);
+  hipLaunchKernelGGL(k_gemm128, grid, dim3(256), 0, st, a);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
+}  // namespace dd
+
+extern "C" int dd_gemm128(const float* X, int x_rows_per_b, long x_stride_b, int ldx, int rows, const float* W,
+                          const float* bias, const float* ln, float* Y, int y_rows_per_b, long y_stride_b, int ldy,
+                          int ncols, int accumulate, void* stream) {
+  if (!X || !W || !Y || x_rows_per_b <= 0 || y_rows_per_b <= 0 || (ldx & 3) != 0) return DD_ERR_BAD_ARG;
+  dd::GemmArgs a{X, x_rows_per_b, x_stride_b, ldx, rows, W, bias, ln, Y, y_rows_per_b, y_stride_b, ldy, ncols, accumulate};
+  return dd::launch_gemm128(a, (hipStream_t)stream);
+}

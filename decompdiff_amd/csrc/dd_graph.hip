@@ -1,0 +1,267 @@
+// Graph construction and light per-node / per-edge kernels:
+//   k_knn            torch_cluster.knn via torch_geometric.nn.knn_graph (uni_transformer_edge.py:353)
+//   k_edge_weights   e_w = sigmoid(MLP_{20->128->1}(G(dist)))           (uni_transformer_edge.py:422-427)
+//   k_embed_*        atom / bond embeddings + context composition        (decompdiff.py:219-256,279,296-297)
+//   k_bl_assemble    per-bond-edge partial sums of the bond_layer first Linear (packing.py docstring)
+// One wavefront (64 lanes) per centre / edge row; feature rows are 128 floats = 2 per lane,
+// so every gather is a single coalesced 512-byte row read.
+#include "dd_kernels.hpp"
+
+namespace dd {
+
+// ------------------------------------------------------------------------------------ kNN
+// One wave per centre.  Each lane owns candidates c = lane, lane+64, ... (<= 16 per lane,
+// N <= 1024).  Key = (bits(d2) << 32) | index is monotone in (d2, index) because d2 >= 0, so
+// K rounds of wave-min give neighbours in ascending (distance, index) — the same total order
+// the oracle's stable sort uses.  d2 = (dx*dx + dy*dy) + dz*dz with no FMA contraction.
+constexpr int KNN_CAND = DD_N_MAX / 64;
+
+__global__ __launch_bounds__(256) void k_knn(const float* __restrict__ x, int B, int N, int K, int32_t* __restrict__ nbr) {
+  const int lane = threadIdx.x & 63;
+  const int centre = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (centre >= B * N) return;
+  const int b = centre / N, i = centre % N;
+  const float* xb = x + (long)b * N * 3;
+  const float cx = xb[3 * i], cy = xb[3 * i + 1], cz = xb[3 * i + 2];
+  unsigned long long key[KNN_CAND];
+#pragma unroll
+  for (int t = 0; t < KNN_CAND; ++t) {
+    int c = lane + 64 * t;
+    unsigned long long k = ~0ull;
+    if (c < N && c != i) {
+      float dx = __fsub_rn(cx, xb[3 * c]), dy = __fsub_rn(cy, xb[3 * c + 1]), dz = __fsub_rn(cz, xb[3 * c + 2]);
+      float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      k = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)c;
+    }
+    key[t] = k;
+  }
+  for (int s = 0; s < K; ++s) {
+    unsigned long long best = key[0];
+#pragma unroll
+    for (int t = 1; t < KNN_CAND; ++t) best = key[t] < best ? key[t] : best;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      unsigned long long other = __shfl_xor(best, o, 64);
+      best = other < best ? other : best;
+    }
+#pragma unroll
+    for (int t = 0; t < KNN_CAND; ++t)
+      if (key[t] == best) key[t] = ~0ull;
+    if (lane == 0) nbr[(long)centre * K + s] = (int32_t)(best & 0xffffffffull);
+  }
+}
+
+// ------------------------------------------------------------------------------ edge weights
+__global__ __launch_bounds__(256) void k_edge_weights(const float* __restrict__ x, const int32_t* __restrict__ nbr, int B,
+                                                      int N, int K, const float* __restrict__ W1T,
+                                                      const float* __restrict__ b1, const float* __restrict__ ln,
+                                                      const float* __restrict__ w2, const float* __restrict__ b2,
+                                                      float* __restrict__ ew) {
+  const int lane = threadIdx.x & 63;
+  const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (node >= B * N) return;
+  const int b = node / N, i = node % N;
+  const float* xb = x + (long)b * N * 3;
+  const float cx = xb[3 * i], cy = xb[3 * i + 1], cz = xb[3 * i + 2];
+  float w1a[DD_NGAUSS], w1b[DD_NGAUSS];
+#pragma unroll
+  for (int g = 0; g < DD_NGAUSS; ++g) {
+    float2 t = *reinterpret_cast<const float2*>(W1T + g * 128 + 2 * lane);
+    w1a[g] = t.x; w1b[g] = t.y;
+  }
+  const float2 bb = *reinterpret_cast<const float2*>(b1 + 2 * lane);
+  const float2 gm = *reinterpret_cast<const float2*>(ln + 2 * lane);
+  const float2 bt = *reinterpret_cast<const float2*>(ln + 128 + 2 * lane);
+  const float2 ww = *reinterpret_cast<const float2*>(w2 + 2 * lane);
+  const float bias2 = b2[0];
+  for (int s = 0; s < K; ++s) {
+    int j = nbr[(long)node * K + s];
+    float dx = cx - xb[3 * j], dy = cy - xb[3 * j + 1], dz = cz - xb[3 * j + 2];
+    float d = sqrtf(dx * dx + dy * dy + dz * dz);
+    float gl = gauss_feat(d, lane < DD_NGAUSS ? lane : 0);
+    float p0 = bb.x, p1 = bb.y;
+#pragma unroll
+    for (int g = 0; g < DD_NGAUSS; ++g) {
+      float gg = __shfl(gl, g, 64);
+      p0 = fmaf(w1a[g], gg, p0);
+      p1 = fmaf(w1b[g], gg, p1);
+    }
+    ln_relu2(p0, p1, gm.x, gm.y, bt.x, bt.y);
+    float logit = wave_sum(p0 * ww.x + p1 * ww.y) + bias2;
+    if (lane == 0) ew[(long)node * K + s] = 1.0f / (1.0f + expf(-logit));
+  }
+}
+
+// -------------------------------------------------------------------------------- embeddings
+// protein_h[r, c] = sum_f W[c, f] * feat[r, f] + b[c]     (W padded to 128 rows: row 127 = 0, b[127] = 0)
+__global__ void k_embed_protein(const float* __restrict__ feat, int rows, const float* __restrict__ W,
+                                const float* __restrict__ b, float* __restrict__ out) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * 128) return;
+  int r = idx >> 7, c = idx & 127;
+  float acc = 0.f;
+  const float* f = feat + (long)r * 29;
+  const float* w = W + c * 29;
+#pragma unroll
+  for (int k = 0; k < 29; ++k) acc = fmaf(w[k], f[k], acc);
+  out[idx] = acc + b[c];
+}
+
+// Per step: h = [protein_h ; ligand_emb(onehot(v) ++ aux)], x = [protein_pos ; lig_pos]
+__global__ void k_embed_nodes(const float* __restrict__ protein_h, const float* __restrict__ protein_pos,
+                              const float* __restrict__ lig_pos, const int32_t* __restrict__ lig_v,
+                              const float* __restrict__ lig_aux, const float* __restrict__ Wl /*[128,10]*/,
+                              const float* __restrict__ bl, int B, int NP, int NL, float* __restrict__ h,
+                              float* __restrict__ xa, float* __restrict__ xb) {
+  const int N = NP + NL;
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * N * 128) return;
+  int c = idx & 127;
+  long node = idx >> 7;
+  int b = node / N, n = node % N;
+  float val;
+  if (n < NP) {
+    val = protein_h[((long)b * NP + n) * 128 + c];
+  } else {
+    int l = n - NP;
+    long a = (long)b * NL + l;
+    const float* w = Wl + c * 10;
+    val = w[lig_v[a]] + w[8] * lig_aux[2 * a] + w[9] * lig_aux[2 * a + 1] + bl[c];
+  }
+  h[idx] = val;
+  if (c < 3) {
+    float p = n < NP ? protein_pos[((long)b * NP + n) * 3 + c] : lig_pos[((long)b * NL + (n - NP)) * 3 + c];
+    xa[node * 3 + c] = p;
+    xb[node * 3 + c] = p;
+  }
+}
+
+__global__ void k_embed_bonds(const int32_t* __restrict__ bond, long rows, const float* __restrict__ Wb /*[128,5]*/,
+                              const float* __restrict__ bb, float* __restrict__ hb) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * 128) return;
+  int c = idx & 127;
+  long e = idx >> 7;
+  hb[idx] = Wb[c * 5 + bond[e]] + bb[c];
+}
+
+// --------------------------------------------------------------------------- bond-layer assemble
+// For bond edge e = (src s -> dst t) of sample b (dst-major id e = t*(NL-1) + s'):
+//   Ek[e] = PB.k_hb[e] + Wg1k . G(d_e) + PL[s].k_hk + PL[t].k_hj        (b1 folded into PB bias)
+//   Ev[e] = same with the v weights
+//   q1[e] = PB.q_hb[e] + PL[t].q_hi
+// PB row layout [640]: NB ke | NB ve | BL k_hb | BL v_hb | BL q_hb;  PL row layout [1280]: see packing.py.
+__global__ __launch_bounds__(256) void k_bl_assemble(const float* __restrict__ x, const float* __restrict__ PB,
+                                                     const float* __restrict__ PL, const float* __restrict__ Wg1k,
+                                                     const float* __restrict__ Wg1v, int B, int NP, int NL,
+                                                     float* __restrict__ Ek, float* __restrict__ Ev,
+                                                     float* __restrict__ q1) {
+  const int lane = threadIdx.x & 63;
+  const long e_glob = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int Eb = NL * (NL - 1), N = NP + NL;
+  if (e_glob >= (long)B * Eb) return;
+  const int b = e_glob / Eb, e = e_glob % Eb;
+  const int t = e / (NL - 1), sp = e % (NL - 1);
+  const int s = sp + (sp >= t ? 1 : 0);
+  const float* xl = x + ((long)b * N + NP) * 3;
+  float dx = xl[3 * t] - xl[3 * s], dy = xl[3 * t + 1] - xl[3 * s + 1], dz = xl[3 * t + 2] - xl[3 * s + 2];
+  float d = sqrtf(dx * dx + dy * dy + dz * dz);
+  float gl = gauss_feat(d, lane < DD_NGAUSS ? lane : 0);
+  const float* pb = PB + e_glob * 640 + 2 * lane;
+  const float* ps = PL + ((long)b * NL + s) * 1280 + 2 * lane;
+  const float* pt = PL + ((long)b * NL + t) * 1280 + 2 * lane;
+  float2 k = *reinterpret_cast<const float2*>(pb + 256);
+  float2 v = *reinterpret_cast<const float2*>(pb + 384);
+  float2 q = *reinterpret_cast<const float2*>(pb + 512);
+#pragma unroll
+  for (int g = 0; g < DD_NGAUSS; ++g) {
+    float gg = __shfl(gl, g, 64);
+    float2 wk = *reinterpret_cast<const float2*>(Wg1k + g * 128 + 2 * lane);
+    float2 wv = *reinterpret_cast<const float2*>(Wg1v + g * 128 + 2 * lane);
+    k.x = fmaf(wk.x, gg, k.x); k.y = fmaf(wk.y, gg, k.y);
+    v.x = fmaf(wv.x, gg, v.x); v.y = fmaf(wv.y, gg, v.y);
+  }
+  float2 a;
+  a = *reinterpret_cast<const float2*>(ps + 640);  k.x += a.x; k.y += a.y;
+  a = *reinterpret_cast<const float2*>(pt + 768);  k.x += a.x; k.y += a.y;
+  a = *reinterpret_cast<const float2*>(ps + 896);  v.x += a.x; v.y += a.y;
+  a = *reinterpret_cast<const float2*>(pt + 1024); v.x += a.x; v.y += a.y;
+  a = *reinterpret_cast<const float2*>(pt + 1152); q.x += a.x; q.y += a.y;
+  *reinterpret_cast<float2*>(Ek + e_glob * 128 + 2 * lane) = k;
+  *reinterpret_cast<float2*>(Ev + e_glob * 128 + 2 * lane) = v;
+  *reinterpret_cast<float2*>(q1 + e_glob * 128 + 2 * lane) = q;
+}
+
+// x0-hat: ligand rows of the final coordinates
+__global__ void k_extract_ligand(const float* __restrict__ x, int B, int NP, int NL, float* __restrict__ out) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * NL * 3) return;
+  int b = idx / (NL * 3), r = idx % (NL * 3);
+  out[idx] = x[((long)b * (NP + NL) + NP) * 3 + r];
+}
+int launch_extract_ligand(const float* x, int B, int NP, int NL, float* out, hipStream_t st) {
+  int n = B * NL * 3;
+  hipLaunchKernelGGL(k_extract_ligand, dim3((n + 255) / 256), dim3(256), 0, st, x, B, NP, NL, out);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
+int launch_knn(const float* x, int B, int N, int K, int32_t* nbr, hipStream_t st) {
+  hipLaunchKernelGGL(k_knn, dim3((B * N + 3) / 4), dim3(256), 0, st, x, B, N, K, nbr);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+int launch_edge_weights(const float* x, const int32_t* nbr, int B, int N, int K, const float* W1T, const float* b1,
+                        const float* ln, const float* w2, const float* b2, float* ew, hipStream_t st) {
+  hipLaunchKernelGGL(k_edge_weights, dim3((B * N + 3) / 4), dim3(256), 0, st, x, nbr, B, N, K, W1T, b1, ln, w2, b2, ew);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+int launch_embed_nodes(const float* protein_h, const float* protein_pos, const float* lig_pos, const int32_t* lig_v,
+                       const float* lig_aux, const float* Wl, const float* bl, int B, int NP, int NL, float* h,
+                       float* xa, float* xb, hipStream_t st) {
+  long n = (long)B * (NP + NL) * 128;
+  hipLaunchKernelGGL(k_embed_nodes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, protein_h, protein_pos, lig_pos,
+                     lig_v, lig_aux, Wl, bl, B, NP, NL, h, xa, xb);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+int launch_embed_bonds(const int32_t* bond, long rows, const float* Wb, const float* bb, float* hb, hipStream_t st) {
+  long n = rows * 128;
+  hipLaunchKernelGGL(k_embed_bonds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bond, rows, Wb, bb, hb);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+int launch_bl_assemble(const float* x, const float* PB, const float* PL, const float* Wg1k, const float* Wg1v, int B,
+                       int NP, int NL, float* Ek, float* Ev, float* q1, hipStream_t st) {
+  long rows = (long)B * NL * (NL - 1);
+  hipLaunchKernelGGL(k_bl_assemble, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, PB, PL, Wg1k, Wg1v, B, NP,
+                     NL, Ek, Ev, q1);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
+}  // namespace dd
+
+extern "C" int dd_knn(const float* x, int B, int N, int K, int32_t* nbr, void* stream) {
+  if (!x || !nbr || B <= 0 || N <= 1) return DD_ERR_BAD_ARG;
+  if (N > DD_N_MAX || K > DD_KNN_MAX || K > N - 1 || K <= 0) return DD_ERR_UNSUPPORTED_SHAPE;
+  return dd::launch_knn(x, B, N, K, nbr, (hipStream_t)stream);
+}
+
+extern "C" int dd_edge_weights(const float* x, const int32_t* nbr, int B, int N, int K, const float* W1T,
+                               const float* b1, const float* ln, const float* w2, const float* b2, float* ew,
+                               void* stream) {
+  if (!x || !nbr || !W1T || !b1 || !ln || !w2 || !b2 || !ew) return DD_ERR_BAD_ARG;
+  return dd::launch_edge_weights(x, nbr, B, N, K, W1T, b1, ln, w2, b2, ew, (hipStream_t)stream);
+}
+
+extern "C" int dd_embed_protein(const float* protein_v, int rows, const float* W, const float* b, float* protein_h,
+                                void* stream) {
+  if (!protein_v || !W || !b || !protein_h || rows <= 0) return DD_ERR_BAD_ARG;
+  long n = (long)rows * 128;
+  hipLaunchKernelGGL(dd::k_embed_protein, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     protein_v, rows, W, b, protein_h);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}

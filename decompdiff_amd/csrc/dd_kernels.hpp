@@ -1,0 +1,82 @@
+// Kernel argument structs and launcher prototypes shared by the translation units.
+#pragma once
+#include "dd_common.hpp"
+
+namespace dd {
+
+struct GemmArgs {
+  const float* X; int x_rows_per_b; long x_stride_b; int ldx; int rows;
+  const float* W; const float* bias; const float* ln;
+  float* Y; int y_rows_per_b; long y_stride_b; int ldy; int ncols; int accumulate;
+};
+int launch_gemm128(const GemmArgs& a, hipStream_t st);
+
+int launch_knn(const float* x, int B, int N, int K, int32_t* nbr, hipStream_t st);
+int launch_edge_weights(const float* x, const int32_t* nbr, int B, int N, int K, const float* W1T, const float* b1,
+                        const float* ln, const float* w2, const float* b2, float* ew, hipStream_t st);
+int launch_embed_nodes(const float* protein_h, const float* protein_pos, const float* lig_pos, const int32_t* lig_v,
+                       const float* lig_aux, const float* Wl, const float* bl, int B, int NP, int NL, float* h,
+                       float* xa, float* xb, hipStream_t st);
+int launch_embed_bonds(const int32_t* bond, long rows, const float* Wb, const float* bb, float* hb, hipStream_t st);
+int launch_bl_assemble(const float* x, const float* PB, const float* PL, const float* Wg1k, const float* Wg1v, int B,
+                       int NP, int NL, float* Ek, float* Ev, float* q1, hipStream_t st);
+int launch_extract_ligand(const float* x, int B, int NP, int NL, float* out, hipStream_t st);
+
+enum { M_NE = 0, M_NB = 1, M_BL = 2, M_PE = 3, M_PB = 4 };
+
+struct AttnArgs {
+  int B, NP, NL, K;
+  const float* x;          // [B,N,3] positions at layer input
+  const int32_t* nbr;      // [B,N,K]
+  const float* ew;         // [B,N,K]
+  const float *kd, *ks, *vd, *vs, *ke, *ve;   // projection tables
+  int ld_kd, ld_ks, ld_vd, ld_vs, ld_ke, ld_ve;
+  const float* q;          // [segments,128]
+  const float *Ak, *Av;    // [4,21,128]
+  const float *Wg2k, *Wg2v, *Wak, *Wav;
+  const float *lnk, *lnv;  // [2,128]
+  const float* W2k;        // [128,128]
+  const float *W2vT, *b2v; // node modes
+  const float *W2v16, *b2v16;  // pos modes
+  float* out;
+  const float* dxe;        // PB: result of PE
+  float* x_next;           // PB
+};
+int launch_attn(int mode, const AttnArgs& a, hipStream_t st);
+
+struct StepRowsArgs {
+  const float* hid;        // [rows,128] first Linear of the head (pre-activation incl. bias)
+  const float* W2;         // [NC,128]
+  const float* b2;         // [NC]
+  int rows, NC, rows_per_sample;
+  const float* tab;        // [4][T] log_alphas, log_1m_alphas, log_cumprod, log_1m_cumprod
+  int T, t_start;
+  const int32_t* step_counter;
+  int32_t* state;          // [rows] current class, updated in place
+  const float* uniforms;   // [n_steps, rows, NC] or NULL
+  uint64_t seed; uint32_t stream_id;
+  float* logits_out;       // [rows,NC] raw logits (pred_*), may be NULL
+  float* traj_recon;       // [n_steps, rows, NC] log_softmax(logits), may be NULL
+  float* traj_prob;        // [n_steps, rows, NC] posterior log-probs, may be NULL
+  int32_t* traj_state;     // [n_steps, rows] sampled classes, may be NULL
+};
+struct StepPosArgs {
+  int B, NL, T, t_start;
+  const int32_t* step_counter;
+  const float* x0;          // [B*NL,3] predicted x0 (centred)
+  float* xt;                // [B*NL,3] current positions, updated in place
+  const float* tab_pos;     // [3][T] c0, ct, logvar
+  const float* tab_score;   // [T]
+  const float* atom_std;    // [B*NL,3]
+  const float* offset;      // [B,3]
+  const float* grad_a; int scale_a;   // armsca gradient (may be NULL)
+  const float* grad_c; int scale_c;   // clash gradient (may be NULL)
+  const float* eps;         // [n_steps,B*NL,3] or NULL
+  uint64_t seed;
+  float* traj_pos;          // [n_steps,B*NL,3] or NULL
+};
+int launch_step_rows(const StepRowsArgs& a, hipStream_t st);
+int launch_step_pos(const StepPosArgs& a, hipStream_t st);
+int launch_advance(int32_t* ctr, hipStream_t st);
+
+}  // namespace dd

@@ -1,0 +1,265 @@
+// Reverse-diffusion step kernels (models/decompdiff.py:601-689, models/transitions.py:65-161)
+// and drift guidance with analytic gradients (utils/guidance_funcs.py:24-78).
+//
+//   k_step_rows   one wave per ligand atom / per bond row: type head second Linear
+//                 (ShiftedSoftplus -> Linear, decompdiff.py:194-211), log_softmax, categorical
+//                 posterior q(v_{t-1}|v_t, v0) in log space, Gumbel-argmax sample, trajectories.
+//   k_step_pos    one thread per ligand coordinate: C0 posterior mean, drift, noise.
+//   k_drift_*     gradients of the armsca_prox / clash energies at x_t.
+// The current step index lives in device memory (step_counter) so that one captured hipGraph
+// can be replayed for every step.
+#include "dd_kernels.hpp"
+
+namespace dd {
+
+__device__ __forceinline__ float log_add_exp(float a, float b) {
+  float m = fmaxf(a, b);
+  return m + logf(expf(a - m) + expf(b - m));
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void k_step_rows(const StepRowsArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  const int step = *a.step_counter;
+  const int t = a.t_start - step;
+  // ShiftedSoftplus (common.py:66-72): softplus(x) - log 2, torch threshold 20
+  float2 hv = *reinterpret_cast<const float2*>(a.hid + row * 128 + 2 * lane);
+  hv.x = (hv.x > 20.f ? hv.x : log1pf(expf(hv.x))) - 0.6931471805599453f;
+  hv.y = (hv.y > 20.f ? hv.y : log1pf(expf(hv.y))) - 0.6931471805599453f;
+  float logit[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const float2 w = *reinterpret_cast<const float2*>(a.W2 + c * 128 + 2 * lane);
+    logit[c] = wave_sum(fmaf(hv.y, w.y, hv.x * w.x)) + a.b2[c];
+  }
+  if (lane != 0) return;
+  // log_softmax
+  float mx = logit[0];
+#pragma unroll
+  for (int c = 1; c < NC; ++c) mx = fmaxf(mx, logit[c]);
+  float se = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) se += expf(logit[c] - mx);
+  const float lse = mx + logf(se);
+  const int tm1 = t - 1 < 0 ? 0 : t - 1;
+  const float la_t = a.tab[t], l1ma_t = a.tab[a.T + t];
+  const float lca = a.tab[2 * a.T + tm1], l1mca = a.tab[3 * a.T + tm1];
+  const float log_prior = -logf((float)NC);
+  const int cur = a.state[row];
+  float un[NC];
+  float umax = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const float lv0 = logit[c] - lse;
+    const float lvt = (c == cur) ? 0.f : -69.07755278982137f;    // log(clamp(onehot, 1e-30))
+    const float q0 = log_add_exp(lv0 + lca, l1mca + log_prior);  // q(v_{t-1} | v0)
+    const float q1 = log_add_exp(lvt + la_t, l1ma_t + log_prior); // q(v_t | v_{t-1})
+    un[c] = q0 + q1;
+    umax = fmaxf(umax, un[c]);
+    if (a.logits_out) a.logits_out[row * NC + c] = logit[c];
+    if (a.traj_recon) a.traj_recon[((long)step * a.rows + row) * NC + c] = lv0;
+  }
+  float us = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) us += expf(un[c] - umax);
+  const float ulse = umax + logf(us);
+  // Gumbel-argmax (transitions.py:78-84)
+  float u[NC];
+  if (a.uniforms) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) u[c] = a.uniforms[((long)step * a.rows + row) * NC + c];
+  } else {
+    Philox ph(a.seed);
+    uint32_t r[4], r2[4];
+    ph.gen((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)step, a.stream_id, r);
+    ph.gen((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)step, a.stream_id | 0x100u, r2);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) u[c] = u01(c < 4 ? r[c] : r2[c - 4]);
+  }
+  int best = 0;
+  float bestv = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const float lp = un[c] - ulse;
+    const float g = -logf(-logf(u[c] + 1e-30f) + 1e-30f);
+    const float s = g + lp;
+    if (s > bestv) { bestv = s; best = c; }
+    if (a.traj_prob) a.traj_prob[((long)step * a.rows + row) * NC + c] = lp;
+  }
+  a.state[row] = best;
+  if (a.traj_state) a.traj_state[(long)step * a.rows + row] = best;
+}
+
+__global__ void k_step_pos(const StepPosArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = a.B * a.NL * 3;
+  if (idx >= n) return;
+  const int step = *a.step_counter;
+  const int t = a.t_start - step;
+  const int atom = idx / 3, c = idx % 3, b = atom / a.NL;
+  const float xt = a.xt[idx];
+  float mean = a.tab_pos[t] * a.x0[idx] + a.tab_pos[a.T + t] * xt;
+  float g = 0.f;
+  if (a.grad_a) g += a.scale_a ? a.grad_a[idx] * a.tab_score[t] : a.grad_a[idx];
+  if (a.grad_c) g += a.scale_c ? a.grad_c[idx] * a.tab_score[t] : a.grad_c[idx];
+  mean -= g;
+  float e;
+  if (a.eps) {
+    e = a.eps[(long)step * n + idx];
+  } else {
+    Philox ph(a.seed);
+    uint32_t r[4];
+    ph.gen((uint32_t)idx, 0u, (uint32_t)step, 7u, r);
+    const float u1 = fmaxf(u01(r[0]), 5.9604645e-8f), u2 = u01(r[1]);
+    e = sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+  }
+  const float nz = t == 0 ? 0.f : 1.f;
+  const float nxt = mean + nz * expf(0.5f * a.tab_pos[2 * a.T + t]) * e * a.atom_std[idx];
+  a.xt[idx] = nxt;
+  if (a.traj_pos) a.traj_pos[(long)step * n + idx] = nxt + a.offset[b * 3 + c];
+}
+
+__global__ void k_advance(int32_t* step_counter) { *step_counter += 1; }
+
+// ------------------------------------------------------------------------------ drift: armsca
+// Per sample: d_arm = min over (arm atom a in arm, scaffold atom s) |x_a - x_s|;
+// loss = sum_b mean_arms( relu(min_d - d) + relu(d - max_d) ) / B       (guidance_funcs.py:50-78)
+// One workgroup (64 threads) per sample; NL <= 64.
+__global__ __launch_bounds__(64) void k_drift_armsca(const float* __restrict__ pos, const int32_t* __restrict__ decomp,
+                                                     int B, int NL, float min_d, float max_d, float* __restrict__ grad,
+                                                     int accumulate) {
+  __shared__ float px[DD_NL_MAX], py[DD_NL_MAX], pz[DD_NL_MAX];
+  __shared__ int arm[DD_NL_MAX];
+  __shared__ float gx[DD_NL_MAX], gy[DD_NL_MAX], gz[DD_NL_MAX];
+  const int b = blockIdx.x, l = threadIdx.x;
+  int my_arm = -2;
+  if (l < NL) {
+    px[l] = pos[((long)b * NL + l) * 3]; py[l] = pos[((long)b * NL + l) * 3 + 1]; pz[l] = pos[((long)b * NL + l) * 3 + 2];
+    my_arm = decomp[(long)b * NL + l];
+    arm[l] = my_arm;
+    gx[l] = 0.f; gy[l] = 0.f; gz[l] = 0.f;
+  }
+  __syncthreads();
+  // number of arms = max id + 1 (scatter_min output rows); a sample is "valid" iff it has arm and scaffold atoms
+  int n_arms = 0, n_sca = 0, n_armatoms = 0;
+  for (int i = 0; i < NL; ++i) {
+    n_arms = arm[i] + 1 > n_arms ? arm[i] + 1 : n_arms;
+    n_sca += arm[i] == -1;
+    n_armatoms += arm[i] >= 0;
+  }
+  if (n_sca > 0 && n_armatoms > 0) {
+    // thread `a` < n_arms handles one arm (tiny problem: <= 64 x 64 pairs)
+    if (l < n_arms) {
+      float best = INFINITY;
+      int ba = -1, bs = -1;
+      for (int s = 0; s < NL; ++s) {             // torch: min over scaffold of (scatter_min over arm atoms)
+        if (arm[s] != -1) continue;
+        float bcol = INFINITY; int bca = -1;
+        for (int i = 0; i < NL; ++i) {
+          if (arm[i] != l) continue;
+          float dx = px[i] - px[s], dy = py[i] - py[s], dz = pz[i] - pz[s];
+          float d = sqrtf(dx * dx + dy * dy + dz * dz);
+          if (d < bcol) { bcol = d; bca = i; }
+        }
+        if (bcol < best) { best = bcol; ba = bca; bs = s; }
+      }
+      if (ba >= 0) {
+        float coef = 0.f;
+        if (min_d - best > 0.f) coef -= 1.f;
+        if (best - max_d > 0.f) coef += 1.f;
+        coef /= ((float)n_arms * (float)B);
+        if (coef != 0.f) {
+          float dx = px[ba] - px[bs], dy = py[ba] - py[bs], dz = pz[ba] - pz[bs];
+          float inv = 1.0f / best;
+          atomicAdd(&gx[ba], coef * dx * inv); atomicAdd(&gy[ba], coef * dy * inv); atomicAdd(&gz[ba], coef * dz * inv);
+          atomicAdd(&gx[bs], -coef * dx * inv); atomicAdd(&gy[bs], -coef * dy * inv); atomicAdd(&gz[bs], -coef * dz * inv);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (l < NL) {
+    float* g = grad + ((long)b * NL + l) * 3;
+    if (accumulate) { g[0] += gx[l]; g[1] += gy[l]; g[2] += gz[l]; }
+    else { g[0] = gx[l]; g[1] = gy[l]; g[2] = gz[l]; }
+  }
+}
+
+// ------------------------------------------------------------------------------ drift: clash
+// G_i = -sigma * log(1e-3 + sum_j exp(-|p_j - y_i|^2 / sigma)), y_i = x_i + offset_b
+// loss = sum_b mean_i relu(gamma - G_i)   (guidance_funcs.py:24-42)
+// dloss/dx_i = -(1/NL) [G_i < gamma] * 2/(1e-3+S) * sum_j e_j (y_i - p_j)
+// One workgroup (256 threads) per ligand atom.
+__global__ __launch_bounds__(256) void k_drift_clash(const float* __restrict__ pos, const float* __restrict__ offset,
+                                                     const float* __restrict__ prot, int B, int NL, int NF, float sigma,
+                                                     float gamma, float* __restrict__ grad, int accumulate) {
+  __shared__ float red[4][4];
+  const int atom = blockIdx.x, b = atom / NL;
+  const float yx = pos[(long)atom * 3] + offset[b * 3], yy = pos[(long)atom * 3 + 1] + offset[b * 3 + 1],
+              yz = pos[(long)atom * 3 + 2] + offset[b * 3 + 2];
+  const float* pb = prot + (long)b * NF * 3;
+  float S = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
+  const float inv_sigma = 1.0f / sigma;
+  for (int j = threadIdx.x; j < NF; j += 256) {
+    float dx = yx - pb[3 * j], dy = yy - pb[3 * j + 1], dz = yz - pb[3 * j + 2];
+    float e = expf(-(dx * dx + dy * dy + dz * dz) * inv_sigma);
+    S += e; sx = fmaf(e, dx, sx); sy = fmaf(e, dy, sy); sz = fmaf(e, dz, sz);
+  }
+  S = wave_sum(S); sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { red[wave][0] = S; red[wave][1] = sx; red[wave][2] = sy; red[wave][3] = sz; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float St = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+    float v = red[0][1 + threadIdx.x] + red[1][1 + threadIdx.x] + red[2][1 + threadIdx.x] + red[3][1 + threadIdx.x];
+    float G = -sigma * logf(1e-3f + St);
+    float g = 0.f;
+    if (gamma - G > 0.f) g = -(1.0f / (float)NL) * 2.0f / (1e-3f + St) * v;
+    float* dst = grad + (long)atom * 3 + threadIdx.x;
+    *dst = accumulate ? *dst + g : g;
+  }
+}
+
+int launch_step_rows(const StepRowsArgs& a, hipStream_t st) {
+  if (a.rows <= 0) return DD_OK;
+  dim3 grid((a.rows + 3) / 4);
+  if (a.NC == DD_NUM_V) hipLaunchKernelGGL(k_step_rows<DD_NUM_V>, grid, dim3(256), 0, st, a);
+  else if (a.NC == DD_NUM_B) hipLaunchKernelGGL(k_step_rows<DD_NUM_B>, grid, dim3(256), 0, st, a);
+  else return DD_ERR_UNSUPPORTED_SHAPE;
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+int launch_step_pos(const StepPosArgs& a, hipStream_t st) {
+  int n = a.B * a.NL * 3;
+  hipLaunchKernelGGL(k_step_pos, dim3((n + 255) / 256), dim3(256), 0, st, a);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+int launch_advance(int32_t* ctr, hipStream_t st) {
+  hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, st, ctr);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
+}  // namespace dd
+
+extern "C" int dd_drift_armsca(const float* lig_pos, const int32_t* decomp_index, int B, int NL, float min_d,
+                               float max_d, float* grad, int accumulate, void* stream) {
+  if (!lig_pos || !decomp_index || !grad || B <= 0 || NL <= 0) return DD_ERR_BAD_ARG;
+  if (NL > DD_NL_MAX) return DD_ERR_UNSUPPORTED_SHAPE;
+  hipLaunchKernelGGL(dd::k_drift_armsca, dim3(B), dim3(64), 0, (hipStream_t)stream, lig_pos, decomp_index, B, NL, min_d,
+                     max_d, grad, accumulate);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
+extern "C" int dd_drift_clash(const float* lig_pos, const float* offset, const float* full_protein_pos, int B, int NL,
+                              int NF, float sigma, float gamma, float* grad, int accumulate, void* stream) {
+  if (!lig_pos || !offset || !full_protein_pos || !grad || B <= 0 || NL <= 0 || NF <= 0) return DD_ERR_BAD_ARG;
+  hipLaunchKernelGGL(dd::k_drift_clash, dim3(B * NL), dim3(256), 0, (hipStream_t)stream, lig_pos, offset,
+                     full_protein_pos, B, NL, NF, sigma, gamma, grad, accumulate);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}

@@ -1,0 +1,120 @@
+"""ctypes binding of libdecompdiff_hip.so (the C ABI of include/decompdiff_hip.h).
+
+PyTorch is used only as the owner of device memory and streams: tensors are handed to the
+library as raw device pointers (``tensor.data_ptr()``) and launches go to torch's current HIP
+stream.  There is NO fallback: if the shared library is missing or fails to load, every entry
+point raises — the product path never computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_long, c_size_t, c_uint64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdecompdiff_hip.so")
+
+EXPORTED_SYMBOLS = [
+    "dd_status_string", "dd_abi_version", "dd_workspace_floats", "dd_knn", "dd_edge_weights", "dd_gemm128",
+    "dd_embed_protein", "dd_forward", "dd_sample_steps", "dd_sample_steps_graph", "dd_drift_armsca",
+    "dd_drift_clash", "dd_workspace_view", "dd_profile_step",
+]
+
+
+class DDSampler(ctypes.Structure):
+    """struct dd_sampler — field order must match include/decompdiff_hip.h exactly."""
+    _fields_ = [
+        ("B", c_int32), ("NP", c_int32), ("NL", c_int32), ("K", c_int32), ("NF", c_int32),
+        ("num_layers", c_int32), ("T", c_int32), ("t_start", c_int32),
+        ("weights", c_void_p), ("slot_off", c_void_p),
+        ("tab_pos", c_void_p), ("tab_v", c_void_p), ("tab_b", c_void_p), ("tab_score", c_void_p),
+        ("protein_pos", c_void_p), ("protein_h", c_void_p), ("lig_aux", c_void_p), ("atom_std", c_void_p),
+        ("offset", c_void_p), ("decomp_index", c_void_p), ("full_protein_pos", c_void_p),
+        ("lig_pos", c_void_p), ("lig_v", c_void_p), ("lig_bond", c_void_p), ("step_counter", c_void_p),
+        ("drift_armsca", c_int32), ("armsca_min_d", c_float), ("armsca_max_d", c_float), ("armsca_scale", c_int32),
+        ("drift_clash", c_int32), ("clash_sigma", c_float), ("clash_gamma", c_float), ("clash_scale", c_int32),
+        ("u_v", c_void_p), ("u_b", c_void_p), ("eps", c_void_p), ("seed", c_uint64),
+        ("traj_pos", c_void_p), ("traj_v", c_void_p), ("traj_bond", c_void_p), ("traj_v0", c_void_p),
+        ("traj_vt", c_void_p), ("traj_bt", c_void_p),
+        ("pred_pos", c_void_p), ("pred_v", c_void_p), ("pred_bond", c_void_p),
+        ("workspace", c_void_p), ("workspace_floats", c_size_t),
+    ]
+
+
+class DDWsView(ctypes.Structure):
+    _fields_ = [("x", c_void_p), ("h", c_void_p), ("hb", c_void_p), ("ew", c_void_p), ("A", c_void_p),
+                ("nbr", c_void_p)]
+
+
+PROF_CATS = ["misc", "gemm", "assemble", "attn_NE", "attn_NB", "attn_BL", "attn_PE", "attn_PB", "step"]
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises HipLibraryError if it is absent — build it with
+    ``python -m decompdiff_amd.build`` (or ``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(f"{LIB_PATH} not found: build it with `python -m decompdiff_amd.build`; "
+                              "there is no CPU fallback for the sampling hot path")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:                                   # e.g. libamdhip64 missing
+        raise HipLibraryError(f"could not load {LIB_PATH}: {e}") from e
+    lib.dd_status_string.restype = c_char_p
+    lib.dd_status_string.argtypes = [c_int]
+    lib.dd_abi_version.restype = c_int
+    lib.dd_workspace_floats.restype = c_size_t
+    lib.dd_workspace_floats.argtypes = [c_int, c_int, c_int, c_int]
+    lib.dd_knn.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.dd_edge_weights.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 7
+    lib.dd_gemm128.argtypes = [c_void_p, c_int, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                               c_long, c_int, c_int, c_int, c_void_p]
+    lib.dd_embed_protein.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.dd_forward.argtypes = [POINTER(DDSampler), c_void_p]
+    lib.dd_sample_steps.argtypes = [POINTER(DDSampler), c_int, c_void_p]
+    lib.dd_sample_steps_graph.argtypes = [POINTER(DDSampler), c_int, c_void_p]
+    lib.dd_drift_armsca.argtypes = [c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_int, c_void_p]
+    lib.dd_drift_clash.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p,
+                                   c_int, c_void_p]
+    lib.dd_workspace_view.argtypes = [POINTER(DDSampler), POINTER(DDWsView)]
+    lib.dd_profile_step.argtypes = [POINTER(DDSampler), c_int, POINTER(c_float), c_void_p]
+    for name in EXPORTED_SYMBOLS:
+        if name not in ("dd_status_string", "dd_workspace_floats"):
+            getattr(lib, name).restype = c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().dd_status_string(rc).decode()
+        raise RuntimeError(f"decompdiff_hip {what} failed: {msg} (status {rc})")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "decompdiff_hip needs contiguous tensors"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_gpu(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise HipLibraryError(f"{name} must live on a HIP device (got {t.device}); the sampling hot path has no "
+                              "CPU implementation in this package")

@@ -1,0 +1,399 @@
+"""Host-side mirror of the reference's model API for the sampling hot path.
+
+:class:`DecompScorePosNet3D` keeps the constructor, ``forward`` and ``sample_diffusion``
+signatures, the attribute surface read by scripts/sample_diffusion_decomp.py
+(``num_classes``, ``num_bond_classes``, ``bond_diffusion``, ``num_timesteps``) and the complete
+``state_dict`` key layout of /root/reference/models/decompdiff.py:75-703, so a reference
+checkpoint loads with ``strict=True`` and the reference's sampling script can call it unchanged.
+All arithmetic of the loop runs in libdecompdiff_hip.so (HIP, gfx950); this file only converts
+the PyG-style flat batch into the dense fixed-shape layout, owns device buffers and unpacks
+results.  Nothing here computes the network on the CPU — CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip_lib, packing, schedules
+from .synth import learnable_param_shapes
+
+H = 128
+
+
+class _Node(nn.Module):
+    """Anonymous container used to reproduce the reference's dotted state_dict keys."""
+
+
+def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor, kind: str):
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, _Node())
+        mod = mod._modules[p]
+    if kind == "param":
+        mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=True))
+    elif kind == "const":                       # to_torch_const(): nn.Parameter(requires_grad=False)
+        mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+    else:
+        mod.register_buffer(parts[-1], tensor)
+
+
+GAUSS_OFFSETS = [0, 1, 1.25, 1.5, 1.75, 2, 2.25, 2.5, 2.75, 3, 3.5, 4, 4.5, 5, 5.5, 6, 7, 8, 9, 10]
+
+
+def log_sample_categorical(logits: torch.Tensor) -> torch.Tensor:
+    """Gumbel-argmax sampling, re-exported because the reference's script imports it from
+    models.decompdiff (scripts/sample_diffusion_decomp.py:25; models/transitions.py:78-84).
+    Used by the harness for the *initial* types only (outside the hot loop)."""
+    uniform = torch.rand_like(logits)
+    gumbel = -torch.log(-torch.log(uniform + 1e-30) + 1e-30)
+    return (gumbel + logits).argmax(dim=-1)
+
+
+class DecompScorePosNet3D(nn.Module):
+
+    def __init__(self, config, protein_atom_feature_dim, ligand_atom_feature_dim, num_classes,
+                 prior_atom_types=None, prior_bond_types=None):
+        super().__init__()
+        self.config = config
+        self.model_mean_type = config.model_mean_type
+        self.add_prior_node = getattr(config, "add_prior_node", False)
+        self.bond_diffusion = getattr(config, "bond_diffusion", False)
+        self.bond_net_type = getattr(config, "bond_net_type", "mlp")
+        self.sample_time_method = getattr(config, "sample_time_method", "symmetric")
+        self.loss_pos_type = getattr(config, "loss_pos_type", "mse")
+        self.refine_net_type = config.model_type
+        self.hidden_dim = config.hidden_dim
+        self.center_pos_mode = config.center_pos_mode
+        self.time_emb_dim = config.time_emb_dim
+        self.num_classes = num_classes
+        self.num_bond_classes = getattr(config, "num_bond_classes", 1)
+        self._check_supported(config, protein_atom_feature_dim, ligand_atom_feature_dim)
+
+        # ---- schedule tables (same keys as the reference checkpoint)
+        for k, v in schedules.position_tables(config).items():
+            _attach(self, k, v, "const")
+        self.num_timesteps = self.betas.size(0)
+        for name, ncls, prior in (("atom_type_trans", num_classes, prior_atom_types),
+                                  ("bond_type_trans", self.num_bond_classes, prior_bond_types)):
+            tabs = schedules.categorical_tables(config.v_beta_schedule, self.num_timesteps, config.v_beta_s, ncls, prior)
+            for k, v in tabs.items():
+                _attach(self, f"{name}.{k}", v, "const")
+        self.register_buffer("Lt_history", torch.zeros(self.num_timesteps))
+        self.register_buffer("Lt_count", torch.zeros(self.num_timesteps))
+
+        # ---- learnable tensors (reference module tree; default init ~ nn.Linear / nn.LayerNorm)
+        gen = torch.Generator().manual_seed(0)
+        shapes = learnable_param_shapes(config, protein_atom_feature_dim=protein_atom_feature_dim,
+                                        ligand_atom_feature_dim=ligand_atom_feature_dim, num_classes=num_classes)
+        for k, shp in shapes.items():
+            if len(shp) == 2:
+                bound = 1.0 / np.sqrt(shp[1])
+                t = (torch.rand(shp, generator=gen) * 2 - 1) * bound
+            elif k.endswith(".net.1.weight"):
+                t = torch.ones(shp)
+            elif k.endswith(".net.1.bias"):
+                t = torch.zeros(shp)
+            else:
+                t = (torch.rand(shp, generator=gen) * 2 - 1) * 0.05
+            _attach(self, k, t, "param")
+
+        # ---- non-learnable buffers of the reference modules
+        off = torch.tensor(GAUSS_OFFSETS, dtype=torch.float32)
+        _attach(self, "refine_net.distance_expansion.offset", off.clone(), "buffer")
+        for l in range(config.num_layers):
+            p = f"refine_net.base_block.{l}"
+            _attach(self, f"{p}.distance_expansion.offset", off.clone(), "buffer")
+            _attach(self, f"{p}.bond_layer.distance_expansion.offset", off.clone(), "buffer")
+            _attach(self, f"{p}.bond_layer.angle_expansion.freq_bands",
+                    torch.tensor([1.0, 2.0, 3.0, 1.0, 1.0 / 2.0, 1.0 / 3.0]), "buffer")
+        if self.bond_diffusion:
+            _attach(self, "distance_expansion.offset", torch.linspace(0.0, 5.0, config.num_r_gaussian), "buffer")
+
+        self._packed = None
+        self._packed_key = None
+
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _check_supported(config, pdim, ldim):
+        def need(cond, what):
+            if not cond:
+                raise NotImplementedError(
+                    f"decompdiff_amd implements the shipped sampling configuration only ({what}); "
+                    "see DESIGN.md 'out of scope'")
+        need(config.model_type == "uni_o2_bond", "model_type=uni_o2_bond")
+        need(config.hidden_dim == 128 and config.n_heads == 16, "hidden_dim=128, n_heads=16")
+        need(config.cutoff_mode == "knn", "cutoff_mode=knn")
+        need(getattr(config, "bond_diffusion", False) and getattr(config, "bond_net_type", "mlp") == "lin",
+             "bond_diffusion with bond_net_type=lin")
+        need(not getattr(config, "add_prior_node", False), "add_prior_node=False")
+        need(config.time_emb_dim == 0, "time_emb_dim=0")
+        need(config.node_indicator, "node_indicator=True")
+        need(config.num_blocks == 1, "num_blocks=1")
+        need(config.edge_feat_dim == 4 and config.num_r_gaussian == 20, "edge_feat_dim=4, num_r_gaussian=20")
+        need(getattr(config, "h_node_in_bond_net", False), "h_node_in_bond_net=True")
+        need(not config.x2h_out_fc and config.norm and config.act_fn == "relu", "x2h_out_fc=False, norm, relu")
+        need(getattr(config, "num_bond_classes", 1) == 5, "num_bond_classes=5")
+        need(pdim == 29 and ldim == 10, "protein/ligand feature dims 29/10")
+        need(config.knn <= 32, "knn<=32")
+
+    # ------------------------------------------------------------------------------------------
+    def _device(self):
+        return self.betas.device
+
+    def _packed_weights(self):
+        dev = self._device()
+        key = (str(dev), sum(int(p._version) for p in self.parameters()))
+        if self._packed is None or self._packed_key != key:
+            sd = {k: v for k, v in self.state_dict().items()}
+            arena, offsets, _ = packing.pack_model(sd, self.config)
+            tab_pos = torch.stack([self.posterior_mean_c0_coef, self.posterior_mean_ct_coef,
+                                   self.posterior_logvar]).detach().float().contiguous()
+            tv = self.atom_type_trans
+            tb = self.bond_type_trans
+            tab_v = torch.stack([tv.log_alphas_v, tv.log_one_minus_alphas_v, tv.log_alphas_cumprod_v,
+                                 tv.log_one_minus_alphas_cumprod_v]).detach().float().contiguous()
+            tab_b = torch.stack([tb.log_alphas_v, tb.log_one_minus_alphas_v, tb.log_alphas_cumprod_v,
+                                 tb.log_one_minus_alphas_cumprod_v]).detach().float().contiguous()
+            self._packed = dict(arena=arena.to(dev), offsets=offsets.numpy().astype(np.int64).copy(),
+                                tab_pos=tab_pos.to(dev), tab_v=tab_v.to(dev), tab_b=tab_b.to(dev),
+                                tab_score=self.pos_score_coef.detach().float().contiguous().to(dev))
+            self._packed_key = key
+        return self._packed
+
+    # ------------------------------------------------------------------------------------------
+    def _dense_inputs(self, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, ligand_v_aux, batch_ligand,
+                      ligand_fc_bond_index, ligand_bond_type, ligand_atom_mask):
+        """Flat PyG-style batch -> dense [B, ...] tensors (validated, no arithmetic)."""
+        for name, t in (("protein_pos", protein_pos), ("ligand_pos", ligand_pos)):
+            hip_lib.require_gpu(t, name)
+        if ligand_atom_mask is not None:
+            raise NotImplementedError("ligand_atom_mask (partially fixed ligands) is not part of the shipped sampling path")
+        if ligand_fc_bond_index is None or ligand_bond_type is None:
+            raise NotImplementedError("the uni_o2_bond path needs the fully connected ligand bond graph")
+        B = int(batch_protein.max().item()) + 1 if batch_protein.numel() else 0
+        if B <= 0:
+            raise ValueError("empty batch")
+        n_p, n_l = batch_protein.numel(), batch_ligand.numel()
+        if n_p % B or n_l % B:
+            raise NotImplementedError("ragged batches (different atom counts per sample) are not supported yet; "
+                                      "batch samples of one pocket with equal ligand sizes")
+        NP, NL = n_p // B, n_l // B
+        dev = protein_pos.device
+        exp_p = torch.arange(B, device=dev).repeat_interleave(NP)
+        exp_l = torch.arange(B, device=dev).repeat_interleave(NL)
+        if not (torch.equal(batch_protein, exp_p) and torch.equal(batch_ligand, exp_l)):
+            raise NotImplementedError("batch vectors must be sorted with equal counts per sample (PyG Batch order)")
+        if NL < 2 or NL > 64:
+            raise NotImplementedError(f"ligand size {NL} outside the supported range [2, 64]")
+        if NP + NL > 1024:
+            raise NotImplementedError("more than 1024 atoms per sample")
+        # the fused kernels use the closed-form fc layout of FeaturizeLigandBond('fc') (utils/transforms.py:331-337)
+        dst = torch.arange(NL, device=dev).repeat_interleave(NL)
+        src = torch.arange(NL, device=dev).repeat(NL)
+        keep = dst != src
+        fc = torch.stack([src[keep], dst[keep]], 0)
+        exp_fc = torch.cat([fc + b * NL for b in range(B)], 1)
+        if ligand_fc_bond_index.shape != exp_fc.shape or not torch.equal(ligand_fc_bond_index, exp_fc):
+            raise NotImplementedError("ligand_fc_bond_index must be the dst-major fully connected graph ('fc' mode)")
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        return dict(B=B, NP=NP, NL=NL, protein_pos=f32(protein_pos).view(B, NP, 3), protein_v=f32(protein_v).view(B, NP, -1),
+                    ligand_pos=f32(ligand_pos).view(B, NL, 3), ligand_v=ligand_v.detach().to(torch.int32).contiguous(),
+                    ligand_aux=f32(ligand_v_aux).view(B, NL, -1),
+                    bond=ligand_bond_type.detach().to(torch.int32).contiguous())
+
+    def _make_sampler(self, d, pw, n_steps, t_start, noise, keep_traj, drift, atom_std, offset, decomp_index,
+                      full_protein_pos, seed):
+        lib = hip_lib.load()
+        dev = d["protein_pos"].device
+        B, NP, NL = d["B"], d["NP"], d["NL"]
+        N = NP + NL
+        K = min(int(self.config.knn), N - 1)
+        Eb = NL * (NL - 1)
+        bufs: Dict[str, Optional[torch.Tensor]] = {}
+        z = lambda *shape, dtype=torch.float32: torch.zeros(*shape, dtype=dtype, device=dev)
+        # static inputs
+        bufs["protein_pos"] = d["protein_pos_centered"]
+        bufs["protein_h"] = z(B * NP, H)
+        goff = self._global_offsets(pw)
+        arena, offs = pw["arena"], pw["offsets"]
+        w_pemb = arena[goff["W_pemb"]:]
+        b_pemb = arena[goff["b_pemb"]:]
+        hip_lib.check(lib.dd_embed_protein(hip_lib.ptr(d["protein_v"].view(B * NP, -1)), B * NP,
+                                           ctypes.c_void_p(w_pemb.data_ptr()), ctypes.c_void_p(b_pemb.data_ptr()),
+                                           hip_lib.ptr(bufs["protein_h"]), hip_lib.stream_ptr(dev)), "dd_embed_protein")
+        bufs["lig_aux"] = d["ligand_aux"]
+        bufs["atom_std"] = atom_std
+        bufs["offset"] = offset
+        bufs["decomp_index"] = decomp_index
+        bufs["full_protein_pos"] = full_protein_pos
+        # state
+        bufs["lig_pos"] = d["ligand_pos_centered"].clone()
+        bufs["lig_v"] = d["ligand_v"].clone()
+        bufs["lig_bond"] = d["bond"].clone()
+        bufs["step_counter"] = z(1, dtype=torch.int32)
+        bufs["pred_pos"], bufs["pred_v"], bufs["pred_bond"] = z(B * NL, 3), z(B * NL, 8), z(B * Eb, 5)
+        ws_floats = int(lib.dd_workspace_floats(B, NP, NL, K))
+        bufs["workspace"] = z(ws_floats)
+        if keep_traj and n_steps > 0:
+            bufs["traj_pos"] = z(n_steps, B * NL, 3)
+            bufs["traj_v"] = z(n_steps, B * NL, dtype=torch.int32)
+            bufs["traj_bond"] = z(n_steps, B * Eb, dtype=torch.int32)
+            bufs["traj_v0"] = z(n_steps, B * NL, 8)
+            bufs["traj_vt"] = z(n_steps, B * NL, 8)
+            bufs["traj_bt"] = z(n_steps, B * Eb, 5)
+        if noise is not None:
+            for k, shp in (("u_v", (n_steps, B * NL, 8)), ("u_b", (n_steps, B * Eb, 5)), ("eps", (n_steps, B * NL, 3))):
+                t = noise[k]
+                if tuple(t.shape) != shp:
+                    raise ValueError(f"noise['{k}'] must have shape {shp}, got {tuple(t.shape)}")
+                bufs[k] = t.to(device=dev, dtype=torch.float32).contiguous()
+        s = hip_lib.DDSampler()
+        s.B, s.NP, s.NL, s.K = B, NP, NL, K
+        s.NF = 0 if full_protein_pos is None else full_protein_pos.shape[1]
+        s.num_layers, s.T, s.t_start = int(self.config.num_layers), int(self.betas.numel()), int(t_start)
+        s.weights = arena.data_ptr()
+        s.slot_off = offs.ctypes.data
+        s.tab_pos, s.tab_v, s.tab_b = pw["tab_pos"].data_ptr(), pw["tab_v"].data_ptr(), pw["tab_b"].data_ptr()
+        s.tab_score = pw["tab_score"].data_ptr()
+        for k in ("protein_pos", "protein_h", "lig_aux", "atom_std", "offset", "decomp_index", "full_protein_pos",
+                  "lig_pos", "lig_v", "lig_bond", "step_counter", "u_v", "u_b", "eps", "traj_pos", "traj_v",
+                  "traj_bond", "traj_v0", "traj_vt", "traj_bt", "pred_pos", "pred_v", "pred_bond", "workspace"):
+            t = bufs.get(k)
+            if t is not None:
+                assert t.is_contiguous() and t.device == dev, k
+                setattr(s, k, t.data_ptr())
+        s.workspace_floats = ws_floats
+        s.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        for dr in drift or []:
+            if dr["type"] == "armsca_prox":
+                s.drift_armsca, s.armsca_min_d, s.armsca_max_d = 1, float(dr["min_d"]), float(dr["max_d"])
+                s.armsca_scale = int(bool(dr.get("scale", False)))
+            elif dr["type"] == "clash":
+                s.drift_clash, s.clash_sigma, s.clash_gamma = 1, float(dr["sigma"]), float(dr["gamma"])
+                s.clash_scale = int(bool(dr.get("scale", False)))
+            elif dr["type"] in ("center_prox", "mmff_min"):
+                raise NotImplementedError(f"drift '{dr['type']}' is outside the shipped sampling path "
+                                          "(center_prox raises in the reference; mmff_min is RDKit/CPU)")
+            else:
+                raise ValueError(dr["type"])
+        return s, bufs, pw
+
+    def _global_offsets(self, pw):
+        n = int(self.config.num_layers) * len(packing.LAYER_SLOTS)
+        return {k: int(pw["offsets"][n + i]) for i, k in enumerate(packing.GLOBAL_SLOTS)}
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, protein_pos, protein_v, batch_protein, protein_group_idx,
+                init_ligand_pos, init_ligand_v, init_ligand_v_aux, batch_ligand, ligand_group_idx,
+                prior_centers, prior_stds, batch_prior, prior_group_idx,
+                ligand_fc_bond_index, init_ligand_fc_bond_type,
+                ligand_atom_mask=None, time_step=None, return_all=False):
+        """Score network once (reference: models/decompdiff.py:213-351).  ``time_step``, the group
+        indices and the prior tensors are accepted for signature compatibility; the shipped
+        configuration never reads them (time_emb_dim=0, add_prior_node=False)."""
+        if return_all:
+            raise NotImplementedError("return_all (per-block intermediates) is a training-time option")
+        with torch.no_grad():
+            d = self._dense_inputs(protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v,
+                                   init_ligand_v_aux, batch_ligand, ligand_fc_bond_index, init_ligand_fc_bond_type,
+                                   ligand_atom_mask)
+            d["protein_pos_centered"], d["ligand_pos_centered"] = d["protein_pos"], d["ligand_pos"]
+            pw = self._packed_weights()
+            dev = d["protein_pos"].device
+            B, NL = d["B"], d["NL"]
+            dummy3 = torch.ones(B * NL, 3, device=dev)
+            s, bufs, _ = self._make_sampler(d, pw, 0, 0, None, False, None, dummy3,
+                                            torch.zeros(B, 3, device=dev), None, None, 0)
+            hip_lib.check(hip_lib.load().dd_forward(ctypes.byref(s), hip_lib.stream_ptr(dev)), "dd_forward")
+            preds = {"pred_ligand_pos": bufs["pred_pos"].view(B * NL, 3),
+                     "pred_ligand_v": bufs["pred_v"].view(B * NL, 8)}
+            if self.bond_diffusion:
+                preds["pred_bond"] = bufs["pred_bond"]
+            self._last = (s, bufs)
+            return preds
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def sample_diffusion(self, protein_pos, protein_v, batch_protein, protein_group_idx,
+                         init_ligand_pos, init_ligand_v, ligand_v_aux, batch_ligand, ligand_group_idx,
+                         prior_centers, prior_stds, prior_num_atoms, batch_prior, prior_group_idx,
+                         ligand_decomp_batch, ligand_decomp_index,
+                         ligand_atom_mask=None,
+                         ligand_fc_bond_index=None, init_ligand_fc_bond_type=None, batch_ligand_bond=None,
+                         num_steps=None, center_pos_mode=None,
+                         energy_drift_opt=None,
+                         full_protein_pos=None, full_batch_protein=None,
+                         noise=None, seed=0, keep_traj=True, use_graph=True):
+        """Reverse diffusion (reference: models/decompdiff.py:552-703), same arguments and return
+        keys.  Extra keyword-only knobs (all optional, reference call sites never pass them):
+
+        * ``noise``  dict(u_v [T,B*NL,8], u_b [T,B*Eb,5], eps [T,B*NL,3]) — pre-drawn noise in the
+          reference's draw order (parity mode); ``None`` -> device Philox keyed by ``seed``.
+        * ``keep_traj`` — record the six trajectories on the device and copy them once at the end.
+        * ``use_graph`` — replay one captured hipGraph per step instead of eager launches.
+        """
+        if self.model_mean_type != "C0":
+            if self.model_mean_type == "noise":
+                raise NotImplementedError("model_mean_type='noise' is not the shipped configuration")
+            raise ValueError(self.model_mean_type)
+        if num_steps is None:
+            num_steps = self.num_timesteps
+        d = self._dense_inputs(protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, ligand_v_aux,
+                               batch_ligand, ligand_fc_bond_index, init_ligand_fc_bond_type, ligand_atom_mask)
+        dev = d["protein_pos"].device
+        B, NP, NL = d["B"], d["NP"], d["NL"]
+        # center_pos (decompdiff.py:20-32): subtract the per-sample protein centroid
+        if center_pos_mode == "protein":
+            offset = d["protein_pos"].double().mean(1).float()
+        elif center_pos_mode == "none":
+            offset = torch.zeros(B, 3, device=dev)
+        else:
+            raise NotImplementedError(center_pos_mode)
+        d["protein_pos_centered"] = (d["protein_pos"] - offset[:, None, :]).contiguous()
+        d["ligand_pos_centered"] = (d["ligand_pos"] - offset[:, None, :]).contiguous()
+        atom_std = prior_stds.to(dev).float()[ligand_decomp_batch.to(dev)].contiguous()           # [B*NL,3]
+        decomp = ligand_decomp_index.to(device=dev, dtype=torch.int32).contiguous() if ligand_decomp_index is not None else None
+        fpp = None
+        if energy_drift_opt is not None and any(dr["type"] == "clash" for dr in energy_drift_opt):
+            if full_protein_pos is None or full_batch_protein is None:
+                raise ValueError("clash drift needs full_protein_pos / full_batch_protein")
+            nf = full_protein_pos.shape[0] // B
+            exp = torch.arange(B, device=dev).repeat_interleave(nf)
+            if full_protein_pos.shape[0] % B or not torch.equal(full_batch_protein.to(dev), exp):
+                raise NotImplementedError("full_protein_pos must hold the same number of atoms per sample")
+            fpp = full_protein_pos.to(dev).float().contiguous().view(B, nf, 3)
+        t_start = self.num_timesteps - 1              # time_seq = reversed(range(T - num_steps, T)), decompdiff.py:575
+        if num_steps > self.num_timesteps:
+            raise ValueError("num_steps exceeds num_timesteps")
+        pw = self._packed_weights()
+        s, bufs, _ = self._make_sampler(d, pw, num_steps, t_start, noise, keep_traj, energy_drift_opt, atom_std,
+                                        offset.contiguous(), decomp, fpp, seed)
+        lib = hip_lib.load()
+        fn = lib.dd_sample_steps_graph if use_graph else lib.dd_sample_steps
+        hip_lib.check(fn(ctypes.byref(s), int(num_steps), hip_lib.stream_ptr(dev)),
+                      "dd_sample_steps_graph" if use_graph else "dd_sample_steps")
+        ligand_pos = bufs["lig_pos"].view(B, NL, 3) + offset[:, None, :]
+        out = {
+            "pos": ligand_pos.reshape(B * NL, 3),
+            "v": bufs["lig_v"].long(),
+            "bond": bufs["lig_bond"].long(),
+        }
+        if keep_traj and num_steps > 0:
+            cpu = {k: bufs[k].cpu() for k in ("traj_pos", "traj_v", "traj_bond", "traj_v0", "traj_vt", "traj_bt")}
+            out["pos_traj"] = list(cpu["traj_pos"].unbind(0))
+            out["v_traj"] = list(cpu["traj_v"].long().unbind(0))
+            out["bond_traj"] = list(cpu["traj_bond"].long().unbind(0))
+            out["v0_traj"] = list(cpu["traj_v0"].unbind(0))
+            out["vt_traj"] = list(cpu["traj_vt"].unbind(0))
+            out["bt_traj"] = list(cpu["traj_bt"].unbind(0))
+        else:
+            for k in ("pos_traj", "v_traj", "bond_traj", "v0_traj", "vt_traj", "bt_traj"):
+                out[k] = []
+        self._last = (s, bufs)
+        return out

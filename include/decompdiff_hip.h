@@ -1,0 +1,186 @@
+/*
+ * decompdiff_hip.h — C ABI of libdecompdiff_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the reverse-diffusion sampling hot path of bytedance/DecompDiff
+ * (SURVEY.md §8b).  The reference is pure Python on PyTorch; the native ops its hot path
+ * reaches live in third-party wheels (torch_scatter / torch_cluster / torch_sparse / ATen).
+ * Each entry point below names the reference call site(s) it replaces.  All pointers are
+ * DEVICE pointers unless marked HOST; the caller owns every buffer; nothing is allocated,
+ * freed or synchronised inside (two documented exceptions: dd_sample_steps_graph waits for its
+ * own replays before destroying the graph, dd_profile_step reads its events); every launch goes
+ * to `stream` (a hipStream_t passed as void*).  Return value: 0 on success, negative dd_status on error (no exceptions cross
+ * the ABI); dd_status_string() gives the text.
+ *
+ * Dense fixed-shape layout ("padded/masked fixed-size pocket+ligand graphs"):
+ *   B samples; per sample NP protein atoms then NL ligand atoms (N = NP+NL, the context
+ *   order of models/common.py:167-194); kNN lists [B,N,K]; the fully connected ligand bond
+ *   graph is implicit and dst-major: edge e = dst*(NL-1) + src - (src>dst)
+ *   (utils/transforms.py:331-337); triplets (k->j->i) are implicit (closed-form indices).
+ */
+#ifndef DECOMPDIFF_HIP_H
+#define DECOMPDIFF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DD_HIDDEN 128
+#define DD_HEADS 16
+#define DD_NGAUSS 20
+#define DD_KNN_MAX 32
+#define DD_NL_MAX 64      /* ligand atoms per sample supported by the fused kernels */
+#define DD_N_MAX 1024     /* atoms per sample supported by the kNN kernel */
+#define DD_NUM_V 8        /* atom classes  (scripts/sample_diffusion_decomp.py:540) */
+#define DD_NUM_B 5        /* bond classes  (configs/training.yml:33) */
+
+typedef enum dd_status {
+  DD_OK = 0,
+  DD_ERR_BAD_ARG = -1,
+  DD_ERR_UNSUPPORTED_SHAPE = -2,
+  DD_ERR_WORKSPACE_TOO_SMALL = -3,
+  DD_ERR_HIP = -4
+} dd_status;
+
+/* Packed-weight slots, per layer (decompdiff_amd/packing.py: LAYER_SLOTS, same order). */
+typedef enum dd_wslot {
+  DD_W_n1, DD_b_n1, DD_W_l1, DD_b_l1, DD_W_b1, DD_b_b1,
+  DD_NE_Ak, DD_NE_Av, DD_NE_lnk, DD_NE_lnv, DD_NE_lnq, DD_NE_W2q, DD_NE_b2q, DD_NE_W2k, DD_NE_W2vT, DD_NE_b2v,
+  DD_NB_lnk, DD_NB_lnv, DD_NB_lnq, DD_NB_W2q, DD_NB_b2q, DD_NB_W2k, DD_NB_W2vT, DD_NB_b2v,
+  DD_BL_Wg1k, DD_BL_Wg1v, DD_BL_Wg2k, DD_BL_Wg2v, DD_BL_Wak, DD_BL_Wav,
+  DD_BL_lnk, DD_BL_lnv, DD_BL_lnq, DD_BL_W2q, DD_BL_b2q, DD_BL_W2k, DD_BL_W2vT, DD_BL_b2v,
+  DD_W_lin, DD_b_lin,
+  DD_W_n2, DD_b_n2, DD_W_l2, DD_b_l2, DD_W_b2, DD_b_b2,
+  DD_PE_Ak, DD_PE_Av, DD_PE_lnk, DD_PE_lnv, DD_PE_lnq, DD_PE_W2q, DD_PE_b2q, DD_PE_W2k, DD_PE_W2v, DD_PE_b2v,
+  DD_PB_lnk, DD_PB_lnv, DD_PB_lnq, DD_PB_W2q, DD_PB_b2q, DD_PB_W2k, DD_PB_W2v, DD_PB_b2v,
+  DD_NUM_LAYER_SLOTS
+} dd_wslot;
+
+/* Global slots (packing.py: GLOBAL_SLOTS), stored after all layers. */
+typedef enum dd_gslot {
+  DD_G_W_pemb, DD_G_b_pemb, DD_G_W_lemb, DD_G_b_lemb, DD_G_W_bemb, DD_G_b_bemb,
+  DD_G_EW_W1T, DD_G_EW_b1, DD_G_EW_ln, DD_G_EW_w2, DD_G_EW_b2,
+  DD_G_VH_W1, DD_G_VH_b1, DD_G_VH_W2, DD_G_VH_b2,
+  DD_G_BH_W1, DD_G_BH_b1, DD_G_BH_W2, DD_G_BH_b2,
+  DD_NUM_GLOBAL_SLOTS
+} dd_gslot;
+
+/* One sampler run: everything `DecompScorePosNet3D.sample_diffusion`
+ * (models/decompdiff.py:552-703) keeps alive across its loop. */
+typedef struct dd_sampler {
+  /* shapes */
+  int32_t B, NP, NL, K, NF;        /* NF: full-protein atoms per sample (clash drift), 0 = none */
+  int32_t num_layers;
+  int32_t T;                       /* length of the schedule tables */
+  int32_t t_start;                 /* timestep of step 0 (reference: num_timesteps-1) */
+  /* model */
+  const float* weights;            /* packed arena */
+  const int64_t* slot_off;         /* HOST: offsets (floats) [num_layers*DD_NUM_LAYER_SLOTS + DD_NUM_GLOBAL_SLOTS] */
+  const float* tab_pos;            /* [3][T]: posterior_mean_c0_coef, posterior_mean_ct_coef, posterior_logvar */
+  const float* tab_v;              /* [4][T]: log_alphas_v, log_one_minus_alphas_v, log_alphas_cumprod_v, log_one_minus_alphas_cumprod_v (atoms) */
+  const float* tab_b;              /* [4][T]: same for bonds */
+  const float* tab_score;          /* [T]: pos_score_coef (drift 'scale' option) */
+  /* static inputs */
+  const float* protein_pos;        /* [B,NP,3] centred (center_pos, decompdiff.py:20-32) */
+  const float* protein_h;          /* [B,NP,128] protein embeddings + node indicator (dd_embed_protein) */
+  const float* lig_aux;            /* [B,NL,2] */
+  const float* atom_std;           /* [B,NL,3] prior_stds[ligand_decomp_batch] */
+  const float* offset;             /* [B,3] protein centroid */
+  const int32_t* decomp_index;     /* [B,NL] arm id or -1 (armsca drift); may be NULL */
+  const float* full_protein_pos;   /* [B,NF,3] un-centred (clash drift); may be NULL */
+  /* state, updated in place */
+  float* lig_pos;                  /* [B,NL,3] centred x_t */
+  int32_t* lig_v;                  /* [B,NL] */
+  int32_t* lig_bond;               /* [B,NL*(NL-1)] */
+  int32_t* step_counter;           /* [1] device int: steps done so far in this run */
+  /* drift (configs/sampling_drift.yml:31-37) */
+  int32_t drift_armsca; float armsca_min_d, armsca_max_d; int32_t armsca_scale;
+  int32_t drift_clash;  float clash_sigma, clash_gamma;    int32_t clash_scale;
+  /* noise: injected (reference draw order, decompdiff.py:620,633,680) or Philox when NULL */
+  const float* u_v;                /* [n_steps,B*NL,8]  uniforms for atom types   */
+  const float* u_b;                /* [n_steps,B*Eb,5]  uniforms for bond types   */
+  const float* eps;                /* [n_steps,B*NL,3]  normals for positions     */
+  uint64_t seed;
+  /* trajectories (may each be NULL): indexed by step */
+  float* traj_pos;                 /* [n_steps,B*NL,3]  x_{t-1} + offset          */
+  int32_t* traj_v;                 /* [n_steps,B*NL]                              */
+  int32_t* traj_bond;              /* [n_steps,B*Eb]                              */
+  float* traj_v0;                  /* [n_steps,B*NL,8]  log_softmax(v logits)     */
+  float* traj_vt;                  /* [n_steps,B*NL,8]  posterior log-probs       */
+  float* traj_bt;                  /* [n_steps,B*Eb,5]  bond posterior log-probs  */
+  /* outputs of the last forward (always written) */
+  float* pred_pos;                 /* [B,NL,3]  x0-hat (centred)                  */
+  float* pred_v;                   /* [B,NL,8]  logits                            */
+  float* pred_bond;                /* [B,Eb,5]  logits                            */
+  /* scratch */
+  float* workspace; size_t workspace_floats;
+} dd_sampler;
+
+const char* dd_status_string(int status);
+int dd_abi_version(void);
+
+/* Floats of workspace needed by dd_forward/dd_sample_steps for these shapes. */
+size_t dd_workspace_floats(int B, int NP, int NL, int K);
+
+/* torch_geometric.nn.knn_graph -> torch_cluster.knn (call site uni_transformer_edge.py:353):
+ * per-sample K nearest other atoms, ascending (d2, index); d2 = (dx*dx+dy*dy)+dz*dz in fp32. */
+int dd_knn(const float* x /*[B,N,3]*/, int B, int N, int K, int32_t* nbr /*[B,N,K]*/, void* stream);
+
+/* e_w = sigmoid(MLP(GaussianSmearing(dist)))  (uni_transformer_edge.py:422-427). */
+int dd_edge_weights(const float* x, const int32_t* nbr, int B, int N, int K, const float* W1T /*[20,128]*/,
+                    const float* b1, const float* ln /*[2,128]*/, const float* w2 /*[128]*/, const float* b2 /*[1]*/,
+                    float* ew /*[B,N,K]*/, void* stream);
+
+/* nn.Linear / MLP first-layer projections (ATen addmm call sites in models/common.py:85-105):
+ * Y[r, 0:ncols] (+)= op(X[r, 0:128]) * W[ncols,128]^T + bias, fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * Row r of X lives at X + (r / x_rows_per_b) * x_stride_b + (r % x_rows_per_b) * ldx (floats);
+ * same for Y.  ln != NULL applies LayerNorm(gamma,beta)+ReLU to each X row first (the MLP's
+ * hidden activation); accumulate != 0 adds into Y. */
+int dd_gemm128(const float* X, int x_rows_per_b, long x_stride_b, int ldx, int rows, const float* W,
+               const float* bias, const float* ln, float* Y, int y_rows_per_b, long y_stride_b, int ldy,
+               int ncols, int accumulate, void* stream);
+
+/* Embeddings (decompdiff.py:219-256, 296-297). protein_h is step-invariant. */
+int dd_embed_protein(const float* protein_v /*[B*NP,29]*/, int rows, const float* W /*[128,29]*/, const float* b,
+                     float* protein_h /*[rows,128]*/, void* stream);
+
+/* Whole score network once: DecompScorePosNet3D.forward for the shipped config
+ * (decompdiff.py:213-351 -> uni_transformer_edge.py:394-443).  Reads s->lig_pos/lig_v/lig_bond,
+ * writes s->pred_pos/pred_v/pred_bond. */
+int dd_forward(const dd_sampler* s, void* stream);
+
+/* n_steps iterations of the reverse loop (decompdiff.py:575-689): forward, categorical
+ * posteriors + Gumbel-argmax, Gaussian posterior mean, optional drift, noise, trajectories. */
+int dd_sample_steps(const dd_sampler* s, int n_steps, void* stream);
+
+/* Same loop with one step captured into a hipGraph and replayed n_steps times. */
+int dd_sample_steps_graph(const dd_sampler* s, int n_steps, void* stream);
+
+/* Drift guidance gradients at x_t (utils/guidance_funcs.py:24-78), analytic. grad [B,NL,3]. */
+int dd_drift_armsca(const float* lig_pos, const int32_t* decomp_index, int B, int NL, float min_d, float max_d,
+                    float* grad, int accumulate, void* stream);
+int dd_drift_clash(const float* lig_pos, const float* offset, const float* full_protein_pos, int B, int NL, int NF,
+                   float sigma, float gamma, float* grad, int accumulate, void* stream);
+
+/* Measurement aid for bench.py: runs n_iters reverse steps with HIP events recorded on `stream`
+ * around every launch and returns the mean milliseconds per step spent in each kernel class.
+ * (Synchronises `stream`; not for use inside a capture.) */
+typedef enum dd_prof_cat {
+  DD_PROF_MISC, DD_PROF_GEMM, DD_PROF_ASSEMBLE, DD_PROF_ATTN_NE, DD_PROF_ATTN_NB, DD_PROF_ATTN_BL, DD_PROF_ATTN_PE,
+  DD_PROF_ATTN_PB, DD_PROF_STEP, DD_NUM_PROF_CATS
+} dd_prof_cat;
+int dd_profile_step(const dd_sampler* s, int n_iters, float* ms_per_category /*HOST [DD_NUM_PROF_CATS]*/, void* stream);
+
+/* Debug/test access to intermediate buffers of the last dd_forward (pointers into workspace). */
+typedef struct dd_ws_view {
+  float *x, *h, *hb, *ew, *A;
+  int32_t* nbr;
+} dd_ws_view;
+int dd_workspace_view(const dd_sampler* s, dd_ws_view* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DECOMPDIFF_HIP_H */

@@ -1,0 +1,394 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against
+  * the committed golden fixtures generated from the reference (tests/golden),
+  * the oracle on the same seeded inputs,
+  * per-kernel torch statements of the restructured math (tests/dense_spec.py).
+Tolerances (BASELINE.json north_star): coordinates 1e-4, discrete types exact.
+Every test prints the error it measured (run with -s to see them)."""
+import ctypes
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import dense_spec as DS
+import golden_utils as GU
+from decompdiff_amd import DecompScorePosNet3D, hip_lib, packing, shipped_config, synth
+from oracle import diffusion as OD
+from oracle import model as OM
+
+pytestmark = pytest.mark.gpu
+POS_TOL = 1e-4      # north_star tolerance on coordinates
+LOGIT_TOL = 1e-4
+
+
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+_MODELS = {}
+
+
+def model(seed=0):
+    if seed not in _MODELS:
+        cfg = shipped_config()
+        m = DecompScorePosNet3D(cfg, 29, 10, 8)
+        sd = m.state_dict()
+        sd.update(synth.synthetic_state_dict(cfg, seed))
+        m.load_state_dict(sd, strict=True)
+        _MODELS[seed] = m.to(dev())
+    return _MODELS[seed]
+
+
+def to_dev(batch):
+    return {k: (v.to(dev()) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+def maxabs(a, b):
+    return float((torch.as_tensor(a).double().cpu() - torch.as_tensor(b).double().cpu()).abs().max())
+
+
+# ------------------------------------------------------------------------------------ kernels
+@pytest.mark.parametrize("B,N,K", [(2, 330, 32), (1, 660, 32), (3, 12, 11), (2, 40, 8), (1, 1000, 32)])
+def test_knn_exact(B, N, K):
+    lib = hip_lib.load()
+    g = torch.Generator().manual_seed(N)
+    x = (torch.rand(B, N, 3, generator=g) * 20).round(decimals=3)     # PDB-like 3 decimals -> real ties
+    want = DS.knn_dense(x, K).to(torch.int32)
+    xd = x.to(dev()).contiguous()
+    nbr = torch.full((B, N, K), -1, dtype=torch.int32, device=dev())
+    hip_lib.check(lib.dd_knn(hip_lib.ptr(xd), B, N, K, hip_lib.ptr(nbr), hip_lib.stream_ptr()), "dd_knn")
+    torch.cuda.synchronize()
+    assert torch.equal(nbr.cpu(), want)
+
+
+def test_knn_rejects_unsupported_shapes():
+    lib = hip_lib.load()
+    x = torch.zeros(1, 8, 3, device=dev())
+    nbr = torch.zeros(1, 8, 8, dtype=torch.int32, device=dev())
+    assert lib.dd_knn(hip_lib.ptr(x), 1, 8, 8, hip_lib.ptr(nbr), hip_lib.stream_ptr()) < 0       # K > N-1
+    assert lib.dd_knn(hip_lib.ptr(x), 1, 8, 33, hip_lib.ptr(nbr), hip_lib.stream_ptr()) < 0      # K > 32
+    assert lib.dd_knn(None, 1, 8, 4, hip_lib.ptr(nbr), hip_lib.stream_ptr()) < 0
+
+
+@pytest.mark.parametrize("rows,ncols,ln,acc", [(330, 640, False, False), (61, 128, True, False), (870, 256, False, True),
+                                               (1, 64, True, True)])
+def test_gemm128(rows, ncols, ln, acc):
+    lib = hip_lib.load()
+    g = torch.Generator().manual_seed(rows + ncols)
+    ldx, ldy = 256, ncols + 64
+    X = torch.randn(rows, ldx, generator=g)
+    W = torch.randn(ncols, 128, generator=g) / 11.3
+    bias = torch.randn(ncols, generator=g)
+    lnp = torch.stack([1 + 0.1 * torch.randn(128, generator=g), 0.1 * torch.randn(128, generator=g)])
+    Y0 = torch.randn(rows, ldy, generator=g)
+    xin = X[:, 64:192].double()
+    if ln:
+        xin = torch.relu(torch.nn.functional.layer_norm(xin, (128,), lnp[0].double(), lnp[1].double(), 1e-5))
+    want = xin @ W.double().t() + bias.double()
+    if acc:
+        want = want + Y0[:, 32:32 + ncols].double()
+    Xd, Wd, bd, lnd, Yd = (t.to(dev()).contiguous() for t in (X, W, bias, lnp, Y0))
+    rc = lib.dd_gemm128(ctypes.c_void_p(Xd.data_ptr() + 64 * 4), rows, 0, ldx, rows, hip_lib.ptr(Wd), hip_lib.ptr(bd),
+                        hip_lib.ptr(lnd) if ln else None, ctypes.c_void_p(Yd.data_ptr() + 32 * 4), rows, 0, ldy, ncols,
+                        int(acc), hip_lib.stream_ptr())
+    hip_lib.check(rc, "dd_gemm128")
+    torch.cuda.synchronize()
+    got = Yd.cpu()
+    err = maxabs(got[:, 32:32 + ncols], want)
+    print(f"gemm rows={rows} ncols={ncols} ln={ln} acc={acc}: maxabs {err:.3g}")
+    assert err < 2e-5
+    # columns outside [32, 32+ncols) untouched
+    assert torch.equal(got[:, :32], Y0[:, :32]) and torch.equal(got[:, 32 + ncols:], Y0[:, 32 + ncols:])
+
+
+def test_gemm128_row_blocks():
+    """ligand-row addressing: rows_per_b / stride_b mapping used for h[:, NP:] and friends."""
+    lib = hip_lib.load()
+    B, N, NP, NL = 3, 50, 41, 9
+    g = torch.Generator().manual_seed(1)
+    h = torch.randn(B, N, 128, generator=g)
+    W = torch.randn(192, 128, generator=g) / 11.3
+    want = h[:, NP:].double() @ W.double().t()
+    hd, Wd = h.to(dev()).contiguous(), W.to(dev()).contiguous()
+    Y = torch.zeros(B * NL, 192, device=dev())
+    rc = lib.dd_gemm128(ctypes.c_void_p(hd.data_ptr() + NP * 128 * 4), NL, N * 128, 128, B * NL, hip_lib.ptr(Wd), None, None,
+                        hip_lib.ptr(Y), B * NL, 0, 192, 192, 0, hip_lib.stream_ptr())
+    hip_lib.check(rc, "dd_gemm128")
+    torch.cuda.synchronize()
+    err = maxabs(Y.view(B, NL, 192), want)
+    print(f"gemm row-block maxabs {err:.3g}")
+    assert err < 2e-5
+
+
+def test_drift_gradients_match_autograd():
+    lib = hip_lib.load()
+    pocket = synth.make_pocket_small(4)
+    torch.manual_seed(3)
+    b = synth.build_sampling_batch(pocket, 3, per_sample_std_scale=[1.0, 0.7, 1.3])
+    B, NL = 3, pocket.num_ligand_atoms
+    off = b["protein_pos"].view(B, -1, 3).double().mean(1).float()
+    xt = (b["init_ligand_pos"].view(B, NL, 3) - off[:, None]).reshape(-1, 3)
+    # pull two sub-structures together / apart so both hinge branches are exercised
+    xt[0:8] = xt[20:28] + 0.5
+    x1 = xt.clone().requires_grad_(True)
+    e, _ = OD.armsca_prox_loss(x1, b["batch_ligand"], b["ligand_decomp_index"], 1.2, 1.9)
+    ga = torch.autograd.grad(e, x1)[0]
+    x2 = xt.clone().requires_grad_(True)
+    e2 = OD.clash_loss(b["full_protein_pos"], x2 + off[b["batch_ligand"]], b["full_batch_protein"], b["batch_ligand"], 2, 4)
+    gc = torch.autograd.grad(e2, x2)[0]
+    xd = xt.to(dev()).contiguous()
+    g1 = torch.zeros_like(xd)
+    g2 = torch.zeros_like(xd)
+    dec = b["ligand_decomp_index"].to(device=dev(), dtype=torch.int32)
+    hip_lib.check(lib.dd_drift_armsca(hip_lib.ptr(xd), hip_lib.ptr(dec), B, NL, 1.2, 1.9, hip_lib.ptr(g1), 0, hip_lib.stream_ptr()))
+    fp = b["full_protein_pos"].to(dev()).contiguous()
+    hip_lib.check(lib.dd_drift_clash(hip_lib.ptr(xd), hip_lib.ptr(off.to(dev()).contiguous()), hip_lib.ptr(fp), B, NL,
+                                     fp.shape[0] // B, 2.0, 4.0, hip_lib.ptr(g2), 0, hip_lib.stream_ptr()))
+    torch.cuda.synchronize()
+    ea, ec = maxabs(g1, ga), maxabs(g2, gc)
+    print(f"drift grads: armsca maxabs {ea:.3g} (|g| {float(ga.abs().max()):.3g}), clash maxabs {ec:.3g} (|g| {float(gc.abs().max()):.3g})")
+    assert float(ga.abs().max()) > 0 and float(gc.abs().max()) > 0
+    assert ea < 1e-6 and ec < 1e-5
+
+
+# ------------------------------------------------------------------------------------ forward
+def _forward_hip(m, b):
+    bd = to_dev(b)
+    return m(protein_pos=bd["protein_pos"], protein_v=bd["protein_v"], batch_protein=bd["batch_protein"],
+             protein_group_idx=bd["protein_group_idx"], init_ligand_pos=bd["init_ligand_pos"],
+             init_ligand_v=bd["init_ligand_v"], init_ligand_v_aux=bd["ligand_v_aux"], batch_ligand=bd["batch_ligand"],
+             ligand_group_idx=bd["ligand_group_idx"], prior_centers=bd["prior_centers"], prior_stds=bd["prior_stds"],
+             batch_prior=bd["batch_prior"], prior_group_idx=bd["prior_group_idx"],
+             ligand_fc_bond_index=bd["ligand_fc_bond_index"], init_ligand_fc_bond_type=bd["init_ligand_fc_bond_type"])
+
+
+def test_forward_golden_full_size():
+    g = GU.load("forward_small")
+    m = model(int(g["weight_seed"]))
+    out = _forward_hip(m, GU.batch_from_npz(g))
+    torch.cuda.synchronize()
+    errs = {k: maxabs(out[k], g["out_" + k]) for k in ("pred_ligand_pos", "pred_ligand_v", "pred_bond")}
+    print("forward vs reference golden:", {k: f"{v:.3g}" for k, v in errs.items()})
+    assert errs["pred_ligand_pos"] < POS_TOL and errs["pred_ligand_v"] < LOGIT_TOL and errs["pred_bond"] < LOGIT_TOL
+
+
+def test_forward_intermediates_vs_dense_spec():
+    """Layer-by-layer localisation aid: final h / h_bond / x / e_w / kNN of the workspace."""
+    g = GU.load("forward_small")
+    m = model(0)
+    b = GU.batch_from_npz(g)
+    _forward_hip(m, b)
+    torch.cuda.synchronize()
+    s, bufs = m._last
+    view = hip_lib.DDWsView()
+    hip_lib.check(hip_lib.load().dd_workspace_view(ctypes.byref(s), ctypes.byref(view)))
+    B, NP, NL, K = s.B, s.NP, s.NL, s.K
+    N = NP + NL
+
+    def grab(ptr, shape, dtype=torch.float32):
+        n = int(np.prod(shape))
+        base = bufs["workspace"]
+        off = (ptr - base.data_ptr()) // 4
+        t = base[off:off + n]
+        return (t.view(torch.int32) if dtype == torch.int32 else t).view(*shape).cpu()
+    cfg = shipped_config()
+    _, _, named = packing.pack_model(synth.synthetic_state_dict(cfg, 0), cfg)
+    x0, vl, bl, tr = DS.forward_dense(named, cfg, b["protein_pos"].view(B, NP, 3), b["protein_v"].view(B, NP, 29),
+                                      b["init_ligand_pos"].view(B, NL, 3), b["init_ligand_v"].view(B, NL),
+                                      b["ligand_v_aux"].view(B, NL, 2), b["init_ligand_fc_bond_type"].view(B, -1))
+    nbr = grab(view.nbr, (B, N, K), torch.int32)
+    assert torch.equal(nbr, tr[0]["nbr"].to(torch.int32))
+    errs = dict(ew=maxabs(grab(view.ew, (B, N, K)), tr[0]["ew"]), h=maxabs(grab(view.h, (B, N, 128)), tr[-1]["h"]),
+                hb=maxabs(grab(view.hb, (B, NL * (NL - 1), 128)), tr[-1]["hb"]), x=maxabs(grab(view.x, (B, N, 3)), tr[-1]["x"]),
+                A=maxabs(grab(view.A, (B, N, 128)), tr[-1]["A"]))
+    print("workspace vs dense spec:", {k: f"{v:.3g}" for k, v in errs.items()})
+    assert errs["ew"] < 1e-5 and errs["h"] < 1e-4 and errs["hb"] < 1e-4 and errs["x"] < POS_TOL and errs["A"] < 1e-4
+
+
+@pytest.mark.parametrize("np_,arms,sca,B", [(600, (15, 15), 30, 1), (40, (2, 2), 2, 3), (20, (1, 1), 1, 2), (120, (5, 0), 3, 2)])
+def test_forward_vs_oracle_other_shapes(np_, arms, sca, B):
+    """C-large, tiny graphs with fewer than 32 candidates (K = N-1), NL = 3, an empty arm."""
+    cfg, sd = GU.weights(0)
+    arms = tuple(a for a in arms)
+    pocket = synth.make_pocket(11, np_, arms, sca, num_full_protein=np_ + 10)
+    torch.manual_seed(9)
+    b = synth.build_sampling_batch(pocket, B)
+    with torch.no_grad():
+        want = OM.forward(sd, cfg, b["protein_pos"], b["protein_v"], b["batch_protein"], b["init_ligand_pos"],
+                          b["init_ligand_v"], b["ligand_v_aux"], b["batch_ligand"], b["ligand_fc_bond_index"],
+                          b["init_ligand_fc_bond_type"])
+    out = _forward_hip(model(0), b)
+    torch.cuda.synchronize()
+    errs = {k: maxabs(out[k], want[k]) for k in want}
+    print(f"forward NP={np_} NL={pocket.num_ligand_atoms} B={B}:", {k: f"{v:.3g}" for k, v in errs.items()})
+    assert errs["pred_ligand_pos"] < POS_TOL and errs["pred_ligand_v"] < LOGIT_TOL and errs["pred_bond"] < LOGIT_TOL
+
+
+# ------------------------------------------------------------------------------------ reverse steps
+def _sample_hip(m, b, num_steps, drift, noise, t_start=None, **kw):
+    bd = to_dev(b)
+    T = m.num_timesteps
+    try:
+        if t_start is not None:
+            m.num_timesteps = t_start + 1          # same trick the goldens used on the reference
+        return m.sample_diffusion(num_steps=num_steps, center_pos_mode="protein", energy_drift_opt=drift, noise=noise, **bd, **kw)
+    finally:
+        m.num_timesteps = T
+
+
+def test_single_steps_golden():
+    g = GU.load("steps")
+    m = model(int(g["weight_seed"]))
+    base = GU.batch_from_npz(g)
+    worst = 0.0
+    for t_start in (999, 500, 1, 0):
+        for tag, drift in (("plain", None), ("drift", GU.DRIFT)):
+            p = f"t{t_start}_{tag}_"
+            b = dict(base)
+            for k in ("init_ligand_pos", "init_ligand_v", "init_ligand_fc_bond_type", "prior_stds"):
+                b[k] = torch.from_numpy(g[p + "in_" + k])
+            torch.manual_seed(int(g[p + "seed"]))
+            synth.build_sampling_batch(synth.make_pocket_small(1), 2, per_sample_std_scale=[1.0, 0.8] if drift else None)
+            noise = synth.draw_step_noise(1, b["init_ligand_pos"].size(0), b["init_ligand_fc_bond_type"].size(0))
+            assert np.array_equal(GU.checksum(noise), g[p + "noise_checksum"])
+            r = _sample_hip(m, b, 1, drift, noise, t_start)
+            e_pos = maxabs(r["pos"], g[p + "pos"])
+            e_vp = maxabs(r["vt_traj"][0], g[p + "log_v_prob"])
+            e_bp = maxabs(r["bt_traj"][0], g[p + "log_b_prob"])
+            e_v0 = maxabs(r["v0_traj"][0], g[p + "log_v_recon"])
+            nv = int((r["v"].cpu() != torch.from_numpy(g[p + "v"])).sum())
+            nb = int((r["bond"].cpu() != torch.from_numpy(g[p + "bond"])).sum())
+            print(f"step t={t_start} {tag}: pos {e_pos:.3g} log_v_prob {e_vp:.3g} log_b_prob {e_bp:.3g} "
+                  f"log_v0 {e_v0:.3g} v-mismatch {nv} bond-mismatch {nb}")
+            worst = max(worst, e_pos)
+            assert e_pos < POS_TOL and e_vp < LOGIT_TOL and e_bp < LOGIT_TOL and e_v0 < LOGIT_TOL
+            assert nv == 0 and nb == 0
+
+
+def _traj_inputs(name, std_scale=None):
+    g = GU.load(name)
+    b = GU.batch_from_npz(g)
+    n_data = int(b["batch_ligand"].max()) + 1
+    seedpocket = {"traj20_plain": 2, "traj20_drift": 2, "traj1000_plain": 3}[name]
+    torch.manual_seed(int(g["seed"]))
+    synth.build_sampling_batch(synth.make_pocket_small(seedpocket), n_data, per_sample_std_scale=std_scale)
+    noise = synth.draw_step_noise(int(g["num_steps"]), b["init_ligand_pos"].size(0), b["init_ligand_fc_bond_type"].size(0))
+    assert np.array_equal(GU.checksum(noise), g["noise_checksum"])
+    return g, b, noise
+
+
+@pytest.mark.parametrize("name,std_scale", [("traj20_plain", None), ("traj20_drift", [1.0, 0.85])])
+def test_trajectory_20_steps_golden(name, std_scale):
+    g, b, noise = _traj_inputs(name, std_scale)
+    drift = json.loads(str(g["drift"]))
+    r = _sample_hip(model(0), b, 20, drift, noise)
+    tp = torch.stack(r["pos_traj"]).numpy()
+    per_step = np.abs(tp.astype(np.float64) - g["traj_pos"]).reshape(20, -1).max(1)
+    nv = int((torch.stack(r["v_traj"]).numpy() != g["traj_v"]).sum())
+    nb = int((torch.stack(r["bond_traj"]).numpy() != g["traj_bond"]).sum())
+    print(f"{name}: per-step max pos err first/last {per_step[0]:.3g}/{per_step[-1]:.3g} max {per_step.max():.3g}; "
+          f"type mismatches v={nv} bond={nb}")
+    assert maxabs(r["pos"], g["out_pos"]) < POS_TOL
+    assert nv == 0 and nb == 0
+    assert np.array_equal(r["v"].cpu().numpy(), g["out_v"]) and np.array_equal(r["bond"].cpu().numpy(), g["out_bond"])
+
+
+def test_trajectory_1000_steps_golden():
+    """The headline parity claim: a full 1000-step chain on injected reference noise stays within
+    1e-4 on coordinates with identical discrete types at every stored checkpoint."""
+    g, b, noise = _traj_inputs("traj1000_plain")
+    r = _sample_hip(model(0), b, 1000, None, noise)
+    every = int(g["every"])
+    tp = torch.stack(r["pos_traj"]).numpy()[every - 1::every]
+    tv = torch.stack(r["v_traj"]).numpy()[every - 1::every]
+    tb = torch.stack(r["bond_traj"]).numpy()[every - 1::every]
+    err = np.abs(tp.astype(np.float64) - g["traj_pos"]).reshape(len(tp), -1).max(1)
+    mv = (tv != g["traj_v"]).reshape(len(tv), -1).sum(1)
+    mb = (tb != g["traj_bond"]).reshape(len(tb), -1).sum(1)
+    print("1000-step chain, checkpoints every 50 steps")
+    print("  max |pos - golden| :", " ".join(f"{e:.2g}" for e in err))
+    print("  atom-type mismatches:", mv.tolist())
+    print("  bond-type mismatches:", mb.tolist())
+    assert err.max() < POS_TOL, f"coordinate drift {err.max():.3g}"
+    assert mv.sum() == 0 and mb.sum() == 0
+    assert maxabs(r["pos"], g["out_pos"]) < POS_TOL
+    assert np.array_equal(r["v"].cpu().numpy(), g["out_v"]) and np.array_equal(r["bond"].cpu().numpy(), g["out_bond"])
+
+
+def test_graph_replay_equals_eager_launches():
+    g, b, noise = _traj_inputs("traj20_plain")
+    n5 = {k: v[:5] for k, v in noise.items()}
+    r1 = _sample_hip(model(0), b, 5, None, n5, use_graph=True)
+    r2 = _sample_hip(model(0), b, 5, None, n5, use_graph=False)
+    assert torch.equal(r1["pos"], r2["pos"]) and torch.equal(r1["v"], r2["v"]) and torch.equal(r1["bond"], r2["bond"])
+    assert torch.equal(torch.stack(r1["bt_traj"]), torch.stack(r2["bt_traj"]))
+    # and the run is repeatable bit for bit (no atomics, fixed reduction order)
+    r3 = _sample_hip(model(0), b, 5, None, n5, use_graph=True)
+    assert torch.equal(r1["pos"], r3["pos"]) and torch.equal(torch.stack(r1["vt_traj"]), torch.stack(r3["vt_traj"]))
+
+
+def test_philox_noise_mode_is_deterministic_and_sane():
+    pocket = synth.make_pocket_small(5)
+    torch.manual_seed(1)
+    b = synth.build_sampling_batch(pocket, 4)
+    m = model(0)
+    r1 = _sample_hip(m, b, 8, None, None, seed=123)
+    r2 = _sample_hip(m, b, 8, None, None, seed=123)
+    r3 = _sample_hip(m, b, 8, None, None, seed=124)
+    assert torch.equal(r1["pos"], r2["pos"]) and torch.equal(r1["bond"], r2["bond"])
+    assert not torch.equal(r1["pos"], r3["pos"])
+    assert torch.isfinite(r1["pos"]).all()
+    assert int(r1["v"].min()) >= 0 and int(r1["v"].max()) < 8 and int(r1["bond"].min()) >= 0 and int(r1["bond"].max()) < 5
+    # the sampled chain must actually move the types away from their initial values somewhere
+    assert int((r1["bond"].cpu() != b["init_ligand_fc_bond_type"]).sum()) > 0
+    assert len(r1["pos_traj"]) == 8 and r1["pos_traj"][0].shape == (4 * 30, 3) and not r1["pos_traj"][0].is_cuda
+
+
+def test_batch_rows_are_independent():
+    """Sharding property: a sample's chain does not depend on what else is in the batch."""
+    g, b, noise = _traj_inputs("traj20_plain")
+    m = model(0)
+    n3 = {k: v[:3] for k, v in noise.items()}
+    full = _sample_hip(m, b, 3, None, n3)
+    NL, NP, Eb = 30, 300, 870
+    one = {}
+    for k, v in b.items():
+        if not torch.is_tensor(v):
+            one[k] = v
+    sl = lambda t, per: t[per:2 * per]
+    one.update(protein_pos=sl(b["protein_pos"], NP), protein_v=sl(b["protein_v"], NP), batch_protein=torch.zeros(NP, dtype=torch.long),
+               protein_group_idx=sl(b["protein_group_idx"], NP), init_ligand_pos=sl(b["init_ligand_pos"], NL),
+               init_ligand_v=sl(b["init_ligand_v"], NL), ligand_v_aux=sl(b["ligand_v_aux"], NL),
+               batch_ligand=torch.zeros(NL, dtype=torch.long), ligand_group_idx=sl(b["ligand_group_idx"], NL),
+               prior_centers=sl(b["prior_centers"], 3), prior_stds=sl(b["prior_stds"], 3), prior_num_atoms=sl(b["prior_num_atoms"], 3),
+               batch_prior=torch.zeros(3, dtype=torch.long), prior_group_idx=sl(b["prior_group_idx"], 3),
+               ligand_fc_bond_index=b["ligand_fc_bond_index"][:, :Eb], init_ligand_fc_bond_type=sl(b["init_ligand_fc_bond_type"], Eb),
+               batch_ligand_bond=torch.zeros(Eb, dtype=torch.long), ligand_decomp_batch=b["ligand_decomp_batch"][:NL],
+               ligand_decomp_index=sl(b["ligand_decomp_index"], NL), full_protein_pos=sl(b["full_protein_pos"], 3000),
+               full_batch_protein=torch.zeros(3000, dtype=torch.long), ligand_atom_mask=None)
+    n1 = dict(u_v=n3["u_v"][:, NL:2 * NL], u_b=n3["u_b"][:, Eb:2 * Eb], eps=n3["eps"][:, NL:2 * NL])
+    part = _sample_hip(m, one, 3, None, {k: v.contiguous() for k, v in n1.items()})
+    e = maxabs(part["pos"], full["pos"][NL:2 * NL])
+    print(f"shard independence: second sample alone vs inside the batch, maxabs {e:.3g}")
+    assert e == 0.0
+    assert torch.equal(part["v"], full["v"][NL:2 * NL]) and torch.equal(part["bond"], full["bond"][Eb:2 * Eb])
+
+
+def test_unsupported_inputs_fail_loudly():
+    g = GU.load("forward_small")
+    b = GU.batch_from_npz(g)
+    m = model(0)
+    bad = dict(b)
+    bad["ligand_fc_bond_index"] = b["ligand_fc_bond_index"].flip(1)
+    with pytest.raises(NotImplementedError):
+        _forward_hip(m, bad)
+    with pytest.raises(hip_lib.HipLibraryError):       # CPU tensors: no silent fallback
+        m(protein_pos=b["protein_pos"], protein_v=b["protein_v"], batch_protein=b["batch_protein"],
+          protein_group_idx=None, init_ligand_pos=b["init_ligand_pos"], init_ligand_v=b["init_ligand_v"],
+          init_ligand_v_aux=b["ligand_v_aux"], batch_ligand=b["batch_ligand"], ligand_group_idx=None,
+          prior_centers=None, prior_stds=None, batch_prior=None, prior_group_idx=None,
+          ligand_fc_bond_index=b["ligand_fc_bond_index"], init_ligand_fc_bond_type=b["init_ligand_fc_bond_type"])
+    with pytest.raises(ValueError):
+        _sample_hip(m, b, 1, [dict(type="nonsense")], None)

@@ -1,0 +1,138 @@
+"""CPU: host logic of the product package — checkpoint key layout, schedule tables, weight
+packing + the restructured algebra (vs the oracle), the C-ABI library's exports, and the
+'no CPU fallback' contract."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import dense_spec as DS
+import golden_utils as GU
+from decompdiff_amd import DecompScorePosNet3D, hip_lib, packing, shipped_config, synth
+from oracle import model as OM
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_state_dict_layout_matches_reference_checkpoint(golden_dir):
+    spec = json.load(open(os.path.join(golden_dir, "state_dict_spec.json")))
+    m = DecompScorePosNet3D(shipped_config(), 29, 10, 8)
+    sd = m.state_dict()
+    assert set(sd) == set(spec) and len(sd) == 616
+    for k, v in sd.items():
+        assert list(v.shape) == spec[k]["shape"], k
+    trainable = {n for n, p in m.named_parameters() if p.requires_grad}
+    assert trainable == {k for k, v in spec.items() if v["trainable"]}
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 4975269
+    # strict load of a reference-shaped checkpoint
+    full = {k: torch.zeros(v["shape"]) for k, v in spec.items()}
+    m.load_state_dict(full, strict=True)
+
+
+def test_schedule_tables_equal_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "schedules.npz"))
+    sd = DecompScorePosNet3D(shipped_config(), 29, 10, 8).state_dict()
+    for k in g.files:
+        assert np.array_equal(g[k], sd[k.replace("__", ".")].numpy()), k
+    assert DecompScorePosNet3D(shipped_config(), 29, 10, 8).num_timesteps == 1000
+
+
+def test_unsupported_configs_raise():
+    for over in (dict(model_type="uni_o2"), dict(cutoff_mode="radius"), dict(hidden_dim=64), dict(time_emb_dim=8),
+                 dict(add_prior_node=True), dict(bond_diffusion=False)):
+        with pytest.raises(NotImplementedError):
+            DecompScorePosNet3D(shipped_config(**over), 29, 10, 8)
+
+
+def test_packing_slots_match_c_enum():
+    hdr = open(os.path.join(ROOT, "include", "decompdiff_hip.h")).read()
+    body = re.search(r"typedef enum dd_wslot \{(.*?)DD_NUM_LAYER_SLOTS", hdr, re.S).group(1)
+    names = [n.strip()[3:] for n in body.replace("\n", " ").split(",") if n.strip()]
+    assert names == packing.LAYER_SLOTS
+    body = re.search(r"typedef enum dd_gslot \{(.*?)DD_NUM_GLOBAL_SLOTS", hdr, re.S).group(1)
+    names = [n.strip()[5:] for n in body.replace("\n", " ").split(",") if n.strip()]
+    assert names == packing.GLOBAL_SLOTS
+
+
+def test_packed_arena_offsets_aligned_and_complete():
+    cfg = shipped_config()
+    arena, offs, named = packing.pack_model(synth.synthetic_state_dict(cfg, 0), cfg)
+    assert len(offs) == cfg.num_layers * len(packing.LAYER_SLOTS) + len(packing.GLOBAL_SLOTS)
+    assert all(int(o) % 64 == 0 for o in offs)
+    for (key, t), o in zip(named.items(), offs.tolist()):
+        assert torch.equal(arena[o:o + t.numel()], t.reshape(-1)), key
+    # every learnable reference tensor ends up in the arena exactly once (bias of W2k is dropped: it cancels in the softmax)
+    total = sum(t.numel() for t in named.values())
+    assert 4.9e6 < total < 5.1e6
+
+
+@pytest.mark.parametrize("NPn,arms,sca,B", [(48, (3, 2), 3, 2), (20, (1, 1), 1, 1)])
+def test_restructured_algebra_matches_oracle(NPn, arms, sca, B):
+    """packing.py + tests/dense_spec.py (the math the HIP kernels implement) == the oracle."""
+    cfg, sd = GU.weights(0)
+    pocket = synth.make_pocket(13, NPn, arms, sca, num_full_protein=NPn + 8)
+    torch.manual_seed(4)
+    b = synth.build_sampling_batch(pocket, B)
+    NL = pocket.num_ligand_atoms
+    with torch.no_grad():
+        want = OM.forward(sd, cfg, b["protein_pos"], b["protein_v"], b["batch_protein"], b["init_ligand_pos"],
+                          b["init_ligand_v"], b["ligand_v_aux"], b["batch_ligand"], b["ligand_fc_bond_index"],
+                          b["init_ligand_fc_bond_type"])
+        _, _, named = packing.pack_model(sd, cfg)
+        x0, vl, bl, _ = DS.forward_dense(named, cfg, b["protein_pos"].view(B, NPn, 3), b["protein_v"].view(B, NPn, 29),
+                                         b["init_ligand_pos"].view(B, NL, 3), b["init_ligand_v"].view(B, NL),
+                                         b["ligand_v_aux"].view(B, NL, 2), b["init_ligand_fc_bond_type"].view(B, -1))
+    assert float((x0.reshape(-1, 3) - want["pred_ligand_pos"]).abs().max()) < 2e-5
+    assert float((vl.reshape(-1, 8) - want["pred_ligand_v"]).abs().max()) < 2e-5
+    assert float((bl.reshape(-1, 5) - want["pred_bond"]).abs().max()) < 2e-5
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    import __graft_entry__
+    __graft_entry__.build()
+    lib = hip_lib.load()
+    hdr = open(os.path.join(ROOT, "include", "decompdiff_hip.h")).read()
+    declared = set(re.findall(r"\b(dd_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(hip_lib.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.dd_abi_version() == 1
+    assert lib.dd_status_string(0) == b"ok" and b"workspace" in lib.dd_status_string(-3)
+    # pure host helper: workspace size grows with the batch and is non-zero
+    w1, w8 = lib.dd_workspace_floats(1, 300, 30, 32), lib.dd_workspace_floats(8, 300, 30, 32)
+    assert 0 < w1 < w8 and lib.dd_workspace_floats(0, 300, 30, 32) == 0
+    assert ctypes.sizeof(hip_lib.DDSampler) % 8 == 0
+
+
+def test_no_cpu_fallback():
+    """CPU tensors must raise; the product never routes through the oracle or torch-CPU math."""
+    m = DecompScorePosNet3D(shipped_config(), 29, 10, 8)
+    pocket = synth.make_pocket_tiny(1)
+    b = synth.build_sampling_batch(pocket, 1)
+    with pytest.raises(hip_lib.HipLibraryError):
+        m.sample_diffusion(num_steps=1, center_pos_mode="protein", **b)
+    src = "".join(open(os.path.join(ROOT, "decompdiff_amd", f)).read()
+                  for f in os.listdir(os.path.join(ROOT, "decompdiff_amd")) if f.endswith(".py"))
+    assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_harness_batch_builder_layout():
+    pocket = synth.make_pocket_small(0)
+    torch.manual_seed(0)
+    b = synth.build_sampling_batch(pocket, 3)
+    NL, NP, Eb = 30, 300, 870
+    assert b["init_ligand_pos"].shape == (3 * NL, 3) and b["ligand_fc_bond_index"].shape == (2, 3 * Eb)
+    assert int(b["ligand_fc_bond_index"].max()) == 3 * NL - 1
+    assert torch.equal(b["ligand_decomp_batch"][NL:2 * NL], b["ligand_decomp_batch"][:NL] + 3)      # PyG __inc__ = num_arms+1
+    assert torch.equal(b["ligand_decomp_index"][:NL], b["ligand_decomp_index"][NL:2 * NL])           # not incremented
+    assert set(b["ligand_decomp_index"].tolist()) == {-1, 0, 1}
+    assert b["prior_stds"].shape == (9, 3) and b["protein_v"].shape == (3 * NP, 29)
+    assert int(b["init_ligand_v"].max()) < 8 and int(b["init_ligand_fc_bond_type"].max()) < 5
+    # protein atoms keep a 1.2 A minimum spacing and PDB-like 3-decimal coordinates
+    d = torch.cdist(torch.from_numpy(pocket.protein_pos), torch.from_numpy(pocket.protein_pos)) + 10 * torch.eye(NP)
+    assert float(d.min()) > 1.19
+    assert np.allclose(pocket.protein_pos, np.round(pocket.protein_pos, 3), atol=1e-6)

@@ -1,0 +1,175 @@
+"""CPU: the oracle (oracle/*.py) replayed against fixtures generated from the REFERENCE itself
+(oracle/make_golden.py).  Bit-exact on CPU: the oracle is a restatement, not an approximation."""
+import json
+
+import numpy as np
+import torch
+
+import golden_utils as GU
+from decompdiff_amd import synth
+from decompdiff_amd.config import shipped_config
+from oracle import diffusion as OD
+from oracle import model as OM
+from oracle import ops
+
+
+def _fwd(sd, cfg, b, trace=None):
+    with torch.no_grad():
+        return OM.forward(sd, cfg, b["protein_pos"], b["protein_v"], b["batch_protein"], b["init_ligand_pos"],
+                          b["init_ligand_v"], b["ligand_v_aux"], b["batch_ligand"], b["ligand_fc_bond_index"],
+                          b["init_ligand_fc_bond_type"], trace=trace)
+
+
+def test_schedule_tables_match_reference():
+    g = GU.load("schedules")
+    cfg = shipped_config()
+    pt = OD.position_tables(cfg)
+    vt = OD.categorical_tables(cfg, 8)
+    bt = OD.categorical_tables(cfg, 5)
+    for k, v in pt.items():
+        assert np.array_equal(g[k], v.numpy()), k
+    for k, v in vt.items():
+        assert np.array_equal(g["atom_type_trans__" + k], v.numpy()), k
+    for k, v in bt.items():
+        assert np.array_equal(g["bond_type_trans__" + k], v.numpy()), k
+    # known-answer values, SURVEY.md Appendix A.1
+    assert abs(float(pt["betas"][0]) - 5.04499894e-06) < 1e-12
+    assert abs(float(pt["posterior_logvar"][0]) - (-12.8844023)) < 1e-5
+    assert float(pt["posterior_logvar"][0]) == float(pt["posterior_logvar"][1])
+    assert abs(float(vt["log_alphas_cumprod_v"][999]) - (-9.91987991)) < 1e-5
+
+
+def test_forward_tiny_with_layer_intermediates():
+    g = GU.load("forward_tiny")
+    over = json.loads(str(g["cfg_json"]))
+    cfg = shipped_config(**over)
+    sd = synth.synthetic_state_dict(cfg, seed=int(g["weight_seed"]))
+    b = GU.batch_from_npz(g)
+    trace = []
+    out = _fwd(sd, cfg, b, trace)
+    for k in ("pred_ligand_pos", "pred_ligand_v", "pred_bond"):
+        assert np.array_equal(g["out_" + k], out[k].numpy()), k
+    for l in range(cfg.num_layers):
+        assert np.array_equal(g[f"layer{l}_h"], trace[1 + l]["h"].numpy())
+        assert np.array_equal(g[f"layer{l}_h_bond"], trace[1 + l]["h_bond"].numpy())
+        assert np.array_equal(g[f"layer{l}_x"], trace[1 + l]["x"].numpy())
+
+
+def test_forward_full_size():
+    g = GU.load("forward_small")
+    cfg, sd = GU.weights(int(g["weight_seed"]))
+    out = _fwd(sd, cfg, GU.batch_from_npz(g))
+    for k in ("pred_ligand_pos", "pred_ligand_v", "pred_bond"):
+        assert np.array_equal(g["out_" + k], out[k].numpy()), k
+
+
+def test_single_steps_all_times_plain_and_drift():
+    g = GU.load("steps")
+    cfg, sd = GU.weights(int(g["weight_seed"]))
+    base = GU.batch_from_npz(g)
+    for t_start in (999, 500, 1, 0):
+        for tag, drift in (("plain", None), ("drift", GU.DRIFT)):
+            p = f"t{t_start}_{tag}_"
+            b = dict(base)
+            for k in ("init_ligand_pos", "init_ligand_v", "init_ligand_fc_bond_type", "prior_stds"):
+                b[k] = torch.from_numpy(g[p + "in_" + k])
+            torch.manual_seed(int(g[p + "seed"]))
+            synth.build_sampling_batch(synth.make_pocket_small(1), 2,
+                                       per_sample_std_scale=[1.0, 0.8] if drift else None)   # advance the RNG
+            noise = synth.draw_step_noise(1, b["init_ligand_pos"].size(0), b["init_ligand_fc_bond_type"].size(0))
+            assert np.allclose(GU.checksum(noise), g[p + "noise_checksum"], rtol=0, atol=0)
+            r = OD.sample_diffusion(sd, cfg, num_steps=1, energy_drift_opt=drift, noise=noise, t_start=t_start, **b)
+            assert np.array_equal(g[p + "pos"], r["pos"].numpy()), p
+            assert np.array_equal(g[p + "v"], r["v"].numpy()), p
+            assert np.array_equal(g[p + "bond"], r["bond"].numpy()), p
+            assert np.array_equal(g[p + "log_v_prob"], r["vt_traj"][0].numpy()), p
+            assert np.array_equal(g[p + "log_b_prob"], r["bt_traj"][0].numpy()), p
+
+
+def _replay_traj(name, num_steps, std_scale=None):
+    g = GU.load(name)
+    cfg, sd = GU.weights(int(g["weight_seed"]))
+    b = GU.batch_from_npz(g)
+    drift = json.loads(str(g["drift"]))
+    n_data = int(b["batch_ligand"].max()) + 1
+    torch.manual_seed(int(g["seed"]))
+    synth.build_sampling_batch(_pocket_for(name), n_data, per_sample_std_scale=std_scale)
+    noise = synth.draw_step_noise(int(g["num_steps"]), b["init_ligand_pos"].size(0),
+                                  b["init_ligand_fc_bond_type"].size(0))
+    assert np.array_equal(GU.checksum(noise), g["noise_checksum"])
+    noise = {k: v[:num_steps] for k, v in noise.items()}
+    r = OD.sample_diffusion(sd, cfg, num_steps=num_steps, energy_drift_opt=drift, noise=noise,
+                            t_start=cfg.num_diffusion_timesteps - 1, **b)
+    return g, r
+
+
+def _pocket_for(name):
+    return {"traj20_plain": synth.make_pocket_small(2), "traj20_drift": synth.make_pocket_small(2),
+            "traj1000_plain": synth.make_pocket_small(3)}[name]
+
+
+def test_trajectory_20_steps_plain():
+    g, r = _replay_traj("traj20_plain", 20)
+    assert np.array_equal(g["out_pos"], r["pos"].numpy())
+    assert np.array_equal(g["out_v"], r["v"].numpy())
+    assert np.array_equal(g["out_bond"], r["bond"].numpy())
+    assert np.array_equal(g["traj_pos"], torch.stack(r["pos_traj"]).numpy())
+
+
+def test_trajectory_20_steps_drift():
+    g, r = _replay_traj("traj20_drift", 20, std_scale=[1.0, 0.85])
+    assert np.array_equal(g["out_pos"], r["pos"].numpy())
+    assert np.array_equal(g["out_v"], r["v"].numpy())
+    assert np.array_equal(g["out_bond"], r["bond"].numpy())
+
+
+def test_trajectory_1000_first_checkpoint():
+    """The 1000-step golden stores every 50th state; replay the first 50 steps (full chain is
+    replayed on the GPU by tests/test_gpu_parity.py)."""
+    g, r = _replay_traj("traj1000_plain", 50)
+    assert np.array_equal(g["traj_pos"][0], r["pos_traj"][49].numpy())
+    assert np.array_equal(g["traj_v"][0], r["v_traj"][49].numpy().astype(np.int8))
+    assert np.array_equal(g["traj_bond"][0], r["bond_traj"][49].numpy().astype(np.int8))
+
+
+def test_injected_noise_equals_global_rng_draws():
+    """rand(n,k)/randn(n,3) pre-draws are the same stream rand_like/randn_like consume in the loop."""
+    cfg, sd = GU.weights(0)
+    pocket = synth.make_pocket_tiny(7, num_protein=48, arm_atoms=(3, 2), scaffold_atoms=3)
+    torch.manual_seed(5)
+    b = synth.build_sampling_batch(pocket, 2)
+    state = torch.get_rng_state()
+    r1 = OD.sample_diffusion(sd, cfg, num_steps=3, **b)
+    torch.set_rng_state(state)
+    noise = synth.draw_step_noise(3, b["init_ligand_pos"].size(0), b["init_ligand_fc_bond_type"].size(0))
+    r2 = OD.sample_diffusion(sd, cfg, num_steps=3, noise=noise, **b)
+    assert torch.equal(r1["pos"], r2["pos"]) and torch.equal(r1["v"], r2["v"]) and torch.equal(r1["bond"], r2["bond"])
+
+
+def test_bond_triplets_order_and_counts():
+    fc = synth.fc_bond_index(5)
+    i, j, idx_i, idx_j, idx_k, idx_kj, idx_ji = ops.bond_triplets(fc, 5)
+    assert idx_ji.numel() == 5 * 4 * 3
+    assert torch.all(idx_i != idx_k) and torch.all(idx_j != idx_k)
+    # segments are contiguous, sorted, fixed length NL-2, k ascending inside a segment
+    assert torch.equal(idx_ji, torch.arange(20).repeat_interleave(3))
+    seg_k = idx_k.view(20, 3)
+    assert torch.all(seg_k[:, 1:] > seg_k[:, :-1])
+    # edge (k -> j) id in the dst-major layout: j*(NL-1) + k - (k > j)
+    assert torch.equal(idx_kj, idx_j * 4 + idx_k - (idx_k > idx_j).long())
+
+
+def test_knn_graph_semantics():
+    torch.manual_seed(0)
+    x = torch.randn(30, 3)
+    batch = torch.cat([torch.zeros(18, dtype=torch.long), torch.ones(12, dtype=torch.long)])
+    ei = ops.knn_graph(x, k=5, batch=batch)
+    assert ei.shape == (2, 30 * 5)
+    src, dst = ei
+    assert torch.all(batch[src] == batch[dst]) and torch.all(src != dst)
+    assert torch.equal(dst, torch.arange(30).repeat_interleave(5))
+    d = (x[src] - x[dst]).norm(dim=-1).view(30, 5)
+    assert torch.all(d[:, 1:] >= d[:, :-1])
+    # fewer than k candidates -> all of them
+    ei2 = ops.knn_graph(x[:4], k=5)
+    assert ei2.shape == (2, 4 * 3)
