@@ -322,15 +322,21 @@ extern "C" int dd_sample_steps_graph(const dd_sampler* s, int n_steps, void* str
   if (rc != DD_OK) return rc;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
-  if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) return DD_ERR_HIP;
+  if (st == nullptr) return DD_ERR_BAD_ARG;      // the legacy default stream cannot be captured
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();                     // do not leave a sticky error behind for the caller
+    return DD_ERR_HIP;
+  }
   rc = one_step(s, st);
   hipError_t e = hipStreamEndCapture(st, &graph);
   if (rc != DD_OK || e != hipSuccess || !graph) {
     if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
     return rc != DD_OK ? rc : DD_ERR_HIP;
   }
   if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
     (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
     return DD_ERR_HIP;
   }
   rc = DD_OK;

@@ -284,6 +284,13 @@ class DecompScorePosNet3D(nn.Module):
                 raise ValueError(dr["type"])
         return s, bufs, pw
 
+    def _side_stream(self, dev):
+        st = getattr(self, "_stream", None)
+        if st is None or st.device != dev:
+            st = torch.cuda.Stream(device=dev)
+            self._stream = st
+        return st
+
     def _global_offsets(self, pw):
         n = int(self.config.num_layers) * len(packing.LAYER_SLOTS)
         return {k: int(pw["offsets"][n + i]) for i, k in enumerate(packing.GLOBAL_SLOTS)}
@@ -376,8 +383,13 @@ class DecompScorePosNet3D(nn.Module):
                                         offset.contiguous(), decomp, fpp, seed)
         lib = hip_lib.load()
         fn = lib.dd_sample_steps_graph if use_graph else lib.dd_sample_steps
-        hip_lib.check(fn(ctypes.byref(s), int(num_steps), hip_lib.stream_ptr(dev)),
-                      "dd_sample_steps_graph" if use_graph else "dd_sample_steps")
+        # the loop runs on a dedicated HIP stream (the legacy default stream cannot be captured into a hipGraph)
+        side = self._side_stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            hip_lib.check(fn(ctypes.byref(s), int(num_steps), hip_lib.stream_ptr(dev)),
+                          "dd_sample_steps_graph" if use_graph else "dd_sample_steps")
+        torch.cuda.current_stream(dev).wait_stream(side)
         ligand_pos = bufs["lig_pos"].view(B, NL, 3) + offset[:, None, :]
         out = {
             "pos": ligand_pos.reshape(B * NL, 3),
