@@ -31,10 +31,25 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ void stage_weights(float* dst, const float* __restrict__ src, int nfloat4) {
+// Cooperative global -> LDS copy by the 512-thread workgroup.  All loads of a thread are issued
+// before its first LDS store (8 independent 16-byte loads in flight per lane) — the naive
+// load/store loop serialises one L2 round trip per iteration.
+template <int NF4>
+__device__ __forceinline__ void stage_weights(float* dst, const float* __restrict__ src) {
+  constexpr int PER = (NF4 + 511) / 512;
   const float4* s4 = reinterpret_cast<const float4*>(src);
   float4* d4 = reinterpret_cast<float4*>(dst);
-  for (int i = threadIdx.x; i < nfloat4; i += blockDim.x) d4[i] = s4[i];
+  float4 tmp[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = threadIdx.x + k * 512;
+    if (i < NF4) tmp[k] = s4[i];
+  }
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = threadIdx.x + k * 512;
+    if (i < NF4) d4[i] = tmp[k];
+  }
 }
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
@@ -81,7 +96,7 @@ __global__ __launch_bounds__(512) void k_attn(const AttnArgs a) {
   const float* xl = xb + (long)a.NP * 3;
 
   // ---- phase A: Q~[h][c] = scale * sum_d q[h*8+d] * W2k[h*8+d][c] ------------------------------
-  stage_weights(Wl, a.W2k, WL / 4);
+  stage_weights<WL / 4>(Wl, a.W2k);
   __syncthreads();
   float Qa[16], Qb[16];
   if (active) {
@@ -92,7 +107,7 @@ __global__ __launch_bounds__(512) void k_attn(const AttnArgs a) {
 #pragma unroll
       for (int d = 0; d < 8; ++d) {
         const int idx = h * 8 + d;
-        const float qs = __shfl((idx & 1) ? qv.y : qv.x, idx >> 1, 64);
+        const float qs = lane_bcast((idx & 1) ? qv.y : qv.x, idx >> 1);
         const float2 w = *reinterpret_cast<const float2*>(&Wl[idx * 128 + 2 * lane]);
         s0 = fmaf(qs, w.x, s0);
         s1 = fmaf(qs, w.y, s1);
@@ -158,7 +173,7 @@ __global__ __launch_bounds__(512) void k_attn(const AttnArgs a) {
       const float gl = gauss_feat(d, lane < 20 ? lane : 0);
 #pragma unroll
       for (int g = 0; g < 20; ++g) {
-        const float gg = __shfl(gl, g, 64);
+        const float gg = lane_bcast(gl, g);
         const float2 wk = *reinterpret_cast<const float2*>(a.Wg2k + g * 128 + 2 * lane);
         const float2 wv = *reinterpret_cast<const float2*>(a.Wg2v + g * 128 + 2 * lane);
         ck.x = fmaf(wk.x, gg, ck.x); ck.y = fmaf(wk.y, gg, ck.y);
@@ -172,10 +187,27 @@ __global__ __launch_bounds__(512) void k_attn(const AttnArgs a) {
   }
   const long src_base = (MODE == M_NE || MODE == M_PE) ? (long)b * N : (long)b * a.NL;
   const long erow0 = (long)seg * NLm1;      // NB/PB: bond rows of this dst atom
+  // gathered first-Linear partial sums of member m (issued one member ahead of their use; the two rows
+  // are summed only at the point of use so that the loads stay in flight across the previous member)
+  struct Rows { float2 r, e; };
+  auto gather = [&](int m, const float* tab_s, int ld_s, const float* tab_e, int ld_e) -> Rows {
+    const int sidx = __builtin_amdgcn_readfirstlane(scri[SRC + m]);
+    Rows o;
+    o.e = make_float2(0.f, 0.f);
+    if (KNN) {
+      o.r = *reinterpret_cast<const float2*>(tab_s + (src_base + sidx) * ld_s + 2 * lane);
+    } else if (!TRIP) {
+      o.r = *reinterpret_cast<const float2*>(tab_s + (src_base + sidx) * ld_s + 2 * lane);
+      o.e = *reinterpret_cast<const float2*>(tab_e + (erow0 + m) * ld_e + 2 * lane);
+    } else {
+      o.r = *reinterpret_cast<const float2*>(tab_e + (long)sidx * ld_e + 2 * lane);
+    }
+    return o;
+  };
 
   // ---- stage pass-1 table ------------------------------------------------------------------------
   __syncthreads();                           // everyone is done with W2k
-  if (KNN) { stage_weights(Wl, a.Ak, 4 * 21 * 128 / 4); }
+  if (KNN) { stage_weights<4 * 21 * 128 / 4>(Wl, a.Ak); }
   __syncthreads();
 
   // ---- pass 1: scores ------------------------------------------------------------------------------
@@ -191,13 +223,17 @@ __global__ __launch_bounds__(512) void k_attn(const AttnArgs a) {
       }
     }
     wave_lds_sync();
+    Rows nxt;
+    nxt.r = nxt.e = make_float2(0.f, 0.f);
+    if (M > 0) nxt = gather(0, a.ks, a.ld_ks, a.ke, a.ld_ke);
     for (int m = 0; m < M; ++m) {
-      const int sidx = __builtin_amdgcn_readfirstlane(scri[SRC + m]);
-      float2 pre = ck;
+      float2 pre = make_float2(ck.x + (nxt.r.x + nxt.e.x), ck.y + (nxt.r.y + nxt.e.y));
+      // consume the rows fetched during the previous member BEFORE issuing the next fetch: hipcc waits
+      // vmcnt(0) at a loop-carried load's first use, which would otherwise also drain the new loads
+      asm volatile("" : "+v"(pre.x), "+v"(pre.y) : : "memory");
+      if (m + 1 < M) nxt = gather(m + 1, a.ks, a.ld_ks, a.ke, a.ld_ke);
       if (KNN) {
         const int ty = __builtin_amdgcn_readfirstlane(scri[TY + m]);
-        const float2 r = *reinterpret_cast<const float2*>(a.ks + (src_base + sidx) * a.ld_ks + 2 * lane);
-        pre.x += r.x; pre.y += r.y;
         const float* tab = Wl + ty * 21 * 128 + 2 * lane;
         const float4* G4 = reinterpret_cast<const float4*>(scr + FEAT + 20 * m);
 #pragma unroll
@@ -214,13 +250,7 @@ __global__ __launch_bounds__(512) void k_attn(const AttnArgs a) {
         }
         const float2 tc = *reinterpret_cast<const float2*>(tab + 20 * 128);
         pre.x += tc.x; pre.y += tc.y;
-      } else if (!TRIP) {
-        const float2 r = *reinterpret_cast<const float2*>(a.ks + (src_base + sidx) * a.ld_ks + 2 * lane);
-        const float2 e = *reinterpret_cast<const float2*>(a.ke + (erow0 + m) * a.ld_ke + 2 * lane);
-        pre.x += r.x + e.x; pre.y += r.y + e.y;
-      } else {
-        const float2 e = *reinterpret_cast<const float2*>(a.ke + (long)sidx * a.ld_ke + 2 * lane);
-        pre.x += e.x; pre.y += e.y;
+      } else if (TRIP) {
         const float4* C4 = reinterpret_cast<const float4*>(scr + FEAT + 16 * m);
         const float4 c0 = C4[0], c1 = C4[1], c2 = C4[2], c3 = C4[3];
         const float cc[13] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x};
@@ -240,24 +270,23 @@ __global__ __launch_bounds__(512) void k_attn(const AttnArgs a) {
       const int h = lane & 15, part = lane >> 4;
       float mx = -INFINITY;
       for (int m = part; m < M; m += 4) mx = fmaxf(mx, scr[SC + 16 * m + h]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = swap32_max(swap16_max(mx));
       float sum = 0.f;
       for (int m = part; m < M; m += 4) {
         const float e = expf(scr[SC + 16 * m + h] - mx);
         scr[SC + 16 * m + h] = e;
         sum += e;
       }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
+      sum = swap16_sum(sum, sum);
+      sum = swap32_sum(sum, sum);
       float tot = 0.f;
       for (int m = part; m < M; m += 4) {
         const float aw = (scr[SC + 16 * m + h] / sum) * scr[WGT + m];
         scr[SC + 16 * m + h] = aw;
         tot += aw;
       }
-      tot += __shfl_xor(tot, 16, 64);
-      tot += __shfl_xor(tot, 32, 64);
+      tot = swap16_sum(tot, tot);
+      tot = swap32_sum(tot, tot);
       if (part == 0) scr[SSUM + h] = tot;
     }
     wave_lds_sync();
@@ -266,7 +295,7 @@ __global__ __launch_bounds__(512) void k_attn(const AttnArgs a) {
   // ---- stage pass-2 table ------------------------------------------------------------------------
   if (KNN) {
     __syncthreads();
-    stage_weights(Wl, a.Av, 4 * 21 * 128 / 4);
+    stage_weights<4 * 21 * 128 / 4>(Wl, a.Av);
     __syncthreads();
   }
 
@@ -296,13 +325,15 @@ __global__ __launch_bounds__(512) void k_attn(const AttnArgs a) {
       }
       bv16 = a.b2v16[head_of_lane(lane)];
     }
+    Rows nxt;
+    nxt.r = nxt.e = make_float2(0.f, 0.f);
+    if (M > 0) nxt = gather(0, a.vs, a.ld_vs, a.ve, a.ld_ve);
     for (int m = 0; m < M; ++m) {
-      const int sidx = __builtin_amdgcn_readfirstlane(scri[SRC + m]);
-      float2 pre = cv;
+      float2 pre = make_float2(cv.x + (nxt.r.x + nxt.e.x), cv.y + (nxt.r.y + nxt.e.y));
+      asm volatile("" : "+v"(pre.x), "+v"(pre.y) : : "memory");
+      if (m + 1 < M) nxt = gather(m + 1, a.vs, a.ld_vs, a.ve, a.ld_ve);
       if (KNN) {
         const int ty = __builtin_amdgcn_readfirstlane(scri[TY + m]);
-        const float2 r = *reinterpret_cast<const float2*>(a.vs + (src_base + sidx) * a.ld_vs + 2 * lane);
-        pre.x += r.x; pre.y += r.y;
         const float* tab = Wl + ty * 21 * 128 + 2 * lane;
         const float4* G4 = reinterpret_cast<const float4*>(scr + FEAT + 20 * m);
 #pragma unroll
@@ -319,13 +350,7 @@ __global__ __launch_bounds__(512) void k_attn(const AttnArgs a) {
         }
         const float2 tc = *reinterpret_cast<const float2*>(tab + 20 * 128);
         pre.x += tc.x; pre.y += tc.y;
-      } else if (!TRIP) {
-        const float2 r = *reinterpret_cast<const float2*>(a.vs + (src_base + sidx) * a.ld_vs + 2 * lane);
-        const float2 e = *reinterpret_cast<const float2*>(a.ve + (erow0 + m) * a.ld_ve + 2 * lane);
-        pre.x += r.x + e.x; pre.y += r.y + e.y;
-      } else {
-        const float2 e = *reinterpret_cast<const float2*>(a.ve + (long)sidx * a.ld_ve + 2 * lane);
-        pre.x += e.x; pre.y += e.y;
+      } else if (TRIP) {
         const float4* C4 = reinterpret_cast<const float4*>(scr + FEAT + 16 * m);
         const float4 c0 = C4[0], c1 = C4[1], c2 = C4[2], c3 = C4[3];
         const float cc[13] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x};
@@ -373,7 +398,7 @@ __global__ __launch_bounds__(512) void k_attn(const AttnArgs a) {
     return;
   }
   __syncthreads();                           // all waves finished reading the pass-2 table
-  stage_weights(Wl, a.W2vT, WL / 4);
+  stage_weights<WL / 4>(Wl, a.W2vT);
   float ssum = 0.f;
   if (active) {
     wave_lds_sync();

@@ -21,15 +21,58 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
-// 64-lane butterfly all-reduce (deterministic order).
+// ---- cross-lane primitives on the VALU (DPP + v_permlane{16,32}_swap): no LDS round trips ------------
+// DPP controls: quad_perm[1,0,3,2]=0xB1 (lane^1), quad_perm[2,3,0,1]=0x4E (lane^2), row_half_mirror=0x141
+// (i -> 7-i within 8 lanes), row_mirror=0x140 (i -> 15-i within 16), row_ror:8=0x128 (lane^8).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xF, 0xF, true));
+}
+// v_permlane16_swap a, b : rows 1,3 of a <-> rows 0,2 of b.  a' + b' is then, on rows 0/2, own a + partner's a
+// and, on rows 1/3, own b + partner's b (partner = lane ^ 16): one exchange step of a butterfly, select-free.
+__device__ __forceinline__ float swap16_sum(float a, float b) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  return __uint_as_float(r0) + __uint_as_float(r1);
+}
+__device__ __forceinline__ float swap32_sum(float a, float b) {   // same with lanes 32-63 of a <-> lanes 0-31 of b
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  return __uint_as_float(r0) + __uint_as_float(r1);
+}
+__device__ __forceinline__ float swap16_max(float a) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(a), false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  return fmaxf(__uint_as_float(r0), __uint_as_float(r1));
+}
+__device__ __forceinline__ float swap32_max(float a) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(a), false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  return fmaxf(__uint_as_float(r0), __uint_as_float(r1));
+}
+
+// broadcast lane `idx` (compile-time constant) of v to the whole wave through an SGPR
+__device__ __forceinline__ float lane_bcast(float v, int idx) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), idx));
+}
+
+// 64-lane all-reduce, fixed (deterministic) combination order.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  v = swap16_sum(v, v);
+  v = swap32_sum(v, v);
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  v = swap16_max(v);
+  v = swap32_max(v);
   return v;
 }
 
@@ -49,7 +92,7 @@ __device__ __forceinline__ void ln_relu2(float& a, float& b, float g0, float g1,
   float mean = wave_sum(a + b) * (1.0f / 128.0f);
   float da = a - mean, db = b - mean;
   float var = wave_sum(da * da + db * db) * (1.0f / 128.0f);
-  float rstd = 1.0f / sqrtf(var + 1e-5f);
+  float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);   // v_rsq_f32, 1 ulp
   a = fmaxf(da * rstd * g0 + be0, 0.f);
   b = fmaxf(db * rstd * g1 + be1, 0.f);
 }
@@ -61,34 +104,27 @@ __device__ __forceinline__ int head_of_lane(int lane) {
 }
 __device__ __forceinline__ float reduce16(const float (&p)[16], int lane) {
   float a[8], b[4], c[2];
-  bool hi = (lane & 32) != 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    float keep = hi ? p[i + 8] : p[i];
-    float send = hi ? p[i] : p[i + 8];
-    a[i] = keep + __shfl_xor(send, 32, 64);
-  }
-  hi = (lane & 16) != 0;
+  for (int i = 0; i < 8; ++i) a[i] = swap32_sum(p[i], p[i + 8]);     // lane bit 5 selects p[i] / p[i+8]
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float keep = hi ? a[i + 4] : a[i];
-    float send = hi ? a[i] : a[i + 4];
-    b[i] = keep + __shfl_xor(send, 16, 64);
-  }
-  hi = (lane & 8) != 0;
+  for (int i = 0; i < 4; ++i) b[i] = swap16_sum(a[i], a[i + 4]);     // lane bit 4
+  bool hi = (lane & 8) != 0;                                          // lane bit 3: partner = lane ^ 8
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    float keep = hi ? b[i + 2] : b[i];
-    float send = hi ? b[i] : b[i + 2];
-    c[i] = keep + __shfl_xor(send, 8, 64);
+    const float keep = hi ? b[i + 2] : b[i];
+    const float send = hi ? b[i] : b[i + 2];
+    c[i] = keep + dpp_mov<0x128>(send);
   }
-  hi = (lane & 4) != 0;
-  float keep = hi ? c[1] : c[0];
-  float send = hi ? c[0] : c[1];
-  float d = keep + __shfl_xor(send, 4, 64);
-  d += __shfl_xor(d, 2, 64);
-  d += __shfl_xor(d, 1, 64);
-  return d;
+  // all-reduce over lane bits 0,1 first, so that row_half_mirror (i -> i^7) serves as the lane^4 exchange
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    c[i] += dpp_mov<0xB1>(c[i]);
+    c[i] += dpp_mov<0x4E>(c[i]);
+  }
+  hi = (lane & 4) != 0;                                               // lane bit 2
+  const float keep = hi ? c[1] : c[0];
+  const float send = hi ? c[0] : c[1];
+  return keep + dpp_mov<0x141>(send);
 }
 
 // Philox4x32-10 counter RNG (production noise path).

@@ -23,25 +23,34 @@ __global__ __launch_bounds__(256) void k_gemm128(GemmArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * GT, col0 = blockIdx.y * GT;
 
-  // ---- stage X tile (64 rows x 128) and W tile (64 cols x 128): float4 global loads,
-  //      two ds_write_b64 each (pitch 130 is only 8-byte aligned)
-  for (int i = tid; i < GT * 32; i += 256) {
-    int r = i >> 5, c4 = (i & 31) * 4;
-    int gr = row0 + r;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (gr < a.rows) {
-      const float* src = a.X + (long)(gr / a.x_rows_per_b) * a.x_stride_b + (long)(gr % a.x_rows_per_b) * a.ldx + c4;
-      v = *reinterpret_cast<const float4*>(src);
+  // ---- stage X tile (64 rows x 128) and W tile (64 cols x 128): all 16 float4 global loads of a thread
+  //      are issued before the first LDS store; two ds_write_b64 each (pitch 130 is only 8-byte aligned)
+  {
+    float4 xv[8], wv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = tid + k * 256;
+      const int r = i >> 5, c4 = (i & 31) * 4;
+      const int gr = row0 + r, gc = col0 + r;
+      xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      wv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gr < a.rows) {
+        const float* src = a.X + (long)(gr / a.x_rows_per_b) * a.x_stride_b + (long)(gr % a.x_rows_per_b) * a.ldx + c4;
+        xv[k] = *reinterpret_cast<const float4*>(src);
+      }
+      if (gc < a.ncols) wv[k] = *reinterpret_cast<const float4*>(a.W + (long)gc * 128 + c4);
     }
-    float2* d = reinterpret_cast<float2*>(&Xs[r * GP + c4]);
-    d[0] = make_float2(v.x, v.y);
-    d[1] = make_float2(v.z, v.w);
-    int gc = col0 + r;
-    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (gc < a.ncols) w = *reinterpret_cast<const float4*>(a.W + (long)gc * 128 + c4);
-    float2* e = reinterpret_cast<float2*>(&Ws[r * GP + c4]);
-    e[0] = make_float2(w.x, w.y);
-    e[1] = make_float2(w.z, w.w);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = tid + k * 256;
+      const int r = i >> 5, c4 = (i & 31) * 4;
+      float2* d = reinterpret_cast<float2*>(&Xs[r * GP + c4]);
+      d[0] = make_float2(xv[k].x, xv[k].y);
+      d[1] = make_float2(xv[k].z, xv[k].w);
+      float2* e = reinterpret_cast<float2*>(&Ws[r * GP + c4]);
+      e[0] = make_float2(wv[k].x, wv[k].y);
+      e[1] = make_float2(wv[k].z, wv[k].w);
+    }
   }
   __syncthreads();
 

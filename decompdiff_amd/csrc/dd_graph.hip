@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_edge_weights(const float* __restrict__ 
     float p0 = bb.x, p1 = bb.y;
 #pragma unroll
     for (int g = 0; g < DD_NGAUSS; ++g) {
-      float gg = __shfl(gl, g, 64);
+      float gg = lane_bcast(gl, g);
       p0 = fmaf(w1a[g], gg, p0);
       p1 = fmaf(w1b[g], gg, p1);
     }
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void k_bl_assemble(const float* __restrict__ x
   float2 q = *reinterpret_cast<const float2*>(pb + 512);
 #pragma unroll
   for (int g = 0; g < DD_NGAUSS; ++g) {
-    float gg = __shfl(gl, g, 64);
+    float gg = lane_bcast(gl, g);
     float2 wk = *reinterpret_cast<const float2*>(Wg1k + g * 128 + 2 * lane);
     float2 wv = *reinterpret_cast<const float2*>(Wg1v + g * 128 + 2 * lane);
     k.x = fmaf(wk.x, gg, k.x); k.y = fmaf(wk.y, gg, k.y);
