@@ -1,6 +1,7 @@
 // C ABI orchestration: workspace carving, the score-network forward (launch sequence of
 // models/decompdiff.py:213-351 + uni_transformer_edge.py:259-287,394-443) and the reverse loop
 // (decompdiff.py:575-689), eager or as a replayed hipGraph.
+#include <stdlib.h>
 #include <string.h>
 
 #include "dd_kernels.hpp"
@@ -9,7 +10,7 @@ namespace dd {
 
 // ---- workspace --------------------------------------------------------------------------------
 struct Workspace {
-  float *xa, *xb, *h, *hb, *ew, *P, *PL, *PB, *Ek, *Ev, *q1bl, *qn, *ql, *qb, *A, *dxe, *ga, *gc;
+  float *xa, *xb, *h, *hb, *ew, *P, *PL, *PB, *Ek, *Ev, *Rk, *Rv, *q1bl, *qn, *ql, *qb, *A, *dxe, *ga, *gc;
   int32_t* nbr;
   size_t total;
 };
@@ -32,6 +33,8 @@ static Workspace carve(float* base, int B, int NP, int NL, int K) {
   w.PB = take(B * Eb * 640);
   w.Ek = take(B * Eb * 128);
   w.Ev = take(B * Eb * 128);
+  w.Rk = take(B * Eb * 128);
+  w.Rv = take(B * Eb * 128);
   w.q1bl = take(B * Eb * 128);
   w.qn = take(B * N * 128);
   w.ql = take((size_t)B * NL * 128);
@@ -86,6 +89,16 @@ struct ProfScope {
     if (rc__ != DD_OK) return rc__; \
   } while (0)
 
+static long long* g_dbg_clock = nullptr;   // set by dd_debug_set_clock_buffer (profiling aid)
+static int g_dbg_mode = -1;
+
+static int attn_dispatch(int mode, const AttnArgs& a0, hipStream_t st) {
+  AttnArgs a = a0;
+  a.dbg_clock = (mode == g_dbg_mode) ? g_dbg_clock : nullptr;
+  static const int use_v1 = [] { const char* e = getenv("DD_ATTN_V1"); return e && e[0] == '1'; }();
+  return use_v1 ? launch_attn(mode, a, st) : launch_attn2(mode, a, st);
+}
+
 static int forward_impl(const dd_sampler* s, hipStream_t st) {
   DD_TRY(check_shapes(s));
   const int B = s->B, NP = s->NP, NL = s->NL, K = s->K, N = NP + NL;
@@ -115,7 +128,8 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
                            B * NL, 0, 1280, 1280, 0}, st));
     DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.hb, (int)(B * Eb), 0, 128, (int)(B * Eb), LW(l, DD_W_b1), LW(l, DD_b_b1), nullptr, w.PB,
                            (int)(B * Eb), 0, 640, 640, 0}, st));
-    DD_TRYP(DD_PROF_ASSEMBLE, launch_bl_assemble(xcur, w.PB, w.PL, LW(l, DD_BL_Wg1k), LW(l, DD_BL_Wg1v), B, NP, NL, w.Ek, w.Ev, w.q1bl, st));
+    DD_TRYP(DD_PROF_ASSEMBLE, launch_bl_assemble(xcur, w.PB, w.PL, LW(l, DD_BL_Wg1k), LW(l, DD_BL_Wg1v), LW(l, DD_BL_Wg2k),
+                                                  LW(l, DD_BL_Wg2v), B, NP, NL, w.Ek, w.Ev, w.q1bl, w.Rk, w.Rv, st));
     // ---- queries: second Linear of the q MLPs (LayerNorm+ReLU prologue)
     DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.P + 512, B * N, 0, 640, B * N, LW(l, DD_NE_W2q), LW(l, DD_NE_b2q), LW(l, DD_NE_lnq), w.qn,
                            B * N, 0, 128, 128, 0}, st));
@@ -130,7 +144,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
     a.kd = w.P; a.ks = w.P + 128; a.vd = w.P + 256; a.vs = w.P + 384; a.ld_kd = a.ld_ks = a.ld_vd = a.ld_vs = 640;
     a.q = w.qn; a.Ak = LW(l, DD_NE_Ak); a.Av = LW(l, DD_NE_Av); a.lnk = LW(l, DD_NE_lnk); a.lnv = LW(l, DD_NE_lnv);
     a.W2k = LW(l, DD_NE_W2k); a.W2vT = LW(l, DD_NE_W2vT); a.b2v = LW(l, DD_NE_b2v); a.out = w.A;
-    DD_TRYP(DD_PROF_ATTN_NE, launch_attn(M_NE, a, st));
+    DD_TRYP(DD_PROF_ATTN_NE, attn_dispatch(M_NE, a, st));
     // ---- node_layer_with_bond (adds into the ligand rows of A)
     memset(&a, 0, sizeof(a));
     a.B = B; a.NP = NP; a.NL = NL; a.K = K; a.x = xcur;
@@ -138,7 +152,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
     a.ke = w.PB; a.ve = w.PB + 128; a.ld_ke = a.ld_ve = 640;
     a.q = w.ql; a.lnk = LW(l, DD_NB_lnk); a.lnv = LW(l, DD_NB_lnv);
     a.W2k = LW(l, DD_NB_W2k); a.W2vT = LW(l, DD_NB_W2vT); a.b2v = LW(l, DD_NB_b2v); a.out = w.A;
-    DD_TRYP(DD_PROF_ATTN_NB, launch_attn(M_NB, a, st));
+    DD_TRYP(DD_PROF_ATTN_NB, attn_dispatch(M_NB, a, st));
     // ---- bond_layer (residual add into h_bond)
     memset(&a, 0, sizeof(a));
     a.B = B; a.NP = NP; a.NL = NL; a.K = K; a.x = xcur;
@@ -146,7 +160,8 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
     a.q = w.qb; a.Wg2k = LW(l, DD_BL_Wg2k); a.Wg2v = LW(l, DD_BL_Wg2v); a.Wak = LW(l, DD_BL_Wak); a.Wav = LW(l, DD_BL_Wav);
     a.lnk = LW(l, DD_BL_lnk); a.lnv = LW(l, DD_BL_lnv);
     a.W2k = LW(l, DD_BL_W2k); a.W2vT = LW(l, DD_BL_W2vT); a.b2v = LW(l, DD_BL_b2v); a.out = w.hb;
-    DD_TRYP(DD_PROF_ATTN_BL, launch_attn(M_BL, a, st));
+    a.Rk = w.Rk; a.Rv = w.Rv;
+    DD_TRYP(DD_PROF_ATTN_BL, attn_dispatch(M_BL, a, st));
     // ---- h += lin_node(A)
     DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.A, B * N, 0, 128, B * N, LW(l, DD_W_lin), LW(l, DD_b_lin), nullptr, w.h, B * N, 0, 128, 128, 1}, st));
     // ---- projections of the new h / h_bond
@@ -163,7 +178,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
     a.kd = w.PL; a.vd = w.PL + 128; a.ld_kd = a.ld_vd = 1024; a.ks = w.P; a.vs = w.P + 128; a.ld_ks = a.ld_vs = 256;
     a.q = w.ql; a.Ak = LW(l, DD_PE_Ak); a.Av = LW(l, DD_PE_Av); a.lnk = LW(l, DD_PE_lnk); a.lnv = LW(l, DD_PE_lnv);
     a.W2k = LW(l, DD_PE_W2k); a.W2v16 = LW(l, DD_PE_W2v); a.b2v16 = LW(l, DD_PE_b2v); a.out = w.dxe;
-    DD_TRYP(DD_PROF_ATTN_PE, launch_attn(M_PE, a, st));
+    DD_TRYP(DD_PROF_ATTN_PE, attn_dispatch(M_PE, a, st));
     // ---- pos_layer_with_bond + coordinate update (ligand rows only: mask_ligand_atom)
     DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.PL + 896, B * NL, 0, 1024, B * NL, LW(l, DD_PB_W2q), LW(l, DD_PB_b2q), LW(l, DD_PB_lnq), w.ql,
                            B * NL, 0, 128, 128, 0}, st));
@@ -173,7 +188,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
     a.ke = w.PB; a.ve = w.PB + 128; a.ld_ke = a.ld_ve = 256;
     a.q = w.ql; a.lnk = LW(l, DD_PB_lnk); a.lnv = LW(l, DD_PB_lnv);
     a.W2k = LW(l, DD_PB_W2k); a.W2v16 = LW(l, DD_PB_W2v); a.b2v16 = LW(l, DD_PB_b2v); a.dxe = w.dxe; a.x_next = xnext;
-    DD_TRYP(DD_PROF_ATTN_PB, launch_attn(M_PB, a, st));
+    DD_TRYP(DD_PROF_ATTN_PB, attn_dispatch(M_PB, a, st));
     float* t = xcur; xcur = xnext; xnext = t;
   }
   // heads, first Linear (decompdiff.py:194-211): v head on ligand rows of h, bond head on h_bond
@@ -376,4 +391,12 @@ extern "C" int dd_profile_step(const dd_sampler* s, int n_iters, float* ms_per_c
   }
   for (int c = 0; c < DD_NUM_PROF_CATS; ++c) ms_per_category[c] /= (float)n_iters;
   return rc;
+}
+
+// Profiling aid: when set, the tiled attention kernel of class `mode` (0 NE,1 NB,2 BL,3 PE,4 PB) writes 16
+// s_memtime stamps per workgroup (wave 0) into `buf` ([n_workgroups][16] int64, device memory).
+extern "C" int dd_debug_set_clock_buffer(long long* buf, int mode) {
+  dd::g_dbg_clock = buf;
+  dd::g_dbg_mode = buf ? mode : -1;
+  return DD_OK;
 }

@@ -151,11 +151,14 @@ __global__ void k_embed_bonds(const int32_t* __restrict__ bond, long rows, const
 //   Ev[e] = same with the v weights
 //   q1[e] = PB.q_hb[e] + PL[t].q_hi
 // PB row layout [640]: NB ke | NB ve | BL k_hb | BL v_hb | BL q_hb;  PL row layout [1280]: see packing.py.
+//   Rk[e] = Wg2k . G(d_e),  Rv[e] = Wg2v . G(d_e)   (the G(d_ji) columns, constant over a triplet segment)
 __global__ __launch_bounds__(256) void k_bl_assemble(const float* __restrict__ x, const float* __restrict__ PB,
                                                      const float* __restrict__ PL, const float* __restrict__ Wg1k,
-                                                     const float* __restrict__ Wg1v, int B, int NP, int NL,
+                                                     const float* __restrict__ Wg1v, const float* __restrict__ Wg2k,
+                                                     const float* __restrict__ Wg2v, int B, int NP, int NL,
                                                      float* __restrict__ Ek, float* __restrict__ Ev,
-                                                     float* __restrict__ q1) {
+                                                     float* __restrict__ q1, float* __restrict__ Rk,
+                                                     float* __restrict__ Rv) {
   const int lane = threadIdx.x & 63;
   const long e_glob = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int Eb = NL * (NL - 1), N = NP + NL;
@@ -173,6 +176,7 @@ __global__ __launch_bounds__(256) void k_bl_assemble(const float* __restrict__ x
   float2 k = *reinterpret_cast<const float2*>(pb + 256);
   float2 v = *reinterpret_cast<const float2*>(pb + 384);
   float2 q = *reinterpret_cast<const float2*>(pb + 512);
+  float2 rk = make_float2(0.f, 0.f), rv = make_float2(0.f, 0.f);
 #pragma unroll
   for (int g = 0; g < DD_NGAUSS; ++g) {
     float gg = lane_bcast(gl, g);
@@ -180,6 +184,10 @@ __global__ __launch_bounds__(256) void k_bl_assemble(const float* __restrict__ x
     float2 wv = *reinterpret_cast<const float2*>(Wg1v + g * 128 + 2 * lane);
     k.x = fmaf(wk.x, gg, k.x); k.y = fmaf(wk.y, gg, k.y);
     v.x = fmaf(wv.x, gg, v.x); v.y = fmaf(wv.y, gg, v.y);
+    float2 uk = *reinterpret_cast<const float2*>(Wg2k + g * 128 + 2 * lane);
+    float2 uv = *reinterpret_cast<const float2*>(Wg2v + g * 128 + 2 * lane);
+    rk.x = fmaf(uk.x, gg, rk.x); rk.y = fmaf(uk.y, gg, rk.y);
+    rv.x = fmaf(uv.x, gg, rv.x); rv.y = fmaf(uv.y, gg, rv.y);
   }
   float2 a;
   a = *reinterpret_cast<const float2*>(ps + 640);  k.x += a.x; k.y += a.y;
@@ -190,6 +198,8 @@ __global__ __launch_bounds__(256) void k_bl_assemble(const float* __restrict__ x
   *reinterpret_cast<float2*>(Ek + e_glob * 128 + 2 * lane) = k;
   *reinterpret_cast<float2*>(Ev + e_glob * 128 + 2 * lane) = v;
   *reinterpret_cast<float2*>(q1 + e_glob * 128 + 2 * lane) = q;
+  *reinterpret_cast<float2*>(Rk + e_glob * 128 + 2 * lane) = rk;
+  *reinterpret_cast<float2*>(Rv + e_glob * 128 + 2 * lane) = rv;
 }
 
 // x0-hat: ligand rows of the final coordinates
@@ -232,11 +242,12 @@ int launch_embed_bonds(const int32_t* bond, long rows, const float* Wb, const fl
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
-int launch_bl_assemble(const float* x, const float* PB, const float* PL, const float* Wg1k, const float* Wg1v, int B,
-                       int NP, int NL, float* Ek, float* Ev, float* q1, hipStream_t st) {
+int launch_bl_assemble(const float* x, const float* PB, const float* PL, const float* Wg1k, const float* Wg1v,
+                       const float* Wg2k, const float* Wg2v, int B, int NP, int NL, float* Ek, float* Ev, float* q1,
+                       float* Rk, float* Rv, hipStream_t st) {
   long rows = (long)B * NL * (NL - 1);
-  hipLaunchKernelGGL(k_bl_assemble, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, PB, PL, Wg1k, Wg1v, B, NP,
-                     NL, Ek, Ev, q1);
+  hipLaunchKernelGGL(k_bl_assemble, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, PB, PL, Wg1k, Wg1v, Wg2k, Wg2v,
+                     B, NP, NL, Ek, Ev, q1, Rk, Rv);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }

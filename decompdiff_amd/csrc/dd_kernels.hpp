@@ -18,8 +18,9 @@ int launch_embed_nodes(const float* protein_h, const float* protein_pos, const f
                        const float* lig_aux, const float* Wl, const float* bl, int B, int NP, int NL, float* h,
                        float* xa, float* xb, hipStream_t st);
 int launch_embed_bonds(const int32_t* bond, long rows, const float* Wb, const float* bb, float* hb, hipStream_t st);
-int launch_bl_assemble(const float* x, const float* PB, const float* PL, const float* Wg1k, const float* Wg1v, int B,
-                       int NP, int NL, float* Ek, float* Ev, float* q1, hipStream_t st);
+int launch_bl_assemble(const float* x, const float* PB, const float* PL, const float* Wg1k, const float* Wg1v,
+                       const float* Wg2k, const float* Wg2v, int B, int NP, int NL, float* Ek, float* Ev, float* q1,
+                       float* Rk, float* Rv, hipStream_t st);
 int launch_extract_ligand(const float* x, int B, int NP, int NL, float* out, hipStream_t st);
 
 enum { M_NE = 0, M_NB = 1, M_BL = 2, M_PE = 3, M_PB = 4 };
@@ -41,8 +42,11 @@ struct AttnArgs {
   float* out;
   const float* dxe;        // PB: result of PE
   float* x_next;           // PB
+  const float *Rk, *Rv;    // BL (tiled kernel): per-edge G(d_ji) partial sums [B*Eb,128]
+  long long* dbg_clock;    // optional [n_blocks][16] s_memtime stamps of wave 0 (profiling aid), may be NULL
 };
-int launch_attn(int mode, const AttnArgs& a, hipStream_t st);
+int launch_attn(int mode, const AttnArgs& a, hipStream_t st);    // v1: one member at a time, VALU only
+int launch_attn2(int mode, const AttnArgs& a, hipStream_t st);   // v2: 16-member tiles, scores/aggregation on MFMA
 
 struct StepRowsArgs {
   const float* hid;        // [rows,128] first Linear of the head (pre-activation incl. bias)

@@ -173,6 +173,9 @@ typedef enum dd_prof_cat {
 } dd_prof_cat;
 int dd_profile_step(const dd_sampler* s, int n_iters, float* ms_per_category /*HOST [DD_NUM_PROF_CATS]*/, void* stream);
 
+/* Profiling aid: per-workgroup s_memtime phase stamps of one attention kernel class (see dd_api.hip). */
+int dd_debug_set_clock_buffer(long long* buf, int mode);
+
 /* Debug/test access to intermediate buffers of the last dd_forward (pointers into workspace). */
 typedef struct dd_ws_view {
   float *x, *h, *hb, *ew, *A;

@@ -1,0 +1,27 @@
+#!/usr/bin/env python
+"""Print s_memtime phase durations of the tiled attention kernels (profiling aid, needs a GPU)."""
+import ctypes, sys, torch, numpy as np
+sys.path.insert(0, ".")
+from decompdiff_amd import DecompScorePosNet3D, hip_lib, shipped_config, synth
+dev = torch.device("cuda:0")
+cfg = shipped_config()
+m = DecompScorePosNet3D(cfg, 29, 10, 8); sd = m.state_dict(); sd.update(synth.synthetic_state_dict(cfg, 0)); m.load_state_dict(sd); m = m.to(dev)
+pocket = synth.make_pocket_small(0); torch.manual_seed(0)
+b = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synth.build_sampling_batch(pocket, 8).items()}
+lib = hip_lib.load()
+names = ["stage W2k", "Q~", "codes", "sync+stage A1", "pass1 tiles", "softmax", "stage A2", "pass2 tiles", "stage W2vT+zt", "epilogue"]
+for mode, nm in enumerate(["NE", "NB", "BL", "PE", "PB"]):
+    buf = torch.zeros(4096, 16, dtype=torch.int64, device=dev)
+    lib.dd_debug_set_clock_buffer(ctypes.c_void_p(buf.data_ptr()), mode)
+    m.sample_diffusion(num_steps=1, center_pos_mode="protein", keep_traj=False, use_graph=False, **b)
+    torch.cuda.synchronize()
+    lib.dd_debug_set_clock_buffer(None, -1)
+    c = buf.cpu().numpy()
+    c = c[c[:, 0] != 0]
+    last = 10
+    d = np.diff(c[:, :last + 1], axis=1).astype(np.float64)
+    tot = (c[:, last] - c[:, 0]).astype(np.float64)
+    print(f"{nm}: {len(c)} workgroups x 6 layers, median total {np.median(tot):.0f} ticks of s_memtime (100 MHz -> {np.median(tot)/100:.1f} us)")
+    print("   " + " | ".join(f"{n} {np.median(d[:, i]):.0f}" for i, n in enumerate(names[:d.shape[1]])))
+    f = c[:, 11:16].astype(np.float64)
+    print("   tile0/pass1: gather-loop %.0f | transpose-read %.0f | features %.0f | LN %.0f | (MFMA+rest of pass: see above)" % tuple(np.median(np.diff(f, axis=1), axis=0)))
