@@ -108,8 +108,12 @@ def main():
         s2, bufs2 = model._last
         bufs2["step_counter"].zero_()
         n_prof = 10
-        hip_lib.check(hip_lib.load().dd_profile_step(ctypes.byref(s2), n_prof, cats, hip_lib.stream_ptr(dev)),
-                      "dd_profile_step")
+        lib = hip_lib.load()
+        lib.dd_debug_set_fusion(0)                # one launch per sub-layer so that each kernel class is timed alone
+        try:
+            hip_lib.check(lib.dd_profile_step(ctypes.byref(s2), n_prof, cats, hip_lib.stream_ptr(dev)), "dd_profile_step")
+        finally:
+            lib.dd_debug_set_fusion(1)
         per_cat = {k: float(cats[i]) for i, k in enumerate(hip_lib.PROF_CATS)}
         dom = max((k for k in per_cat if k.startswith("attn")), key=lambda k: per_cat[k])
         n_layers = cfg.num_layers

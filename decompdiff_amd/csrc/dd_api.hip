@@ -10,7 +10,7 @@ namespace dd {
 
 // ---- workspace --------------------------------------------------------------------------------
 struct Workspace {
-  float *xa, *xb, *h, *hb, *ew, *P, *PL, *PB, *Ek, *Ev, *Rk, *Rv, *q1bl, *qn, *ql, *qb, *A, *dxe, *ga, *gc;
+  float *xa, *xb, *h, *hb, *ew, *P, *PL, *PB, *Ek, *Ev, *Rk, *Rv, *q1bl, *qn, *ql, *ql2, *qb, *A, *Anb, *dxe, *dxb, *ga, *gc;
   int32_t* nbr;
   size_t total;
 };
@@ -38,9 +38,12 @@ static Workspace carve(float* base, int B, int NP, int NL, int K) {
   w.q1bl = take(B * Eb * 128);
   w.qn = take(B * N * 128);
   w.ql = take((size_t)B * NL * 128);
+  w.ql2 = take((size_t)B * NL * 128);
   w.qb = take(B * Eb * 128);
   w.A = take(B * N * 128);
+  w.Anb = take((size_t)B * NL * 128);
   w.dxe = take((size_t)B * NL * 3);
+  w.dxb = take((size_t)B * NL * 3);
   w.ga = take((size_t)B * NL * 3);
   w.gc = take((size_t)B * NL * 3);
   w.total = off;
@@ -89,14 +92,16 @@ struct ProfScope {
     if (rc__ != DD_OK) return rc__; \
   } while (0)
 
+static int g_fuse = 1;                       // dd_debug_set_fusion: 0 = one launch per sub-layer (per-kernel timing)
 static long long* g_dbg_clock = nullptr;   // set by dd_debug_set_clock_buffer (profiling aid)
 static int g_dbg_mode = -1;
+
+static int g_use_v1 = [] { const char* e = getenv("DD_ATTN_V1"); return (e && e[0] == '1') ? 1 : 0; }();
 
 static int attn_dispatch(int mode, const AttnArgs& a0, hipStream_t st) {
   AttnArgs a = a0;
   a.dbg_clock = (mode == g_dbg_mode) ? g_dbg_clock : nullptr;
-  static const int use_v1 = [] { const char* e = getenv("DD_ATTN_V1"); return e && e[0] == '1'; }();
-  return use_v1 ? launch_attn(mode, a, st) : launch_attn2(mode, a, st);
+  return g_use_v1 ? launch_attn(mode, a, st) : launch_attn2(mode, a, st);
 }
 
 static int forward_impl(const dd_sampler* s, hipStream_t st) {
@@ -121,7 +126,87 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
   float* xcur = w.xa;
   float* xnext = w.xb;
   const long hN = (long)N * 128;
-  for (int l = 0; l < s->num_layers; ++l) {
+  const bool fused = g_fuse && !g_use_v1 && NL <= 33 && g_dbg_clock == nullptr;
+  for (int l = 0; l < s->num_layers && fused; ++l) {
+    const int nE = (int)(B * Eb);
+    // ---- projections of the old h / h_bond: one launch
+    {
+      GemmArgs j[3] = {
+          gemm_args(w.h, B * N, 0, 128, B * N, LW(l, DD_W_n1), LW(l, DD_b_n1), nullptr, w.P, B * N, 0, 640, 640, 0),
+          gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(l, DD_W_l1), LW(l, DD_b_l1), nullptr, w.PL, B * NL, 0, 1280, 1280, 0),
+          gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b1), LW(l, DD_b_b1), nullptr, w.PB, nE, 0, 640, 640, 0)};
+      DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, 3, st));
+    }
+    DD_TRYP(DD_PROF_ASSEMBLE, launch_bl_assemble(xcur, w.PB, w.PL, LW(l, DD_BL_Wg1k), LW(l, DD_BL_Wg1v), LW(l, DD_BL_Wg2k),
+                                                  LW(l, DD_BL_Wg2v), B, NP, NL, w.Ek, w.Ev, w.q1bl, w.Rk, w.Rv, st));
+    // ---- queries (second Linear of the q MLPs, LayerNorm+ReLU prologue): one launch
+    {
+      GemmArgs j[3] = {
+          gemm_args(w.q1bl, nE, 0, 128, nE, LW(l, DD_BL_W2q), LW(l, DD_BL_b2q), LW(l, DD_BL_lnq), w.qb, nE, 0, 128, 128, 0),
+          gemm_args(w.P + 512, B * N, 0, 640, B * N, LW(l, DD_NE_W2q), LW(l, DD_NE_b2q), LW(l, DD_NE_lnq), w.qn, B * N, 0, 128, 128, 0),
+          gemm_args(w.PL + 512, B * NL, 0, 1280, B * NL, LW(l, DD_NB_W2q), LW(l, DD_NB_b2q), LW(l, DD_NB_lnq), w.ql, B * NL, 0, 128, 128, 0)};
+      DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, 3, st));
+    }
+    // ---- node_layer_with_edge + node_layer_with_bond + bond_layer: one launch
+    {
+      AttnArgs ne, nb, bl;
+      memset(&ne, 0, sizeof(ne)); memset(&nb, 0, sizeof(nb)); memset(&bl, 0, sizeof(bl));
+      ne.B = B; ne.NP = NP; ne.NL = NL; ne.K = K; ne.x = xcur; ne.nbr = w.nbr; ne.ew = w.ew;
+      ne.kd = w.P; ne.ks = w.P + 128; ne.vd = w.P + 256; ne.vs = w.P + 384; ne.ld_kd = ne.ld_ks = ne.ld_vd = ne.ld_vs = 640;
+      ne.q = w.qn; ne.Ak = LW(l, DD_NE_Ak); ne.Av = LW(l, DD_NE_Av); ne.lnk = LW(l, DD_NE_lnk); ne.lnv = LW(l, DD_NE_lnv);
+      ne.W2k = LW(l, DD_NE_W2k); ne.W2vT = LW(l, DD_NE_W2vT); ne.b2v = LW(l, DD_NE_b2v); ne.out = w.A;
+      nb.B = B; nb.NP = NP; nb.NL = NL; nb.K = K; nb.x = xcur;
+      nb.kd = w.PL; nb.ks = w.PL + 128; nb.vd = w.PL + 256; nb.vs = w.PL + 384; nb.ld_kd = nb.ld_ks = nb.ld_vd = nb.ld_vs = 1280;
+      nb.ke = w.PB; nb.ve = w.PB + 128; nb.ld_ke = nb.ld_ve = 640;
+      nb.q = w.ql; nb.lnk = LW(l, DD_NB_lnk); nb.lnv = LW(l, DD_NB_lnv);
+      nb.W2k = LW(l, DD_NB_W2k); nb.W2vT = LW(l, DD_NB_W2vT); nb.b2v = LW(l, DD_NB_b2v); nb.out = w.Anb; nb.out_assign = 1;
+      bl.B = B; bl.NP = NP; bl.NL = NL; bl.K = K; bl.x = xcur;
+      bl.ke = w.Ek; bl.ve = w.Ev; bl.ld_ke = bl.ld_ve = 128;
+      bl.q = w.qb; bl.Wg2k = LW(l, DD_BL_Wg2k); bl.Wg2v = LW(l, DD_BL_Wg2v); bl.Wak = LW(l, DD_BL_Wak); bl.Wav = LW(l, DD_BL_Wav);
+      bl.lnk = LW(l, DD_BL_lnk); bl.lnv = LW(l, DD_BL_lnv);
+      bl.W2k = LW(l, DD_BL_W2k); bl.W2vT = LW(l, DD_BL_W2vT); bl.b2v = LW(l, DD_BL_b2v); bl.out = w.hb;
+      bl.Rk = w.Rk; bl.Rv = w.Rv;
+      DD_TRYP(DD_PROF_ATTN_BL, launch_attn2_node(ne, nb, bl, st));
+    }
+    // ---- h += lin_node(A + A_nb on ligand rows)
+    {
+      GemmArgs g = gemm_args(w.A, B * N, 0, 128, B * N, LW(l, DD_W_lin), LW(l, DD_b_lin), nullptr, w.h, B * N, 0, 128, 128, 1);
+      g.X2 = w.Anb; g.x2_N = N; g.x2_NP = NP;
+      DD_TRYP(DD_PROF_GEMM, launch_gemm128(g, st));
+    }
+    // ---- projections of the new h / h_bond: one launch
+    {
+      GemmArgs j[3] = {
+          gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b2), LW(l, DD_b_b2), nullptr, w.PB, nE, 0, 256, 256, 0),
+          gemm_args(w.h, B * N, 0, 128, B * N, LW(l, DD_W_n2), LW(l, DD_b_n2), nullptr, w.P, B * N, 0, 256, 256, 0),
+          gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(l, DD_W_l2), LW(l, DD_b_l2), nullptr, w.PL, B * NL, 0, 1024, 1024, 0)};
+      DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, 3, st));
+    }
+    {
+      GemmArgs j[2] = {
+          gemm_args(w.PL + 256, B * NL, 0, 1024, B * NL, LW(l, DD_PE_W2q), LW(l, DD_PE_b2q), LW(l, DD_PE_lnq), w.ql, B * NL, 0, 128, 128, 0),
+          gemm_args(w.PL + 896, B * NL, 0, 1024, B * NL, LW(l, DD_PB_W2q), LW(l, DD_PB_b2q), LW(l, DD_PB_lnq), w.ql2, B * NL, 0, 128, 128, 0)};
+      DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, 2, st));
+    }
+    // ---- pos_layer_with_edge + pos_layer_with_bond: one launch, then the coordinate update (ligand rows only)
+    {
+      AttnArgs pe, pb;
+      memset(&pe, 0, sizeof(pe)); memset(&pb, 0, sizeof(pb));
+      pe.B = B; pe.NP = NP; pe.NL = NL; pe.K = K; pe.x = xcur; pe.nbr = w.nbr; pe.ew = w.ew;
+      pe.kd = w.PL; pe.vd = w.PL + 128; pe.ld_kd = pe.ld_vd = 1024; pe.ks = w.P; pe.vs = w.P + 128; pe.ld_ks = pe.ld_vs = 256;
+      pe.q = w.ql; pe.Ak = LW(l, DD_PE_Ak); pe.Av = LW(l, DD_PE_Av); pe.lnk = LW(l, DD_PE_lnk); pe.lnv = LW(l, DD_PE_lnv);
+      pe.W2k = LW(l, DD_PE_W2k); pe.W2v16 = LW(l, DD_PE_W2v); pe.b2v16 = LW(l, DD_PE_b2v); pe.out = w.dxe;
+      pb.B = B; pb.NP = NP; pb.NL = NL; pb.K = K; pb.x = xcur;
+      pb.kd = w.PL + 384; pb.ks = w.PL + 512; pb.vd = w.PL + 640; pb.vs = w.PL + 768; pb.ld_kd = pb.ld_ks = pb.ld_vd = pb.ld_vs = 1024;
+      pb.ke = w.PB; pb.ve = w.PB + 128; pb.ld_ke = pb.ld_ve = 256;
+      pb.q = w.ql2; pb.lnk = LW(l, DD_PB_lnk); pb.lnv = LW(l, DD_PB_lnv);
+      pb.W2k = LW(l, DD_PB_W2k); pb.W2v16 = LW(l, DD_PB_W2v); pb.b2v16 = LW(l, DD_PB_b2v); pb.out = w.dxb; pb.x_next = nullptr;
+      DD_TRYP(DD_PROF_ATTN_PE, launch_attn2_pos(pe, pb, st));
+    }
+    DD_TRYP(DD_PROF_MISC, launch_xupdate(xcur, w.dxe, w.dxb, B, NP, NL, xnext, st));
+    float* t = xcur; xcur = xnext; xnext = t;
+  }
+  for (int l = 0; l < s->num_layers && !fused; ++l) {
     // ---- projections of the old h / h_bond
     DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.h, B * N, 0, 128, B * N, LW(l, DD_W_n1), LW(l, DD_b_n1), nullptr, w.P, B * N, 0, 640, 640, 0}, st));
     DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(l, DD_W_l1), LW(l, DD_b_l1), nullptr, w.PL,
@@ -192,10 +277,12 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
     float* t = xcur; xcur = xnext; xnext = t;
   }
   // heads, first Linear (decompdiff.py:194-211): v head on ligand rows of h, bond head on h_bond
-  DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.h + (long)NP * 128, NL, hN, 128, B * NL, GW(DD_G_VH_W1), GW(DD_G_VH_b1), nullptr, w.ql, B * NL, 0,
-                         128, 128, 0}, st));
-  DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.hb, (int)(B * Eb), 0, 128, (int)(B * Eb), GW(DD_G_BH_W1), GW(DD_G_BH_b1), nullptr, w.qb,
-                         (int)(B * Eb), 0, 128, 128, 0}, st));
+  {
+    GemmArgs j[2] = {
+        gemm_args(w.hb, (int)(B * Eb), 0, 128, (int)(B * Eb), GW(DD_G_BH_W1), GW(DD_G_BH_b1), nullptr, w.qb, (int)(B * Eb), 0, 128, 128, 0),
+        gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, GW(DD_G_VH_W1), GW(DD_G_VH_b1), nullptr, w.ql, B * NL, 0, 128, 128, 0)};
+    DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, 2, st));
+  }
   // x0-hat = ligand rows of the final x
   if (!s->pred_pos) return DD_ERR_BAD_ARG;
   DD_TRYP(DD_PROF_MISC, launch_extract_ligand(xcur, B, NP, NL, s->pred_pos, st));
@@ -287,6 +374,7 @@ extern "C" int dd_workspace_view(const dd_sampler* s, dd_ws_view* out) {
   dd::Workspace w = dd::carve(s->workspace, s->B, s->NP, s->NL, s->K);
   out->x = (s->num_layers & 1) ? w.xb : w.xa;
   out->h = w.h; out->hb = w.hb; out->ew = w.ew; out->A = w.A; out->nbr = w.nbr;
+  out->Anb = (dd::g_fuse && !dd::g_use_v1 && s->NL <= 33) ? w.Anb : nullptr;
   return DD_OK;
 }
 
@@ -398,5 +486,12 @@ extern "C" int dd_profile_step(const dd_sampler* s, int n_iters, float* ms_per_c
 extern "C" int dd_debug_set_clock_buffer(long long* buf, int mode) {
   dd::g_dbg_clock = buf;
   dd::g_dbg_mode = buf ? mode : -1;
+  return DD_OK;
+}
+
+// Profiling aid: 0 = one launch per sub-layer (so dd_profile_step can time each kernel class), 1 = fused launches.
+extern "C" int dd_debug_set_fusion(int mode) {
+  dd::g_fuse = mode == 1 ? 1 : 0;
+  dd::g_use_v1 = mode == 2 ? 1 : 0;
   return DD_OK;
 }

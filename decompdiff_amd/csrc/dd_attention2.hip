@@ -155,22 +155,33 @@ __device__ __forceinline__ f32x4 mfma_rows(const float (&z)[32], const float (&B
 }
 
 template <int MODE, int MAXT, int NW>
-__global__ __launch_bounds__(NW * 64) void k_attn2(const AttnArgs a) {
+struct Lds {
+  static constexpr bool KNN = (MODE == M_NE || MODE == M_PE);
+  static constexpr bool POS = (MODE == M_PE || MODE == M_PB);
+  static constexpr bool TRIP = (MODE == M_BL);
+  static constexpr int LNP = WB_FLOATS;                       // [4][128]  gamma_k, beta_k, gamma_v, beta_v
+  static constexpr int WAO = LNP + 512;                       // [2][13][128] angle weights (BL)
+  static constexpr int SCR0 = WAO + (TRIP ? 2 * 13 * 128 : 0);
+  static constexpr int FE_SZ = KNN ? 16 * 20 : (TRIP ? MAXT * 256 : 0);
+  static constexpr int FE = POS ? 0 : ZS_FLOATS;              // feature scratch sits behind the transpose tile
+  static constexpr int UNI = POS ? FE_SZ : (ZS_FLOATS + FE_SZ > 16 * 132 ? ZS_FLOATS + FE_SZ : 16 * 132);
+  static constexpr int SS = UNI;                              // [16] sum_m alpha*w per head
+  static constexpr int SCRW = UNI + 16;
+  static constexpr int TOTAL = SCR0 + NW * SCRW;
+};
+
+// Body of one workgroup (NW waves = NW segments).  `block` is the workgroup index within this mode's range and
+// `smem` the workgroup's LDS (>= Lds<MODE,MAXT,NW>::TOTAL floats), so several modes can share one launch.
+template <int MODE, int MAXT, int NW>
+__device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, float* smem) {
   constexpr bool KNN = (MODE == M_NE || MODE == M_PE);
   constexpr bool POS = (MODE == M_PE || MODE == M_PB);
   constexpr bool TRIP = (MODE == M_BL);
   constexpr bool BOND = (MODE == M_NB || MODE == M_PB);
   constexpr int NT = NW * 64;
-  // ---- LDS -------------------------------------------------------------------------------------------
-  constexpr int LNP = WB_FLOATS;                       // [4][128]  gamma_k, beta_k, gamma_v, beta_v
-  constexpr int WAO = LNP + 512;                       // [2][13][128] angle weights (BL)
-  constexpr int SCR0 = WAO + (TRIP ? 2 * 13 * 128 : 0);
-  constexpr int FE_SZ = KNN ? 16 * 20 : (TRIP ? MAXT * 256 : 0);
-  constexpr int FE = POS ? 0 : ZS_FLOATS;              // feature scratch sits behind the transpose tile
-  constexpr int UNI = POS ? FE_SZ : (ZS_FLOATS + FE_SZ > 16 * 132 ? ZS_FLOATS + FE_SZ : 16 * 132);
-  constexpr int SS = UNI;                              // [16] sum_m alpha*w per head
-  constexpr int SCRW = UNI + 16;
-  __shared__ __attribute__((aligned(16))) float smem[SCR0 + NW * SCRW];
+  using L = Lds<MODE, MAXT, NW>;
+  constexpr int LNP = L::LNP, WAO = L::WAO, SCR0 = L::SCR0, FE = L::FE, SS = L::SS, SCRW = L::SCRW;
+  (void)BOND;
   float* WB = smem;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int mm = lane & 15, cg = lane >> 4;            // member slot / channel group; also (head, row-group)
@@ -180,9 +191,9 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(const AttnArgs a) {
   const int nseg = (MODE == M_NE) ? a.B * N : (TRIP ? a.B * Eb : a.B * a.NL);
   const int M = KNN ? a.K : (TRIP ? a.NL - 2 : NLm1);
   const int T = (M + 15) >> 4;
-  const int seg = blockIdx.x * NW + wave;
+  const int seg = block * NW + wave;
   const bool active = seg < nseg;
-  long long* dbg = a.dbg_clock ? a.dbg_clock + (long)blockIdx.x * 16 : nullptr;
+  long long* dbg = a.dbg_clock ? a.dbg_clock + (long)block * 16 : nullptr;
 #define DD_STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
   DD_STAMP(0);
 
@@ -441,8 +452,8 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(const AttnArgs a) {
       dz = wave_sum(dz) * (1.0f / 16.0f);
       if (lane < 3) {
         const float v = lane == 0 ? dx : (lane == 1 ? dy : dz);
-        if (MODE == M_PE) {
-          a.out[(long)seg * 3 + lane] = v;
+        if (MODE == M_PE || a.x_next == nullptr) {
+          a.out[(long)seg * 3 + lane] = v;            // delta only; x is advanced by k_xupdate
         } else {
           const long xi = ((long)b * N + node) * 3 + lane;
           a.x_next[xi] = a.x[xi] + a.dxe[(long)seg * 3 + lane] + v;
@@ -523,9 +534,10 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(const AttnArgs a) {
     o0 = fmaf(bb.x, sh, o0);
     o1 = fmaf(bb.y, sh, o1);
     float* dst;
-    if (MODE == M_NB) dst = a.out + ((long)b * N + node) * 128 + 2 * lane;
+    const bool nb_assign = (MODE == M_NB) && a.out_assign;
+    if (MODE == M_NB && !nb_assign) dst = a.out + ((long)b * N + node) * 128 + 2 * lane;
     else dst = a.out + (long)seg * 128 + 2 * lane;
-    if (MODE == M_NE) {
+    if (MODE == M_NE || nb_assign) {
       *reinterpret_cast<float2*>(dst) = make_float2(o0, o1);
     } else {
       const float2 old = *reinterpret_cast<const float2*>(dst);
@@ -534,6 +546,35 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(const AttnArgs a) {
   }
   DD_STAMP(10);
 #undef DD_STAMP
+}
+
+template <int MODE, int MAXT, int NW>
+__global__ __launch_bounds__(NW * 64) void k_attn2(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[Lds<MODE, MAXT, NW>::TOTAL];
+  attn2_body<MODE, MAXT, NW>(a, blockIdx.x, smem);
+}
+
+constexpr int imax(int a, int b) { return a > b ? a : b; }
+
+// The three sub-layers that read the *old* h / h_bond (NE, NB, BL) are independent: one launch, the longest
+// workgroups (BL) first, the 30-workgroup NB hidden in the tail instead of costing a launch of its own.
+template <int MAXT>
+__global__ __launch_bounds__(512) void k_attn2_node(const AttnArgs ne, const AttnArgs nb, const AttnArgs bl, int n_bl, int n_ne) {
+  constexpr int SZ = imax(imax(Lds<M_NE, 2, 8>::TOTAL, Lds<M_NB, MAXT, 8>::TOTAL), Lds<M_BL, MAXT, 8>::TOTAL);
+  __shared__ __attribute__((aligned(16))) float smem[SZ];
+  const int blk = blockIdx.x;
+  if (blk < n_bl) attn2_body<M_BL, MAXT, 8>(bl, blk, smem);
+  else if (blk < n_bl + n_ne) attn2_body<M_NE, 2, 8>(ne, blk - n_bl, smem);
+  else attn2_body<M_NB, MAXT, 8>(nb, blk - n_bl - n_ne, smem);
+}
+// Same for the two coordinate sub-layers (both write their own delta buffer; x is updated afterwards).
+template <int MAXT>
+__global__ __launch_bounds__(512) void k_attn2_pos(const AttnArgs pe, const AttnArgs pb, int n_pe) {
+  constexpr int SZ = imax(Lds<M_PE, 2, 8>::TOTAL, Lds<M_PB, MAXT, 8>::TOTAL);
+  __shared__ __attribute__((aligned(16))) float smem[SZ];
+  const int blk = blockIdx.x;
+  if (blk < n_pe) attn2_body<M_PE, 2, 8>(pe, blk, smem);
+  else attn2_body<M_PB, MAXT, 8>(pb, blk - n_pe, smem);
 }
 
 template <int MODE, int MAXT, int NW>
@@ -559,6 +600,26 @@ int launch_attn2(int mode, const AttnArgs& a, hipStream_t st) {
                             : launch_mode<M_BL, 4, 6>(a, a.B * a.NL * (a.NL - 1), st);
   }
   return DD_ERR_BAD_ARG;
+}
+
+// Fused launches (ligands with <= 33 atoms: every mode uses 8-wave workgroups).  Returns DD_ERR_UNSUPPORTED_SHAPE
+// for larger ligands; the caller then falls back to one launch per sub-layer.
+int launch_attn2_node(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs& bl, hipStream_t st) {
+  using namespace v2;
+  if (ne.NL > 33) return DD_ERR_UNSUPPORTED_SHAPE;
+  const int N = ne.NP + ne.NL;
+  const int n_ne = (ne.B * N + 7) / 8, n_nb = (ne.B * ne.NL + 7) / 8, n_bl = (ne.B * ne.NL * (ne.NL - 1) + 7) / 8;
+  hipLaunchKernelGGL((k_attn2_node<2>), dim3(n_bl + n_ne + n_nb), dim3(512), 0, st, ne, nb, bl, n_bl, n_ne);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+int launch_attn2_pos(const AttnArgs& pe, const AttnArgs& pb, hipStream_t st) {
+  using namespace v2;
+  if (pe.NL > 33) return DD_ERR_UNSUPPORTED_SHAPE;
+  const int n = (pe.B * pe.NL + 7) / 8;
+  hipLaunchKernelGGL((k_attn2_pos<2>), dim3(2 * n), dim3(512), 0, st, pe, pb, n);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
 }
 
 }  // namespace dd

@@ -17,11 +17,11 @@ constexpr int GT = 64;        // tile rows / cols
 constexpr int GP = 130;       // LDS row pitch (floats)
 
 
-__global__ __launch_bounds__(256) void k_gemm128(GemmArgs a) {
+__device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int bx, const int by) {
   __shared__ float Xs[GT * GP];
   __shared__ float Ws[GT * GP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row0 = blockIdx.x * GT, col0 = blockIdx.y * GT;
+  const int row0 = bx * GT, col0 = by * GT;
 
   // ---- stage X tile (64 rows x 128) and W tile (64 cols x 128): all 16 float4 global loads of a thread
   //      are issued before the first LDS store; two ds_write_b64 each (pitch 130 is only 8-byte aligned)
@@ -37,6 +37,13 @@ __global__ __launch_bounds__(256) void k_gemm128(GemmArgs a) {
       if (gr < a.rows) {
         const float* src = a.X + (long)(gr / a.x_rows_per_b) * a.x_stride_b + (long)(gr % a.x_rows_per_b) * a.ldx + c4;
         xv[k] = *reinterpret_cast<const float4*>(src);
+        if (a.X2 != nullptr) {
+          const int bb = gr / a.x2_N, n = gr % a.x2_N;
+          if (n >= a.x2_NP) {
+            const float4 t = *reinterpret_cast<const float4*>(a.X2 + ((long)bb * (a.x2_N - a.x2_NP) + (n - a.x2_NP)) * 128 + c4);
+            xv[k].x += t.x; xv[k].y += t.y; xv[k].z += t.z; xv[k].w += t.w;
+          }
+        }
       }
       if (gc < a.ncols) wv[k] = *reinterpret_cast<const float4*>(a.W + (long)gc * 128 + c4);
     }
@@ -100,6 +107,45 @@ __global__ __launch_bounds__(256) void k_gemm128(GemmArgs a) {
   }
 }
 
+__global__ __launch_bounds__(256) void k_gemm128(GemmArgs a) { gemm_tile(a, blockIdx.x, blockIdx.y); }
+
+struct GemmBatch { GemmArgs job[4]; int end[4]; int nbx[4]; int njobs; };
+__global__ __launch_bounds__(256) void k_gemm128_batch(GemmBatch gb) {
+  int j = 0, base = 0;
+  const int blk = blockIdx.x;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    if (j == i && blk >= gb.end[i] && i + 1 < gb.njobs) { base = gb.end[i]; j = i + 1; }
+  const int lb = blk - base;
+  // block-uniform job selection; explicit cases keep the job arguments in SGPRs
+  if (j == 0) gemm_tile(gb.job[0], lb % gb.nbx[0], lb / gb.nbx[0]);
+  else if (j == 1) gemm_tile(gb.job[1], lb % gb.nbx[1], lb / gb.nbx[1]);
+  else if (j == 2) gemm_tile(gb.job[2], lb % gb.nbx[2], lb / gb.nbx[2]);
+  else gemm_tile(gb.job[3], lb % gb.nbx[3], lb / gb.nbx[3]);
+}
+
+int launch_gemm128_batch(const GemmArgs* jobs, int njobs, hipStream_t st) {
+  if (njobs <= 0 || njobs > 4) return DD_ERR_BAD_ARG;
+  GemmBatch gb;
+  gb.njobs = njobs;
+  int total = 0;
+  for (int i = 0; i < 4; ++i) {
+    if (i < njobs) {
+      gb.job[i] = jobs[i];
+      gb.nbx[i] = (jobs[i].rows + GT - 1) / GT;
+      total += gb.nbx[i] * ((jobs[i].ncols + GT - 1) / GT);
+    } else {
+      gb.job[i] = jobs[0];
+      gb.nbx[i] = 1;
+    }
+    gb.end[i] = total;
+  }
+  if (total <= 0) return DD_OK;
+  hipLaunchKernelGGL(k_gemm128_batch, dim3(total), dim3(256), 0, st, gb);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
 int launch_gemm128(const GemmArgs& a, hipStream_t st) {
   if (a.rows <= 0 || a.ncols <= 0) return DD_OK;
   dim3 grid((a.rows + GT - 1) / GT, (a.ncols + GT - 1) / GT);
@@ -114,6 +160,6 @@ extern "C" int dd_gemm128(const float* X, int x_rows_per_b, long x_stride_b, int
                           const float* bias, const float* ln, float* Y, int y_rows_per_b, long y_stride_b, int ldy,
                           int ncols, int accumulate, void* stream) {
   if (!X || !W || !Y || x_rows_per_b <= 0 || y_rows_per_b <= 0 || (ldx & 3) != 0) return DD_ERR_BAD_ARG;
-  dd::GemmArgs a{X, x_rows_per_b, x_stride_b, ldx, rows, W, bias, ln, Y, y_rows_per_b, y_stride_b, ldy, ncols, accumulate};
+  dd::GemmArgs a = dd::gemm_args(X, x_rows_per_b, x_stride_b, ldx, rows, W, bias, ln, Y, y_rows_per_b, y_stride_b, ldy, ncols, accumulate);
   return dd::launch_gemm128(a, (hipStream_t)stream);
 }

@@ -216,6 +216,22 @@ int launch_extract_ligand(const float* x, int B, int NP, int NL, float* out, hip
   return DD_OK;
 }
 
+// x_next[ligand rows] = x + dx_edge + dx_bond   (x = x + delta_x * mask_ligand, uni_transformer_edge.py:285)
+__global__ void k_xupdate(const float* __restrict__ x, const float* __restrict__ dxe, const float* __restrict__ dxb,
+                          int B, int NP, int NL, float* __restrict__ x_next) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * NL * 3) return;
+  int b = idx / (NL * 3), r = idx % (NL * 3);
+  long xi = ((long)b * (NP + NL) + NP) * 3 + r;
+  x_next[xi] = x[xi] + dxe[idx] + dxb[idx];
+}
+int launch_xupdate(const float* x, const float* dxe, const float* dxb, int B, int NP, int NL, float* x_next, hipStream_t st) {
+  int n = B * NL * 3;
+  hipLaunchKernelGGL(k_xupdate, dim3((n + 255) / 256), dim3(256), 0, st, x, dxe, dxb, B, NP, NL, x_next);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
 int launch_knn(const float* x, int B, int N, int K, int32_t* nbr, hipStream_t st) {
   hipLaunchKernelGGL(k_knn, dim3((B * N + 3) / 4), dim3(256), 0, st, x, B, N, K, nbr);
   DD_CHECK_LAUNCH();

@@ -8,8 +8,19 @@ struct GemmArgs {
   const float* X; int x_rows_per_b; long x_stride_b; int ldx; int rows;
   const float* W; const float* bias; const float* ln;
   float* Y; int y_rows_per_b; long y_stride_b; int ldy; int ncols; int accumulate;
+  // optional second addend for X rows that are ligand nodes: X[b*N + n] += X2[b*NL + n - NP] (n >= NP)
+  const float* X2; int x2_N, x2_NP;
 };
+inline GemmArgs gemm_args(const float* X, int x_rows_per_b, long x_stride_b, int ldx, int rows, const float* W,
+                          const float* bias, const float* ln, float* Y, int y_rows_per_b, long y_stride_b, int ldy,
+                          int ncols, int accumulate) {
+  GemmArgs g{X, x_rows_per_b, x_stride_b, ldx, rows, W, bias, ln, Y, y_rows_per_b, y_stride_b, ldy, ncols, accumulate,
+             nullptr, 0, 0};
+  return g;
+}
 int launch_gemm128(const GemmArgs& a, hipStream_t st);
+// up to 4 independent projections in one launch (small ones ride along with the big ones)
+int launch_gemm128_batch(const GemmArgs* jobs, int njobs, hipStream_t st);
 
 int launch_knn(const float* x, int B, int N, int K, int32_t* nbr, hipStream_t st);
 int launch_edge_weights(const float* x, const int32_t* nbr, int B, int N, int K, const float* W1T, const float* b1,
@@ -44,9 +55,13 @@ struct AttnArgs {
   float* x_next;           // PB
   const float *Rk, *Rv;    // BL (tiled kernel): per-edge G(d_ji) partial sums [B*Eb,128]
   long long* dbg_clock;    // optional [n_blocks][16] s_memtime stamps of wave 0 (profiling aid), may be NULL
+  int out_assign;          // NB: 1 = write (=) rows [B*NL,128] of `out` instead of accumulating into the node table
 };
 int launch_attn(int mode, const AttnArgs& a, hipStream_t st);    // v1: one member at a time, VALU only
 int launch_attn2(int mode, const AttnArgs& a, hipStream_t st);   // v2: 16-member tiles, scores/aggregation on MFMA
+int launch_attn2_node(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs& bl, hipStream_t st);   // NE+NB+BL, one launch
+int launch_attn2_pos(const AttnArgs& pe, const AttnArgs& pb, hipStream_t st);                        // PE+PB, one launch
+int launch_xupdate(const float* x, const float* dxe, const float* dxb, int B, int NP, int NL, float* x_next, hipStream_t st);
 
 struct StepRowsArgs {
   const float* hid;        // [rows,128] first Linear of the head (pre-activation incl. bias)

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdecompdiff_hip.so")
 EXPORTED_SYMBOLS = [
     "dd_status_string", "dd_abi_version", "dd_workspace_floats", "dd_knn", "dd_edge_weights", "dd_gemm128",
     "dd_embed_protein", "dd_forward", "dd_sample_steps", "dd_sample_steps_graph", "dd_drift_armsca",
-    "dd_drift_clash", "dd_workspace_view", "dd_profile_step", "dd_debug_set_clock_buffer",
+    "dd_drift_clash", "dd_workspace_view", "dd_profile_step", "dd_debug_set_clock_buffer", "dd_debug_set_fusion",
 ]
 
 
@@ -45,7 +45,7 @@ class DDSampler(ctypes.Structure):
 
 class DDWsView(ctypes.Structure):
     _fields_ = [("x", c_void_p), ("h", c_void_p), ("hb", c_void_p), ("ew", c_void_p), ("A", c_void_p),
-                ("nbr", c_void_p)]
+                ("nbr", c_void_p), ("Anb", c_void_p)]
 
 
 PROF_CATS = ["misc", "gemm", "assemble", "attn_NE", "attn_NB", "attn_BL", "attn_PE", "attn_PB", "step"]
@@ -89,6 +89,7 @@ def load():
                                    c_int, c_void_p]
     lib.dd_workspace_view.argtypes = [POINTER(DDSampler), POINTER(DDWsView)]
     lib.dd_debug_set_clock_buffer.argtypes = [c_void_p, c_int]
+    lib.dd_debug_set_fusion.argtypes = [c_int]
     lib.dd_profile_step.argtypes = [POINTER(DDSampler), c_int, POINTER(c_float), c_void_p]
     for name in EXPORTED_SYMBOLS:
         if name not in ("dd_status_string", "dd_workspace_floats"):

@@ -175,11 +175,16 @@ int dd_profile_step(const dd_sampler* s, int n_iters, float* ms_per_category /*H
 
 /* Profiling aid: per-workgroup s_memtime phase stamps of one attention kernel class (see dd_api.hip). */
 int dd_debug_set_clock_buffer(long long* buf, int mode);
+/* Launch structure of the attention sub-layers: 1 (default) = fused multi-mode launches of the tiled kernels,
+ * 0 = one launch per sub-layer (per-kernel timing), 2 = one launch per sub-layer with the v1 (one member at a
+ * time, VALU-only) kernels.  All three produce the same results up to fp32 summation order. */
+int dd_debug_set_fusion(int mode);
 
 /* Debug/test access to intermediate buffers of the last dd_forward (pointers into workspace). */
 typedef struct dd_ws_view {
   float *x, *h, *hb, *ew, *A;
   int32_t* nbr;
+  float* Anb;   /* [B,NL,128] node_layer_with_bond output of the last layer when the fused launch is used, else NULL */
 } dd_ws_view;
 int dd_workspace_view(const dd_sampler* s, dd_ws_view* out);
 
