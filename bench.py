@@ -52,6 +52,15 @@ def parse():
     return ap.parse_args()
 
 
+def executed_flops_bond_layer(B, NL):
+    """FLOPs the fused kernel really performs after the exact restructurings of DESIGN.md §3 (query-side folding of
+    W2k, value projection after aggregation): per member angle contraction (2 x 13x128) + scores (16x128) +
+    aggregation (16x128) MACs, per segment Q~ (128x128) + output projection (128x128) MACs."""
+    eb = NL * (NL - 1)
+    macs = eb * ((NL - 2) * (2 * 13 * 128 + 2 * 16 * 128) + 2 * 128 * 128)
+    return 2.0 * B * macs
+
+
 def algorithmic_flops_bond_layer(B, NL):
     """FLOPs of one bond_layer attention launch, factored count (SURVEY.md §8d / DESIGN.md):
     per triplet, two MLPs x (13-wide angle contraction + 128x128 second Linear), 2 FLOP per MAC."""
@@ -120,11 +129,15 @@ def main():
         launch_ms = per_cat["attn_BL"] / n_layers
         flops = algorithmic_flops_bond_layer(args.batch, NL)
         achieved = flops / (launch_ms * 1e-3) / 1e12
+        executed = executed_flops_bond_layer(args.batch, NL) / (launch_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "k_attn<BL> (bond_layer triplet attention)", "achieved": round(achieved, 3),
                     "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4),
-                    "traffic": None, "launch_ms": round(launch_ms, 4),
-                    "note": "fp32 FLOP roofline (CDNA4 fp32 vector peak == fp32 MFMA peak); algorithmic FLOPs = factored "
-                            "count, DESIGN.md; the kernel is fused so q/k/v never touch HBM (SURVEY.md 8d)",
+                    "traffic": None, "launch_ms": round(launch_ms, 4), "executed_tflops": round(executed, 3),
+                    "executed_frac": round(executed / FP32_PEAK_TFLOPS, 4),
+                    "note": "fp32 FLOP roofline (CDNA4 fp32 vector peak == fp32 MFMA peak); achieved = algorithmic FLOPs "
+                            "(factored count of SURVEY.md 8d) / live HIP-event launch time of the bond-layer launch, measured "
+                            "with one launch per sub-layer; executed_tflops = FLOPs really performed after the exact "
+                            "restructurings (DESIGN.md 3,5); the kernel is fused, q/k/v never touch HBM",
                     "ms_per_step_by_kernel_class": {k: round(v, 4) for k, v in per_cat.items()},
                     "dominant_attention_class": dom}
         cpu = None
