@@ -10,7 +10,7 @@ namespace dd {
 
 // ---- workspace --------------------------------------------------------------------------------
 struct Workspace {
-  float *xa, *xb, *h, *hb, *ew, *P, *PL, *PB, *Ek, *Ev, *Rk, *Rv, *q1bl, *qn, *ql, *ql2, *qb, *A, *Anb, *dxe, *dxb, *ga, *gc;
+  float *xa, *xb, *h, *hb, *ew, *P, *PL, *PB, *P2, *PL2, *PB2, *Ek, *Ev, *Rk, *Rv, *q1bl, *qn, *ql, *ql2, *qb, *A, *Anb, *dxe, *dxb, *ga, *gc;
   int32_t* nbr;
   size_t total;
 };
@@ -31,6 +31,9 @@ static Workspace carve(float* base, int B, int NP, int NL, int K) {
   w.P = take(B * N * 640);
   w.PL = take((size_t)B * NL * 1280);
   w.PB = take(B * Eb * 640);
+  w.P2 = take(B * N * 256);
+  w.PL2 = take((size_t)B * NL * 1024);
+  w.PB2 = take(B * Eb * 256);
   w.Ek = take(B * Eb * 128);
   w.Ev = take(B * Eb * 128);
   w.Rk = take(B * Eb * 128);
@@ -92,6 +95,21 @@ struct ProfScope {
     if (rc__ != DD_OK) return rc__; \
   } while (0)
 
+// second stream for the coordinate sub-layers (they only feed the NEXT layer's geometry, so they overlap its
+// projection GEMMs); fork/join through events, which stream capture turns into graph edges
+static hipStream_t g_side = nullptr;
+static hipEvent_t g_ev_fork[8], g_ev_join[8];
+static int g_overlap = 0;                     // measured: no gain on MI355X (graph branches do not overlap profitably)
+static int ensure_side_stream() {
+  if (g_side) return DD_OK;
+  if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) return DD_ERR_HIP;
+  for (int i = 0; i < 8; ++i)
+    if (hipEventCreateWithFlags(&g_ev_fork[i], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g_ev_join[i], hipEventDisableTiming) != hipSuccess)
+      return DD_ERR_HIP;
+  return DD_OK;
+}
+
 static int g_fuse = 1;                       // dd_debug_set_fusion: 0 = one launch per sub-layer (per-kernel timing)
 static long long* g_dbg_clock = nullptr;   // set by dd_debug_set_clock_buffer (profiling aid)
 static int g_dbg_mode = -1;
@@ -127,6 +145,9 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
   float* xnext = w.xb;
   const long hN = (long)N * 128;
   const bool fused = g_fuse && !g_use_v1 && NL <= 33 && g_dbg_clock == nullptr;
+  const bool overlap = fused && g_overlap && g_prof == nullptr && s->num_layers <= 8;
+  if (overlap) DD_TRY(ensure_side_stream());
+  int pending_join = -1;
   for (int l = 0; l < s->num_layers && fused; ++l) {
     const int nE = (int)(B * Eb);
     // ---- projections of the old h / h_bond: one launch
@@ -136,6 +157,10 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
           gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(l, DD_W_l1), LW(l, DD_b_l1), nullptr, w.PL, B * NL, 0, 1280, 1280, 0),
           gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b1), LW(l, DD_b_b1), nullptr, w.PB, nE, 0, 640, 640, 0)};
       DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, 3, st));
+    }
+    if (pending_join >= 0) {
+      if (hipStreamWaitEvent(st, g_ev_join[pending_join], 0) != hipSuccess) return DD_ERR_HIP;
+      pending_join = -1;
     }
     DD_TRYP(DD_PROF_ASSEMBLE, launch_bl_assemble(xcur, w.PB, w.PL, LW(l, DD_BL_Wg1k), LW(l, DD_BL_Wg1v), LW(l, DD_BL_Wg2k),
                                                   LW(l, DD_BL_Wg2v), B, NP, NL, w.Ek, w.Ev, w.q1bl, w.Rk, w.Rv, st));
@@ -177,15 +202,15 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
     // ---- projections of the new h / h_bond: one launch
     {
       GemmArgs j[3] = {
-          gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b2), LW(l, DD_b_b2), nullptr, w.PB, nE, 0, 256, 256, 0),
-          gemm_args(w.h, B * N, 0, 128, B * N, LW(l, DD_W_n2), LW(l, DD_b_n2), nullptr, w.P, B * N, 0, 256, 256, 0),
-          gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(l, DD_W_l2), LW(l, DD_b_l2), nullptr, w.PL, B * NL, 0, 1024, 1024, 0)};
+          gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b2), LW(l, DD_b_b2), nullptr, w.PB2, nE, 0, 256, 256, 0),
+          gemm_args(w.h, B * N, 0, 128, B * N, LW(l, DD_W_n2), LW(l, DD_b_n2), nullptr, w.P2, B * N, 0, 256, 256, 0),
+          gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(l, DD_W_l2), LW(l, DD_b_l2), nullptr, w.PL2, B * NL, 0, 1024, 1024, 0)};
       DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, 3, st));
     }
     {
       GemmArgs j[2] = {
-          gemm_args(w.PL + 256, B * NL, 0, 1024, B * NL, LW(l, DD_PE_W2q), LW(l, DD_PE_b2q), LW(l, DD_PE_lnq), w.ql, B * NL, 0, 128, 128, 0),
-          gemm_args(w.PL + 896, B * NL, 0, 1024, B * NL, LW(l, DD_PB_W2q), LW(l, DD_PB_b2q), LW(l, DD_PB_lnq), w.ql2, B * NL, 0, 128, 128, 0)};
+          gemm_args(w.PL2 + 256, B * NL, 0, 1024, B * NL, LW(l, DD_PE_W2q), LW(l, DD_PE_b2q), LW(l, DD_PE_lnq), w.ql, B * NL, 0, 128, 128, 0),
+          gemm_args(w.PL2 + 896, B * NL, 0, 1024, B * NL, LW(l, DD_PB_W2q), LW(l, DD_PB_b2q), LW(l, DD_PB_lnq), w.ql2, B * NL, 0, 128, 128, 0)};
       DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, 2, st));
     }
     // ---- pos_layer_with_edge + pos_layer_with_bond: one launch, then the coordinate update (ligand rows only)
@@ -193,17 +218,27 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
       AttnArgs pe, pb;
       memset(&pe, 0, sizeof(pe)); memset(&pb, 0, sizeof(pb));
       pe.B = B; pe.NP = NP; pe.NL = NL; pe.K = K; pe.x = xcur; pe.nbr = w.nbr; pe.ew = w.ew;
-      pe.kd = w.PL; pe.vd = w.PL + 128; pe.ld_kd = pe.ld_vd = 1024; pe.ks = w.P; pe.vs = w.P + 128; pe.ld_ks = pe.ld_vs = 256;
+      pe.kd = w.PL2; pe.vd = w.PL2 + 128; pe.ld_kd = pe.ld_vd = 1024; pe.ks = w.P2; pe.vs = w.P2 + 128; pe.ld_ks = pe.ld_vs = 256;
       pe.q = w.ql; pe.Ak = LW(l, DD_PE_Ak); pe.Av = LW(l, DD_PE_Av); pe.lnk = LW(l, DD_PE_lnk); pe.lnv = LW(l, DD_PE_lnv);
       pe.W2k = LW(l, DD_PE_W2k); pe.W2v16 = LW(l, DD_PE_W2v); pe.b2v16 = LW(l, DD_PE_b2v); pe.out = w.dxe;
       pb.B = B; pb.NP = NP; pb.NL = NL; pb.K = K; pb.x = xcur;
-      pb.kd = w.PL + 384; pb.ks = w.PL + 512; pb.vd = w.PL + 640; pb.vs = w.PL + 768; pb.ld_kd = pb.ld_ks = pb.ld_vd = pb.ld_vs = 1024;
-      pb.ke = w.PB; pb.ve = w.PB + 128; pb.ld_ke = pb.ld_ve = 256;
+      pb.kd = w.PL2 + 384; pb.ks = w.PL2 + 512; pb.vd = w.PL2 + 640; pb.vs = w.PL2 + 768; pb.ld_kd = pb.ld_ks = pb.ld_vd = pb.ld_vs = 1024;
+      pb.ke = w.PB2; pb.ve = w.PB2 + 128; pb.ld_ke = pb.ld_ve = 256;
       pb.q = w.ql2; pb.lnk = LW(l, DD_PB_lnk); pb.lnv = LW(l, DD_PB_lnv);
       pb.W2k = LW(l, DD_PB_W2k); pb.W2v16 = LW(l, DD_PB_W2v); pb.b2v16 = LW(l, DD_PB_b2v); pb.out = w.dxb; pb.x_next = nullptr;
-      DD_TRYP(DD_PROF_ATTN_PE, launch_attn2_pos(pe, pb, st));
+      if (overlap) {
+        // fork: the coordinate sub-layers run on the side stream and are joined before the next consumer of x
+        if (hipEventRecord(g_ev_fork[l], st) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_fork[l], 0) != hipSuccess) return DD_ERR_HIP;
+        int rc = launch_attn2_pos(pe, pb, g_side);
+        if (rc == DD_OK) rc = launch_xupdate(xcur, w.dxe, w.dxb, B, NP, NL, xnext, g_side);
+        if (rc != DD_OK) return rc;
+        if (hipEventRecord(g_ev_join[l], g_side) != hipSuccess) return DD_ERR_HIP;
+        pending_join = l;
+      } else {
+        DD_TRYP(DD_PROF_ATTN_PE, launch_attn2_pos(pe, pb, st));
+        DD_TRYP(DD_PROF_MISC, launch_xupdate(xcur, w.dxe, w.dxb, B, NP, NL, xnext, st));
+      }
     }
-    DD_TRYP(DD_PROF_MISC, launch_xupdate(xcur, w.dxe, w.dxb, B, NP, NL, xnext, st));
     float* t = xcur; xcur = xnext; xnext = t;
   }
   for (int l = 0; l < s->num_layers && !fused; ++l) {
@@ -280,8 +315,12 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
   {
     GemmArgs j[2] = {
         gemm_args(w.hb, (int)(B * Eb), 0, 128, (int)(B * Eb), GW(DD_G_BH_W1), GW(DD_G_BH_b1), nullptr, w.qb, (int)(B * Eb), 0, 128, 128, 0),
-        gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, GW(DD_G_VH_W1), GW(DD_G_VH_b1), nullptr, w.ql, B * NL, 0, 128, 128, 0)};
-    DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, 2, st));
+        gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, GW(DD_G_VH_W1), GW(DD_G_VH_b1), nullptr, w.qn, B * NL, 0, 128, 128, 0)};
+    DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, 2, st));   // (v-head hidden -> qn: ql may still be read by the overlapped pos sub-layer)
+  }
+  if (pending_join >= 0) {
+    if (hipStreamWaitEvent(st, g_ev_join[pending_join], 0) != hipSuccess) return DD_ERR_HIP;
+    pending_join = -1;
   }
   // x0-hat = ligand rows of the final x
   if (!s->pred_pos) return DD_ERR_BAD_ARG;
@@ -298,7 +337,7 @@ static int heads_and_step(const dd_sampler* s, hipStream_t st) {
   auto GW = [&](int slot) { return W + off[(long)s->num_layers * DD_NUM_LAYER_SLOTS + slot]; };
   StepRowsArgs r;
   memset(&r, 0, sizeof(r));
-  r.hid = w.ql; r.W2 = GW(DD_G_VH_W2); r.b2 = GW(DD_G_VH_b2); r.rows = B * NL; r.NC = DD_NUM_V; r.rows_per_sample = NL;
+  r.hid = w.qn; r.W2 = GW(DD_G_VH_W2); r.b2 = GW(DD_G_VH_b2); r.rows = B * NL; r.NC = DD_NUM_V; r.rows_per_sample = NL;
   r.tab = s->tab_v; r.T = s->T; r.t_start = s->t_start; r.step_counter = s->step_counter;
   r.state = s->lig_v; r.uniforms = s->u_v; r.seed = s->seed; r.stream_id = 1;
   r.logits_out = s->pred_v; r.traj_recon = s->traj_v0; r.traj_prob = s->traj_vt; r.traj_state = s->traj_v;
@@ -389,7 +428,7 @@ extern "C" int dd_forward(const dd_sampler* s, void* stream) {
   auto GW = [&](int slot) { return W + off[(long)s->num_layers * DD_NUM_LAYER_SLOTS + slot]; };
   const int rows_v = s->B * s->NL;
   const long rows_b = (long)s->B * s->NL * (s->NL - 1);
-  hipLaunchKernelGGL(dd::k_head_logits, dim3((rows_v + 3) / 4), dim3(256), 0, st, w.ql, GW(DD_G_VH_W2), GW(DD_G_VH_b2),
+  hipLaunchKernelGGL(dd::k_head_logits, dim3((rows_v + 3) / 4), dim3(256), 0, st, w.qn, GW(DD_G_VH_W2), GW(DD_G_VH_b2),
                      rows_v, DD_NUM_V, s->pred_v);
   hipLaunchKernelGGL(dd::k_head_logits, dim3((unsigned)((rows_b + 3) / 4)), dim3(256), 0, st, w.qb, GW(DD_G_BH_W2),
                      GW(DD_G_BH_b2), (int)rows_b, DD_NUM_B, s->pred_bond);
@@ -491,7 +530,8 @@ extern "C" int dd_debug_set_clock_buffer(long long* buf, int mode) {
 
 // Profiling aid: 0 = one launch per sub-layer (so dd_profile_step can time each kernel class), 1 = fused launches.
 extern "C" int dd_debug_set_fusion(int mode) {
-  dd::g_fuse = mode == 1 ? 1 : 0;
+  dd::g_fuse = (mode == 1 || mode == 3) ? 1 : 0;
+  dd::g_overlap = mode == 3 ? 1 : 0;
   dd::g_use_v1 = mode == 2 ? 1 : 0;
   return DD_OK;
 }

@@ -177,7 +177,9 @@ int dd_profile_step(const dd_sampler* s, int n_iters, float* ms_per_category /*H
 int dd_debug_set_clock_buffer(long long* buf, int mode);
 /* Launch structure of the attention sub-layers: 1 (default) = fused multi-mode launches of the tiled kernels,
  * 0 = one launch per sub-layer (per-kernel timing), 2 = one launch per sub-layer with the v1 (one member at a
- * time, VALU-only) kernels.  All three produce the same results up to fp32 summation order. */
+ * time, VALU-only) kernels, 3 = fused launches plus a second-stream overlap of the coordinate sub-layers with the next
+ * layer's projections (experimental: measured no gain).
+ * All variants produce the same results up to fp32 summation order. */
 int dd_debug_set_fusion(int mode);
 
 /* Debug/test access to intermediate buffers of the last dd_forward (pointers into workspace). */

@@ -340,14 +340,14 @@ def test_launch_variants_agree():
     lib = hip_lib.load()
     outs = {}
     try:
-        for mode in (1, 0, 2):
+        for mode in (1, 0, 2, 3):
             lib.dd_debug_set_fusion(mode)
             o = _forward_hip(model(0), b)
             torch.cuda.synchronize()
             outs[mode] = {k: v.clone() for k, v in o.items()}
     finally:
         lib.dd_debug_set_fusion(1)
-    for mode in (0, 2):
+    for mode in (0, 2, 3):
         errs = {k: maxabs(outs[mode][k], outs[1][k]) for k in outs[1]}
         print(f"launch variant {mode} vs fused:", {k: f"{v:.3g}" for k, v in errs.items()})
         assert max(errs.values()) < 2e-5
