@@ -107,9 +107,101 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int bx, const
   }
 }
 
+// K-split variant for jobs without the LayerNorm prologue: the two 64-wide halves of K go through a 33 KB LDS
+// image (4 workgroups/CU instead of 2); the second half's global loads are in flight while the first half is
+// multiplied.  Same MFMA order per output element as gemm_tile (k ascending), hence bit-identical results.
+constexpr int GPH = 66;       // LDS pitch of a K-half tile: (66*row) mod 64 = 2*row -> conflict-free ds_read_b64
+__device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx, const int by) {
+  __shared__ float Xh[GT * GPH];
+  __shared__ float Wh[GT * GPH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = bx * GT, col0 = by * GT;
+  float4 xv[4], wv[4];
+  auto fetch = [&](int half) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + k * 256;
+      const int r = i >> 4, c4 = half * 64 + (i & 15) * 4;
+      const int gr = row0 + r, gc = col0 + r;
+      xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      wv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gr < a.rows) {
+        const float* src = a.X + (long)(gr / a.x_rows_per_b) * a.x_stride_b + (long)(gr % a.x_rows_per_b) * a.ldx + c4;
+        xv[k] = *reinterpret_cast<const float4*>(src);
+        if (a.X2 != nullptr) {
+          const int bb = gr / a.x2_N, n = gr % a.x2_N;
+          if (n >= a.x2_NP) {
+            const float4 t = *reinterpret_cast<const float4*>(a.X2 + ((long)bb * (a.x2_N - a.x2_NP) + (n - a.x2_NP)) * 128 + c4);
+            xv[k].x += t.x; xv[k].y += t.y; xv[k].z += t.z; xv[k].w += t.w;
+          }
+        }
+      }
+      if (gc < a.ncols) wv[k] = *reinterpret_cast<const float4*>(a.W + (long)gc * 128 + c4);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + k * 256;
+      const int r = i >> 4, c4 = (i & 15) * 4;
+      float2* d = reinterpret_cast<float2*>(&Xh[r * GPH + c4]);
+      d[0] = make_float2(xv[k].x, xv[k].y);
+      d[1] = make_float2(xv[k].z, xv[k].w);
+      float2* e = reinterpret_cast<float2*>(&Wh[r * GPH + c4]);
+      e[0] = make_float2(wv[k].x, wv[k].y);
+      e[1] = make_float2(wv[k].z, wv[k].w);
+    }
+  };
+  const int wr = wave >> 1, wc = wave & 1;
+  const int li = lane & 31, hh = lane >> 5;
+  const float* xa = &Xh[(wr * 32 + li) * GPH + 2 * hh];
+  const float* wb = &Wh[(wc * 32 + li) * GPH + 2 * hh];
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  fetch(0);
+  commit();
+  __syncthreads();
+  fetch(1);
+#pragma unroll 8
+  for (int kk = 0; kk < 16; ++kk) {
+    float2 av = *reinterpret_cast<const float2*>(xa + 4 * kk);
+    float2 bv = *reinterpret_cast<const float2*>(wb + 4 * kk);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+  }
+  __syncthreads();
+  commit();
+  __syncthreads();
+#pragma unroll 8
+  for (int kk = 0; kk < 16; ++kk) {
+    float2 av = *reinterpret_cast<const float2*>(xa + 4 * kk);
+    float2 bv = *reinterpret_cast<const float2*>(wb + 4 * kk);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+  }
+  const int gc = col0 + wc * 32 + li;
+  if (gc < a.ncols) {
+    const float bias = a.bias ? a.bias[gc] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      int gr = row0 + wr * 32 + row;
+      if (gr < a.rows) {
+        float* dst = a.Y + (long)(gr / a.y_rows_per_b) * a.y_stride_b + (long)(gr % a.y_rows_per_b) * a.ldy + gc;
+        float v = acc[r] + bias;
+        if (a.accumulate) v += *dst;
+        *dst = v;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_gemm128(GemmArgs a) { gemm_tile(a, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void k_gemm128_ks(GemmArgs a) { gemm_tile_ksplit(a, blockIdx.x, blockIdx.y); }
 
 struct GemmBatch { GemmArgs job[4]; int end[4]; int nbx[4]; int njobs; };
+template <bool KS>
 __global__ __launch_bounds__(256) void k_gemm128_batch(GemmBatch gb) {
   int j = 0, base = 0;
   const int blk = blockIdx.x;
@@ -118,11 +210,13 @@ __global__ __launch_bounds__(256) void k_gemm128_batch(GemmBatch gb) {
     if (j == i && blk >= gb.end[i] && i + 1 < gb.njobs) { base = gb.end[i]; j = i + 1; }
   const int lb = blk - base;
   // block-uniform job selection; explicit cases keep the job arguments in SGPRs
-  if (j == 0) gemm_tile(gb.job[0], lb % gb.nbx[0], lb / gb.nbx[0]);
-  else if (j == 1) gemm_tile(gb.job[1], lb % gb.nbx[1], lb / gb.nbx[1]);
-  else if (j == 2) gemm_tile(gb.job[2], lb % gb.nbx[2], lb / gb.nbx[2]);
-  else gemm_tile(gb.job[3], lb % gb.nbx[3], lb / gb.nbx[3]);
+  if (j == 0) { if (KS) gemm_tile_ksplit(gb.job[0], lb % gb.nbx[0], lb / gb.nbx[0]); else gemm_tile(gb.job[0], lb % gb.nbx[0], lb / gb.nbx[0]); }
+  else if (j == 1) { if (KS) gemm_tile_ksplit(gb.job[1], lb % gb.nbx[1], lb / gb.nbx[1]); else gemm_tile(gb.job[1], lb % gb.nbx[1], lb / gb.nbx[1]); }
+  else if (j == 2) { if (KS) gemm_tile_ksplit(gb.job[2], lb % gb.nbx[2], lb / gb.nbx[2]); else gemm_tile(gb.job[2], lb % gb.nbx[2], lb / gb.nbx[2]); }
+  else { if (KS) gemm_tile_ksplit(gb.job[3], lb % gb.nbx[3], lb / gb.nbx[3]); else gemm_tile(gb.job[3], lb % gb.nbx[3], lb / gb.nbx[3]); }
 }
+
+int g_gemm_ksplit = 1;   // dd_debug_set_option(1, v): K-split tiles for jobs without a LayerNorm prologue
 
 int launch_gemm128_batch(const GemmArgs* jobs, int njobs, hipStream_t st) {
   if (njobs <= 0 || njobs > 4) return DD_ERR_BAD_ARG;
@@ -141,7 +235,10 @@ int launch_gemm128_batch(const GemmArgs* jobs, int njobs, hipStream_t st) {
     gb.end[i] = total;
   }
   if (total <= 0) return DD_OK;
-  hipLaunchKernelGGL(k_gemm128_batch, dim3(total), dim3(256), 0, st, gb);
+  bool any_ln = false;
+  for (int i = 0; i < njobs; ++i) any_ln = any_ln || jobs[i].ln != nullptr;
+  if (any_ln || !g_gemm_ksplit) hipLaunchKernelGGL(k_gemm128_batch<false>, dim3(total), dim3(256), 0, st, gb);
+  else hipLaunchKernelGGL(k_gemm128_batch<true>, dim3(total), dim3(256), 0, st, gb);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
@@ -149,7 +246,8 @@ int launch_gemm128_batch(const GemmArgs* jobs, int njobs, hipStream_t st) {
 int launch_gemm128(const GemmArgs& a, hipStream_t st) {
   if (a.rows <= 0 || a.ncols <= 0) return DD_OK;
   dim3 grid((a.rows + GT - 1) / GT, (a.ncols + GT - 1) / GT);
-  hipLaunchKernelGGL(k_gemm128, grid, dim3(256), 0, st, a);
+  if (a.ln != nullptr || !g_gemm_ksplit) hipLaunchKernelGGL(k_gemm128, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(k_gemm128_ks, grid, dim3(256), 0, st, a);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdecompdiff_hip.so")
 EXPORTED_SYMBOLS = [
     "dd_status_string", "dd_abi_version", "dd_workspace_floats", "dd_knn", "dd_edge_weights", "dd_gemm128",
     "dd_embed_protein", "dd_forward", "dd_sample_steps", "dd_sample_steps_graph", "dd_drift_armsca",
-    "dd_drift_clash", "dd_workspace_view", "dd_profile_step", "dd_debug_set_clock_buffer", "dd_debug_set_fusion",
+    "dd_drift_clash", "dd_workspace_view", "dd_profile_step", "dd_debug_set_clock_buffer", "dd_debug_set_fusion", "dd_debug_set_option",
 ]
 
 
@@ -90,6 +90,7 @@ def load():
     lib.dd_workspace_view.argtypes = [POINTER(DDSampler), POINTER(DDWsView)]
     lib.dd_debug_set_clock_buffer.argtypes = [c_void_p, c_int]
     lib.dd_debug_set_fusion.argtypes = [c_int]
+    lib.dd_debug_set_option.argtypes = [c_int, c_int]
     lib.dd_profile_step.argtypes = [POINTER(DDSampler), c_int, POINTER(c_float), c_void_p]
     for name in EXPORTED_SYMBOLS:
         if name not in ("dd_status_string", "dd_workspace_floats"):
