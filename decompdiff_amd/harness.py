@@ -1,0 +1,96 @@
+"""Sampling harness: the batch loop around ``model.sample_diffusion``.
+
+Counterpart of ``sample_diffusion_ligand_decomp`` in
+/root/reference/scripts/sample_diffusion_decomp.py:57-457 for the ``ref_prior`` / ``beta_prior(v2)`` modes
+(equal atom counts per sample): per batch it draws the initial ligand coordinates around the arm / scaffold
+prior centres, the initial bond and atom types (same torch-CPU RNG order as the reference, :163-194,306-312),
+assembles the PyG-style flat batch (:300-326, increments of utils/data.py:439-444), calls
+``model.sample_diffusion`` (:329-360) and splits the result per sample exactly like :361-410:
+
+    pred_pos [NL,3] float64, pred_v [NL] int64, pred_pos_traj [T,NL,3] float64, pred_v_traj [T,NL],
+    pred_v0_traj / pred_vt_traj [T,NL,8], pred_bond_index [2,Eb] (sample-local atom ids), pred_bond_type [Eb],
+    pred_b_traj [T,Eb], pred_bt_traj [T,Eb,5], decomp_mask [NL] (arm id, -1 = scaffold)
+
+RDKit reconstruction (:416-457) is a CPU chemistry step outside the hot path and is not done
+here; the returned dicts carry everything it consumes.
+"""
+from __future__ import annotations
+
+import time
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import synth
+
+
+def unbatch_traj(traj: List[torch.Tensor], n_data: int, cum: np.ndarray, dtype=None) -> List[np.ndarray]:
+    """reference: unbatch_v_traj (:46-53) — list over steps of [sum_n, ...] -> per sample [T, n_i, ...]"""
+    if len(traj) == 0:
+        return [np.zeros((0,)) for _ in range(n_data)]
+    stacked = torch.stack([t.cpu() for t in traj]).numpy()            # [T, sum_n, ...]
+    if dtype is not None:
+        stacked = stacked.astype(dtype)
+    return [stacked[:, cum[k]:cum[k + 1]] for k in range(n_data)]
+
+
+@torch.no_grad()
+def sample_diffusion_ligand_decomp(model, pocket: synth.Pocket, num_samples: int, batch_size: int = 16,
+                                   device="cuda:0", num_steps: Optional[int] = None, center_pos_mode: str = "protein",
+                                   energy_drift_opt=None, per_sample_std_scale=None, noise_fn=None, seed: int = 0,
+                                   use_graph: bool = True) -> Dict[str, list]:
+    """Sample ``num_samples`` ligands for one pocket in batches of ``batch_size``.
+
+    ``noise_fn(batch_index, n_ligand_atoms, n_bonds, num_steps)`` may return pre-drawn reference-order noise for
+    a batch (parity mode); otherwise the device Philox generator is used with ``seed + batch_index``.
+    """
+    out = {k: [] for k in ("pred_pos", "pred_v", "pred_pos_traj", "pred_v_traj", "pred_v0_traj", "pred_vt_traj",
+                           "pred_bond_index", "pred_bond_type", "pred_b_traj", "pred_bt_traj", "decomp_mask")}
+    time_list = []
+    num_batch = int(np.ceil(num_samples / batch_size))
+    NL = pocket.num_ligand_atoms
+    Eb = NL * (NL - 1)
+    for i in range(num_batch):
+        n_data = batch_size if i < num_batch - 1 else num_samples - batch_size * (num_batch - 1)
+        scale = None
+        if per_sample_std_scale is not None:
+            scale = list(per_sample_std_scale[i * batch_size: i * batch_size + n_data])
+        batch = synth.build_sampling_batch(pocket, n_data, num_bond_classes=model.num_bond_classes,
+                                           num_classes=model.num_classes, per_sample_std_scale=scale)
+        steps = model.num_timesteps if num_steps is None else num_steps
+        noise = noise_fn(i, n_data * NL, n_data * Eb, steps) if noise_fn is not None else None
+        dev_batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        t1 = time.time()
+        r = model.sample_diffusion(num_steps=num_steps, center_pos_mode=center_pos_mode,
+                                   energy_drift_opt=energy_drift_opt, noise=noise, seed=seed + i,
+                                   use_graph=use_graph, **dev_batch)
+        cum_atoms = np.arange(n_data + 1) * NL
+        cum_bonds = np.arange(n_data + 1) * Eb
+        pos = r["pos"].cpu().numpy().astype(np.float64)
+        v = r["v"].cpu().numpy()
+        bond = r["bond"].cpu().numpy()
+        bond_index = batch["ligand_fc_bond_index"].numpy()
+        decomp = batch["ligand_decomp_index"].numpy()
+        pos_traj = unbatch_traj(r["pos_traj"], n_data, cum_atoms, np.float64)
+        v_traj = unbatch_traj(r["v_traj"], n_data, cum_atoms)
+        v0_traj = unbatch_traj(r["v0_traj"], n_data, cum_atoms)
+        vt_traj = unbatch_traj(r["vt_traj"], n_data, cum_atoms)
+        b_traj = unbatch_traj(r["bond_traj"], n_data, cum_bonds)
+        bt_traj = unbatch_traj(r["bt_traj"], n_data, cum_bonds)
+        for k in range(n_data):
+            a0, a1, b0, b1 = cum_atoms[k], cum_atoms[k + 1], cum_bonds[k], cum_bonds[k + 1]
+            out["pred_pos"].append(pos[a0:a1])
+            out["pred_v"].append(v[a0:a1])
+            out["pred_bond_index"].append(bond_index[:, b0:b1] - a0)          # sample-local atom ids (:395)
+            out["pred_bond_type"].append(bond[b0:b1])
+            out["decomp_mask"].append(decomp[a0:a1])
+            out["pred_pos_traj"].append(pos_traj[k])
+            out["pred_v_traj"].append(v_traj[k])
+            out["pred_v0_traj"].append(v0_traj[k])
+            out["pred_vt_traj"].append(vt_traj[k])
+            out["pred_b_traj"].append(b_traj[k])
+            out["pred_bt_traj"].append(bt_traj[k])
+        time_list.append(time.time() - t1)
+    out["time_list"] = time_list
+    return out

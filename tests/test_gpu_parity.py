@@ -401,6 +401,36 @@ def test_batch_rows_are_independent():
     assert torch.equal(part["v"], full["v"][NL:2 * NL]) and torch.equal(part["bond"], full["bond"][Eb:2 * Eb])
 
 
+def test_harness_batches_and_unbatching():
+    """sample_diffusion_ligand_decomp (batch loop + per-sample split, reference :57-410) vs the oracle run batch by batch."""
+    from decompdiff_amd.harness import sample_diffusion_ligand_decomp
+    cfg, sd = GU.weights(0)
+    pocket = synth.make_pocket(31, 70, (3, 2), 4, num_full_protein=150)
+    NL, Eb, steps = 9, 72, 3
+    torch.manual_seed(5)
+    out = sample_diffusion_ligand_decomp(model(0), pocket, num_samples=3, batch_size=2, device=dev(), num_steps=steps,
+                                         energy_drift_opt=GU.DRIFT,
+                                         noise_fn=lambda i, na, nb, T: synth.draw_step_noise(T, na, nb))
+    assert len(out["pred_pos"]) == 3 and out["pred_pos"][0].shape == (NL, 3) and out["pred_pos"][0].dtype == np.float64
+    assert out["pred_pos_traj"][2].shape == (steps, NL, 3) and out["pred_bt_traj"][1].shape == (steps, Eb, 5)
+    assert out["pred_bond_index"][1].shape == (2, Eb) and out["pred_bond_index"][1].max() == NL - 1
+    assert set(out["decomp_mask"][0].tolist()) == {-1, 0, 1}
+    # oracle, same RNG sequence: batch 0 (2 samples) then batch 1 (1 sample)
+    torch.manual_seed(5)
+    k = 0
+    for n_data in (2, 1):
+        b = synth.build_sampling_batch(pocket, n_data)
+        noise = synth.draw_step_noise(steps, n_data * NL, n_data * Eb)
+        r = OD.sample_diffusion(sd, cfg, num_steps=steps, energy_drift_opt=GU.DRIFT, noise=noise, **b)
+        for s in range(n_data):
+            e = maxabs(out["pred_pos"][k], r["pos"][s * NL:(s + 1) * NL])
+            assert e < POS_TOL, e
+            assert np.array_equal(out["pred_v"][k], r["v"][s * NL:(s + 1) * NL].numpy())
+            assert np.array_equal(out["pred_bond_type"][k], r["bond"][s * Eb:(s + 1) * Eb].numpy())
+            assert maxabs(out["pred_pos_traj"][k][-1], r["pos_traj"][-1][s * NL:(s + 1) * NL]) < POS_TOL
+            k += 1
+
+
 def test_unsupported_inputs_fail_loudly():
     g = GU.load("forward_small")
     b = GU.batch_from_npz(g)
