@@ -178,18 +178,18 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
       memset(&ne, 0, sizeof(ne)); memset(&nb, 0, sizeof(nb)); memset(&bl, 0, sizeof(bl));
       ne.B = B; ne.NP = NP; ne.NL = NL; ne.K = K; ne.x = xcur; ne.nbr = w.nbr; ne.ew = w.ew;
       ne.kd = w.P; ne.ks = w.P + 128; ne.vd = w.P + 256; ne.vs = w.P + 384; ne.ld_kd = ne.ld_ks = ne.ld_vd = ne.ld_vs = 640;
-      ne.q = w.qn; ne.Ak = LW(l, DD_NE_Ak); ne.Av = LW(l, DD_NE_Av); ne.lnk = LW(l, DD_NE_lnk); ne.lnv = LW(l, DD_NE_lnv);
-      ne.W2k = LW(l, DD_NE_W2k); ne.W2vT = LW(l, DD_NE_W2vT); ne.b2v = LW(l, DD_NE_b2v); ne.out = w.A;
+      ne.q = w.qn; ne.Ak = LW(l, DD_NE_Ak); ne.Av = LW(l, DD_NE_Av); ne.Akp = LW(l, DD_NE_Akp); ne.Avp = LW(l, DD_NE_Avp); ne.lnk = LW(l, DD_NE_lnk); ne.lnv = LW(l, DD_NE_lnv);
+      ne.W2k = LW(l, DD_NE_W2k); ne.W2vT = LW(l, DD_NE_W2vT); ne.W2v = LW(l, DD_NE_W2v); ne.b2v = LW(l, DD_NE_b2v); ne.out = w.A;
       nb.B = B; nb.NP = NP; nb.NL = NL; nb.K = K; nb.x = xcur;
       nb.kd = w.PL; nb.ks = w.PL + 128; nb.vd = w.PL + 256; nb.vs = w.PL + 384; nb.ld_kd = nb.ld_ks = nb.ld_vd = nb.ld_vs = 1280;
       nb.ke = w.PB; nb.ve = w.PB + 128; nb.ld_ke = nb.ld_ve = 640;
       nb.q = w.ql; nb.lnk = LW(l, DD_NB_lnk); nb.lnv = LW(l, DD_NB_lnv);
-      nb.W2k = LW(l, DD_NB_W2k); nb.W2vT = LW(l, DD_NB_W2vT); nb.b2v = LW(l, DD_NB_b2v); nb.out = w.Anb; nb.out_assign = 1;
+      nb.W2k = LW(l, DD_NB_W2k); nb.W2vT = LW(l, DD_NB_W2vT); nb.W2v = LW(l, DD_NB_W2v); nb.b2v = LW(l, DD_NB_b2v); nb.out = w.Anb; nb.out_assign = 1;
       bl.B = B; bl.NP = NP; bl.NL = NL; bl.K = K; bl.x = xcur;
       bl.ke = w.Ek; bl.ve = w.Ev; bl.ld_ke = bl.ld_ve = 128;
-      bl.q = w.qb; bl.Wg2k = LW(l, DD_BL_Wg2k); bl.Wg2v = LW(l, DD_BL_Wg2v); bl.Wak = LW(l, DD_BL_Wak); bl.Wav = LW(l, DD_BL_Wav);
+      bl.q = w.qb; bl.Wg2k = LW(l, DD_BL_Wg2k); bl.Wg2v = LW(l, DD_BL_Wg2v); bl.Wak = LW(l, DD_BL_Wak); bl.Wav = LW(l, DD_BL_Wav); bl.Wakp = LW(l, DD_BL_Wakp); bl.Wavp = LW(l, DD_BL_Wavp);
       bl.lnk = LW(l, DD_BL_lnk); bl.lnv = LW(l, DD_BL_lnv);
-      bl.W2k = LW(l, DD_BL_W2k); bl.W2vT = LW(l, DD_BL_W2vT); bl.b2v = LW(l, DD_BL_b2v); bl.out = w.hb;
+      bl.W2k = LW(l, DD_BL_W2k); bl.W2vT = LW(l, DD_BL_W2vT); bl.W2v = LW(l, DD_BL_W2v); bl.b2v = LW(l, DD_BL_b2v); bl.out = w.hb;
       bl.Rk = w.Rk; bl.Rv = w.Rv;
       DD_TRYP(DD_PROF_ATTN_BL, launch_attn2_node(ne, nb, bl, st));
     }
@@ -219,7 +219,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
       memset(&pe, 0, sizeof(pe)); memset(&pb, 0, sizeof(pb));
       pe.B = B; pe.NP = NP; pe.NL = NL; pe.K = K; pe.x = xcur; pe.nbr = w.nbr; pe.ew = w.ew;
       pe.kd = w.PL2; pe.vd = w.PL2 + 128; pe.ld_kd = pe.ld_vd = 1024; pe.ks = w.P2; pe.vs = w.P2 + 128; pe.ld_ks = pe.ld_vs = 256;
-      pe.q = w.ql; pe.Ak = LW(l, DD_PE_Ak); pe.Av = LW(l, DD_PE_Av); pe.lnk = LW(l, DD_PE_lnk); pe.lnv = LW(l, DD_PE_lnv);
+      pe.q = w.ql; pe.Ak = LW(l, DD_PE_Ak); pe.Av = LW(l, DD_PE_Av); pe.Akp = LW(l, DD_PE_Akp); pe.Avp = LW(l, DD_PE_Avp); pe.lnk = LW(l, DD_PE_lnk); pe.lnv = LW(l, DD_PE_lnv);
       pe.W2k = LW(l, DD_PE_W2k); pe.W2v16 = LW(l, DD_PE_W2v); pe.b2v16 = LW(l, DD_PE_b2v); pe.out = w.dxe;
       pb.B = B; pb.NP = NP; pb.NL = NL; pb.K = K; pb.x = xcur;
       pb.kd = w.PL2 + 384; pb.ks = w.PL2 + 512; pb.vd = w.PL2 + 640; pb.vs = w.PL2 + 768; pb.ld_kd = pb.ld_ks = pb.ld_vd = pb.ld_vs = 1024;
@@ -262,8 +262,8 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
     memset(&a, 0, sizeof(a));
     a.B = B; a.NP = NP; a.NL = NL; a.K = K; a.x = xcur; a.nbr = w.nbr; a.ew = w.ew;
     a.kd = w.P; a.ks = w.P + 128; a.vd = w.P + 256; a.vs = w.P + 384; a.ld_kd = a.ld_ks = a.ld_vd = a.ld_vs = 640;
-    a.q = w.qn; a.Ak = LW(l, DD_NE_Ak); a.Av = LW(l, DD_NE_Av); a.lnk = LW(l, DD_NE_lnk); a.lnv = LW(l, DD_NE_lnv);
-    a.W2k = LW(l, DD_NE_W2k); a.W2vT = LW(l, DD_NE_W2vT); a.b2v = LW(l, DD_NE_b2v); a.out = w.A;
+    a.q = w.qn; a.Ak = LW(l, DD_NE_Ak); a.Av = LW(l, DD_NE_Av); a.Akp = LW(l, DD_NE_Akp); a.Avp = LW(l, DD_NE_Avp); a.lnk = LW(l, DD_NE_lnk); a.lnv = LW(l, DD_NE_lnv);
+    a.W2k = LW(l, DD_NE_W2k); a.W2vT = LW(l, DD_NE_W2vT); a.W2v = LW(l, DD_NE_W2v); a.b2v = LW(l, DD_NE_b2v); a.out = w.A;
     DD_TRYP(DD_PROF_ATTN_NE, attn_dispatch(M_NE, a, st));
     // ---- node_layer_with_bond (adds into the ligand rows of A)
     memset(&a, 0, sizeof(a));
@@ -271,15 +271,15 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
     a.kd = w.PL; a.ks = w.PL + 128; a.vd = w.PL + 256; a.vs = w.PL + 384; a.ld_kd = a.ld_ks = a.ld_vd = a.ld_vs = 1280;
     a.ke = w.PB; a.ve = w.PB + 128; a.ld_ke = a.ld_ve = 640;
     a.q = w.ql; a.lnk = LW(l, DD_NB_lnk); a.lnv = LW(l, DD_NB_lnv);
-    a.W2k = LW(l, DD_NB_W2k); a.W2vT = LW(l, DD_NB_W2vT); a.b2v = LW(l, DD_NB_b2v); a.out = w.A;
+    a.W2k = LW(l, DD_NB_W2k); a.W2vT = LW(l, DD_NB_W2vT); a.W2v = LW(l, DD_NB_W2v); a.b2v = LW(l, DD_NB_b2v); a.out = w.A;
     DD_TRYP(DD_PROF_ATTN_NB, attn_dispatch(M_NB, a, st));
     // ---- bond_layer (residual add into h_bond)
     memset(&a, 0, sizeof(a));
     a.B = B; a.NP = NP; a.NL = NL; a.K = K; a.x = xcur;
     a.ke = w.Ek; a.ve = w.Ev; a.ld_ke = a.ld_ve = 128;
-    a.q = w.qb; a.Wg2k = LW(l, DD_BL_Wg2k); a.Wg2v = LW(l, DD_BL_Wg2v); a.Wak = LW(l, DD_BL_Wak); a.Wav = LW(l, DD_BL_Wav);
+    a.q = w.qb; a.Wg2k = LW(l, DD_BL_Wg2k); a.Wg2v = LW(l, DD_BL_Wg2v); a.Wak = LW(l, DD_BL_Wak); a.Wav = LW(l, DD_BL_Wav); a.Wakp = LW(l, DD_BL_Wakp); a.Wavp = LW(l, DD_BL_Wavp);
     a.lnk = LW(l, DD_BL_lnk); a.lnv = LW(l, DD_BL_lnv);
-    a.W2k = LW(l, DD_BL_W2k); a.W2vT = LW(l, DD_BL_W2vT); a.b2v = LW(l, DD_BL_b2v); a.out = w.hb;
+    a.W2k = LW(l, DD_BL_W2k); a.W2vT = LW(l, DD_BL_W2vT); a.W2v = LW(l, DD_BL_W2v); a.b2v = LW(l, DD_BL_b2v); a.out = w.hb;
     a.Rk = w.Rk; a.Rv = w.Rv;
     DD_TRYP(DD_PROF_ATTN_BL, attn_dispatch(M_BL, a, st));
     // ---- h += lin_node(A)
@@ -296,7 +296,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
     memset(&a, 0, sizeof(a));
     a.B = B; a.NP = NP; a.NL = NL; a.K = K; a.x = xcur; a.nbr = w.nbr; a.ew = w.ew;
     a.kd = w.PL; a.vd = w.PL + 128; a.ld_kd = a.ld_vd = 1024; a.ks = w.P; a.vs = w.P + 128; a.ld_ks = a.ld_vs = 256;
-    a.q = w.ql; a.Ak = LW(l, DD_PE_Ak); a.Av = LW(l, DD_PE_Av); a.lnk = LW(l, DD_PE_lnk); a.lnv = LW(l, DD_PE_lnv);
+    a.q = w.ql; a.Ak = LW(l, DD_PE_Ak); a.Av = LW(l, DD_PE_Av); a.Akp = LW(l, DD_PE_Akp); a.Avp = LW(l, DD_PE_Avp); a.lnk = LW(l, DD_PE_lnk); a.lnv = LW(l, DD_PE_lnv);
     a.W2k = LW(l, DD_PE_W2k); a.W2v16 = LW(l, DD_PE_W2v); a.b2v16 = LW(l, DD_PE_b2v); a.out = w.dxe;
     DD_TRYP(DD_PROF_ATTN_PE, attn_dispatch(M_PE, a, st));
     // ---- pos_layer_with_bond + coordinate update (ligand rows only: mask_ligand_atom)

@@ -28,7 +28,7 @@ namespace v2 {
 
 constexpr int WPITCH = 132;                    // pitch of the head-permuted W2k image
 constexpr int WB_FLOATS = 128 * WPITCH;        // 67.6 KB weight buffer (W2k -> Gaussian tables -> W2v^T)
-constexpr int TYPE_STRIDE = 21 * 128 + 16;     // Gaussian table stride per edge type (+64 B: different bank slot)
+constexpr int TABP = 24 * 128;                 // Gaussian table stride per edge type (21 rows + 3 zero rows)
 constexpr int ZS_PITCH = 80;                   // half tile [16 members][64 channels] + pad
 constexpr int ZS_FLOATS = 16 * ZS_PITCH;
 
@@ -69,25 +69,6 @@ __device__ __forceinline__ void stage_w2k_permuted(float* WB, const float* __res
     if (i < 4096) {
       const int r = i >> 5, c4 = (i & 31) * 4;
       *reinterpret_cast<float4*>(&WB[((r & 7) * 16 + (r >> 3)) * WPITCH + c4]) = tmp[k];
-    }
-  }
-}
-template <int NT>
-__device__ __forceinline__ void stage_gauss_tables(float* WB, const float* __restrict__ A) {
-  constexpr int N4 = 4 * 21 * 32;
-  constexpr int PER = (N4 + NT - 1) / NT;
-  float4 tmp[PER];
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    const int i = threadIdx.x + k * NT;
-    if (i < N4) tmp[k] = reinterpret_cast<const float4*>(A)[i];
-  }
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    const int i = threadIdx.x + k * NT;
-    if (i < N4) {
-      const int ty = i / (21 * 32), rem = i - ty * (21 * 32);
-      *reinterpret_cast<float4*>(&WB[ty * TYPE_STRIDE + rem * 4]) = tmp[k];
     }
   }
 }
@@ -160,8 +141,8 @@ struct Lds {
   static constexpr bool POS = (MODE == M_PE || MODE == M_PB);
   static constexpr bool TRIP = (MODE == M_BL);
   static constexpr int LNP = WB_FLOATS;                       // [4][128]  gamma_k, beta_k, gamma_v, beta_v
-  static constexpr int WAO = LNP + 512;                       // [2][13][128] angle weights (BL)
-  static constexpr int SCR0 = WAO + (TRIP ? 2 * 13 * 128 : 0);
+  static constexpr int WAO = LNP + 512;                       // [2][16][128] angle weights (BL), MFMA A-operand layout
+  static constexpr int SCR0 = WAO + (TRIP ? 2 * 16 * 128 : 0);
   static constexpr int FE_SZ = KNN ? 16 * 20 : (TRIP ? MAXT * 256 : 0);
   static constexpr int FE = POS ? 0 : ZS_FLOATS;              // feature scratch sits behind the transpose tile
   static constexpr int UNI = POS ? FE_SZ : (ZS_FLOATS + FE_SZ > 16 * 132 ? ZS_FLOATS + FE_SZ : 16 * 132);
@@ -216,9 +197,9 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
     reinterpret_cast<float4*>(smem + LNP + 256)[threadIdx.x] = reinterpret_cast<const float4*>(a.lnv)[threadIdx.x];
   }
   if (TRIP) {
-    for (int i = threadIdx.x; i < 13 * 32; i += NT) {
-      reinterpret_cast<float4*>(smem + WAO)[i] = reinterpret_cast<const float4*>(a.Wak)[i];
-      reinterpret_cast<float4*>(smem + WAO + 13 * 128)[i] = reinterpret_cast<const float4*>(a.Wav)[i];
+    for (int i = threadIdx.x; i < 16 * 32; i += NT) {
+      reinterpret_cast<float4*>(smem + WAO)[i] = reinterpret_cast<const float4*>(a.Wakp)[i];
+      reinterpret_cast<float4*>(smem + WAO + 16 * 128)[i] = reinterpret_cast<const float4*>(a.Wavp)[i];
     }
   }
   __syncthreads();
@@ -283,39 +264,45 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
       const int j = a.nbr[nrow * a.K + mc];
       const float rx = xb[3 * node] - xb[3 * j], ry = xb[3 * node + 1] - xb[3 * j + 1], rz = xb[3 * node + 2] - xb[3 * j + 2];
       const float d = sqrtf(rx * rx + ry * ry + rz * rz);
-      const int ty = 2 * (j < a.NP ? 1 : 0) + (node < a.NP ? 1 : 0);
-      // the 4 lanes of a member compute 5 Gaussians each and share them through LDS
-      float* gt = scr + FE + 20 * mm;
-#pragma unroll
-      for (int i = 0; i < 5; ++i) gt[5 * cg + i] = gauss_feat(d, 5 * cg + i);
       const long drow = (MODE == M_NE) ? (long)seg : (long)b * a.NL + si;
       load_row(P, tab_d + drow * ld_d, cg);
       add_row(P, tab_s + (src_base + j) * ld_s, cg);
-      wave_lds_sync();
-      float G[20];
+      // Gaussian / type part on the matrix cores:  P^T[c][m] += sum_g A_ty[g][c] * F[m][g]  with F = 20 Gaussians and
+      // the per-type constant (24 rows, 6 k-steps).  Lane (mm, cg) supplies F[mm][4s+cg] and the table entries of row
+      // 4s+cg; the result lands directly in the P layout.  A tile whose members mix ligand and protein sources runs
+      // once per table with the other members' features zeroed.
+      float F[6];
 #pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        const float4 g4 = *reinterpret_cast<const float4*>(gt + 4 * i);
-        G[4 * i] = g4.x; G[4 * i + 1] = g4.y; G[4 * i + 2] = g4.z; G[4 * i + 3] = g4.w;
-      }
-      const float* tab = WB + ty * TYPE_STRIDE + 4 * cg;
+      for (int s = 0; s < 5; ++s) F[s] = gauss_feat(d, 4 * s + cg);
+      F[5] = cg == 0 ? 1.0f : 0.0f;
+      const bool hi = j < a.NP;
+      const float* tab = WB + (node < a.NP ? 1 : 0) * TABP + cg * 128 + mm * 4;
+      f32x4 acc[8];
 #pragma unroll
-      for (int nt = 0; nt < 8; ++nt) {
-        const float4 c = *reinterpret_cast<const float4*>(tab + 20 * 128 + 16 * nt);   // per-type constant column
-        P[4 * nt] += c.x; P[4 * nt + 1] += c.y; P[4 * nt + 2] += c.z; P[4 * nt + 3] += c.w;
-      }
+      for (int nt = 0; nt < 8; ++nt) acc[nt] = f32x4{P[4 * nt], P[4 * nt + 1], P[4 * nt + 2], P[4 * nt + 3]};
 #pragma unroll
-      for (int g = 0; g < 20; ++g) {
+      for (int half = 0; half < 2; ++half) {
+        const bool want = half ? hi : !hi;
+        if (__builtin_amdgcn_ballot_w64(want) != 0ull) {
+          const float* tb = tab + half * 2 * TABP;
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) {
-          const float4 w = *reinterpret_cast<const float4*>(tab + g * 128 + 16 * nt);
-          P[4 * nt] = fmaf(w.x, G[g], P[4 * nt]);
-          P[4 * nt + 1] = fmaf(w.y, G[g], P[4 * nt + 1]);
-          P[4 * nt + 2] = fmaf(w.z, G[g], P[4 * nt + 2]);
-          P[4 * nt + 3] = fmaf(w.w, G[g], P[4 * nt + 3]);
+          for (int s = 0; s < 6; ++s) {
+            const float f = want ? F[s] : 0.0f;
+            const float4 w0 = *reinterpret_cast<const float4*>(tb + s * 512);
+            const float4 w1 = *reinterpret_cast<const float4*>(tb + s * 512 + 64);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, f, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, f, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, f, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, f, acc[3], 0, 0, 0);
+            acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, f, acc[4], 0, 0, 0);
+            acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, f, acc[5], 0, 0, 0);
+            acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, f, acc[6], 0, 0, 0);
+            acc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, f, acc[7], 0, 0, 0);
+          }
         }
       }
-      wave_lds_sync();                                 // Gaussians consumed before the next tile rewrites them
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) { P[4 * nt] = acc[nt][0]; P[4 * nt + 1] = acc[nt][1]; P[4 * nt + 2] = acc[nt][2]; P[4 * nt + 3] = acc[nt][3]; }
     } else if (!TRIP) {
       const int j = mc + (mc >= si ? 1 : 0);
       load_row(P, tab_d + ((long)b * a.NL + si) * ld_d, cg);
@@ -329,28 +316,35 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
       const long kj = (long)b * Eb + sj * NLm1 + (k - (k > sj ? 1 : 0));
       load_row(P, (pass ? a.Rv : a.Rk) + (long)seg * 128, cg);
       add_row(P, tab_e + kj * ld_e, cg);
-      const float4* C4 = reinterpret_cast<const float4*>(scr + FE + 16 * mc);
-      const float4 c0 = C4[0], c1 = C4[1], c2 = C4[2], c3 = C4[3];
-      const float cc[13] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x};
-      const float* wa = smem + WAO + pass * 13 * 128 + 4 * cg;
+      // angle part on the matrix cores (13 codes padded to 16 = 4 k-steps), same scheme as the Gaussian tables
+      const float* cd = scr + FE + 16 * mc + cg;
+      const float* tb = smem + WAO + pass * 16 * 128 + cg * 128 + mm * 4;
+      f32x4 acc[8];
 #pragma unroll
-      for (int t13 = 0; t13 < 13; ++t13) {
+      for (int nt = 0; nt < 8; ++nt) acc[nt] = f32x4{P[4 * nt], P[4 * nt + 1], P[4 * nt + 2], P[4 * nt + 3]};
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) {
-          const float4 w = *reinterpret_cast<const float4*>(wa + t13 * 128 + 16 * nt);
-          P[4 * nt] = fmaf(w.x, cc[t13], P[4 * nt]);
-          P[4 * nt + 1] = fmaf(w.y, cc[t13], P[4 * nt + 1]);
-          P[4 * nt + 2] = fmaf(w.z, cc[t13], P[4 * nt + 2]);
-          P[4 * nt + 3] = fmaf(w.w, cc[t13], P[4 * nt + 3]);
-        }
+      for (int s = 0; s < 4; ++s) {
+        const float f = cd[4 * s];
+        const float4 w0 = *reinterpret_cast<const float4*>(tb + s * 512);
+        const float4 w1 = *reinterpret_cast<const float4*>(tb + s * 512 + 64);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, f, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, f, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, f, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, f, acc[3], 0, 0, 0);
+        acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, f, acc[4], 0, 0, 0);
+        acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, f, acc[5], 0, 0, 0);
+        acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, f, acc[6], 0, 0, 0);
+        acc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, f, acc[7], 0, 0, 0);
       }
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) { P[4 * nt] = acc[nt][0]; P[4 * nt + 1] = acc[nt][1]; P[4 * nt + 2] = acc[nt][2]; P[4 * nt + 3] = acc[nt][3]; }
     }
     ln_relu32(P, smem + LNP + pass * 256, cg);
   };
 
   // ---- Gaussian tables for pass 1 --------------------------------------------------------------------------
   __syncthreads();                                     // all waves done with W2k
-  if (KNN) stage_gauss_tables<NT>(WB, a.Ak);
+  if (KNN) stage_plain<NT>(WB, a.Akp, 4 * 24 * 32);
   __syncthreads();
   DD_STAMP(4);
 
@@ -409,7 +403,7 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
   DD_STAMP(6);
   if (KNN) {
     __syncthreads();
-    stage_gauss_tables<NT>(WB, a.Av);
+    stage_plain<NT>(WB, a.Avp, 4 * 24 * 32);
     __syncthreads();
   }
   DD_STAMP(7);

@@ -45,10 +45,13 @@ struct AttnArgs {
   int ld_kd, ld_ks, ld_vd, ld_vs, ld_ke, ld_ve;
   const float* q;          // [segments,128]
   const float *Ak, *Av;    // [4,21,128]
+  const float *Akp, *Avp;  // [4,24,128] MFMA A-operand layout (tiled kernel)
+  const float *Wakp, *Wavp; // [16,128] (BL, tiled kernel)
   const float *Wg2k, *Wg2v, *Wak, *Wav;
   const float *lnk, *lnv;  // [2,128]
   const float* W2k;        // [128,128]
   const float *W2vT, *b2v; // node modes
+  const float* W2v;        // node modes, tiled kernel: [128 o][128 c]
   const float *W2v16, *b2v16;  // pos modes
   float* out;
   const float* dxe;        // PB: result of PE

@@ -14,7 +14,8 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_long, 
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdecompdiff_hip.so")
+# DD_HIP_LIB selects another build of the same ABI (used by tools/ab_builds.py to compare two builds on one box)
+LIB_PATH = os.environ.get("DD_HIP_LIB") or os.path.join(_HERE, "lib", "libdecompdiff_hip.so")
 
 EXPORTED_SYMBOLS = [
     "dd_status_string", "dd_abi_version", "dd_workspace_floats", "dd_knn", "dd_edge_weights", "dd_gemm128",

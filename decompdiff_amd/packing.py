@@ -45,13 +45,16 @@ LAYER_SLOTS = [
     "NE_W2q", "NE_b2q",      # [128,128],[128]
     "NE_W2k",                # [128,128]  (d, c)
     "NE_W2vT", "NE_b2v",     # [128(c),128(o)], [128]
+    "NE_W2v",                # [128(o),128(c)] (tiled kernel: head-permuted LDS image)
+    "NE_Akp", "NE_Avp",      # [4,24,128] the tables as MFMA A operands: rows padded with zeros, channels permuted
     # --- node_layer_with_bond (NB) ---------------------------------------------------
-    "NB_lnk", "NB_lnv", "NB_lnq", "NB_W2q", "NB_b2q", "NB_W2k", "NB_W2vT", "NB_b2v",
+    "NB_lnk", "NB_lnv", "NB_lnq", "NB_W2q", "NB_b2q", "NB_W2k", "NB_W2vT", "NB_b2v", "NB_W2v",
     # --- bond_layer (BL) ---------------------------------------------------------------
     "BL_Wg1k", "BL_Wg1v",    # [20,128]  G(d_kj) columns
     "BL_Wg2k", "BL_Wg2v",    # [20,128]  G(d_ji) columns
     "BL_Wak", "BL_Wav",      # [13,128]  angle-code columns
-    "BL_lnk", "BL_lnv", "BL_lnq", "BL_W2q", "BL_b2q", "BL_W2k", "BL_W2vT", "BL_b2v",
+    "BL_lnk", "BL_lnv", "BL_lnq", "BL_W2q", "BL_b2q", "BL_W2k", "BL_W2vT", "BL_b2v", "BL_W2v",
+    "BL_Wakp", "BL_Wavp",    # [16,128] angle-code columns, MFMA A-operand layout
     # --- lin_node --------------------------------------------------------------------------
     "W_lin", "b_lin",
     # --- projections on the *new* h / h_bond -------------------------------------------
@@ -61,6 +64,7 @@ LAYER_SLOTS = [
     # --- pos_layer_with_edge (PE) ----------------------------------------------------------
     "PE_Ak", "PE_Av", "PE_lnk", "PE_lnv", "PE_lnq", "PE_W2q", "PE_b2q", "PE_W2k",
     "PE_W2v", "PE_b2v",      # [16,128],[16]
+    "PE_Akp", "PE_Avp",      # [4,24,128]
     # --- pos_layer_with_bond (PB) ----------------------------------------------------------
     "PB_lnk", "PB_lnv", "PB_lnq", "PB_W2q", "PB_b2q", "PB_W2k", "PB_W2v", "PB_b2v",
 ]
@@ -89,6 +93,18 @@ def _gauss_table(W1):
     return t
 
 
+# channel order of the MFMA A-operand tables: position half*64 + mm*4 + r holds channel 16*(4*half + r) + mm,
+# so lane (mm, cg) of the tiled attention kernel reads its 8 channel tiles of row g with two 16-byte LDS reads
+_MFMA_PERM = torch.tensor([16 * (4 * half + r) + mm for half in range(2) for mm in range(16) for r in range(4)])
+
+
+def _mfma_rows(W, rows):
+    """[..., g, 128] -> [..., rows, 128]: zero rows appended (k padded to a multiple of 4), channels permuted."""
+    out = torch.zeros(*W.shape[:-2], rows, H, dtype=W.dtype)
+    out[..., :W.shape[-2], :] = W[..., _MFMA_PERM]
+    return out
+
+
 def pack_layer(sd: Dict[str, torch.Tensor], prefix: str) -> "OrderedDict[str, torch.Tensor]":
     z = lambda n: torch.zeros(n)
     out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
@@ -115,10 +131,13 @@ def pack_layer(sd: Dict[str, torch.Tensor], prefix: str) -> "OrderedDict[str, to
     out["NE_W2q"], out["NE_b2q"] = q[3], q[4]
     out["NE_W2k"] = k[3]
     out["NE_W2vT"], out["NE_b2v"] = v[3].t().contiguous(), v[4]
+    out["NE_W2v"] = v[3]
+    out["NE_Akp"], out["NE_Avp"] = _mfma_rows(out["NE_Ak"], 24), _mfma_rows(out["NE_Av"], 24)
 
     out["NB_lnk"], out["NB_lnv"], out["NB_lnq"] = nk[2], nv[2], nq[2]
     out["NB_W2q"], out["NB_b2q"], out["NB_W2k"] = nq[3], nq[4], nk[3]
     out["NB_W2vT"], out["NB_b2v"] = nv[3].t().contiguous(), nv[4]
+    out["NB_W2v"] = nv[3]
 
     out["BL_Wg1k"], out["BL_Wg1v"] = bk[0][:, 128:148].t().contiguous(), bv[0][:, 128:148].t().contiguous()
     out["BL_Wg2k"], out["BL_Wg2v"] = bk[0][:, 148:168].t().contiguous(), bv[0][:, 148:168].t().contiguous()
@@ -126,6 +145,8 @@ def pack_layer(sd: Dict[str, torch.Tensor], prefix: str) -> "OrderedDict[str, to
     out["BL_lnk"], out["BL_lnv"], out["BL_lnq"] = bk[2], bv[2], bq[2]
     out["BL_W2q"], out["BL_b2q"], out["BL_W2k"] = bq[3], bq[4], bk[3]
     out["BL_W2vT"], out["BL_b2v"] = bv[3].t().contiguous(), bv[4]
+    out["BL_W2v"] = bv[3]
+    out["BL_Wakp"], out["BL_Wavp"] = _mfma_rows(out["BL_Wak"], 16), _mfma_rows(out["BL_Wav"], 16)
 
     out["W_lin"], out["b_lin"] = sd[f"{prefix}.lin_node.weight"], sd[f"{prefix}.lin_node.bias"]
 
@@ -143,6 +164,7 @@ def pack_layer(sd: Dict[str, torch.Tensor], prefix: str) -> "OrderedDict[str, to
     out["PE_lnk"], out["PE_lnv"], out["PE_lnq"] = xk[2], xv[2], xq[2]
     out["PE_W2q"], out["PE_b2q"], out["PE_W2k"] = xq[3], xq[4], xk[3]
     out["PE_W2v"], out["PE_b2v"] = xv[3], xv[4]
+    out["PE_Akp"], out["PE_Avp"] = _mfma_rows(out["PE_Ak"], 24), _mfma_rows(out["PE_Av"], 24)
     out["PB_lnk"], out["PB_lnv"], out["PB_lnq"] = yk[2], yv[2], yq[2]
     out["PB_W2q"], out["PB_b2q"], out["PB_W2k"] = yq[3], yq[4], yk[3]
     out["PB_W2v"], out["PB_b2v"] = yv[3], yv[4]

@@ -1,0 +1,33 @@
+#!/usr/bin/env python
+"""Compare two builds of the library on ONE box: alternating subprocesses, each timing the shipped workload.
+usage: python tools/ab_builds.py libA.so libB.so [rounds]   (paths relative to the repo root)
+
+Note: packed-weight slot layouts must be compatible with the Python package for both builds.
+"""
+import os, subprocess, sys, statistics
+CHILD = r'''
+import sys, time, torch
+sys.path.insert(0, ".")
+from decompdiff_amd import DecompScorePosNet3D, shipped_config, synth
+dev = torch.device("cuda:0"); cfg = shipped_config()
+m = DecompScorePosNet3D(cfg, 29, 10, 8); sd = m.state_dict(); sd.update(synth.synthetic_state_dict(cfg, 0)); m.load_state_dict(sd); m = m.to(dev)
+pocket = synth.make_pocket_small(0); torch.manual_seed(0)
+b = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synth.build_sampling_batch(pocket, 8).items()}
+def run(steps):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    m.sample_diffusion(num_steps=steps, center_pos_mode="protein", keep_traj=True, use_graph=True, **b)
+    torch.cuda.synchronize(); return 1e3 * (time.perf_counter() - t0) / steps
+run(20)
+print(min(run(200) for _ in range(3)))
+'''
+libs = sys.argv[1:3]; rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+res = {l: [] for l in libs}
+for r in range(rounds):
+    for l in libs:
+        env = dict(os.environ, DD_HIP_LIB=os.path.abspath(l))
+        out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
+        if out.returncode != 0:
+            print(l, "FAILED", out.stderr[-800:]); continue
+        res[l].append(float(out.stdout.strip().splitlines()[-1]))
+for l in libs:
+    if res[l]: print(f"{l:50s} median {statistics.median(res[l]):.4f} ms/step  all {[round(x, 4) for x in res[l]]}")
