@@ -18,6 +18,8 @@
 //
 // This removes the per-member 16-value cross-lane reductions and broadcasts of v1 (its dominant
 // instruction count) and moves ~4k MACs per member from the VALU to the otherwise idle MFMA pipe.
+#include <type_traits>
+
 #include "dd_kernels.hpp"
 
 namespace dd {
@@ -29,25 +31,6 @@ namespace v2 {
 constexpr int WPITCH = 132;                    // pitch of the head-permuted W2k image
 constexpr int WB_FLOATS = 128 * WPITCH;        // 67.6 KB weight buffer (W2k -> Gaussian tables -> W2v^T)
 constexpr int TABP = 24 * 128;                 // Gaussian table stride per edge type (21 rows + 3 zero rows)
-constexpr int ZS_PITCH = 80;                   // half tile [16 members][64 channels] + pad
-constexpr int ZS_FLOATS = 16 * ZS_PITCH;
-
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__device__ __forceinline__ void swap16_pair(float& a, float& b) {
-  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  const unsigned r0 = r[0], r1 = r[1];
-  a = __uint_as_float(r0); b = __uint_as_float(r1);
-}
-__device__ __forceinline__ void swap32_pair(float& a, float& b) {
-  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  const unsigned r0 = r[0], r1 = r[1];
-  a = __uint_as_float(r0); b = __uint_as_float(r1);
-}
 // sum / max over the 4 lanes {l, l^16, l^32, l^48}
 __device__ __forceinline__ float quad_sum(float v) { v = swap16_sum(v, v); return swap32_sum(v, v); }
 __device__ __forceinline__ float quad_max(float v) { return swap32_max(swap16_max(v)); }
@@ -135,24 +118,70 @@ __device__ __forceinline__ f32x4 mfma_rows(const float (&z)[32], const float (&B
   return a0 + a1;
 }
 
-template <int MODE, int MAXT, int NW>
+// sum over the 16 lanes of a DPP row (lanes sharing lane >> 4)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  return v;
+}
+
+// LayerNorm(128)+ReLU in the member-major ("T") layout: Tz[4*nt + r] = row of member 4*cg + r, channel 16*nt + mm.
+__device__ __forceinline__ void ln_relu_T(float (&Tz)[32], const float* __restrict__ ln /*LDS*/, int mm) {
+  float g[8], be[8];
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) { g[nt] = ln[16 * nt + mm]; be[nt] = ln[128 + 16 * nt + mm]; }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) s += Tz[4 * nt + r];
+    const float mean = row16_sum(s) * (1.0f / 128.0f);
+    float v = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) { Tz[4 * nt + r] -= mean; v = fmaf(Tz[4 * nt + r], Tz[4 * nt + r], v); }
+    const float rstd = __builtin_amdgcn_rsqf(row16_sum(v) * (1.0f / 128.0f) + 1e-5f);
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) Tz[4 * nt + r] = fmaxf(fmaf(Tz[4 * nt + r] * rstd, g[nt], be[nt]), 0.f);
+  }
+}
+
+// angular code g (0..15) of angle th: [th, sin{1,2,3}th, sin{1,1/2,1/3}th, cos{1,2,3}th, cos{1,1/2,1/3}th, 0,0,0]
+// (AngularEncoding, models/common.py:38-53: freq 1,2,3 then 1,1/2,1/3)
+__device__ __forceinline__ float angle_code(float th, int g) {
+  const int gi = g > 6 ? g - 6 : g;
+  const float mul = (gi == 2) ? 2.0f : (gi == 3 ? 3.0f : (gi == 5 ? 0.5f : (gi == 6 ? (1.0f / 3.0f) : 1.0f)));
+  float sn, cs;
+  sincosf(th * mul, &sn, &cs);
+  return g == 0 ? th : (g > 12 ? 0.f : (g <= 6 ? sn : cs));
+}
+
+// first-layer table part on the matrix cores: one k-step (4 table rows) for the 8 channel tiles.
+//   TR = false: acc[nt][r] = P[member mm][channel 16nt+4cg+r]   (A = table, B = feature)
+//   TR = true : acc[nt][r] = P[member 4cg+r][channel 16nt+mm]   (A = feature, B = table)
+template <bool TR>
+__device__ __forceinline__ void mfma_table_step(f32x4 (&acc)[8], const float* __restrict__ tb /*LDS row 4s+cg, + mm*4*/, float f) {
+  const float4 w0 = *reinterpret_cast<const float4*>(tb);
+  const float4 w1 = *reinterpret_cast<const float4*>(tb + 64);
+  const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt)
+    acc[nt] = TR ? __builtin_amdgcn_mfma_f32_16x16x4f32(f, w[nt], acc[nt], 0, 0, 0)
+                 : __builtin_amdgcn_mfma_f32_16x16x4f32(w[nt], f, acc[nt], 0, 0, 0);
+}
+
+template <int MODE>
 struct Lds {
-  static constexpr bool KNN = (MODE == M_NE || MODE == M_PE);
-  static constexpr bool POS = (MODE == M_PE || MODE == M_PB);
   static constexpr bool TRIP = (MODE == M_BL);
   static constexpr int LNP = WB_FLOATS;                       // [4][128]  gamma_k, beta_k, gamma_v, beta_v
-  static constexpr int WAO = LNP + 512;                       // [2][16][128] angle weights (BL), MFMA A-operand layout
-  static constexpr int SCR0 = WAO + (TRIP ? 2 * 16 * 128 : 0);
-  static constexpr int FE_SZ = KNN ? 16 * 20 : (TRIP ? MAXT * 256 : 0);
-  static constexpr int FE = POS ? 0 : ZS_FLOATS;              // feature scratch sits behind the transpose tile
-  static constexpr int UNI = POS ? FE_SZ : (ZS_FLOATS + FE_SZ > 16 * 132 ? ZS_FLOATS + FE_SZ : 16 * 132);
-  static constexpr int SS = UNI;                              // [16] sum_m alpha*w per head
-  static constexpr int SCRW = UNI + 16;
-  static constexpr int TOTAL = SCR0 + NW * SCRW;
+  static constexpr int WAO = LNP + 512;                       // [2][16][128] angle weights (BL), MFMA operand layout
+  static constexpr int TOTAL = WAO + (TRIP ? 2 * 16 * 128 : 0);
 };
 
 // Body of one workgroup (NW waves = NW segments).  `block` is the workgroup index within this mode's range and
-// `smem` the workgroup's LDS (>= Lds<MODE,MAXT,NW>::TOTAL floats), so several modes can share one launch.
+// `smem` the workgroup's LDS (>= Lds<MODE>::TOTAL floats), so several modes can share one launch.  All per-wave
+// state lives in registers; LDS only holds the (read-only) weight images shared by the workgroup.
 template <int MODE, int MAXT, int NW>
 __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, float* smem) {
   constexpr bool KNN = (MODE == M_NE || MODE == M_PE);
@@ -160,13 +189,11 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
   constexpr bool TRIP = (MODE == M_BL);
   constexpr bool BOND = (MODE == M_NB || MODE == M_PB);
   constexpr int NT = NW * 64;
-  using L = Lds<MODE, MAXT, NW>;
-  constexpr int LNP = L::LNP, WAO = L::WAO, SCR0 = L::SCR0, FE = L::FE, SS = L::SS, SCRW = L::SCRW;
-  (void)BOND;
+  using L = Lds<MODE>;
+  constexpr int LNP = L::LNP, WAO = L::WAO;
   float* WB = smem;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int mm = lane & 15, cg = lane >> 4;            // member slot / channel group; also (head, row-group)
-  float* scr = smem + SCR0 + wave * SCRW;
 
   const int N = a.NP + a.NL, NLm1 = a.NL - 1, Eb = a.NL * NLm1;
   const int nseg = (MODE == M_NE) ? a.B * N : (TRIP ? a.B * Eb : a.B * a.NL);
@@ -189,6 +216,26 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
   const long nrow = (long)b * N + node;                // kNN list row (KNN modes)
   const long src_base = KNN ? (long)b * N : (long)b * a.NL;
   const long erow0 = (long)seg * NLm1;
+  const long drow = (MODE == M_NE) ? (long)seg : (long)b * a.NL + si;
+  const int tlo = si < sj ? si : sj, thi = si < sj ? sj : si;
+  auto trip_k = [&](int mc) { int k = mc; if (k >= tlo) ++k; if (k >= thi) ++k; return k; };   // third atom of member mc
+
+  // kNN: neighbour and distance of member 16t + mm (issued first: two dependent global round trips)
+  int jm[MAXT];
+  float dm[MAXT];
+  if (KNN && active) {
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int m = 16 * t + mm;
+      jm[t] = a.nbr[nrow * a.K + (m < M ? m : M - 1)];
+    }
+    const float cx = xb[3 * node], cy = xb[3 * node + 1], cz = xb[3 * node + 2];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const float rx = cx - xb[3 * jm[t]], ry = cy - xb[3 * jm[t] + 1], rz = cz - xb[3 * jm[t] + 2];
+      dm[t] = sqrtf(rx * rx + ry * ry + rz * rz);
+    }
+  }
 
   // ---- stage: W2k (head-permuted), LayerNorm parameters, angle weights -----------------------------------
   stage_w2k_permuted<NT>(WB, a.W2k);
@@ -230,30 +277,53 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
   }
   DD_STAMP(2);
 
-  // ---- BL: angle codes of all members (lane m computes member m), kept in LDS ---------------------------------
-  if (TRIP && active && lane < M) {
-    const int lo = si < sj ? si : sj, hi = si < sj ? sj : si;
-    int k = lane;
-    if (k >= lo) ++k;
-    if (k >= hi) ++k;
+  // ---- BL: angle codes of member 16t + mm, rows 4s + cg, kept in registers (MFMA feature operand) ------------
+  float cod[MAXT][4];
+  if (TRIP && active) {
     const float ax = xl[3 * sj] - xl[3 * si], ay = xl[3 * sj + 1] - xl[3 * si + 1], az = xl[3 * sj + 2] - xl[3 * si + 2];
-    const float bx = xl[3 * k] - xl[3 * si], by = xl[3 * k + 1] - xl[3 * si + 1], bz = xl[3 * k + 2] - xl[3 * si + 2];
-    const float dot = ax * bx + ay * by + az * bz;
-    const float cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
-    const float th = atan2f(sqrtf(cx * cx + cy * cy + cz * cz), dot);
-    float* c = scr + FE + 16 * lane;
-    c[0] = th;
-    c[1] = sinf(th);            c[7] = cosf(th);
-    c[2] = sinf(th * 2.0f);     c[8] = cosf(th * 2.0f);
-    c[3] = sinf(th * 3.0f);     c[9] = cosf(th * 3.0f);
-    c[4] = c[1];                c[10] = c[7];
-    c[5] = sinf(th * 0.5f);     c[11] = cosf(th * 0.5f);
-    c[6] = sinf(th * (1.0f / 3.0f)); c[12] = cosf(th * (1.0f / 3.0f));
-    c[13] = 0.f; c[14] = 0.f; c[15] = 0.f;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int m = 16 * t + mm;
+      const int k = trip_k(m < M ? m : M - 1);
+      const float bx = xl[3 * k] - xl[3 * si], by = xl[3 * k + 1] - xl[3 * si + 1], bz = xl[3 * k + 2] - xl[3 * si + 2];
+      const float dot = ax * bx + ay * by + az * bz;
+      const float cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+      const float th = atan2f(sqrtf(cx * cx + cy * cy + cz * cz), dot);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) cod[t][s] = angle_code(th, 4 * s + cg);
+    }
   }
   DD_STAMP(3);
 
-  // pre-activation of tile t for the k (pass = 0) or v (pass = 1) MLP, in the lane layout described above
+  // first-layer table part of tile t (features of member 16t + mm), either orientation
+  auto table_part = [&](int t, int pass, f32x4 (&acc)[8], auto tr) {
+    constexpr bool TR = decltype(tr)::value;
+    if (KNN) {
+      // Gaussian / type tables: F = 20 Gaussians + the per-type constant (24 rows = 6 k-steps).  A tile whose members
+      // mix ligand and protein sources runs once per table with the other members' features zeroed.
+      float F[6];
+#pragma unroll
+      for (int s = 0; s < 5; ++s) F[s] = gauss_feat(dm[t], 4 * s + cg);
+      F[5] = cg == 0 ? 1.0f : 0.0f;
+      const bool hi = jm[t] < a.NP;
+      const float* tab = WB + (node < a.NP ? 1 : 0) * TABP + cg * 128 + mm * 4;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const bool want = half ? hi : !hi;
+        if (__builtin_amdgcn_ballot_w64(want) != 0ull) {
+#pragma unroll
+          for (int s = 0; s < 6; ++s) mfma_table_step<TR>(acc, tab + half * 2 * TABP + s * 512, want ? F[s] : 0.0f);
+        }
+      }
+    } else if (TRIP) {
+      const float* tb = smem + WAO + pass * 16 * 128 + cg * 128 + mm * 4;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) mfma_table_step<TR>(acc, tb + s * 512, cod[t][s]);
+    }
+  };
+
+  // pre-activation of tile t for the k (pass = 0) or v (pass = 1) MLP: lane (mm, cg) holds member 16t + mm,
+  // channels 16nt + 4cg + r  (P[4nt + r])
   auto build_pre = [&](int t, int pass, float (&P)[32]) {
     const int m = 16 * t + mm;
     const int mc = m < M ? m : M - 1;                  // clipped: out-of-range slots replay the last member
@@ -261,85 +331,73 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
     const float* tab_s = pass ? a.vs : a.ks;  const int ld_s = pass ? a.ld_vs : a.ld_ks;
     const float* tab_e = pass ? a.ve : a.ke;  const int ld_e = pass ? a.ld_ve : a.ld_ke;
     if (KNN) {
-      const int j = a.nbr[nrow * a.K + mc];
-      const float rx = xb[3 * node] - xb[3 * j], ry = xb[3 * node + 1] - xb[3 * j + 1], rz = xb[3 * node + 2] - xb[3 * j + 2];
-      const float d = sqrtf(rx * rx + ry * ry + rz * rz);
-      const long drow = (MODE == M_NE) ? (long)seg : (long)b * a.NL + si;
       load_row(P, tab_d + drow * ld_d, cg);
-      add_row(P, tab_s + (src_base + j) * ld_s, cg);
-      // Gaussian / type part on the matrix cores:  P^T[c][m] += sum_g A_ty[g][c] * F[m][g]  with F = 20 Gaussians and
-      // the per-type constant (24 rows, 6 k-steps).  Lane (mm, cg) supplies F[mm][4s+cg] and the table entries of row
-      // 4s+cg; the result lands directly in the P layout.  A tile whose members mix ligand and protein sources runs
-      // once per table with the other members' features zeroed.
-      float F[6];
-#pragma unroll
-      for (int s = 0; s < 5; ++s) F[s] = gauss_feat(d, 4 * s + cg);
-      F[5] = cg == 0 ? 1.0f : 0.0f;
-      const bool hi = j < a.NP;
-      const float* tab = WB + (node < a.NP ? 1 : 0) * TABP + cg * 128 + mm * 4;
-      f32x4 acc[8];
-#pragma unroll
-      for (int nt = 0; nt < 8; ++nt) acc[nt] = f32x4{P[4 * nt], P[4 * nt + 1], P[4 * nt + 2], P[4 * nt + 3]};
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const bool want = half ? hi : !hi;
-        if (__builtin_amdgcn_ballot_w64(want) != 0ull) {
-          const float* tb = tab + half * 2 * TABP;
-#pragma unroll
-          for (int s = 0; s < 6; ++s) {
-            const float f = want ? F[s] : 0.0f;
-            const float4 w0 = *reinterpret_cast<const float4*>(tb + s * 512);
-            const float4 w1 = *reinterpret_cast<const float4*>(tb + s * 512 + 64);
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, f, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, f, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, f, acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, f, acc[3], 0, 0, 0);
-            acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, f, acc[4], 0, 0, 0);
-            acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, f, acc[5], 0, 0, 0);
-            acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, f, acc[6], 0, 0, 0);
-            acc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, f, acc[7], 0, 0, 0);
-          }
-        }
-      }
-#pragma unroll
-      for (int nt = 0; nt < 8; ++nt) { P[4 * nt] = acc[nt][0]; P[4 * nt + 1] = acc[nt][1]; P[4 * nt + 2] = acc[nt][2]; P[4 * nt + 3] = acc[nt][3]; }
+      add_row(P, tab_s + (src_base + jm[t]) * ld_s, cg);
     } else if (!TRIP) {
       const int j = mc + (mc >= si ? 1 : 0);
-      load_row(P, tab_d + ((long)b * a.NL + si) * ld_d, cg);
+      load_row(P, tab_d + drow * ld_d, cg);
       add_row(P, tab_s + (src_base + j) * ld_s, cg);
       add_row(P, tab_e + (erow0 + mc) * ld_e, cg);
     } else {
-      const int lo = si < sj ? si : sj, hi = si < sj ? sj : si;
-      int k = mc;
-      if (k >= lo) ++k;
-      if (k >= hi) ++k;
+      const int k = trip_k(mc);
       const long kj = (long)b * Eb + sj * NLm1 + (k - (k > sj ? 1 : 0));
       load_row(P, (pass ? a.Rv : a.Rk) + (long)seg * 128, cg);
       add_row(P, tab_e + kj * ld_e, cg);
-      // angle part on the matrix cores (13 codes padded to 16 = 4 k-steps), same scheme as the Gaussian tables
-      const float* cd = scr + FE + 16 * mc + cg;
-      const float* tb = smem + WAO + pass * 16 * 128 + cg * 128 + mm * 4;
+    }
+    if (KNN || TRIP) {
       f32x4 acc[8];
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) acc[nt] = f32x4{P[4 * nt], P[4 * nt + 1], P[4 * nt + 2], P[4 * nt + 3]};
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const float f = cd[4 * s];
-        const float4 w0 = *reinterpret_cast<const float4*>(tb + s * 512);
-        const float4 w1 = *reinterpret_cast<const float4*>(tb + s * 512 + 64);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, f, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, f, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, f, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, f, acc[3], 0, 0, 0);
-        acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, f, acc[4], 0, 0, 0);
-        acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, f, acc[5], 0, 0, 0);
-        acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, f, acc[6], 0, 0, 0);
-        acc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, f, acc[7], 0, 0, 0);
-      }
+      table_part(t, pass, acc, std::false_type{});
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) { P[4 * nt] = acc[nt][0]; P[4 * nt + 1] = acc[nt][1]; P[4 * nt + 2] = acc[nt][2]; P[4 * nt + 3] = acc[nt][3]; }
     }
     ln_relu32(P, smem + LNP + pass * 256, cg);
+  };
+
+  // v-MLP hidden activation of tile t in the member-major layout the aggregation consumes without a transpose:
+  // lane (mm, cg) holds members 16t + 4cg + r (r < 4), channels 16nt + mm  (Tz[4nt + r])
+  auto build_T = [&](int t, float (&Tz)[32]) {
+    const float* rs[4];
+    const float* re[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = 16 * t + 4 * cg + r;
+      const int mc = m < M ? m : M - 1;
+      re[r] = nullptr;
+      if (KNN) {
+        const int j = a.nbr[nrow * a.K + mc];
+        rs[r] = a.vs + (src_base + j) * a.ld_vs + mm;
+      } else if (!TRIP) {
+        const int j = mc + (mc >= si ? 1 : 0);
+        rs[r] = a.vs + (src_base + j) * a.ld_vs + mm;
+        re[r] = a.ve + (erow0 + mc) * a.ld_ve + mm;
+      } else {
+        const int k = trip_k(mc);
+        rs[r] = a.ve + ((long)b * Eb + sj * NLm1 + (k - (k > sj ? 1 : 0))) * a.ld_ve + mm;
+      }
+    }
+    const float* rc = TRIP ? a.Rv + (long)seg * 128 + mm : a.vd + drow * a.ld_vd + mm;
+    float c[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) c[nt] = rc[16 * nt];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        float v = c[nt] + rs[r][16 * nt];
+        if (BOND) v += re[r][16 * nt];
+        Tz[4 * nt + r] = v;
+      }
+    if (KNN || TRIP) {
+      f32x4 acc[8];
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) acc[nt] = f32x4{Tz[4 * nt], Tz[4 * nt + 1], Tz[4 * nt + 2], Tz[4 * nt + 3]};
+      table_part(t, 1, acc, std::true_type{});
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) { Tz[4 * nt] = acc[nt][0]; Tz[4 * nt + 1] = acc[nt][1]; Tz[4 * nt + 2] = acc[nt][2]; Tz[4 * nt + 3] = acc[nt][3]; }
+    }
+    ln_relu_T(Tz, smem + LNP + 256, mm);
   };
 
   // ---- Gaussian tables for pass 1 --------------------------------------------------------------------------
@@ -352,7 +410,6 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
   f32x4 S[MAXT];
   float ssum = 0.f;                                    // sum_m alpha*w for head mm
   if (active) {
-    if (TRIP) wave_lds_sync();                         // angle codes visible
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
       if (t < T) {
@@ -458,6 +515,9 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
     return;
   }
 
+  // aggregation  Z[nt][r] = Z~[head mm][channel 16nt + 4cg + r] = sum_m aw[m][mm] * z_v[m][c]:  A = z_v in the
+  // member-major layout (row = channel 16nt + mm, k = member 16t + 4cg + ks), B = alpha*w of the same member as
+  // produced by pass 1 (S[t][ks]) -- no transposes, no LDS
   f32x4 Z[8];
 #pragma unroll
   for (int nt = 0; nt < 8; ++nt) Z[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -465,30 +525,13 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
       if (t < T) {
-        // B operand: alpha*w transposed over the 4 lanes of a head so that lane kq holds members 4ks + kq
-        float w0 = S[t][0], w1 = S[t][1], w2 = S[t][2], w3 = S[t][3];
-        swap16_pair(w0, w1); swap16_pair(w2, w3);
-        swap32_pair(w0, w2); swap32_pair(w1, w3);
-        const float awT[4] = {w0, w1, w2, w3};
-        float P[32];
-        build_pre(t, 1, P);
+        float Tz[32];
+        build_T(t, Tz);
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<float4*>(scr + mm * ZS_PITCH + 16 * q + 4 * cg) =
-                make_float4(P[16 * half + 4 * q], P[16 * half + 4 * q + 1], P[16 * half + 4 * q + 2], P[16 * half + 4 * q + 3]);
-          wave_lds_sync();
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-              const float av = scr[(4 * ks + cg) * ZS_PITCH + 16 * q + mm];   // z_v[member 4ks+cg][channel 16(4half+q)+mm]
-              Z[4 * half + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, awT[ks], Z[4 * half + q], 0, 0, 0);
-            }
-          }
-          wave_lds_sync();
-        }
+          for (int nt = 0; nt < 8; ++nt)
+            Z[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Tz[4 * nt + ks], S[t][ks], Z[nt], 0, 0, 0);
       }
     }
   }
@@ -496,46 +539,41 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
 
   // ---- epilogue: out[o] = W2v[o,:] . Z~[head(o),:] + b2v[o] * sum_m alpha*w ----------------------------------
   __syncthreads();                                     // pass-2 tables dead
-  stage_plain<NT>(WB, a.W2vT, 4096);
-  if (active) {
-    wave_lds_sync();
-    if (cg == 0) scr[SS + mm] = ssum;
-    // Z[nt][r] = Z~[head mm][channel 16nt + 4cg + r]  ->  zt[h][c], pitch 132 (aliases the tile scratch)
-#pragma unroll
-    for (int nt = 0; nt < 8; ++nt)
-      *reinterpret_cast<float4*>(scr + mm * 132 + 16 * nt + 4 * cg) = make_float4(Z[nt][0], Z[nt][1], Z[nt][2], Z[nt][3]);
-  }
+  stage_w2k_permuted<NT>(WB, a.W2v);                   // row o = h*8 + j  ->  LDS row j*16 + h
   __syncthreads();
   DD_STAMP(9);
   if (active) {
-    const int hsel = lane >> 2;
-    float o0 = 0.f, o1 = 0.f;
-    const float* zrow = scr + hsel * 132;
-#pragma unroll 4
-    for (int c4 = 0; c4 < 32; ++c4) {
-      const float4 z = *reinterpret_cast<const float4*>(zrow + 4 * c4);
-      const float2 w0 = *reinterpret_cast<const float2*>(&WB[(4 * c4 + 0) * 128 + 2 * lane]);
-      const float2 w1 = *reinterpret_cast<const float2*>(&WB[(4 * c4 + 1) * 128 + 2 * lane]);
-      const float2 w2 = *reinterpret_cast<const float2*>(&WB[(4 * c4 + 2) * 128 + 2 * lane]);
-      const float2 w3 = *reinterpret_cast<const float2*>(&WB[(4 * c4 + 3) * 128 + 2 * lane]);
-      o0 = fmaf(w0.x, z.x, o0); o1 = fmaf(w0.y, z.x, o1);
-      o0 = fmaf(w1.x, z.y, o0); o1 = fmaf(w1.y, z.y, o1);
-      o0 = fmaf(w2.x, z.z, o0); o1 = fmaf(w2.y, z.z, o1);
-      o0 = fmaf(w3.x, z.w, o0); o1 = fmaf(w3.y, z.w, o1);
+    // lane (h = mm, cg): partial dot products over its 32 channels for the 8 outputs of head h
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float* wr = WB + (j * 16 + mm) * WPITCH + 4 * cg;
+      float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 8; nt += 2) {
+        const float4 w0 = *reinterpret_cast<const float4*>(wr + 16 * nt);
+        const float4 w1 = *reinterpret_cast<const float4*>(wr + 16 * nt + 16);
+        acc0 = fmaf(w0.x, Z[nt][0], acc0); acc0 = fmaf(w0.y, Z[nt][1], acc0);
+        acc0 = fmaf(w0.z, Z[nt][2], acc0); acc0 = fmaf(w0.w, Z[nt][3], acc0);
+        acc1 = fmaf(w1.x, Z[nt + 1][0], acc1); acc1 = fmaf(w1.y, Z[nt + 1][1], acc1);
+        acc1 = fmaf(w1.z, Z[nt + 1][2], acc1); acc1 = fmaf(w1.w, Z[nt + 1][3], acc1);
+      }
+      o[j] = acc0 + acc1;
     }
-    const float sh = scr[SS + hsel];
-    const float2 bb = *reinterpret_cast<const float2*>(a.b2v + 2 * lane);
-    o0 = fmaf(bb.x, sh, o0);
-    o1 = fmaf(bb.y, sh, o1);
-    float* dst;
+    // reduce over the 4 lanes of a head and scatter: lane cg ends with outputs j = cg and j = 4 + cg
+    const float p0 = swap16_sum(o[0], o[1]), p1 = swap16_sum(o[2], o[3]);
+    const float p2 = swap16_sum(o[4], o[5]), p3 = swap16_sum(o[6], o[7]);
+    float q0 = swap32_sum(p0, p1), q1 = swap32_sum(p2, p3);
+    q0 = fmaf(a.b2v[mm * 8 + cg], ssum, q0);
+    q1 = fmaf(a.b2v[mm * 8 + 4 + cg], ssum, q1);
     const bool nb_assign = (MODE == M_NB) && a.out_assign;
-    if (MODE == M_NB && !nb_assign) dst = a.out + ((long)b * N + node) * 128 + 2 * lane;
-    else dst = a.out + (long)seg * 128 + 2 * lane;
+    float* dst;
+    if (MODE == M_NB && !nb_assign) dst = a.out + ((long)b * N + node) * 128 + mm * 8 + cg;
+    else dst = a.out + (long)seg * 128 + mm * 8 + cg;
     if (MODE == M_NE || nb_assign) {
-      *reinterpret_cast<float2*>(dst) = make_float2(o0, o1);
+      dst[0] = q0; dst[4] = q1;
     } else {
-      const float2 old = *reinterpret_cast<const float2*>(dst);
-      *reinterpret_cast<float2*>(dst) = make_float2(old.x + o0, old.y + o1);
+      dst[0] += q0; dst[4] += q1;
     }
   }
   DD_STAMP(10);
@@ -544,31 +582,31 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
 
 template <int MODE, int MAXT, int NW>
 __global__ __launch_bounds__(NW * 64) void k_attn2(const AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[Lds<MODE, MAXT, NW>::TOTAL];
+  __shared__ __attribute__((aligned(16))) float smem[Lds<MODE>::TOTAL];
   attn2_body<MODE, MAXT, NW>(a, blockIdx.x, smem);
 }
 
 constexpr int imax(int a, int b) { return a > b ? a : b; }
 
 // The three sub-layers that read the *old* h / h_bond (NE, NB, BL) are independent: one launch, the longest
-// workgroups (BL) first, the 30-workgroup NB hidden in the tail instead of costing a launch of its own.
-template <int MAXT>
-__global__ __launch_bounds__(512) void k_attn2_node(const AttnArgs ne, const AttnArgs nb, const AttnArgs bl, int n_bl, int n_ne) {
-  constexpr int SZ = imax(imax(Lds<M_NE, 2, 8>::TOTAL, Lds<M_NB, MAXT, 8>::TOTAL), Lds<M_BL, MAXT, 8>::TOTAL);
+// workgroups (BL) first, the few NB workgroups hidden in the tail instead of costing a launch of their own.
+template <int MAXT, int NW>
+__global__ __launch_bounds__(NW * 64) void k_attn2_node(const AttnArgs ne, const AttnArgs nb, const AttnArgs bl, int n_bl, int n_ne) {
+  constexpr int SZ = imax(imax(Lds<M_NE>::TOTAL, Lds<M_NB>::TOTAL), Lds<M_BL>::TOTAL);
   __shared__ __attribute__((aligned(16))) float smem[SZ];
   const int blk = blockIdx.x;
-  if (blk < n_bl) attn2_body<M_BL, MAXT, 8>(bl, blk, smem);
-  else if (blk < n_bl + n_ne) attn2_body<M_NE, 2, 8>(ne, blk - n_bl, smem);
-  else attn2_body<M_NB, MAXT, 8>(nb, blk - n_bl - n_ne, smem);
+  if (blk < n_bl) attn2_body<M_BL, MAXT, NW>(bl, blk, smem);
+  else if (blk < n_bl + n_ne) attn2_body<M_NE, 2, NW>(ne, blk - n_bl, smem);
+  else attn2_body<M_NB, MAXT, NW>(nb, blk - n_bl - n_ne, smem);
 }
 // Same for the two coordinate sub-layers (both write their own delta buffer; x is updated afterwards).
-template <int MAXT>
-__global__ __launch_bounds__(512) void k_attn2_pos(const AttnArgs pe, const AttnArgs pb, int n_pe) {
-  constexpr int SZ = imax(Lds<M_PE, 2, 8>::TOTAL, Lds<M_PB, MAXT, 8>::TOTAL);
+template <int MAXT, int NW>
+__global__ __launch_bounds__(NW * 64) void k_attn2_pos(const AttnArgs pe, const AttnArgs pb, int n_pe) {
+  constexpr int SZ = imax(Lds<M_PE>::TOTAL, Lds<M_PB>::TOTAL);
   __shared__ __attribute__((aligned(16))) float smem[SZ];
   const int blk = blockIdx.x;
-  if (blk < n_pe) attn2_body<M_PE, 2, 8>(pe, blk, smem);
-  else attn2_body<M_PB, MAXT, 8>(pb, blk - n_pe, smem);
+  if (blk < n_pe) attn2_body<M_PE, 2, NW>(pe, blk, smem);
+  else attn2_body<M_PB, MAXT, NW>(pb, blk - n_pe, smem);
 }
 
 template <int MODE, int MAXT, int NW>
@@ -581,6 +619,8 @@ static int launch_mode(const AttnArgs& a, int nseg, hipStream_t st) {
 
 }  // namespace v2
 
+int g_attn_waves = 8;        // waves (= segments) per workgroup of the fused launches: 8, 12 or 16
+
 int launch_attn2(int mode, const AttnArgs& a, hipStream_t st) {
   using namespace v2;
   const int N = a.NP + a.NL;
@@ -591,27 +631,34 @@ int launch_attn2(int mode, const AttnArgs& a, hipStream_t st) {
     case M_NB: return small ? launch_mode<M_NB, 2, 8>(a, a.B * a.NL, st) : launch_mode<M_NB, 4, 8>(a, a.B * a.NL, st);
     case M_PB: return small ? launch_mode<M_PB, 2, 8>(a, a.B * a.NL, st) : launch_mode<M_PB, 4, 8>(a, a.B * a.NL, st);
     case M_BL: return small ? launch_mode<M_BL, 2, 8>(a, a.B * a.NL * (a.NL - 1), st)
-                            : launch_mode<M_BL, 4, 6>(a, a.B * a.NL * (a.NL - 1), st);
+                            : launch_mode<M_BL, 4, 8>(a, a.B * a.NL * (a.NL - 1), st);
   }
   return DD_ERR_BAD_ARG;
 }
 
-// Fused launches (ligands with <= 33 atoms: every mode uses 8-wave workgroups).  Returns DD_ERR_UNSUPPORTED_SHAPE
-// for larger ligands; the caller then falls back to one launch per sub-layer.
-int launch_attn2_node(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs& bl, hipStream_t st) {
+// Fused launches (ligands with <= 33 atoms).  Returns DD_ERR_UNSUPPORTED_SHAPE for larger ligands; the caller then
+// falls back to one launch per sub-layer.
+template <int NW>
+static int launch_node_nw(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs& bl, hipStream_t st) {
   using namespace v2;
-  if (ne.NL > 33) return DD_ERR_UNSUPPORTED_SHAPE;
   const int N = ne.NP + ne.NL;
-  const int n_ne = (ne.B * N + 7) / 8, n_nb = (ne.B * ne.NL + 7) / 8, n_bl = (ne.B * ne.NL * (ne.NL - 1) + 7) / 8;
-  hipLaunchKernelGGL((k_attn2_node<2>), dim3(n_bl + n_ne + n_nb), dim3(512), 0, st, ne, nb, bl, n_bl, n_ne);
+  const int n_ne = (ne.B * N + NW - 1) / NW, n_nb = (ne.B * ne.NL + NW - 1) / NW;
+  const int n_bl = (ne.B * ne.NL * (ne.NL - 1) + NW - 1) / NW;
+  hipLaunchKernelGGL((k_attn2_node<2, NW>), dim3(n_bl + n_ne + n_nb), dim3(NW * 64), 0, st, ne, nb, bl, n_bl, n_ne);
   DD_CHECK_LAUNCH();
   return DD_OK;
+}
+int launch_attn2_node(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs& bl, hipStream_t st) {
+  if (ne.NL > 33) return DD_ERR_UNSUPPORTED_SHAPE;
+  if (g_attn_waves == 16) return launch_node_nw<16>(ne, nb, bl, st);
+  if (g_attn_waves == 12) return launch_node_nw<12>(ne, nb, bl, st);
+  return launch_node_nw<8>(ne, nb, bl, st);
 }
 int launch_attn2_pos(const AttnArgs& pe, const AttnArgs& pb, hipStream_t st) {
   using namespace v2;
   if (pe.NL > 33) return DD_ERR_UNSUPPORTED_SHAPE;
   const int n = (pe.B * pe.NL + 7) / 8;
-  hipLaunchKernelGGL((k_attn2_pos<2>), dim3(2 * n), dim3(512), 0, st, pe, pb, n);
+  hipLaunchKernelGGL((k_attn2_pos<2, 8>), dim3(2 * n), dim3(512), 0, st, pe, pb, n);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
