@@ -12,6 +12,7 @@ namespace dd {
 struct Workspace {
   float *xa, *xb, *h, *hb, *ew, *P, *PL, *PB, *P2, *PL2, *PB2, *Ek, *Ev, *Rk, *Rv, *q1bl, *qn, *ql, *ql2, *qb, *A, *Anb, *dxe, *dxb, *ga, *gc;
   int32_t* nbr;
+  int32_t* counters;       // [64] work counters of the persistent attention workgroups (one per layer), zeroed per forward
   size_t total;
 };
 
@@ -49,6 +50,7 @@ static Workspace carve(float* base, int B, int NP, int NL, int K) {
   w.dxb = take((size_t)B * NL * 3);
   w.ga = take((size_t)B * NL * 3);
   w.gc = take((size_t)B * NL * 3);
+  w.counters = reinterpret_cast<int32_t*>(take(64));
   w.total = off;
   return w;
 }
@@ -132,6 +134,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
   auto LW = [&](int l, int slot) { return W + off[(long)l * DD_NUM_LAYER_SLOTS + slot]; };
   auto GW = [&](int slot) { return W + off[(long)s->num_layers * DD_NUM_LAYER_SLOTS + slot]; };
 
+  if (hipMemsetAsync(w.counters, 0, 64 * sizeof(int32_t), st) != hipSuccess) return DD_ERR_HIP;
   // embeddings + context (decompdiff.py:219-297)
   DD_TRYP(DD_PROF_MISC, launch_embed_nodes(s->protein_h, s->protein_pos, s->lig_pos, s->lig_v, s->lig_aux, GW(DD_G_W_lemb),
                             GW(DD_G_b_lemb), B, NP, NL, w.h, w.xa, w.xb, st));
@@ -191,6 +194,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
       bl.lnk = LW(l, DD_BL_lnk); bl.lnv = LW(l, DD_BL_lnv);
       bl.W2k = LW(l, DD_BL_W2k); bl.W2vT = LW(l, DD_BL_W2vT); bl.W2v = LW(l, DD_BL_W2v); bl.b2v = LW(l, DD_BL_b2v); bl.out = w.hb;
       bl.Rk = w.Rk; bl.Rv = w.Rv;
+      bl.work_counter = (l < 64) ? w.counters + l : nullptr;
       DD_TRYP(DD_PROF_ATTN_BL, launch_attn2_node(ne, nb, bl, st));
     }
     // ---- h += lin_node(A + A_nb on ligand rows)
@@ -536,12 +540,13 @@ extern "C" int dd_debug_set_fusion(int mode) {
   return DD_OK;
 }
 
-namespace dd { extern int g_gemm_ksplit; extern int g_attn_waves; }
+namespace dd { extern int g_gemm_ksplit; extern int g_attn_waves; extern int g_attn_persist; }
 // Measurement aid: runtime switches for A/B timing inside one process.  key 0: attention launch structure (same
 // values as dd_debug_set_fusion), key 1: K-split projection GEMM tiles (1 = on).
 extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 0) return dd_debug_set_fusion(value);
   if (key == 1) { dd::g_gemm_ksplit = value ? 1 : 0; return DD_OK; }
+  if (key == 3) { dd::g_attn_persist = value; return DD_OK; }
   if (key == 2) { if (value != 8 && value != 12 && value != 16) return DD_ERR_BAD_ARG; dd::g_attn_waves = value; return DD_OK; }
   return DD_ERR_BAD_ARG;
 }

@@ -44,30 +44,30 @@ __device__ __forceinline__ void stage_w2k_permuted(float* WB, const float* __res
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     const int i = threadIdx.x + k * NT;
-    if (i < 4096) tmp[k] = reinterpret_cast<const float4*>(W2k)[i];
+    if (4096 % NT == 0 || i < 4096) tmp[k] = reinterpret_cast<const float4*>(W2k)[i];
   }
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     const int i = threadIdx.x + k * NT;
-    if (i < 4096) {
+    if (4096 % NT == 0 || i < 4096) {
       const int r = i >> 5, c4 = (i & 31) * 4;
       *reinterpret_cast<float4*>(&WB[((r & 7) * 16 + (r >> 3)) * WPITCH + c4]) = tmp[k];
     }
   }
 }
-template <int NT>
-__device__ __forceinline__ void stage_plain(float* dst, const float* __restrict__ src, int n4) {
-  constexpr int PER = (4096 + NT - 1) / NT;
+template <int NT, int N4>
+__device__ __forceinline__ void stage_plain(float* dst, const float* __restrict__ src) {
+  constexpr int PER = (N4 + NT - 1) / NT;
   float4 tmp[PER];
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     const int i = threadIdx.x + k * NT;
-    if (i < n4) tmp[k] = reinterpret_cast<const float4*>(src)[i];
+    if (N4 % NT == 0 || i < N4) tmp[k] = reinterpret_cast<const float4*>(src)[i];
   }
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     const int i = threadIdx.x + k * NT;
-    if (i < n4) reinterpret_cast<float4*>(dst)[i] = tmp[k];
+    if (N4 % NT == 0 || i < N4) reinterpret_cast<float4*>(dst)[i] = tmp[k];
   }
 }
 
@@ -147,13 +147,31 @@ __device__ __forceinline__ void ln_relu_T(float (&Tz)[32], const float* __restri
   }
 }
 
+// sin and cos of x for 0 <= x <= ~10 (angle codes: x <= 3*pi): three-term Cody-Waite reduction by pi/2 and the
+// cephes single-precision kernels on [-pi/4, pi/4]; absolute error < 1.5e-7.  Branch-free, no large-argument path
+// (the library sincosf drags a Payne-Hanek loop and a private array into every caller).
+__device__ __forceinline__ void sincos_small(float x, float& sn, float& cs) {
+  const float kf = rintf(x * 0.63661977236758134f);
+  float r = fmaf(-kf, 1.5703125f, x);                  // pi/2 = 1.5703125 + 4.837512969970703125e-4 + 7.54978995489188e-8
+  r = fmaf(-kf, 4.837512969970703125e-4f, r);
+  r = fmaf(-kf, 7.54978995489188e-8f, r);
+  const float z = r * r;
+  const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+  const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z,
+                        fmaf(-0.5f, z, 1.0f));
+  const int q = (int)kf;
+  const float s0 = (q & 1) ? pc : ps, c0 = (q & 1) ? ps : pc;
+  sn = (q & 2) ? -s0 : s0;
+  cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
 // angular code g (0..15) of angle th: [th, sin{1,2,3}th, sin{1,1/2,1/3}th, cos{1,2,3}th, cos{1,1/2,1/3}th, 0,0,0]
 // (AngularEncoding, models/common.py:38-53: freq 1,2,3 then 1,1/2,1/3)
 __device__ __forceinline__ float angle_code(float th, int g) {
   const int gi = g > 6 ? g - 6 : g;
   const float mul = (gi == 2) ? 2.0f : (gi == 3 ? 3.0f : (gi == 5 ? 0.5f : (gi == 6 ? (1.0f / 3.0f) : 1.0f)));
   float sn, cs;
-  sincosf(th * mul, &sn, &cs);
+  sincos_small(th * mul, sn, cs);
   return g == 0 ? th : (g > 12 ? 0.f : (g <= 6 ? sn : cs));
 }
 
@@ -174,7 +192,9 @@ __device__ __forceinline__ void mfma_table_step(f32x4 (&acc)[8], const float* __
 template <int MODE>
 struct Lds {
   static constexpr bool TRIP = (MODE == M_BL);
-  static constexpr int LNP = WB_FLOATS;                       // [4][128]  gamma_k, beta_k, gamma_v, beta_v
+  static constexpr bool RES = (MODE == M_NB || MODE == M_BL);  // no Gaussian tables: W2k and W2v images both resident
+  static constexpr int WV = RES ? WB_FLOATS : 0;              // W2v image (aliases the W2k buffer unless RES)
+  static constexpr int LNP = WB_FLOATS * (RES ? 2 : 1);       // [4][128]  gamma_k, beta_k, gamma_v, beta_v
   static constexpr int WAO = LNP + 512;                       // [2][16][128] angle weights (BL), MFMA operand layout
   static constexpr int TOTAL = WAO + (TRIP ? 2 * 16 * 128 : 0);
 };
@@ -182,7 +202,9 @@ struct Lds {
 // Body of one workgroup (NW waves = NW segments).  `block` is the workgroup index within this mode's range and
 // `smem` the workgroup's LDS (>= Lds<MODE>::TOTAL floats), so several modes can share one launch.  All per-wave
 // state lives in registers; LDS only holds the (read-only) weight images shared by the workgroup.
-template <int MODE, int MAXT, int NW>
+// PERSIST (modes without Gaussian tables): the workgroup stages its images once and every wave then pulls segments
+// from the global counter a.work_counter until none are left -- no barriers after the first one.
+template <int MODE, int MAXT, int NW, bool PERSIST = false>
 __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, float* smem) {
   constexpr bool KNN = (MODE == M_NE || MODE == M_PE);
   constexpr bool POS = (MODE == M_PE || MODE == M_PB);
@@ -191,19 +213,64 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
   constexpr int NT = NW * 64;
   using L = Lds<MODE>;
   constexpr int LNP = L::LNP, WAO = L::WAO;
+  constexpr bool RES = L::RES;
+  static_assert(!PERSIST || RES, "persistent workgroups need both weight images resident");
   float* WB = smem;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int mm = lane & 15, cg = lane >> 4;            // member slot / channel group; also (head, row-group)
+  float* WV = smem + L::WV;
+  const int wave = threadIdx.x >> 6, lane0 = threadIdx.x & 63;
 
   const int N = a.NP + a.NL, NLm1 = a.NL - 1, Eb = a.NL * NLm1;
   const int nseg = (MODE == M_NE) ? a.B * N : (TRIP ? a.B * Eb : a.B * a.NL);
   const int M = KNN ? a.K : (TRIP ? a.NL - 2 : NLm1);
   const int T = (M + 15) >> 4;
-  const int seg = block * NW + wave;
-  const bool active = seg < nseg;
   long long* dbg = a.dbg_clock ? a.dbg_clock + (long)block * 16 : nullptr;
 #define DD_STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
   DD_STAMP(0);
+
+  // W2k (head-permuted; W2v too when resident), LayerNorm parameters, angle weights
+  auto stage_all = [&]() {
+    stage_w2k_permuted<NT>(WB, a.W2k);
+    if (RES) stage_w2k_permuted<NT>(WV, a.W2v);          // row o = h*8 + j  ->  LDS row j*16 + h
+    if (threadIdx.x < 64) {
+      reinterpret_cast<float4*>(smem + LNP)[threadIdx.x] = reinterpret_cast<const float4*>(a.lnk)[threadIdx.x];
+      reinterpret_cast<float4*>(smem + LNP + 256)[threadIdx.x] = reinterpret_cast<const float4*>(a.lnv)[threadIdx.x];
+    }
+    if (TRIP) {
+      for (int i = threadIdx.x; i < 16 * 32; i += NT) {
+        reinterpret_cast<float4*>(smem + WAO)[i] = reinterpret_cast<const float4*>(a.Wakp)[i];
+        reinterpret_cast<float4*>(smem + WAO + 16 * 128)[i] = reinterpret_cast<const float4*>(a.Wavp)[i];
+      }
+    }
+    __syncthreads();
+  };
+  if (PERSIST) stage_all();
+
+  for (;;) {
+  // the lane id is laundered per iteration so that the (loop-invariant) per-lane address arithmetic and LDS weight
+  // reads stay inside the iteration instead of being hoisted into a few hundred live registers
+  int lane = lane0;
+  asm volatile("" : "+v"(lane) :: "memory");
+  const int mm = lane & 15, cg = lane >> 4;            // member slot / channel group; also (head, row-group)
+  int seg;
+  if (PERSIST) {
+    if (a.persist_batches) {                           // workgroup-synchronous: NW consecutive segments per trip
+      int* sbase = reinterpret_cast<int*>(smem + L::TOTAL);
+      __syncthreads();
+      if (threadIdx.x == 0) *sbase = atomicAdd(a.work_counter, NW);
+      __syncthreads();
+      const int base = __builtin_amdgcn_readfirstlane(*sbase);
+      if (base >= nseg) break;
+      seg = base + wave;
+    } else {                                           // every wave on its own
+      int s0 = 0;
+      if (lane == 0) s0 = atomicAdd(a.work_counter, 1);
+      seg = __builtin_amdgcn_readfirstlane(s0);
+      if (seg >= nseg) break;
+    }
+  } else {
+    seg = block * NW + wave;
+  }
+  const bool active = seg < nseg;
 
   int b = 0, si = 0, sj = 0, node = 0;
   if (active) {
@@ -237,19 +304,7 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
     }
   }
 
-  // ---- stage: W2k (head-permuted), LayerNorm parameters, angle weights -----------------------------------
-  stage_w2k_permuted<NT>(WB, a.W2k);
-  if (threadIdx.x < 64) {
-    reinterpret_cast<float4*>(smem + LNP)[threadIdx.x] = reinterpret_cast<const float4*>(a.lnk)[threadIdx.x];
-    reinterpret_cast<float4*>(smem + LNP + 256)[threadIdx.x] = reinterpret_cast<const float4*>(a.lnv)[threadIdx.x];
-  }
-  if (TRIP) {
-    for (int i = threadIdx.x; i < 16 * 32; i += NT) {
-      reinterpret_cast<float4*>(smem + WAO)[i] = reinterpret_cast<const float4*>(a.Wakp)[i];
-      reinterpret_cast<float4*>(smem + WAO + 16 * 128)[i] = reinterpret_cast<const float4*>(a.Wavp)[i];
-    }
-  }
-  __syncthreads();
+  if (!PERSIST) stage_all();
   DD_STAMP(1);
 
   // ---- Q~ as the MFMA B operand: lane (h = mm, cg) holds Q~[h][c(kk, cg)] ----------------------------------
@@ -259,17 +314,19 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
   if (active) {
     const float4 q0 = *reinterpret_cast<const float4*>(a.q + (long)seg * 128 + mm * 8);
     const float4 q1 = *reinterpret_cast<const float4*>(a.q + (long)seg * 128 + mm * 8 + 4);
-    const float qd[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-#pragma unroll
+    // a real loop (8 LDS reads in flight per trip): fully unrolled, the scheduler hoists all 64 reads = 256 registers
+#pragma nounroll
     for (int d = 0; d < 8; ++d) {
+      const float qv = d < 4 ? (d < 2 ? (d == 0 ? q0.x : q0.y) : (d == 2 ? q0.z : q0.w))
+                             : (d < 6 ? (d == 4 ? q1.x : q1.y) : (d == 6 ? q1.z : q1.w));
       const float* wr = WB + (d * 16 + mm) * WPITCH + 4 * cg;
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) {
         const float4 w = *reinterpret_cast<const float4*>(wr + 16 * nt);
-        Qb[4 * nt] = fmaf(qd[d], w.x, Qb[4 * nt]);
-        Qb[4 * nt + 1] = fmaf(qd[d], w.y, Qb[4 * nt + 1]);
-        Qb[4 * nt + 2] = fmaf(qd[d], w.z, Qb[4 * nt + 2]);
-        Qb[4 * nt + 3] = fmaf(qd[d], w.w, Qb[4 * nt + 3]);
+        Qb[4 * nt] = fmaf(qv, w.x, Qb[4 * nt]);
+        Qb[4 * nt + 1] = fmaf(qv, w.y, Qb[4 * nt + 1]);
+        Qb[4 * nt + 2] = fmaf(qv, w.z, Qb[4 * nt + 2]);
+        Qb[4 * nt + 3] = fmaf(qv, w.w, Qb[4 * nt + 3]);
       }
     }
 #pragma unroll
@@ -401,9 +458,11 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
   };
 
   // ---- Gaussian tables for pass 1 --------------------------------------------------------------------------
-  __syncthreads();                                     // all waves done with W2k
-  if (KNN) stage_plain<NT>(WB, a.Akp, 4 * 24 * 32);
-  __syncthreads();
+  if (KNN) {
+    __syncthreads();                                   // all waves done with W2k
+    stage_plain<NT, 4 * 24 * 32>(WB, a.Akp);
+    __syncthreads();
+  }
   DD_STAMP(4);
 
   // ---- pass 1: scores S[t][r] = score[member 16t + 4cg + r][head mm] ---------------------------------------
@@ -460,7 +519,7 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
   DD_STAMP(6);
   if (KNN) {
     __syncthreads();
-    stage_plain<NT>(WB, a.Avp, 4 * 24 * 32);
+    stage_plain<NT, 4 * 24 * 32>(WB, a.Avp);
     __syncthreads();
   }
   DD_STAMP(7);
@@ -538,16 +597,18 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
   DD_STAMP(8);
 
   // ---- epilogue: out[o] = W2v[o,:] . Z~[head(o),:] + b2v[o] * sum_m alpha*w ----------------------------------
-  __syncthreads();                                     // pass-2 tables dead
-  stage_w2k_permuted<NT>(WB, a.W2v);                   // row o = h*8 + j  ->  LDS row j*16 + h
-  __syncthreads();
+  if (!RES) {
+    __syncthreads();                                   // pass-2 tables dead
+    stage_w2k_permuted<NT>(WV, a.W2v);                 // row o = h*8 + j  ->  LDS row j*16 + h
+    __syncthreads();
+  }
   DD_STAMP(9);
   if (active) {
     // lane (h = mm, cg): partial dot products over its 32 channels for the 8 outputs of head h
     float o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float* wr = WB + (j * 16 + mm) * WPITCH + 4 * cg;
+      const float* wr = WV + (j * 16 + mm) * WPITCH + 4 * cg;
       float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
       for (int nt = 0; nt < 8; nt += 2) {
@@ -559,6 +620,7 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
         acc1 = fmaf(w1.z, Z[nt + 1][2], acc1); acc1 = fmaf(w1.w, Z[nt + 1][3], acc1);
       }
       o[j] = acc0 + acc1;
+      __builtin_amdgcn_sched_barrier(0);
     }
     // reduce over the 4 lanes of a head and scatter: lane cg ends with outputs j = cg and j = 4 + cg
     const float p0 = swap16_sum(o[0], o[1]), p1 = swap16_sum(o[2], o[3]);
@@ -577,6 +639,8 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
     }
   }
   DD_STAMP(10);
+  if (!PERSIST) break;
+  }
 #undef DD_STAMP
 }
 
@@ -588,16 +652,20 @@ __global__ __launch_bounds__(NW * 64) void k_attn2(const AttnArgs a) {
 
 constexpr int imax(int a, int b) { return a > b ? a : b; }
 
-// The three sub-layers that read the *old* h / h_bond (NE, NB, BL) are independent: one launch, the longest
-// workgroups (BL) first, the few NB workgroups hidden in the tail instead of costing a launch of their own.
+// The three sub-layers that read the *old* h / h_bond (NE, NB, BL) are independent: one launch.  The NE workgroups
+// (long, one batch of NW segments each) come first, then the few NB ones; the BL workgroups are persistent and pull
+// single segments from a global counter, so they fill whatever the coarse NE schedule leaves idle and all finish
+// within one segment of each other.
 template <int MAXT, int NW>
-__global__ __launch_bounds__(NW * 64) void k_attn2_node(const AttnArgs ne, const AttnArgs nb, const AttnArgs bl, int n_bl, int n_ne) {
-  constexpr int SZ = imax(imax(Lds<M_NE>::TOTAL, Lds<M_NB>::TOTAL), Lds<M_BL>::TOTAL);
+__global__ __launch_bounds__(NW * 64) void k_attn2_node(const AttnArgs ne, const AttnArgs nb, const AttnArgs bl, int n_ne, int n_nb,
+                                                        int persist) {
+  constexpr int SZ = imax(imax(Lds<M_NE>::TOTAL, Lds<M_NB>::TOTAL), Lds<M_BL>::TOTAL) + 4;
   __shared__ __attribute__((aligned(16))) float smem[SZ];
   const int blk = blockIdx.x;
-  if (blk < n_bl) attn2_body<M_BL, MAXT, NW>(bl, blk, smem);
-  else if (blk < n_bl + n_ne) attn2_body<M_NE, 2, NW>(ne, blk - n_bl, smem);
-  else attn2_body<M_NB, MAXT, NW>(nb, blk - n_bl - n_ne, smem);
+  if (blk < n_ne) attn2_body<M_NE, 2, NW>(ne, blk, smem);
+  else if (blk < n_ne + n_nb) attn2_body<M_NB, MAXT, NW>(nb, blk - n_ne, smem);
+  else if (persist) attn2_body<M_BL, MAXT, NW, true>(bl, blk - n_ne - n_nb, smem);
+  else attn2_body<M_BL, MAXT, NW>(bl, blk - n_ne - n_nb, smem);
 }
 // Same for the two coordinate sub-layers (both write their own delta buffer; x is updated afterwards).
 template <int MAXT, int NW>
@@ -620,6 +688,7 @@ static int launch_mode(const AttnArgs& a, int nseg, hipStream_t st) {
 }  // namespace v2
 
 int g_attn_waves = 8;        // waves (= segments) per workgroup of the fused launches: 8, 12 or 16
+int g_attn_persist = 2;      // bond_layer workgroups of the fused launch are persistent (global segment counter)
 
 int launch_attn2(int mode, const AttnArgs& a, hipStream_t st) {
   using namespace v2;
@@ -643,8 +712,21 @@ static int launch_node_nw(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs
   using namespace v2;
   const int N = ne.NP + ne.NL;
   const int n_ne = (ne.B * N + NW - 1) / NW, n_nb = (ne.B * ne.NL + NW - 1) / NW;
-  const int n_bl = (ne.B * ne.NL * (ne.NL - 1) + NW - 1) / NW;
-  hipLaunchKernelGGL((k_attn2_node<2, NW>), dim3(n_bl + n_ne + n_nb), dim3(NW * 64), 0, st, ne, nb, bl, n_bl, n_ne);
+  int n_bl = (ne.B * ne.NL * (ne.NL - 1) + NW - 1) / NW;
+  const int persist = (g_attn_persist && bl.work_counter != nullptr) ? 1 : 0;
+  AttnArgs blp = bl;
+  blp.persist_batches = g_attn_persist == 2 ? 1 : 0;
+  if (persist) {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return DD_ERR_HIP;
+      n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    if (n_bl > n_cu) n_bl = n_cu;                      // one workgroup per CU (LDS-limited)
+  }
+  hipLaunchKernelGGL((k_attn2_node<2, NW>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, blp, n_ne, n_nb, persist);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
