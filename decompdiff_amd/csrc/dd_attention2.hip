@@ -307,18 +307,60 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
   if (!PERSIST) stage_all();
   DD_STAMP(1);
 
+  // query first: the Q~ fold must not queue behind the prefetched gathers (loads return in order)
+  float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
+  if (active) {
+    q0 = *reinterpret_cast<const float4*>(a.q + (long)seg * 128 + mm * 8);
+    q1 = *reinterpret_cast<const float4*>(a.q + (long)seg * 128 + mm * 8 + 4);
+  }
+  // ---- prefetch: rows of the k pass and the triplet geometry are requested now, ahead of the Q~ fold and the angle
+  //      codes, so that the 2-3 us the gathers take (the tables exceed L2) are not exposed at the head of pass 1
+  float Rc[32], Pf[32], Pf2[32];                          // segment row; gather row(s) of the next k-pass tile
+  float tri_i[3] = {0.f, 0.f, 0.f}, tri_j[3] = {0.f, 0.f, 0.f}, tri_k[MAXT][3];
+  auto fetch_k_rows = [&](int t) {
+    const int m = 16 * t + mm;
+    const int mc = m < M ? m : M - 1;
+    if (KNN) {
+      load_row(Pf, a.ks + (src_base + jm[t < MAXT ? t : 0]) * a.ld_ks, cg);
+    } else if (!TRIP) {
+      load_row(Pf, a.ks + (src_base + mc + (mc >= si ? 1 : 0)) * a.ld_ks, cg);
+      load_row(Pf2, a.ke + (erow0 + mc) * a.ld_ke, cg);
+    } else {
+      const int k = trip_k(mc);
+      load_row(Pf, a.ke + ((long)b * Eb + sj * NLm1 + (k - (k > sj ? 1 : 0))) * a.ld_ke, cg);
+    }
+  };
+  if (active) {
+    load_row(Rc, TRIP ? a.Rk + (long)seg * 128 : a.kd + drow * a.ld_kd, cg);
+    fetch_k_rows(0);
+    if (TRIP) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { tri_i[c] = xl[3 * si + c]; tri_j[c] = xl[3 * sj + c]; }
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t) {
+        const int m = 16 * t + mm;
+        const int k = trip_k(m < M ? m : M - 1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tri_k[t][c] = xl[3 * k + c];
+      }
+    }
+  }
+  // the query is needed first: wait for it alone (exact count: straight-line code), and hand it to the rolled fold
+  // loop below as plain register values -- a load result consumed inside a loop costs a conservative vmcnt(0)
+  asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w));
+
   // ---- Q~ as the MFMA B operand: lane (h = mm, cg) holds Q~[h][c(kk, cg)] ----------------------------------
   float Qb[32];
 #pragma unroll
   for (int k = 0; k < 32; ++k) Qb[k] = 0.f;
   if (active) {
-    const float4 q0 = *reinterpret_cast<const float4*>(a.q + (long)seg * 128 + mm * 8);
-    const float4 q1 = *reinterpret_cast<const float4*>(a.q + (long)seg * 128 + mm * 8 + 4);
-    // a real loop (8 LDS reads in flight per trip): fully unrolled, the scheduler hoists all 64 reads = 256 registers
+    // a real loop (8 LDS reads in flight per trip): fully unrolled, the scheduler hoists all 64 reads = 256 registers.
+    // The 8 query values rotate through r0 so that no dynamic register indexing is needed.
+    float r0 = q0.x, r1 = q0.y, r2 = q0.z, r3 = q0.w, r4 = q1.x, r5 = q1.y, r6 = q1.z, r7 = q1.w;
 #pragma nounroll
     for (int d = 0; d < 8; ++d) {
-      const float qv = d < 4 ? (d < 2 ? (d == 0 ? q0.x : q0.y) : (d == 2 ? q0.z : q0.w))
-                             : (d < 6 ? (d == 4 ? q1.x : q1.y) : (d == 6 ? q1.z : q1.w));
+      const float qv = r0;
+      r0 = r1; r1 = r2; r2 = r3; r3 = r4; r4 = r5; r5 = r6; r6 = r7; r7 = qv;
       const float* wr = WB + (d * 16 + mm) * WPITCH + 4 * cg;
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) {
@@ -337,12 +379,10 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
   // ---- BL: angle codes of member 16t + mm, rows 4s + cg, kept in registers (MFMA feature operand) ------------
   float cod[MAXT][4];
   if (TRIP && active) {
-    const float ax = xl[3 * sj] - xl[3 * si], ay = xl[3 * sj + 1] - xl[3 * si + 1], az = xl[3 * sj + 2] - xl[3 * si + 2];
+    const float ax = tri_j[0] - tri_i[0], ay = tri_j[1] - tri_i[1], az = tri_j[2] - tri_i[2];
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
-      const int m = 16 * t + mm;
-      const int k = trip_k(m < M ? m : M - 1);
-      const float bx = xl[3 * k] - xl[3 * si], by = xl[3 * k + 1] - xl[3 * si + 1], bz = xl[3 * k + 2] - xl[3 * si + 2];
+      const float bx = tri_k[t][0] - tri_i[0], by = tri_k[t][1] - tri_i[1], bz = tri_k[t][2] - tri_i[2];
       const float dot = ax * bx + ay * by + az * bz;
       const float cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
       const float th = atan2f(sqrtf(cx * cx + cy * cy + cz * cz), dot);
@@ -387,7 +427,14 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
     const float* tab_d = pass ? a.vd : a.kd;  const int ld_d = pass ? a.ld_vd : a.ld_kd;
     const float* tab_s = pass ? a.vs : a.ks;  const int ld_s = pass ? a.ld_vs : a.ld_ks;
     const float* tab_e = pass ? a.ve : a.ke;  const int ld_e = pass ? a.ld_ve : a.ld_ke;
-    if (KNN) {
+    if (pass == 0) {
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        P[k] = Rc[k] + Pf[k];
+        if (BOND) P[k] += Pf2[k];
+      }
+      if (t + 1 < MAXT && t + 1 < T) fetch_k_rows(t + 1);   // next tile's rows fly during this tile's arithmetic
+    } else if (KNN) {
       load_row(P, tab_d + drow * ld_d, cg);
       add_row(P, tab_s + (src_base + jm[t]) * ld_s, cg);
     } else if (!TRIP) {
@@ -401,6 +448,7 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
       load_row(P, (pass ? a.Rv : a.Rk) + (long)seg * 128, cg);
       add_row(P, tab_e + kj * ld_e, cg);
     }
+    if (dbg && t == 0 && pass == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); DD_STAMP(11); }   // rows arrived
     if (KNN || TRIP) {
       f32x4 acc[8];
 #pragma unroll
@@ -409,7 +457,9 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) { P[4 * nt] = acc[nt][0]; P[4 * nt + 1] = acc[nt][1]; P[4 * nt + 2] = acc[nt][2]; P[4 * nt + 3] = acc[nt][3]; }
     }
+    if (dbg && t == 0 && pass == 0) { asm volatile("" : "+v"(P[0]), "+v"(P[31])); DD_STAMP(12); }           // table part done
     ln_relu32(P, smem + LNP + pass * 256, cg);
+    if (dbg && t == 0 && pass == 0) { asm volatile("" : "+v"(P[0]), "+v"(P[31])); DD_STAMP(13); }           // LayerNorm done
   };
 
   // v-MLP hidden activation of tile t in the member-major layout the aggregation consumes without a transpose:
@@ -475,6 +525,7 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
         float P[32];
         build_pre(t, 0, P);
         S[t] = mfma_rows(P, Qb);
+        if (dbg && t == 0) { asm volatile("" : "+v"(S[t])); DD_STAMP(14); }                                      // scores done
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (16 * t + 4 * cg + r >= M) S[t][r] = -INFINITY;
