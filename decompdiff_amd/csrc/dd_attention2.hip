@@ -165,14 +165,27 @@ __device__ __forceinline__ void sincos_small(float x, float& sn, float& cs) {
   cs = ((q + 1) & 2) ? -c0 : c0;
 }
 
-// angular code g (0..15) of angle th: [th, sin{1,2,3}th, sin{1,1/2,1/3}th, cos{1,2,3}th, cos{1,1/2,1/3}th, 0,0,0]
-// (AngularEncoding, models/common.py:38-53: freq 1,2,3 then 1,1/2,1/3)
-__device__ __forceinline__ float angle_code(float th, int g) {
-  const int gi = g > 6 ? g - 6 : g;
-  const float mul = (gi == 2) ? 2.0f : (gi == 3 ? 3.0f : (gi == 5 ? 0.5f : (gi == 6 ? (1.0f / 3.0f) : 1.0f)));
-  float sn, cs;
-  sincos_small(th * mul, sn, cs);
-  return g == 0 ? th : (g > 12 ? 0.f : (g <= 6 ? sn : cs));
+// The four angular codes g = cg, 4 + cg, 8 + cg, 12 + cg of the angle between a and b:
+//   code = [th, sin{1,2,3}th, sin{1,1/2,1/3}th, cos{1,2,3}th, cos{1,1/2,1/3}th, 0, 0, 0]
+// (AngularEncoding, models/common.py:38-53: freq 1,2,3 then 1,1/2,1/3; th = atan2(|a x b|, a.b)).
+// sin/cos of th come straight from the cross and dot products, the multiples from the addition formulas and the
+// half angle from sin th = 2 sin(th/2) cos(th/2) with the well-conditioned root; only th/3 needs a sincos.
+__device__ __forceinline__ void angle_codes(float n /*|a x b|*/, float dt /*a.b*/, int cg, float (&out)[4]) {
+  const float th = atan2f(n, dt);
+  const float n2 = fmaf(n, n, dt * dt);
+  const float r = n2 > 0.f ? __builtin_amdgcn_rsqf(n2) : 0.f;
+  const float s1 = n * r, c1 = n2 > 0.f ? dt * r : 1.0f;
+  const float s2 = 2.0f * s1 * c1, c2 = fmaf(c1, c1, -s1 * s1);
+  const float s3 = fmaf(s2, c1, c2 * s1), c3 = fmaf(c2, c1, -s2 * s1);
+  float sh, ch;
+  if (c1 >= 0.f) { ch = sqrtf(0.5f * (1.0f + c1)); sh = 0.5f * s1 / ch; }
+  else           { sh = sqrtf(0.5f * (1.0f - c1)); ch = 0.5f * s1 / sh; }
+  float st, ct;
+  sincos_small(th * (1.0f / 3.0f), st, ct);
+  out[0] = cg == 0 ? th : (cg == 1 ? s1 : (cg == 2 ? s2 : s3));      // g = 0..3
+  out[1] = cg == 0 ? s1 : (cg == 1 ? sh : (cg == 2 ? st : c1));      // g = 4..7
+  out[2] = cg == 0 ? c2 : (cg == 1 ? c3 : (cg == 2 ? c1 : ch));      // g = 8..11
+  out[3] = cg == 0 ? ct : 0.f;                                        // g = 12..15
 }
 
 // first-layer table part on the matrix cores: one k-step (4 table rows) for the 8 channel tiles.
@@ -385,9 +398,7 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
       const float bx = tri_k[t][0] - tri_i[0], by = tri_k[t][1] - tri_i[1], bz = tri_k[t][2] - tri_i[2];
       const float dot = ax * bx + ay * by + az * bz;
       const float cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
-      const float th = atan2f(sqrtf(cx * cx + cy * cy + cz * cz), dot);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) cod[t][s] = angle_code(th, 4 * s + cg);
+      angle_codes(sqrtf(cx * cx + cy * cy + cz * cz), dot, cg, cod[t]);
     }
   }
   DD_STAMP(3);
@@ -462,9 +473,11 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
     if (dbg && t == 0 && pass == 0) { asm volatile("" : "+v"(P[0]), "+v"(P[31])); DD_STAMP(13); }           // LayerNorm done
   };
 
-  // v-MLP hidden activation of tile t in the member-major layout the aggregation consumes without a transpose:
-  // lane (mm, cg) holds members 16t + 4cg + r (r < 4), channels 16nt + mm  (Tz[4nt + r])
-  auto build_T = [&](int t, float (&Tz)[32]) {
+  // v-MLP hidden activation in the member-major layout the aggregation consumes without a transpose: lane (mm, cg)
+  // holds members 16t + 4cg + r (r < 4), channels 16nt + mm  (Tz[4nt + r]).  fetch_T requests the rows of a tile
+  // (issued one tile ahead), finish_T turns them into the activation.
+  float Tc[8], Tr[32], Tr2[32];
+  auto fetch_T = [&](int t) {
     const float* rs[4];
     const float* re[4];
 #pragma unroll
@@ -484,18 +497,29 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
         rs[r] = a.ve + ((long)b * Eb + sj * NLm1 + (k - (k > sj ? 1 : 0))) * a.ld_ve + mm;
       }
     }
-    const float* rc = TRIP ? a.Rv + (long)seg * 128 + mm : a.vd + drow * a.ld_vd + mm;
-    float c[8];
+    if (t == 0) {
+      const float* rc = TRIP ? a.Rv + (long)seg * 128 + mm : a.vd + drow * a.ld_vd + mm;
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt) c[nt] = rc[16 * nt];
+      for (int nt = 0; nt < 8; ++nt) Tc[nt] = rc[16 * nt];
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) {
-        float v = c[nt] + rs[r][16 * nt];
-        if (BOND) v += re[r][16 * nt];
+        Tr[4 * nt + r] = rs[r][16 * nt];
+        if (BOND) Tr2[4 * nt + r] = re[r][16 * nt];
+      }
+  };
+  auto finish_T = [&](int t, float (&Tz)[32]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        float v = Tc[nt] + Tr[4 * nt + r];
+        if (BOND) v += Tr2[4 * nt + r];
         Tz[4 * nt + r] = v;
       }
+    if (t + 1 < MAXT && t + 1 < T) fetch_T(t + 1);       // next tile's rows fly during this tile's arithmetic
     if (KNN || TRIP) {
       f32x4 acc[8];
 #pragma unroll
@@ -534,6 +558,7 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
       }
     }
     DD_STAMP(5);
+    if (!POS) fetch_T(0);                              // v-pass rows of tile 0 arrive during the softmax
     // segment softmax per head: max-shift, exp, / sum  (scatter_softmax), then * e_w
     float mx = -INFINITY;
 #pragma unroll
@@ -636,7 +661,7 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
     for (int t = 0; t < MAXT; ++t) {
       if (t < T) {
         float Tz[32];
-        build_T(t, Tz);
+        finish_T(t, Tz);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
