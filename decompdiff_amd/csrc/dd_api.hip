@@ -113,6 +113,7 @@ static int ensure_side_stream() {
 }
 
 static int g_fuse = 1;                       // dd_debug_set_fusion: 0 = one launch per sub-layer (per-kernel timing)
+extern long long* g_gemm_dbg;              // dd_gemm.hip
 static long long* g_dbg_clock = nullptr;   // set by dd_debug_set_clock_buffer (profiling aid)
 static int g_dbg_mode = -1;
 
@@ -527,6 +528,8 @@ extern "C" int dd_profile_step(const dd_sampler* s, int n_iters, float* ms_per_c
 // Profiling aid: when set, the tiled attention kernel of class `mode` (0 NE,1 NB,2 BL,3 PE,4 PB) writes 16
 // s_memtime stamps per workgroup (wave 0) into `buf` ([n_workgroups][16] int64, device memory).
 extern "C" int dd_debug_set_clock_buffer(long long* buf, int mode) {
+  if (mode == 100) { dd::g_gemm_dbg = buf; return DD_OK; }      // dd_gemm128 phase stamps
+  dd::g_gemm_dbg = nullptr;
   dd::g_dbg_clock = buf;
   dd::g_dbg_mode = buf ? mode : -1;
   return DD_OK;

@@ -17,11 +17,60 @@ constexpr int GT = 64;        // tile rows / cols
 constexpr int GP = 130;       // LDS row pitch (floats)
 
 
+// element offset of logical row r: rows are grouped in batches of rows_per_b (stride_b apart), ld apart inside a
+// batch.  The plain case (one batch) needs no division.
+__device__ __forceinline__ long row_offset(int r, int rows_per_b, long stride_b, int ld, bool plain) {
+  return plain ? (long)r * ld : (long)(r / rows_per_b) * stride_b + (long)(r % rows_per_b) * ld;
+}
+
+// Epilogue: the four 32x32 accumulators go through an LDS tile (pitch 68) so that every thread writes whole
+// 16-byte pieces of output rows (4 x global_store_dwordx4 instead of 16 scalar stores).
+constexpr int EP = 68;
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, float* sm /*>= 64*EP floats, free*/, const f32x16& acc,
+                                              int row0, int col0) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, li = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;      // C/D map: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    sm[(wr * 32 + row) * EP + wc * 32 + li] = acc[r];
+  }
+  __syncthreads();
+  const bool plain = a.y_rows_per_b >= a.rows;
+  const bool vec_ok = ((a.ldy & 3) == 0) && ((a.y_stride_b & 3) == 0) && ((reinterpret_cast<size_t>(a.Y) & 15) == 0);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = tid + k * 256;
+    const int r = i >> 4, c4 = (i & 15) * 4;
+    const int gr = row0 + r, gc = col0 + c4;
+    if (gr >= a.rows || gc >= a.ncols) continue;
+    const float4 v = *reinterpret_cast<const float4*>(&sm[r * EP + c4]);
+    float o[4] = {v.x, v.y, v.z, v.w};
+    float* dst = a.Y + row_offset(gr, a.y_rows_per_b, a.y_stride_b, a.ldy, plain) + gc;
+    if (vec_ok && gc + 3 < a.ncols) {
+      if (a.bias) { const float4 bb = *reinterpret_cast<const float4*>(a.bias + gc); o[0] += bb.x; o[1] += bb.y; o[2] += bb.z; o[3] += bb.w; }
+      if (a.accumulate) { const float4 old = *reinterpret_cast<const float4*>(dst); o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w; }
+      *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (gc + e < a.ncols) {
+          float x = o[e] + (a.bias ? a.bias[gc + e] : 0.f);
+          if (a.accumulate) x += dst[e];
+          dst[e] = x;
+        }
+    }
+  }
+}
+
+
 __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int bx, const int by) {
-  __shared__ float Xs[GT * GP];
-  __shared__ float Ws[GT * GP];
+  __shared__ __attribute__((aligned(16))) float smg[2 * GT * GP];
+  float* Xs = smg;
+  float* Ws = smg + GT * GP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = bx * GT, col0 = by * GT;
+  const bool xplain = a.x_rows_per_b >= a.rows;
 
   // ---- stage X tile (64 rows x 128) and W tile (64 cols x 128): all 16 float4 global loads of a thread
   //      are issued before the first LDS store; two ds_write_b64 each (pitch 130 is only 8-byte aligned)
@@ -35,7 +84,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int bx, const
       xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       wv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (gr < a.rows) {
-        const float* src = a.X + (long)(gr / a.x_rows_per_b) * a.x_stride_b + (long)(gr % a.x_rows_per_b) * a.ldx + c4;
+        const float* src = a.X + row_offset(gr, a.x_rows_per_b, a.x_stride_b, a.ldx, xplain) + c4;
         xv[k] = *reinterpret_cast<const float4*>(src);
         if (a.X2 != nullptr) {
           const int bb = gr / a.x2_N, n = gr % a.x2_N;
@@ -89,22 +138,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int bx, const
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
   }
 
-  // ---- epilogue: C/D map  col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  const int gc = col0 + wc * 32 + li;
-  if (gc < a.ncols) {
-    const float bias = a.bias ? a.bias[gc] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-      int gr = row0 + wr * 32 + row;
-      if (gr < a.rows) {
-        float* dst = a.Y + (long)(gr / a.y_rows_per_b) * a.y_stride_b + (long)(gr % a.y_rows_per_b) * a.ldy + gc;
-        float v = acc[r] + bias;
-        if (a.accumulate) v += *dst;
-        *dst = v;
-      }
-    }
-  }
+  __syncthreads();                                     // operands dead: the tile buffer becomes the output stage
+  gemm_epilogue(a, smg, acc, row0, col0);
 }
 
 // K-split variant for jobs without the LayerNorm prologue: the two 64-wide halves of K go through a 33 KB LDS
@@ -112,10 +147,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int bx, const
 // multiplied.  Same MFMA order per output element as gemm_tile (k ascending), hence bit-identical results.
 constexpr int GPH = 66;       // LDS pitch of a K-half tile: (66*row) mod 64 = 2*row -> conflict-free ds_read_b64
 __device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx, const int by) {
-  __shared__ float Xh[GT * GPH];
-  __shared__ float Wh[GT * GPH];
+  __shared__ __attribute__((aligned(16))) float smh[2 * GT * GPH];
+  float* Xh = smh;
+  float* Wh = smh + GT * GPH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = bx * GT, col0 = by * GT;
+  const bool xplain = a.x_rows_per_b >= a.rows;
   float4 xv[4], wv[4];
   auto fetch = [&](int half) {
 #pragma unroll
@@ -126,7 +163,7 @@ __device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx
       xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       wv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (gr < a.rows) {
-        const float* src = a.X + (long)(gr / a.x_rows_per_b) * a.x_stride_b + (long)(gr % a.x_rows_per_b) * a.ldx + c4;
+        const float* src = a.X + row_offset(gr, a.x_rows_per_b, a.x_stride_b, a.ldx, xplain) + c4;
         xv[k] = *reinterpret_cast<const float4*>(src);
         if (a.X2 != nullptr) {
           const int bb = gr / a.x2_N, n = gr % a.x2_N;
@@ -159,9 +196,13 @@ __device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  long long* dbg = a.dbg ? a.dbg + ((long)by * gridDim.x + bx) * 8 : nullptr;
+#define GSTAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+  GSTAMP(0);
   fetch(0);
   commit();
   __syncthreads();
+  GSTAMP(1);
   fetch(1);
 #pragma unroll 8
   for (int kk = 0; kk < 16; ++kk) {
@@ -170,9 +211,12 @@ __device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
   }
+  asm volatile("" : "+v"(acc));
+  GSTAMP(2);
   __syncthreads();
   commit();
   __syncthreads();
+  GSTAMP(3);
 #pragma unroll 8
   for (int kk = 0; kk < 16; ++kk) {
     float2 av = *reinterpret_cast<const float2*>(xa + 4 * kk);
@@ -180,21 +224,12 @@ __device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
   }
-  const int gc = col0 + wc * 32 + li;
-  if (gc < a.ncols) {
-    const float bias = a.bias ? a.bias[gc] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-      int gr = row0 + wr * 32 + row;
-      if (gr < a.rows) {
-        float* dst = a.Y + (long)(gr / a.y_rows_per_b) * a.y_stride_b + (long)(gr % a.y_rows_per_b) * a.ldy + gc;
-        float v = acc[r] + bias;
-        if (a.accumulate) v += *dst;
-        *dst = v;
-      }
-    }
-  }
+  asm volatile("" : "+v"(acc));
+  GSTAMP(4);
+  __syncthreads();                                     // operands dead: the tile buffer becomes the output stage
+  gemm_epilogue(a, smh, acc, row0, col0);
+  if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); GSTAMP(5); }
+#undef GSTAMP
 }
 
 __global__ __launch_bounds__(256) void k_gemm128(GemmArgs a) { gemm_tile(a, blockIdx.x, blockIdx.y); }
@@ -216,6 +251,7 @@ __global__ __launch_bounds__(256) void k_gemm128_batch(GemmBatch gb) {
   else { if (KS) gemm_tile_ksplit(gb.job[3], lb % gb.nbx[3], lb / gb.nbx[3]); else gemm_tile(gb.job[3], lb % gb.nbx[3], lb / gb.nbx[3]); }
 }
 
+long long* g_gemm_dbg = nullptr;
 int g_gemm_ksplit = 1;   // dd_debug_set_option(1, v): K-split tiles for jobs without a LayerNorm prologue
 
 int launch_gemm128_batch(const GemmArgs* jobs, int njobs, hipStream_t st) {
@@ -259,5 +295,6 @@ extern "C" int dd_gemm128(const float* X, int x_rows_per_b, long x_stride_b, int
                           int ncols, int accumulate, void* stream) {
   if (!X || !W || !Y || x_rows_per_b <= 0 || y_rows_per_b <= 0 || (ldx & 3) != 0) return DD_ERR_BAD_ARG;
   dd::GemmArgs a = dd::gemm_args(X, x_rows_per_b, x_stride_b, ldx, rows, W, bias, ln, Y, y_rows_per_b, y_stride_b, ldy, ncols, accumulate);
+  a.dbg = dd::g_gemm_dbg;
   return dd::launch_gemm128(a, (hipStream_t)stream);
 }

@@ -10,12 +10,13 @@ struct GemmArgs {
   float* Y; int y_rows_per_b; long y_stride_b; int ldy; int ncols; int accumulate;
   // optional second addend for X rows that are ligand nodes: X[b*N + n] += X2[b*NL + n - NP] (n >= NP)
   const float* X2; int x2_N, x2_NP;
+  long long* dbg;          // profiling aid: s_memtime phase stamps, 8 per workgroup (single launches only)
 };
 inline GemmArgs gemm_args(const float* X, int x_rows_per_b, long x_stride_b, int ldx, int rows, const float* W,
                           const float* bias, const float* ln, float* Y, int y_rows_per_b, long y_stride_b, int ldy,
                           int ncols, int accumulate) {
   GemmArgs g{X, x_rows_per_b, x_stride_b, ldx, rows, W, bias, ln, Y, y_rows_per_b, y_stride_b, ldy, ncols, accumulate,
-             nullptr, 0, 0};
+             nullptr, 0, 0, nullptr};
   return g;
 }
 int launch_gemm128(const GemmArgs& a, hipStream_t st);
