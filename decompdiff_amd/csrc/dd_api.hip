@@ -100,12 +100,12 @@ struct ProfScope {
 // second stream for the coordinate sub-layers (they only feed the NEXT layer's geometry, so they overlap its
 // projection GEMMs); fork/join through events, which stream capture turns into graph edges
 static hipStream_t g_side = nullptr;
-static hipEvent_t g_ev_fork[8], g_ev_join[8];
+static hipEvent_t g_ev_fork[9], g_ev_join[9];   // [0..7] per layer, [8] graph construction at the head of a forward
 static int g_overlap = 1;                     // measured in-process A/B: -3.5 % step time
 static int ensure_side_stream() {
   if (g_side) return DD_OK;
   if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) return DD_ERR_HIP;
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 9; ++i)
     if (hipEventCreateWithFlags(&g_ev_fork[i], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&g_ev_join[i], hipEventDisableTiming) != hipSuccess)
       return DD_ERR_HIP;
@@ -135,22 +135,36 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
   auto LW = [&](int l, int slot) { return W + off[(long)l * DD_NUM_LAYER_SLOTS + slot]; };
   auto GW = [&](int slot) { return W + off[(long)s->num_layers * DD_NUM_LAYER_SLOTS + slot]; };
 
-  if (hipMemsetAsync(w.counters, 0, 64 * sizeof(int32_t), st) != hipSuccess) return DD_ERR_HIP;
-  // embeddings + context (decompdiff.py:219-297)
-  DD_TRYP(DD_PROF_MISC, launch_embed_nodes(s->protein_h, s->protein_pos, s->lig_pos, s->lig_v, s->lig_aux, GW(DD_G_W_lemb),
-                            GW(DD_G_b_lemb), B, NP, NL, w.h, w.xa, w.xb, st));
-  DD_TRYP(DD_PROF_MISC, launch_embed_bonds(s->lig_bond, (long)B * Eb, GW(DD_G_W_bemb), GW(DD_G_b_bemb), w.hb, st));
-  // graph (uni_transformer_edge.py:404-427)
-  DD_TRYP(DD_PROF_MISC, launch_knn(w.xa, B, N, K, w.nbr, st));
-  DD_TRYP(DD_PROF_MISC, launch_edge_weights(w.xa, w.nbr, B, N, K, GW(DD_G_EW_W1T), GW(DD_G_EW_b1), GW(DD_G_EW_ln), GW(DD_G_EW_w2),
-                             GW(DD_G_EW_b2), w.ew, st));
-
   float* xcur = w.xa;
   float* xnext = w.xb;
   const long hN = (long)N * 128;
   const bool fused = g_fuse && !g_use_v1 && NL <= 33 && g_dbg_clock == nullptr;
   const bool overlap = fused && g_overlap && g_prof == nullptr && s->num_layers <= 8;
   if (overlap) DD_TRY(ensure_side_stream());
+
+  if (hipMemsetAsync(w.counters, 0, 64 * sizeof(int32_t), st) != hipSuccess) return DD_ERR_HIP;
+  // embeddings + context (decompdiff.py:219-297)
+  DD_TRYP(DD_PROF_MISC, launch_embed_nodes(s->protein_h, s->protein_pos, s->lig_pos, s->lig_v, s->lig_aux, GW(DD_G_W_lemb),
+                            GW(DD_G_b_lemb), B, NP, NL, w.h, w.xa, w.xb, st));
+  // graph (uni_transformer_edge.py:404-427): only the attention kernels need it, so with two streams it is built
+  // beside the bond embedding and the first layer's projections
+  bool head_join = false;
+  {
+    hipStream_t gs = st;
+    if (overlap) {
+      if (hipEventRecord(g_ev_fork[8], st) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_fork[8], 0) != hipSuccess) return DD_ERR_HIP;
+      gs = g_side;
+    }
+    DD_TRYP(DD_PROF_MISC, launch_knn(w.xa, B, N, K, w.nbr, gs));
+    DD_TRYP(DD_PROF_MISC, launch_edge_weights(w.xa, w.nbr, B, N, K, GW(DD_G_EW_W1T), GW(DD_G_EW_b1), GW(DD_G_EW_ln), GW(DD_G_EW_w2),
+                               GW(DD_G_EW_b2), w.ew, gs));
+    if (overlap) {
+      if (hipEventRecord(g_ev_join[8], g_side) != hipSuccess) return DD_ERR_HIP;
+      head_join = true;
+    }
+  }
+  DD_TRYP(DD_PROF_MISC, launch_embed_bonds(s->lig_bond, (long)B * Eb, GW(DD_G_W_bemb), GW(DD_G_b_bemb), w.hb, st));
+
   int pending_join = -1;
   for (int l = 0; l < s->num_layers && fused; ++l) {
     const int nE = (int)(B * Eb);
@@ -165,6 +179,10 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
     if (pending_join >= 0) {
       if (hipStreamWaitEvent(st, g_ev_join[pending_join], 0) != hipSuccess) return DD_ERR_HIP;
       pending_join = -1;
+    }
+    if (head_join) {
+      if (hipStreamWaitEvent(st, g_ev_join[8], 0) != hipSuccess) return DD_ERR_HIP;
+      head_join = false;
     }
     DD_TRYP(DD_PROF_ASSEMBLE, launch_bl_assemble(xcur, w.PB, w.PL, LW(l, DD_BL_Wg1k), LW(l, DD_BL_Wg1v), LW(l, DD_BL_Wg2k),
                                                   LW(l, DD_BL_Wg2v), B, NP, NL, w.Ek, w.Ev, w.q1bl, w.Rk, w.Rv, st));
@@ -315,6 +333,10 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
     a.W2k = LW(l, DD_PB_W2k); a.W2v16 = LW(l, DD_PB_W2v); a.b2v16 = LW(l, DD_PB_b2v); a.dxe = w.dxe; a.x_next = xnext;
     DD_TRYP(DD_PROF_ATTN_PB, attn_dispatch(M_PB, a, st));
     float* t = xcur; xcur = xnext; xnext = t;
+  }
+  if (head_join) {                                     // (no layer consumed the graph)
+    if (hipStreamWaitEvent(st, g_ev_join[8], 0) != hipSuccess) return DD_ERR_HIP;
+    head_join = false;
   }
   // heads, first Linear (decompdiff.py:194-211): v head on ligand rows of h, bond head on h_bond
   {
