@@ -96,6 +96,28 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int bx, const
       }
       if (gc < a.ncols) wv[k] = *reinterpret_cast<const float4*>(a.W + (long)gc * 128 + c4);
     }
+    // optional LayerNorm+ReLU prologue (MLP hidden activation), on the registers: a row's 128 channels sit in the 32
+    // lanes of a half wave (4 each), so mean / variance are half-wave reductions (4 DPP steps + one permlane swap)
+    if (a.ln != nullptr) {
+      const int c4 = (tid & 31) * 4;
+      const float4 gm = *reinterpret_cast<const float4*>(a.ln + c4);
+      const float4 bt = *reinterpret_cast<const float4*>(a.ln + 128 + c4);
+      auto half_sum = [](float v) {
+        v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); v += dpp_mov<0x140>(v);
+        return swap16_sum(v, v);
+      };
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float mean = half_sum((xv[k].x + xv[k].y) + (xv[k].z + xv[k].w)) * (1.0f / 128.0f);
+        const float dx = xv[k].x - mean, dy = xv[k].y - mean, dz = xv[k].z - mean, dw = xv[k].w - mean;
+        const float var = half_sum(fmaf(dx, dx, dy * dy) + fmaf(dz, dz, dw * dw)) * (1.0f / 128.0f);
+        const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
+        xv[k].x = fmaxf(fmaf(dx * rstd, gm.x, bt.x), 0.f);
+        xv[k].y = fmaxf(fmaf(dy * rstd, gm.y, bt.y), 0.f);
+        xv[k].z = fmaxf(fmaf(dz * rstd, gm.z, bt.z), 0.f);
+        xv[k].w = fmaxf(fmaf(dw * rstd, gm.w, bt.w), 0.f);
+      }
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int i = tid + k * 256;
@@ -109,18 +131,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int bx, const
     }
   }
   __syncthreads();
-
-  // ---- optional LayerNorm+ReLU prologue on the X rows (MLP hidden activation)
-  if (a.ln != nullptr) {
-    float g0 = a.ln[2 * lane], g1 = a.ln[2 * lane + 1];
-    float b0 = a.ln[128 + 2 * lane], b1 = a.ln[128 + 2 * lane + 1];
-    for (int r = wave; r < GT; r += 4) {
-      float2 v = *reinterpret_cast<float2*>(&Xs[r * GP + 2 * lane]);
-      ln_relu2(v.x, v.y, g0, g1, b0, b1);
-      *reinterpret_cast<float2*>(&Xs[r * GP + 2 * lane]) = v;
-    }
-    __syncthreads();
-  }
 
   // ---- MFMA: wave (wr, wc) computes rows wr*32.., cols wc*32..
   const int wr = wave >> 1, wc = wave & 1;
