@@ -202,6 +202,87 @@ __global__ __launch_bounds__(256) void k_bl_assemble(const float* __restrict__ x
   *reinterpret_cast<float2*>(Rv + e_glob * 128 + 2 * lane) = rv;
 }
 
+
+// Persistent variant used by the sampler: the four 20x128 Gaussian weight tables live in LDS (40 KB), every wave
+// walks over bonds with two bonds in flight (all row gathers of a pair are requested before either is consumed).
+struct BondRows { float2 k, v, q, sk, tk, sv, tv, tq; float d; };
+__global__ __launch_bounds__(256) void k_bl_assemble2(const float* __restrict__ x, const float* __restrict__ PB,
+                                                      const float* __restrict__ PL, const float* __restrict__ Wg1k,
+                                                      const float* __restrict__ Wg1v, const float* __restrict__ Wg2k,
+                                                      const float* __restrict__ Wg2v, int B, int NP, int NL,
+                                                      float* __restrict__ Ek, float* __restrict__ Ev,
+                                                      float* __restrict__ q1, float* __restrict__ Rk,
+                                                      float* __restrict__ Rv) {
+  __shared__ __attribute__((aligned(16))) float tab[4 * DD_NGAUSS * 128];
+  {
+    const float* src[4] = {Wg1k, Wg1v, Wg2k, Wg2v};
+    float4 tmp[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const int idx = threadIdx.x + i * 256;               // 4 tables x 640 float4
+      tmp[i] = reinterpret_cast<const float4*>(src[idx / 640])[idx % 640];
+    }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) reinterpret_cast<float4*>(tab)[threadIdx.x + i * 256] = tmp[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int Eb = NL * (NL - 1), N = NP + NL;
+  const long nrows = (long)B * Eb;
+  const long nwaves = (long)gridDim.x * 4;
+  auto fetch = [&](long e_glob, BondRows& r) {
+    const int b = e_glob / Eb, e = e_glob % Eb;
+    const int t = e / (NL - 1), sp = e % (NL - 1);
+    const int s = sp + (sp >= t ? 1 : 0);
+    const float* xl = x + ((long)b * N + NP) * 3;
+    const float dx = xl[3 * t] - xl[3 * s], dy = xl[3 * t + 1] - xl[3 * s + 1], dz = xl[3 * t + 2] - xl[3 * s + 2];
+    r.d = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float* pb = PB + e_glob * 640 + 2 * lane;
+    const float* ps = PL + ((long)b * NL + s) * 1280 + 2 * lane;
+    const float* pt = PL + ((long)b * NL + t) * 1280 + 2 * lane;
+    r.k = *reinterpret_cast<const float2*>(pb + 256);
+    r.v = *reinterpret_cast<const float2*>(pb + 384);
+    r.q = *reinterpret_cast<const float2*>(pb + 512);
+    r.sk = *reinterpret_cast<const float2*>(ps + 640);
+    r.tk = *reinterpret_cast<const float2*>(pt + 768);
+    r.sv = *reinterpret_cast<const float2*>(ps + 896);
+    r.tv = *reinterpret_cast<const float2*>(pt + 1024);
+    r.tq = *reinterpret_cast<const float2*>(pt + 1152);
+  };
+  auto finish = [&](long e_glob, const BondRows& r) {
+    const float gl = gauss_feat(r.d, lane < DD_NGAUSS ? lane : 0);
+    float2 k = r.k, v = r.v, rk = make_float2(0.f, 0.f), rv = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int g = 0; g < DD_NGAUSS; ++g) {
+      const float gg = lane_bcast(gl, g);
+      const float2 wk = *reinterpret_cast<const float2*>(tab + (0 * DD_NGAUSS + g) * 128 + 2 * lane);
+      const float2 wv = *reinterpret_cast<const float2*>(tab + (1 * DD_NGAUSS + g) * 128 + 2 * lane);
+      const float2 uk = *reinterpret_cast<const float2*>(tab + (2 * DD_NGAUSS + g) * 128 + 2 * lane);
+      const float2 uv = *reinterpret_cast<const float2*>(tab + (3 * DD_NGAUSS + g) * 128 + 2 * lane);
+      k.x = fmaf(wk.x, gg, k.x); k.y = fmaf(wk.y, gg, k.y);
+      v.x = fmaf(wv.x, gg, v.x); v.y = fmaf(wv.y, gg, v.y);
+      rk.x = fmaf(uk.x, gg, rk.x); rk.y = fmaf(uk.y, gg, rk.y);
+      rv.x = fmaf(uv.x, gg, rv.x); rv.y = fmaf(uv.y, gg, rv.y);
+    }
+    k.x += r.sk.x; k.y += r.sk.y; k.x += r.tk.x; k.y += r.tk.y;      // same order as k_bl_assemble
+    v.x += r.sv.x; v.y += r.sv.y; v.x += r.tv.x; v.y += r.tv.y;
+    const float2 q = make_float2(r.q.x + r.tq.x, r.q.y + r.tq.y);
+    *reinterpret_cast<float2*>(Ek + e_glob * 128 + 2 * lane) = k;
+    *reinterpret_cast<float2*>(Ev + e_glob * 128 + 2 * lane) = v;
+    *reinterpret_cast<float2*>(q1 + e_glob * 128 + 2 * lane) = q;
+    *reinterpret_cast<float2*>(Rk + e_glob * 128 + 2 * lane) = rk;
+    *reinterpret_cast<float2*>(Rv + e_glob * 128 + 2 * lane) = rv;
+  };
+  for (long e0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6); e0 < nrows; e0 += 2 * nwaves) {
+    const long e1 = e0 + nwaves;
+    BondRows r0, r1;
+    fetch(e0, r0);
+    if (e1 < nrows) fetch(e1, r1);
+    finish(e0, r0);
+    if (e1 < nrows) finish(e1, r1);
+  }
+}
+
 // x0-hat: ligand rows of the final coordinates
 __global__ void k_extract_ligand(const float* __restrict__ x, int B, int NP, int NL, float* __restrict__ out) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -258,12 +339,20 @@ int launch_embed_bonds(const int32_t* bond, long rows, const float* Wb, const fl
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
+int g_assemble_persist = 1;   // dd_debug_set_option(4, v)
+
 int launch_bl_assemble(const float* x, const float* PB, const float* PL, const float* Wg1k, const float* Wg1v,
                        const float* Wg2k, const float* Wg2v, int B, int NP, int NL, float* Ek, float* Ev, float* q1,
                        float* Rk, float* Rv, hipStream_t st) {
   long rows = (long)B * NL * (NL - 1);
-  hipLaunchKernelGGL(k_bl_assemble, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, PB, PL, Wg1k, Wg1v, Wg2k, Wg2v,
-                     B, NP, NL, Ek, Ev, q1, Rk, Rv);
+  if (g_assemble_persist) {
+    const long want = (rows + 7) / 8;                      // >= 2 bonds per wave
+    hipLaunchKernelGGL(k_bl_assemble2, dim3((unsigned)(want < 512 ? (want > 0 ? want : 1) : 512)), dim3(256), 0, st, x, PB, PL, Wg1k,
+                       Wg1v, Wg2k, Wg2v, B, NP, NL, Ek, Ev, q1, Rk, Rv);
+  } else {
+    hipLaunchKernelGGL(k_bl_assemble, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, PB, PL, Wg1k, Wg1v, Wg2k, Wg2v,
+                       B, NP, NL, Ek, Ev, q1, Rk, Rv);
+  }
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
