@@ -205,12 +205,19 @@ __device__ __forceinline__ void mfma_table_step(f32x4 (&acc)[8], const float* __
 template <int MODE>
 struct Lds {
   static constexpr bool TRIP = (MODE == M_BL);
+  static constexpr bool KNN = (MODE == M_NE || MODE == M_PE);
   static constexpr bool RES = (MODE == M_NB || MODE == M_BL);  // no Gaussian tables: W2k and W2v images both resident
   static constexpr int WV = RES ? WB_FLOATS : 0;              // W2v image (aliases the W2k buffer unless RES)
-  static constexpr int LNP = WB_FLOATS * (RES ? 2 : 1);       // [4][128]  gamma_k, beta_k, gamma_v, beta_v
+  static constexpr int TAB = WB_FLOATS;                       // kNN modes: [k lo, k hi, v lo, v hi] tables of the two
+                                                              // source types a workgroup meets (4 x 24 x 128)
+  static constexpr int LNP = WB_FLOATS * (RES ? 2 : 1) + (KNN ? 4 * TABP : 0);   // [4][128] gamma_k, beta_k, gamma_v, beta_v
   static constexpr int WAO = LNP + 512;                       // [2][16][128] angle weights (BL), MFMA operand layout
   static constexpr int TOTAL = WAO + (TRIP ? 2 * 16 * 128 : 0);
 };
+
+// node_layer_with_edge workgroups never mix protein and ligand centres (the Gaussian tables of only two edge types
+// are then needed): per sample ceil(NP/NW) protein blocks followed by ceil(NL/NW) ligand blocks.
+__host__ __device__ inline int ne_blocks_per_sample(int NP, int NL, int NW) { return (NP + NW - 1) / NW + (NL + NW - 1) / NW; }
 
 // Body of one workgroup (NW waves = NW segments).  `block` is the workgroup index within this mode's range and
 // `smem` the workgroup's LDS (>= Lds<MODE>::TOTAL floats), so several modes can share one launch.  All per-wave
@@ -236,6 +243,10 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
   const int nseg = (MODE == M_NE) ? a.B * N : (TRIP ? a.B * Eb : a.B * a.NL);
   const int M = KNN ? a.K : (TRIP ? a.NL - 2 : NLm1);
   const int T = (M + 15) >> 4;
+  // node_layer_with_edge: block -> (sample, protein or ligand centres, first node)
+  const int ne_bps = ne_blocks_per_sample(a.NP, a.NL, NW), ne_nbp = (a.NP + NW - 1) / NW;
+  const int ne_b = block / ne_bps, ne_rb = block % ne_bps;
+  const bool wg_protein = (MODE == M_NE) && ne_rb < ne_nbp;
   long long* dbg = a.dbg_clock ? a.dbg_clock + (long)block * 16 : nullptr;
 #define DD_STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
   DD_STAMP(0);
@@ -253,6 +264,21 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
         reinterpret_cast<float4*>(smem + WAO)[i] = reinterpret_cast<const float4*>(a.Wakp)[i];
         reinterpret_cast<float4*>(smem + WAO + 16 * 128)[i] = reinterpret_cast<const float4*>(a.Wavp)[i];
       }
+    }
+    if (KNN) {
+      // edge type = 2 * (source is protein) + (centre is protein); the centre kind is uniform over the workgroup
+      const int tyl = wg_protein ? 1 : 0;
+      constexpr int PER = (4 * 768) / NT;                  // float4 per thread (NT divides 3072 for 2, 4, 8, 12 waves)
+      static_assert((4 * 768) % NT == 0, "table staging assumes NT | 3072");
+      float4 tmp[PER];
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const int i = threadIdx.x + k * NT, q = i / 768, w = i - q * 768;
+        const float* src = (q < 2 ? a.Akp : a.Avp) + (tyl + 2 * (q & 1)) * TABP;
+        tmp[k] = reinterpret_cast<const float4*>(src)[w];
+      }
+#pragma unroll
+      for (int k = 0; k < PER; ++k) reinterpret_cast<float4*>(smem + L::TAB)[threadIdx.x + k * NT] = tmp[k];
     }
     __syncthreads();
   };
@@ -280,6 +306,9 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
       seg = __builtin_amdgcn_readfirstlane(s0);
       if (seg >= nseg) break;
     }
+  } else if (MODE == M_NE) {
+    const int nd = wg_protein ? ne_rb * NW + wave : a.NP + (ne_rb - ne_nbp) * NW + wave;
+    seg = (nd < (wg_protein ? a.NP : N) && ne_b < a.B) ? ne_b * N + nd : nseg;
   } else {
     seg = block * NW + wave;
   }
@@ -302,12 +331,17 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
 
   // kNN: neighbour and distance of member 16t + mm (issued first: two dependent global round trips)
   int jm[MAXT];
-  float dm[MAXT];
+  float dm[MAXT], ewm[MAXT][4];                        // ewm: edge weights of members 16t + 4cg + r
   if (KNN && active) {
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
       const int m = 16 * t + mm;
       jm[t] = a.nbr[nrow * a.K + (m < M ? m : M - 1)];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mr = 16 * t + 4 * cg + r;
+        ewm[t][r] = a.ew[nrow * a.K + (mr < M ? mr : 0)];
+      }
     }
     const float cx = xb[3 * node], cy = xb[3 * node + 1], cz = xb[3 * node + 2];
 #pragma unroll
@@ -414,13 +448,13 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
       for (int s = 0; s < 5; ++s) F[s] = gauss_feat(dm[t], 4 * s + cg);
       F[5] = cg == 0 ? 1.0f : 0.0f;
       const bool hi = jm[t] < a.NP;
-      const float* tab = WB + (node < a.NP ? 1 : 0) * TABP + cg * 128 + mm * 4;
+      const float* tab = smem + L::TAB + pass * 2 * TABP + cg * 128 + mm * 4;   // [lo, hi] tables of this pass
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const bool want = half ? hi : !hi;
         if (__builtin_amdgcn_ballot_w64(want) != 0ull) {
 #pragma unroll
-          for (int s = 0; s < 6; ++s) mfma_table_step<TR>(acc, tab + half * 2 * TABP + s * 512, want ? F[s] : 0.0f);
+          for (int s = 0; s < 6; ++s) mfma_table_step<TR>(acc, tab + half * TABP + s * 512, want ? F[s] : 0.0f);
         }
       }
     } else if (TRIP) {
@@ -531,10 +565,12 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
     ln_relu_T(Tz, smem + LNP + 256, mm);
   };
 
-  // ---- Gaussian tables for pass 1 --------------------------------------------------------------------------
-  if (KNN) {
-    __syncthreads();                                   // all waves done with W2k
-    stage_plain<NT, 4 * 24 * 32>(WB, a.Akp);
+  // ---- kNN node mode: the W2k image is dead once every wave has folded its query; W2v takes its place now.  The
+  //      second barrier follows at once (the waves are still aligned here; one in front of the epilogue would make
+  //      every wave wait for the slowest); the Gaussian tables of both passes are resident.
+  if (KNN && !POS) {
+    __syncthreads();
+    stage_w2k_permuted<NT>(WV, a.W2v);                 // row o = h*8 + j  ->  LDS row j*16 + h
     __syncthreads();
   }
   DD_STAMP(4);
@@ -582,7 +618,7 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
       for (int r = 0; r < 4; ++r) {
         const int m = 16 * t + 4 * cg + r;
         float w = 1.0f;
-        if (KNN) w = a.ew[nrow * a.K + (m < M ? m : 0)];
+        if (KNN) w = ewm[t][r];
         const float aw = (m < M) ? (S[t][r] / sum) * w : 0.f;
         S[t][r] = aw;
         ssum += aw;
@@ -593,11 +629,6 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
     for (int t = 0; t < MAXT; ++t) S[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   DD_STAMP(6);
-  if (KNN) {
-    __syncthreads();
-    stage_plain<NT, 4 * 24 * 32>(WB, a.Avp);
-    __syncthreads();
-  }
   DD_STAMP(7);
 
   // ---- pass 2 -----------------------------------------------------------------------------------------------
@@ -673,11 +704,6 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
   DD_STAMP(8);
 
   // ---- epilogue: out[o] = W2v[o,:] . Z~[head(o),:] + b2v[o] * sum_m alpha*w ----------------------------------
-  if (!RES) {
-    __syncthreads();                                   // pass-2 tables dead
-    stage_w2k_permuted<NT>(WV, a.W2v);                 // row o = h*8 + j  ->  LDS row j*16 + h
-    __syncthreads();
-  }
   DD_STAMP(9);
   if (active) {
     // lane (h = mm, cg): partial dot products over its 32 channels for the 8 outputs of head h
@@ -763,7 +789,7 @@ static int launch_mode(const AttnArgs& a, int nseg, hipStream_t st) {
 
 }  // namespace v2
 
-int g_attn_waves = 8;        // waves (= segments) per workgroup of the fused launches: 8, 12 or 16
+int g_attn_waves = 8;        // waves (= segments) per workgroup of the fused node launch
 int g_attn_persist = 2;      // bond_layer workgroups of the fused launch are persistent (global segment counter)
 
 int launch_attn2(int mode, const AttnArgs& a, hipStream_t st) {
@@ -771,7 +797,7 @@ int launch_attn2(int mode, const AttnArgs& a, hipStream_t st) {
   const int N = a.NP + a.NL;
   const bool small = a.NL <= 33;                     // NL-1 <= 32 members -> 2 tiles
   switch (mode) {
-    case M_NE: return launch_mode<M_NE, 2, 8>(a, a.B * N, st);
+    case M_NE: return launch_mode<M_NE, 2, 8>(a, a.B * v2::ne_blocks_per_sample(a.NP, a.NL, 8) * 8, st);   // (blocks * NW)
     case M_PE: return launch_mode<M_PE, 2, 8>(a, a.B * a.NL, st);
     case M_NB: return small ? launch_mode<M_NB, 2, 8>(a, a.B * a.NL, st) : launch_mode<M_NB, 4, 8>(a, a.B * a.NL, st);
     case M_PB: return small ? launch_mode<M_PB, 2, 8>(a, a.B * a.NL, st) : launch_mode<M_PB, 4, 8>(a, a.B * a.NL, st);
@@ -787,7 +813,7 @@ template <int NW>
 static int launch_node_nw(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs& bl, hipStream_t st) {
   using namespace v2;
   const int N = ne.NP + ne.NL;
-  const int n_ne = (ne.B * N + NW - 1) / NW, n_nb = (ne.B * ne.NL + NW - 1) / NW;
+  const int n_ne = ne.B * ne_blocks_per_sample(ne.NP, ne.NL, NW), n_nb = (ne.B * ne.NL + NW - 1) / NW;
   int n_bl = (ne.B * ne.NL * (ne.NL - 1) + NW - 1) / NW;
   const int persist = (g_attn_persist && bl.work_counter != nullptr) ? 1 : 0;
   AttnArgs blp = bl;
@@ -808,17 +834,22 @@ static int launch_node_nw(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs
 }
 int launch_attn2_node(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs& bl, hipStream_t st) {
   if (ne.NL > 33) return DD_ERR_UNSUPPORTED_SHAPE;
-  if (g_attn_waves == 16) return launch_node_nw<16>(ne, nb, bl, st);
-  if (g_attn_waves == 12) return launch_node_nw<12>(ne, nb, bl, st);
-  return launch_node_nw<8>(ne, nb, bl, st);
+  return launch_node_nw<8>(ne, nb, bl, st);             // (12- and 16-wave workgroups were tried: register spills)
 }
-int launch_attn2_pos(const AttnArgs& pe, const AttnArgs& pb, hipStream_t st) {
+template <int NW>
+static int launch_pos_nw(const AttnArgs& pe, const AttnArgs& pb, hipStream_t st) {
   using namespace v2;
-  if (pe.NL > 33) return DD_ERR_UNSUPPORTED_SHAPE;
-  const int n = (pe.B * pe.NL + 7) / 8;
-  hipLaunchKernelGGL((k_attn2_pos<2, 8>), dim3(2 * n), dim3(512), 0, st, pe, pb, n);
+  const int n = (pe.B * pe.NL + NW - 1) / NW;
+  hipLaunchKernelGGL((k_attn2_pos<2, NW>), dim3(2 * n), dim3(NW * 64), 0, st, pe, pb, n);
   DD_CHECK_LAUNCH();
   return DD_OK;
+}
+int g_pos_waves = 4;         // waves per workgroup of the fused coordinate launch: 2, 4 or 8
+int launch_attn2_pos(const AttnArgs& pe, const AttnArgs& pb, hipStream_t st) {
+  if (pe.NL > 33) return DD_ERR_UNSUPPORTED_SHAPE;
+  if (g_pos_waves == 2) return launch_pos_nw<2>(pe, pb, st);
+  if (g_pos_waves == 4) return launch_pos_nw<4>(pe, pb, st);
+  return launch_pos_nw<8>(pe, pb, st);
 }
 
 }  // namespace dd
