@@ -282,7 +282,15 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
     }
     __syncthreads();
   };
-  if (PERSIST) stage_all();
+  // persistent batches: bases of the current / next batch in sb[0..1] (thread 0 draws the next one while the current is
+  // processed; sb[2] = number of bases published so far, release/acquire), next batch's query prefetched over the epilogue
+  int* sb = reinterpret_cast<int*>(smem + L::TOTAL);
+  int it = 0;
+  float4 qn0 = make_float4(0.f, 0.f, 0.f, 0.f), qn1 = qn0;
+  if (PERSIST) {
+    if (threadIdx.x == 0) { sb[0] = atomicAdd(a.work_counter, NW); sb[2] = 0; }
+    stage_all();                                       // (ends with the barrier that also publishes sb[0])
+  }
 
   for (;;) {
   // the lane id is laundered per iteration so that the (loop-invariant) per-lane address arithmetic and LDS weight
@@ -293,12 +301,13 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
   int seg;
   if (PERSIST) {
     if (a.persist_batches) {                           // workgroup-synchronous: NW consecutive segments per trip
-      int* sbase = reinterpret_cast<int*>(smem + L::TOTAL);
-      __syncthreads();
-      if (threadIdx.x == 0) *sbase = atomicAdd(a.work_counter, NW);
-      __syncthreads();
-      const int base = __builtin_amdgcn_readfirstlane(*sbase);
+      if (it > 0) __syncthreads();                     // one barrier per trip keeps the waves in phase (shared I-cache)
+      const int base = __builtin_amdgcn_readfirstlane(sb[it & 1]);
       if (base >= nseg) break;
+      if (threadIdx.x == 0) {
+        sb[(it + 1) & 1] = atomicAdd(a.work_counter, NW);
+        __hip_atomic_store(&sb[2], it + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
       seg = base + wave;
     } else {                                           // every wave on its own
       int s0 = 0;
@@ -331,7 +340,8 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
 
   // kNN: neighbour and distance of member 16t + mm (issued first: two dependent global round trips)
   int jm[MAXT];
-  float dm[MAXT], ewm[MAXT][4];                        // ewm: edge weights of members 16t + 4cg + r
+  int jT[MAXT][4];                                     // neighbours of members 16t + 4cg + r (v pass, member-major)
+  float dm[MAXT], ewm[MAXT][4];                        // ewm: edge weights of the same members
   if (KNN && active) {
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
@@ -341,6 +351,7 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
       for (int r = 0; r < 4; ++r) {
         const int mr = 16 * t + 4 * cg + r;
         ewm[t][r] = a.ew[nrow * a.K + (mr < M ? mr : 0)];
+        jT[t][r] = a.nbr[nrow * a.K + (mr < M ? mr : M - 1)];
       }
     }
     const float cx = xb[3 * node], cy = xb[3 * node + 1], cz = xb[3 * node + 2];
@@ -356,7 +367,9 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
 
   // query first: the Q~ fold must not queue behind the prefetched gathers (loads return in order)
   float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
-  if (active) {
+  if (PERSIST && a.persist_batches && it > 0) {
+    q0 = qn0; q1 = qn1;                                // requested during the previous trip's epilogue
+  } else if (active) {
     q0 = *reinterpret_cast<const float4*>(a.q + (long)seg * 128 + mm * 8);
     q1 = *reinterpret_cast<const float4*>(a.q + (long)seg * 128 + mm * 8 + 4);
   }
@@ -520,8 +533,7 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
       const int mc = m < M ? m : M - 1;
       re[r] = nullptr;
       if (KNN) {
-        const int j = a.nbr[nrow * a.K + mc];
-        rs[r] = a.vs + (src_base + j) * a.ld_vs + mm;
+        rs[r] = a.vs + (src_base + jT[t < MAXT ? t : 0][r]) * a.ld_vs + mm;
       } else if (!TRIP) {
         const int j = mc + (mc >= si ? 1 : 0);
         rs[r] = a.vs + (src_base + j) * a.ld_vs + mm;
@@ -654,7 +666,7 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
             const int mc = m < M ? m : 0;
             int j;
             const float* xs;
-            if (KNN) { j = a.nbr[nrow * a.K + mc]; xs = xb; }
+            if (KNN) { j = jT[t][r]; xs = xb; }
             else { j = mc + (mc >= si ? 1 : 0); xs = xl; }
             const int ii = KNN ? node : si;
             const float coef = S[t][r] * (V[r] + bv);   // S holds alpha*w (0 for out-of-range members)
@@ -705,6 +717,14 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
 
   // ---- epilogue: out[o] = W2v[o,:] . Z~[head(o),:] + b2v[o] * sum_m alpha*w ----------------------------------
   DD_STAMP(9);
+  if (PERSIST && a.persist_batches) {                  // next trip's query
+    while (__hip_atomic_load(&sb[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < it + 1) {}
+    const int nseg2 = sb[(it + 1) & 1] + wave;
+    if (nseg2 < nseg) {
+      qn0 = *reinterpret_cast<const float4*>(a.q + (long)nseg2 * 128 + mm * 8);
+      qn1 = *reinterpret_cast<const float4*>(a.q + (long)nseg2 * 128 + mm * 8 + 4);
+    }
+  }
   if (active) {
     // lane (h = mm, cg): partial dot products over its 32 channels for the 8 outputs of head h
     float o[8];
@@ -742,6 +762,7 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
   }
   DD_STAMP(10);
   if (!PERSIST) break;
+  ++it;
   }
 #undef DD_STAMP
 }
