@@ -10,7 +10,7 @@ namespace dd {
 
 // ---- workspace --------------------------------------------------------------------------------
 struct Workspace {
-  float *xa, *xb, *h, *hb, *ew, *P, *PL, *PB, *P2, *PL2, *PB2, *Ek, *Ev, *Rk, *Rv, *q1bl, *qn, *ql, *ql2, *qb, *A, *Anb, *dxe, *dxb, *ga, *gc;
+  float *xa, *xb, *h, *hb, *ew, *P, *PL, *PB, *P2, *PL2, *PB2, *Ek, *Ev, *Rk, *Rv, *q1bl, *qn, *ql, *ql2, *qlnb, *qb, *A, *Anb, *dxe, *dxb, *ga, *gc;
   int32_t* nbr;
   int32_t* counters;       // [64] work counters of the persistent attention workgroups (one per layer), zeroed per forward
   size_t total;
@@ -43,6 +43,7 @@ static Workspace carve(float* base, int B, int NP, int NL, int K) {
   w.qn = take(B * N * 128);
   w.ql = take((size_t)B * NL * 128);
   w.ql2 = take((size_t)B * NL * 128);
+  w.qlnb = take((size_t)B * NL * 128);
   w.qb = take(B * Eb * 128);
   w.A = take(B * N * 128);
   w.Anb = take((size_t)B * NL * 128);
@@ -99,12 +100,20 @@ struct ProfScope {
 
 // second stream for the coordinate sub-layers (they only feed the NEXT layer's geometry, so they overlap its
 // projection GEMMs); fork/join through events, which stream capture turns into graph edges
-static hipStream_t g_side = nullptr;
+static hipStream_t g_side = nullptr, g_side2 = nullptr;   // g_side2: query MLPs of the node / bond sub-layers
+static hipEvent_t g_ev_qa_fork[8], g_ev_qa_join[8], g_ev_qb_fork[8];
+static int g_mlp_fused = 0;                    // dd_debug_set_option(6, v): fused 2-layer query MLPs beside the projections
 static hipEvent_t g_ev_fork[9], g_ev_join[9];   // [0..7] per layer, [8] graph construction at the head of a forward
 static int g_overlap = 1;                     // measured in-process A/B: -3.5 % step time
 static int ensure_side_stream() {
   if (g_side) return DD_OK;
   if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) return DD_ERR_HIP;
+  if (hipStreamCreateWithFlags(&g_side2, hipStreamNonBlocking) != hipSuccess) return DD_ERR_HIP;
+  for (int i = 0; i < 8; ++i)
+    if (hipEventCreateWithFlags(&g_ev_qa_fork[i], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g_ev_qa_join[i], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g_ev_qb_fork[i], hipEventDisableTiming) != hipSuccess)
+      return DD_ERR_HIP;
   for (int i = 0; i < 9; ++i)
     if (hipEventCreateWithFlags(&g_ev_fork[i], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&g_ev_join[i], hipEventDisableTiming) != hipSuccess)
@@ -168,12 +177,36 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
   int pending_join = -1;
   for (int l = 0; l < s->num_layers && fused; ++l) {
     const int nE = (int)(B * Eb);
-    // ---- projections of the old h / h_bond: one launch
+    const bool mlpf = g_mlp_fused != 0;
+    // ---- query MLPs of the three node / bond sub-layers: fused 2-layer kernels on their own stream, beside the
+    //      projections (they only read the old h / h_bond).  First-Linear blocks: see packing.py (q1 / q_hb / q_hi).
+    if (mlpf) {
+      Mlp2Job q[3];
+      memset(q, 0, sizeof(q));
+      q[0].X1 = w.hb; q[0].x_rows_per_b = nE; q[0].x_stride_b = 0; q[0].ldx = 128; q[0].rows = nE;
+      q[0].X2 = w.h; q[0].x2_Eb = (int)Eb; q[0].x2_N = N; q[0].x2_NP = NP; q[0].x2_NLm1 = NL - 1;
+      q[0].W1a = LW(l, DD_W_b1) + 512 * 128; q[0].W1b = LW(l, DD_W_l1) + 1152 * 128; q[0].b1 = LW(l, DD_b_b1) + 512;
+      q[0].ln = LW(l, DD_BL_lnq); q[0].W2 = LW(l, DD_BL_W2q); q[0].b2 = LW(l, DD_BL_b2q); q[0].Y = w.qb;
+      q[1].X1 = w.h; q[1].x_rows_per_b = B * N; q[1].x_stride_b = 0; q[1].ldx = 128; q[1].rows = B * N;
+      q[1].W1a = LW(l, DD_W_n1) + 512 * 128; q[1].b1 = LW(l, DD_b_n1) + 512;
+      q[1].ln = LW(l, DD_NE_lnq); q[1].W2 = LW(l, DD_NE_W2q); q[1].b2 = LW(l, DD_NE_b2q); q[1].Y = w.qn;
+      q[2].X1 = w.h + (long)NP * 128; q[2].x_rows_per_b = NL; q[2].x_stride_b = hN; q[2].ldx = 128; q[2].rows = B * NL;
+      q[2].W1a = LW(l, DD_W_l1) + 512 * 128; q[2].b1 = LW(l, DD_b_l1) + 512;
+      q[2].ln = LW(l, DD_NB_lnq); q[2].W2 = LW(l, DD_NB_W2q); q[2].b2 = LW(l, DD_NB_b2q); q[2].Y = w.qlnb;
+      if (overlap) {
+        if (hipEventRecord(g_ev_qa_fork[l], st) != hipSuccess || hipStreamWaitEvent(g_side2, g_ev_qa_fork[l], 0) != hipSuccess) return DD_ERR_HIP;
+        DD_TRY(launch_mlp2_batch(q, 3, g_side2));
+        if (hipEventRecord(g_ev_qa_join[l], g_side2) != hipSuccess) return DD_ERR_HIP;
+      } else {
+        DD_TRYP(DD_PROF_GEMM, launch_mlp2_batch(q, 3, st));
+      }
+    }
+    // ---- projections of the old h / h_bond: one launch (the q blocks are the last columns: skipped when fused above)
     {
       GemmArgs j[3] = {
-          gemm_args(w.h, B * N, 0, 128, B * N, LW(l, DD_W_n1), LW(l, DD_b_n1), nullptr, w.P, B * N, 0, 640, 640, 0),
-          gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(l, DD_W_l1), LW(l, DD_b_l1), nullptr, w.PL, B * NL, 0, 1280, 1280, 0),
-          gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b1), LW(l, DD_b_b1), nullptr, w.PB, nE, 0, 640, 640, 0)};
+          gemm_args(w.h, B * N, 0, 128, B * N, LW(l, DD_W_n1), LW(l, DD_b_n1), nullptr, w.P, B * N, 0, 640, mlpf ? 512 : 640, 0),
+          gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(l, DD_W_l1), LW(l, DD_b_l1), nullptr, w.PL, B * NL, 0, 1280, mlpf ? 1152 : 1280, 0),
+          gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b1), LW(l, DD_b_b1), nullptr, w.PB, nE, 0, 640, mlpf ? 512 : 640, 0)};
       DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, 3, st));
     }
     if (pending_join >= 0) {
@@ -185,14 +218,16 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
       head_join = false;
     }
     DD_TRYP(DD_PROF_ASSEMBLE, launch_bl_assemble(xcur, w.PB, w.PL, LW(l, DD_BL_Wg1k), LW(l, DD_BL_Wg1v), LW(l, DD_BL_Wg2k),
-                                                  LW(l, DD_BL_Wg2v), B, NP, NL, w.Ek, w.Ev, w.q1bl, w.Rk, w.Rv, st));
-    // ---- queries (second Linear of the q MLPs, LayerNorm+ReLU prologue): one launch
-    {
+                                                  LW(l, DD_BL_Wg2v), B, NP, NL, w.Ek, w.Ev, mlpf ? nullptr : w.q1bl, w.Rk, w.Rv, st));
+    if (!mlpf) {
+      // ---- queries (second Linear of the q MLPs, LayerNorm+ReLU prologue): one launch
       GemmArgs j[3] = {
           gemm_args(w.q1bl, nE, 0, 128, nE, LW(l, DD_BL_W2q), LW(l, DD_BL_b2q), LW(l, DD_BL_lnq), w.qb, nE, 0, 128, 128, 0),
           gemm_args(w.P + 512, B * N, 0, 640, B * N, LW(l, DD_NE_W2q), LW(l, DD_NE_b2q), LW(l, DD_NE_lnq), w.qn, B * N, 0, 128, 128, 0),
-          gemm_args(w.PL + 512, B * NL, 0, 1280, B * NL, LW(l, DD_NB_W2q), LW(l, DD_NB_b2q), LW(l, DD_NB_lnq), w.ql, B * NL, 0, 128, 128, 0)};
+          gemm_args(w.PL + 512, B * NL, 0, 1280, B * NL, LW(l, DD_NB_W2q), LW(l, DD_NB_b2q), LW(l, DD_NB_lnq), w.qlnb, B * NL, 0, 128, 128, 0)};
       DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, 3, st));
+    } else if (overlap) {
+      if (hipStreamWaitEvent(st, g_ev_qa_join[l], 0) != hipSuccess) return DD_ERR_HIP;
     }
     // ---- node_layer_with_edge + node_layer_with_bond + bond_layer: one launch
     {
@@ -205,7 +240,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
       nb.B = B; nb.NP = NP; nb.NL = NL; nb.K = K; nb.x = xcur;
       nb.kd = w.PL; nb.ks = w.PL + 128; nb.vd = w.PL + 256; nb.vs = w.PL + 384; nb.ld_kd = nb.ld_ks = nb.ld_vd = nb.ld_vs = 1280;
       nb.ke = w.PB; nb.ve = w.PB + 128; nb.ld_ke = nb.ld_ve = 640;
-      nb.q = w.ql; nb.lnk = LW(l, DD_NB_lnk); nb.lnv = LW(l, DD_NB_lnv);
+      nb.q = w.qlnb; nb.lnk = LW(l, DD_NB_lnk); nb.lnv = LW(l, DD_NB_lnv);
       nb.W2k = LW(l, DD_NB_W2k); nb.W2vT = LW(l, DD_NB_W2vT); nb.W2v = LW(l, DD_NB_W2v); nb.b2v = LW(l, DD_NB_b2v); nb.out = w.Anb; nb.out_assign = 1;
       bl.B = B; bl.NP = NP; bl.NL = NL; bl.K = K; bl.x = xcur;
       bl.ke = w.Ek; bl.ve = w.Ev; bl.ld_ke = bl.ld_ve = 128;
@@ -222,15 +257,33 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
       g.X2 = w.Anb; g.x2_N = N; g.x2_NP = NP;
       DD_TRYP(DD_PROF_GEMM, launch_gemm128(g, st));
     }
+    // ---- query MLPs of the two coordinate sub-layers: fused, on the stream the sub-layers themselves run on
+    if (mlpf) {
+      Mlp2Job q[2];
+      memset(q, 0, sizeof(q));
+      for (int i = 0; i < 2; ++i) {
+        q[i].X1 = w.h + (long)NP * 128; q[i].x_rows_per_b = NL; q[i].x_stride_b = hN; q[i].ldx = 128; q[i].rows = B * NL;
+      }
+      q[0].W1a = LW(l, DD_W_l2) + 256 * 128; q[0].b1 = LW(l, DD_b_l2) + 256;
+      q[0].ln = LW(l, DD_PE_lnq); q[0].W2 = LW(l, DD_PE_W2q); q[0].b2 = LW(l, DD_PE_b2q); q[0].Y = w.ql;
+      q[1].W1a = LW(l, DD_W_l2) + 896 * 128; q[1].b1 = LW(l, DD_b_l2) + 896;
+      q[1].ln = LW(l, DD_PB_lnq); q[1].W2 = LW(l, DD_PB_W2q); q[1].b2 = LW(l, DD_PB_b2q); q[1].Y = w.ql2;
+      if (overlap) {
+        if (hipEventRecord(g_ev_qb_fork[l], st) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_qb_fork[l], 0) != hipSuccess) return DD_ERR_HIP;
+        DD_TRY(launch_mlp2_batch(q, 2, g_side));        // (the pos launch follows on the same stream)
+      } else {
+        DD_TRYP(DD_PROF_GEMM, launch_mlp2_batch(q, 2, st));
+      }
+    }
     // ---- projections of the new h / h_bond: one launch
     {
       GemmArgs j[3] = {
           gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b2), LW(l, DD_b_b2), nullptr, w.PB2, nE, 0, 256, 256, 0),
           gemm_args(w.h, B * N, 0, 128, B * N, LW(l, DD_W_n2), LW(l, DD_b_n2), nullptr, w.P2, B * N, 0, 256, 256, 0),
-          gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(l, DD_W_l2), LW(l, DD_b_l2), nullptr, w.PL2, B * NL, 0, 1024, 1024, 0)};
+          gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(l, DD_W_l2), LW(l, DD_b_l2), nullptr, w.PL2, B * NL, 0, 1024, mlpf ? 896 : 1024, 0)};
       DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, 3, st));
     }
-    {
+    if (!mlpf) {
       GemmArgs j[2] = {
           gemm_args(w.PL2 + 256, B * NL, 0, 1024, B * NL, LW(l, DD_PE_W2q), LW(l, DD_PE_b2q), LW(l, DD_PE_lnq), w.ql, B * NL, 0, 128, 128, 0),
           gemm_args(w.PL2 + 896, B * NL, 0, 1024, B * NL, LW(l, DD_PB_W2q), LW(l, DD_PB_b2q), LW(l, DD_PB_lnq), w.ql2, B * NL, 0, 128, 128, 0)};
@@ -572,6 +625,7 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 0) return dd_debug_set_fusion(value);
   if (key == 1) { dd::g_gemm_ksplit = value ? 1 : 0; return DD_OK; }
   if (key == 3) { dd::g_attn_persist = value; return DD_OK; }
+  if (key == 6) { dd::g_mlp_fused = value ? 1 : 0; return DD_OK; }
   if (key == 5) { if (value != 2 && value != 4 && value != 8) return DD_ERR_BAD_ARG; dd::g_pos_waves = value; return DD_OK; }
   if (key == 4) { dd::g_assemble_persist = value ? 1 : 0; return DD_OK; }
   if (key == 2) { if (value != 8) return DD_ERR_BAD_ARG; dd::g_attn_waves = value; return DD_OK; }

@@ -242,6 +242,176 @@ __device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx
 #undef GSTAMP
 }
 
+
+// ---------------------------------------------------------------------------------------------- fused 2-layer MLP
+// Y[r, 0:128] = W2 . relu(LayerNorm(W1a . X1[r] (+ W1b . X2[x2row(r)]) + b1)) + b2       (models/common.py:85-105)
+// One workgroup = 64 rows: the hidden activation never leaves the CU (LDS), so the query MLPs of the five attention
+// sub-layers cost one launch beside the projection GEMMs instead of a GEMM -> GEMM chain on the critical path.
+// LDS: X / hidden tile 64 x 130 (33 KB) + one whole 128 x 130 weight image (66.5 KB) = 99.8 KB.
+constexpr int MP = 130;
+constexpr int MT = 512;                                  // threads per workgroup (8 waves: 2 row halves x 4 column groups)
+struct WImg { float4 v[8]; };
+__device__ __forceinline__ void mlp2_load_w(WImg& t, const float* __restrict__ W /*[128,128]*/) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) t.v[k] = reinterpret_cast<const float4*>(W)[threadIdx.x + k * MT];
+}
+__device__ __forceinline__ void mlp2_store_w(float* Ws, const WImg& t) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int i = threadIdx.x + k * MT, r = i >> 5, c4 = (i & 31) * 4;
+    float2* d = reinterpret_cast<float2*>(&Ws[r * MP + c4]);
+    d[0] = make_float2(t.v[k].x, t.v[k].y);
+    d[1] = make_float2(t.v[k].z, t.v[k].w);
+  }
+}
+// 32 rows x 32 columns per wave, K = 128
+__device__ __forceinline__ void mlp2_mfma(const float* Xs, const float* Ws, f32x16& acc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 2, wc = wave & 3, li = lane & 31, hh = lane >> 5;
+  const float* xa = &Xs[(wr * 32 + li) * MP + 2 * hh];
+  const float* wb = &Ws[(wc * 32 + li) * MP + 2 * hh];
+#pragma unroll 8
+  for (int kk = 0; kk < 32; ++kk) {
+    const float2 av = *reinterpret_cast<const float2*>(xa + 4 * kk);
+    const float2 bv = *reinterpret_cast<const float2*>(wb + 4 * kk);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void mlp2_tile(const Mlp2Job& j, const int tile, float* Xs, float* Ws) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3, li = lane & 31, hh = lane >> 5;
+  const int row0 = tile * GT;
+  const bool xplain = j.x_rows_per_b >= j.rows;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  auto load_x = [&](int part, float4 (&xv)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + k * MT, r = i >> 5, c4 = (i & 31) * 4, gr = row0 + r;
+      xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gr < j.rows) {
+        const float* src;
+        if (part == 0) src = j.X1 + row_offset(gr, j.x_rows_per_b, j.x_stride_b, j.ldx, xplain) + c4;
+        else src = j.X2 + ((long)(gr / j.x2_Eb) * j.x2_N + j.x2_NP + (gr % j.x2_Eb) / j.x2_NLm1) * 128 + c4;   // bond -> its dst atom
+        xv[k] = *reinterpret_cast<const float4*>(src);
+      }
+    }
+  };
+  auto store_x = [&](const float4 (&xv)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + k * MT, r = i >> 5, c4 = (i & 31) * 4;
+      float2* d = reinterpret_cast<float2*>(&Xs[r * MP + c4]);
+      d[0] = make_float2(xv[k].x, xv[k].y);
+      d[1] = make_float2(xv[k].z, xv[k].w);
+    }
+  };
+  // every stage's operands are requested while the previous stage multiplies
+  float4 xv[4];
+  WImg wimg;
+  load_x(0, xv);
+  mlp2_load_w(wimg, j.W1a);
+  store_x(xv);
+  mlp2_store_w(Ws, wimg);
+  __syncthreads();
+  if (j.X2) { load_x(1, xv); mlp2_load_w(wimg, j.W1b); } else { mlp2_load_w(wimg, j.W2); }
+  mlp2_mfma(Xs, Ws, acc);
+  if (j.X2) {
+    __syncthreads();                                     // first half consumed
+    store_x(xv);
+    mlp2_store_w(Ws, wimg);
+    __syncthreads();
+    mlp2_load_w(wimg, j.W2);
+    mlp2_mfma(Xs, Ws, acc);
+  }
+  __syncthreads();                                       // both operand images dead
+  // hidden pre-activation (+ b1) -> Xs; second weight image -> Ws
+  {
+    const int c0 = wc * 32 + li;
+    const float bA = j.b1[c0];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      Xs[row * MP + c0] = acc[r] + bA;
+    }
+  }
+  mlp2_store_w(Ws, wimg);
+  __syncthreads();
+  // LayerNorm + ReLU in place: thread -> rows (tid >> 5) + 16k, channels 4 * (tid & 31) .. +3 (a row = one half wave)
+  {
+    const int c4 = (tid & 31) * 4;
+    const float4 gm = *reinterpret_cast<const float4*>(j.ln + c4);
+    const float4 bt = *reinterpret_cast<const float4*>(j.ln + 128 + c4);
+    auto half_sum = [](float v) {
+      v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); v += dpp_mov<0x140>(v);
+      return swap16_sum(v, v);
+    };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float2* p = reinterpret_cast<float2*>(&Xs[((tid >> 5) + 16 * k) * MP + c4]);
+      const float2 a0 = p[0], a1 = p[1];
+      const float mean = half_sum((a0.x + a0.y) + (a1.x + a1.y)) * (1.0f / 128.0f);
+      const float dx = a0.x - mean, dy = a0.y - mean, dz = a1.x - mean, dw = a1.y - mean;
+      const float var = half_sum(fmaf(dx, dx, dy * dy) + fmaf(dz, dz, dw * dw)) * (1.0f / 128.0f);
+      const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
+      p[0] = make_float2(fmaxf(fmaf(dx * rstd, gm.x, bt.x), 0.f), fmaxf(fmaf(dy * rstd, gm.y, bt.y), 0.f));
+      p[1] = make_float2(fmaxf(fmaf(dz * rstd, gm.z, bt.z), 0.f), fmaxf(fmaf(dw * rstd, gm.w, bt.w), 0.f));
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  mlp2_mfma(Xs, Ws, acc);
+  __syncthreads();
+  // output tile 64 x 128 through LDS (pitch 132, in the weight buffer) -> 16-byte row pieces
+  {
+    float* Os = Ws;
+    const int c0 = wc * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      Os[row * 132 + c0] = acc[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + k * MT, r = i >> 5, c4 = (i & 31) * 4, gr = row0 + r;
+      if (gr >= j.rows) continue;
+      const float4 v = *reinterpret_cast<const float4*>(&Os[r * 132 + c4]);
+      const float4 bb = *reinterpret_cast<const float4*>(j.b2 + c4);
+      *reinterpret_cast<float4*>(j.Y + (long)gr * 128 + c4) = make_float4(v.x + bb.x, v.y + bb.y, v.z + bb.z, v.w + bb.w);
+    }
+  }
+}
+
+struct Mlp2Batch { Mlp2Job job[3]; int end[3]; int njobs; };
+__global__ __launch_bounds__(512) void k_mlp2_batch(Mlp2Batch mb) {
+  __shared__ __attribute__((aligned(16))) float Xs[GT * MP];
+  __shared__ __attribute__((aligned(16))) float Ws[128 * MP];
+  const int blk = blockIdx.x;
+  if (blk < mb.end[0]) mlp2_tile(mb.job[0], blk, Xs, Ws);
+  else if (blk < mb.end[1]) mlp2_tile(mb.job[1], blk - mb.end[0], Xs, Ws);
+  else mlp2_tile(mb.job[2], blk - mb.end[1], Xs, Ws);
+}
+
+int launch_mlp2_batch(const Mlp2Job* jobs, int njobs, hipStream_t st) {
+  if (njobs <= 0 || njobs > 3) return DD_ERR_BAD_ARG;
+  Mlp2Batch mb;
+  mb.njobs = njobs;
+  int total = 0;
+  for (int i = 0; i < 3; ++i) {
+    mb.job[i] = jobs[i < njobs ? i : 0];
+    if (i < njobs) total += (jobs[i].rows + GT - 1) / GT;
+    mb.end[i] = total;
+  }
+  if (total <= 0) return DD_OK;
+  hipLaunchKernelGGL(k_mlp2_batch, dim3(total), dim3(512), 0, st, mb);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
 __global__ __launch_bounds__(256) void k_gemm128(GemmArgs a) { gemm_tile(a, blockIdx.x, blockIdx.y); }
 __global__ __launch_bounds__(256) void k_gemm128_ks(GemmArgs a) { gemm_tile_ksplit(a, blockIdx.x, blockIdx.y); }
 

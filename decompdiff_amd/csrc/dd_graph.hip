@@ -242,12 +242,12 @@ __global__ __launch_bounds__(256) void k_bl_assemble2(const float* __restrict__ 
     const float* pt = PL + ((long)b * NL + t) * 1280 + 2 * lane;
     r.k = *reinterpret_cast<const float2*>(pb + 256);
     r.v = *reinterpret_cast<const float2*>(pb + 384);
-    r.q = *reinterpret_cast<const float2*>(pb + 512);
+    r.q = q1 ? *reinterpret_cast<const float2*>(pb + 512) : make_float2(0.f, 0.f);
     r.sk = *reinterpret_cast<const float2*>(ps + 640);
     r.tk = *reinterpret_cast<const float2*>(pt + 768);
     r.sv = *reinterpret_cast<const float2*>(ps + 896);
     r.tv = *reinterpret_cast<const float2*>(pt + 1024);
-    r.tq = *reinterpret_cast<const float2*>(pt + 1152);
+    r.tq = q1 ? *reinterpret_cast<const float2*>(pt + 1152) : make_float2(0.f, 0.f);
   };
   auto finish = [&](long e_glob, const BondRows& r) {
     const float gl = gauss_feat(r.d, lane < DD_NGAUSS ? lane : 0);
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void k_bl_assemble2(const float* __restrict__ 
     const float2 q = make_float2(r.q.x + r.tq.x, r.q.y + r.tq.y);
     *reinterpret_cast<float2*>(Ek + e_glob * 128 + 2 * lane) = k;
     *reinterpret_cast<float2*>(Ev + e_glob * 128 + 2 * lane) = v;
-    *reinterpret_cast<float2*>(q1 + e_glob * 128 + 2 * lane) = q;
+    if (q1) *reinterpret_cast<float2*>(q1 + e_glob * 128 + 2 * lane) = q;
     *reinterpret_cast<float2*>(Rk + e_glob * 128 + 2 * lane) = rk;
     *reinterpret_cast<float2*>(Rv + e_glob * 128 + 2 * lane) = rv;
   };

@@ -19,6 +19,14 @@ inline GemmArgs gemm_args(const float* X, int x_rows_per_b, long x_stride_b, int
              nullptr, 0, 0, nullptr};
   return g;
 }
+// fused query MLP (dd_gemm.hip): Y = W2 . relu(LN(W1a . X1[r] (+ W1b . X2[dst atom of bond r]) + b1)) + b2
+struct Mlp2Job {
+  const float* X1; int x_rows_per_b; long x_stride_b; int ldx; int rows;
+  const float* X2; int x2_Eb, x2_N, x2_NP, x2_NLm1;    // optional second input: h row of the destination atom of bond r
+  const float *W1a, *W1b, *b1, *ln, *W2, *b2;
+  float* Y;                                            // [rows, 128]
+};
+int launch_mlp2_batch(const Mlp2Job* jobs, int njobs, hipStream_t st);
 int launch_gemm128(const GemmArgs& a, hipStream_t st);
 // up to 4 independent projections in one launch (small ones ride along with the big ones)
 int launch_gemm128_batch(const GemmArgs* jobs, int njobs, hipStream_t st);
