@@ -624,6 +624,7 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
         sum += e;
       }
     sum = quad_sum(sum);
+    const float rsum = 1.0f / sum;                       // one division per head instead of one per member
 #pragma unroll
     for (int t = 0; t < MAXT; ++t)
 #pragma unroll
@@ -631,7 +632,7 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
         const int m = 16 * t + 4 * cg + r;
         float w = 1.0f;
         if (KNN) w = ewm[t][r];
-        const float aw = (m < M) ? (S[t][r] / sum) * w : 0.f;
+        const float aw = (m < M) ? (S[t][r] * rsum) * w : 0.f;
         S[t][r] = aw;
         ssum += aw;
       }
