@@ -130,9 +130,21 @@ def main():
         flops = algorithmic_flops_bond_layer(args.batch, NL)
         achieved = flops / (launch_ms * 1e-3) / 1e12
         executed = executed_flops_bond_layer(args.batch, NL) / (launch_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "k_attn<BL> (bond_layer triplet attention)", "achieved": round(achieved, 3),
+        # HBM bytes per launch of the same kernel: PMC counters cannot be collected from inside this process, so the
+        # figure comes from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json) when the workload matches
+        traffic, traffic_note = None, "no PMC profile for this workload"
+        try:
+            import json as _json
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as fh:
+                pm = _json.load(fh)
+            if pm["workload"] == {"name": args.workload, "batch": args.batch}:
+                traffic = int((pm["fetch_kib_per_launch"] + pm["write_kib_per_launch"]) * 1024)
+                traffic_note = f"FETCH_SIZE + WRITE_SIZE per launch, {pm['collected']} ({pm['source']}); {pm['note']}"
+        except (OSError, KeyError, ValueError):
+            pass
+        roofline = {"bound": "mfma", "kernel": "dd::v2::k_attn2<M_BL> (bond_layer triplet attention)", "achieved": round(achieved, 3),
                     "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4),
-                    "traffic": None, "launch_ms": round(launch_ms, 4), "executed_tflops": round(executed, 3),
+                    "traffic": traffic, "traffic_note": traffic_note, "launch_ms": round(launch_ms, 4), "executed_tflops": round(executed, 3),
                     "executed_frac": round(executed / FP32_PEAK_TFLOPS, 4),
                     "note": "fp32 FLOP roofline (CDNA4 fp32 vector peak == fp32 MFMA peak); achieved = algorithmic FLOPs "
                             "(factored count of SURVEY.md 8d) / live HIP-event launch time of the bond-layer launch, measured "
