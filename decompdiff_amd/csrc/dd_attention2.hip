@@ -165,12 +165,12 @@ __device__ __forceinline__ void sincos_small(float x, float& sn, float& cs) {
   cs = ((q + 1) & 2) ? -c0 : c0;
 }
 
-// The four angular codes g = cg, 4 + cg, 8 + cg, 12 + cg of the angle between a and b:
+// The three angular codes g = cg, 4 + cg, 8 + cg (merged order, see below) of the angle between a and b:
 //   code = [th, sin{1,2,3}th, sin{1,1/2,1/3}th, cos{1,2,3}th, cos{1,1/2,1/3}th, 0, 0, 0]
 // (AngularEncoding, models/common.py:38-53: freq 1,2,3 then 1,1/2,1/3; th = atan2(|a x b|, a.b)).
 // sin/cos of th come straight from the cross and dot products, the multiples from the addition formulas and the
 // half angle from sin th = 2 sin(th/2) cos(th/2) with the well-conditioned root; only th/3 needs a sincos.
-__device__ __forceinline__ void angle_codes(float n /*|a x b|*/, float dt /*a.b*/, int cg, float (&out)[4]) {
+__device__ __forceinline__ void angle_codes(float n /*|a x b|*/, float dt /*a.b*/, int cg, float (&out)[3]) {
   const float th = atan2f(n, dt);
   const float n2 = fmaf(n, n, dt * dt);
   const float r = n2 > 0.f ? __builtin_amdgcn_rsqf(n2) : 0.f;
@@ -182,10 +182,10 @@ __device__ __forceinline__ void angle_codes(float n /*|a x b|*/, float dt /*a.b*
   else           { sh = sqrtf(0.5f * (1.0f - c1)); ch = 0.5f * s1 / sh; }
   float st, ct;
   sincos_small(th * (1.0f / 3.0f), st, ct);
+  // merged code order (packing.py _ANGLE_MERGE): [th, s1, s2, s3 | sin th/2, sin th/3, c1, c2 | c3, cos th/2, cos th/3, 0]
   out[0] = cg == 0 ? th : (cg == 1 ? s1 : (cg == 2 ? s2 : s3));      // g = 0..3
-  out[1] = cg == 0 ? s1 : (cg == 1 ? sh : (cg == 2 ? st : c1));      // g = 4..7
-  out[2] = cg == 0 ? c2 : (cg == 1 ? c3 : (cg == 2 ? c1 : ch));      // g = 8..11
-  out[3] = cg == 0 ? ct : 0.f;                                        // g = 12..15
+  out[1] = cg == 0 ? sh : (cg == 1 ? st : (cg == 2 ? c1 : c2));      // g = 4..7
+  out[2] = cg == 0 ? c3 : (cg == 1 ? ch : (cg == 2 ? ct : 0.f));     // g = 8..11
 }
 
 // first-layer table part on the matrix cores: one k-step (4 table rows) for the 8 channel tiles.
@@ -211,8 +211,8 @@ struct Lds {
   static constexpr int TAB = WB_FLOATS;                       // kNN modes: [k lo, k hi, v lo, v hi] tables of the two
                                                               // source types a workgroup meets (4 x 24 x 128)
   static constexpr int LNP = WB_FLOATS * (RES ? 2 : 1) + (KNN ? 4 * TABP : 0);   // [4][128] gamma_k, beta_k, gamma_v, beta_v
-  static constexpr int WAO = LNP + 512;                       // [2][16][128] angle weights (BL), MFMA operand layout
-  static constexpr int TOTAL = WAO + (TRIP ? 2 * 16 * 128 : 0);
+  static constexpr int WAO = LNP + 512;                       // [2][12][128] angle weights (BL), MFMA operand layout
+  static constexpr int TOTAL = WAO + (TRIP ? 2 * 12 * 128 : 0);
 };
 
 // node_layer_with_edge workgroups never mix protein and ligand centres (the Gaussian tables of only two edge types
@@ -260,9 +260,9 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
       reinterpret_cast<float4*>(smem + LNP + 256)[threadIdx.x] = reinterpret_cast<const float4*>(a.lnv)[threadIdx.x];
     }
     if (TRIP) {
-      for (int i = threadIdx.x; i < 16 * 32; i += NT) {
+      for (int i = threadIdx.x; i < 12 * 32; i += NT) {
         reinterpret_cast<float4*>(smem + WAO)[i] = reinterpret_cast<const float4*>(a.Wakp)[i];
-        reinterpret_cast<float4*>(smem + WAO + 16 * 128)[i] = reinterpret_cast<const float4*>(a.Wavp)[i];
+        reinterpret_cast<float4*>(smem + WAO + 12 * 128)[i] = reinterpret_cast<const float4*>(a.Wavp)[i];
       }
     }
     if (KNN) {
@@ -437,7 +437,7 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
   DD_STAMP(2);
 
   // ---- BL: angle codes of member 16t + mm, rows 4s + cg, kept in registers (MFMA feature operand) ------------
-  float cod[MAXT][4];
+  float cod[MAXT][3];
   if (TRIP && active) {
     const float ax = tri_j[0] - tri_i[0], ay = tri_j[1] - tri_i[1], az = tri_j[2] - tri_i[2];
 #pragma unroll
@@ -471,9 +471,9 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
         }
       }
     } else if (TRIP) {
-      const float* tb = smem + WAO + pass * 16 * 128 + cg * 128 + mm * 4;
+      const float* tb = smem + WAO + pass * 12 * 128 + cg * 128 + mm * 4;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) mfma_table_step<TR>(acc, tb + s * 512, cod[t][s]);
+      for (int s = 0; s < 3; ++s) mfma_table_step<TR>(acc, tb + s * 512, cod[t][s]);
     }
   };
 

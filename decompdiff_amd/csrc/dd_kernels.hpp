@@ -55,7 +55,7 @@ struct AttnArgs {
   const float* q;          // [segments,128]
   const float *Ak, *Av;    // [4,21,128]
   const float *Akp, *Avp;  // [4,24,128] MFMA A-operand layout (tiled kernel)
-  const float *Wakp, *Wavp; // [16,128] (BL, tiled kernel)
+  const float *Wakp, *Wavp; // [12,128] merged angle-code columns (BL, tiled kernel)
   const float *Wg2k, *Wg2v, *Wak, *Wav;
   const float *lnk, *lnv;  // [2,128]
   const float* W2k;        // [128,128]

@@ -54,7 +54,7 @@ LAYER_SLOTS = [
     "BL_Wg2k", "BL_Wg2v",    # [20,128]  G(d_ji) columns
     "BL_Wak", "BL_Wav",      # [13,128]  angle-code columns
     "BL_lnk", "BL_lnv", "BL_lnq", "BL_W2q", "BL_b2q", "BL_W2k", "BL_W2vT", "BL_b2v", "BL_W2v",
-    "BL_Wakp", "BL_Wavp",    # [16,128] angle-code columns, MFMA A-operand layout
+    "BL_Wakp", "BL_Wavp",    # [12,128] angle-code columns, MFMA A-operand layout, duplicate codes merged (see _ANGLE_MERGE)
     # --- lin_node --------------------------------------------------------------------------
     "W_lin", "b_lin",
     # --- projections on the *new* h / h_bond -------------------------------------------
@@ -105,6 +105,18 @@ def _mfma_rows(W, rows):
     return out
 
 
+# AngularEncoding emits [th, sin(f th), cos(f th)] with f = [1, 2, 3, 1, 1/2, 1/3]: sin th and cos th appear twice.
+# Their weight columns are added on the host, which leaves 11 distinct codes = 3 MFMA k-steps instead of 4:
+#   [th, sin th, sin 2th, sin 3th | sin th/2, sin th/3, cos th, cos 2th | cos 3th, cos th/2, cos th/3, 0]
+_ANGLE_MERGE = [(0,), (1, 4), (2,), (3,), (5,), (6,), (7, 10), (8,), (9,), (11,), (12,)]
+
+
+def _angle_rows(W):
+    """[13,128] -> [12,128] merged angle-code rows in the MFMA operand layout."""
+    m = torch.stack([sum(W[i] for i in grp) for grp in _ANGLE_MERGE], 0)
+    return _mfma_rows(m, 12)
+
+
 def pack_layer(sd: Dict[str, torch.Tensor], prefix: str) -> "OrderedDict[str, torch.Tensor]":
     z = lambda n: torch.zeros(n)
     out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
@@ -146,7 +158,7 @@ def pack_layer(sd: Dict[str, torch.Tensor], prefix: str) -> "OrderedDict[str, to
     out["BL_W2q"], out["BL_b2q"], out["BL_W2k"] = bq[3], bq[4], bk[3]
     out["BL_W2vT"], out["BL_b2v"] = bv[3].t().contiguous(), bv[4]
     out["BL_W2v"] = bv[3]
-    out["BL_Wakp"], out["BL_Wavp"] = _mfma_rows(out["BL_Wak"], 16), _mfma_rows(out["BL_Wav"], 16)
+    out["BL_Wakp"], out["BL_Wavp"] = _angle_rows(out["BL_Wak"]), _angle_rows(out["BL_Wav"])
 
     out["W_lin"], out["b_lin"] = sd[f"{prefix}.lin_node.weight"], sd[f"{prefix}.lin_node.bias"]
 
