@@ -176,7 +176,7 @@ def main():
             "unit": "denoising steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: single pocket ref_prior, {NP} protein + {NL} ligand atoms, batch={args.batch} "
+            "config": {"workload": f"{'configs[1]' if args.workload == 'small' else 'C-large (configs[4] size)'}: single pocket ref_prior, {NP} protein + {NL} ligand atoms, batch={args.batch} "
                                    f"per GPU, {'drift guidance, ' if args.drift else ''}trajectories recorded and copied to host",
                        "batch_per_gpu": args.batch, "sample_steps_per_s": round(steps_per_s * args.batch, 2),
                        "parallelism": f"{world} independent pocket batches (no data-path collective)",
