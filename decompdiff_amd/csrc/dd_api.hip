@@ -430,7 +430,8 @@ static int heads_and_step(const dd_sampler* s, hipStream_t st) {
   const float* gc = nullptr;
   if (s->drift_armsca) {
     if (!s->decomp_index) return DD_ERR_BAD_ARG;
-    DD_TRYP(DD_PROF_STEP, dd_drift_armsca(s->lig_pos, s->decomp_index, B, NL, s->armsca_min_d, s->armsca_max_d, w.ga, 0, st));
+    DD_TRYP(DD_PROF_STEP, launch_drift_armsca(s->lig_pos, s->decomp_index, B, NL, s->armsca_min_d, s->armsca_max_d, w.ga, 0,
+                                              s->drift_norm_batch, st));
     ga = w.ga;
   }
   if (s->drift_clash) {
@@ -481,7 +482,7 @@ extern "C" const char* dd_status_string(int status) {
   return "unknown status";
 }
 
-extern "C" int dd_abi_version(void) { return 1; }
+extern "C" int dd_abi_version(void) { return 2; }
 
 extern "C" size_t dd_workspace_floats(int B, int NP, int NL, int K) {
   if (B <= 0 || NP < 0 || NL <= 0 || K <= 0) return 0;

@@ -31,6 +31,8 @@ int launch_gemm128(const GemmArgs& a, hipStream_t st);
 // up to 4 independent projections in one launch (small ones ride along with the big ones)
 int launch_gemm128_batch(const GemmArgs* jobs, int njobs, hipStream_t st);
 
+int launch_drift_armsca(const float* lig_pos, const int32_t* decomp_index, int B, int NL, float min_d, float max_d,
+                        float* grad, int accumulate, int norm_B, hipStream_t st);
 int launch_knn(const float* x, int B, int N, int K, int32_t* nbr, hipStream_t st);
 int launch_edge_weights(const float* x, const int32_t* nbr, int B, int N, int K, const float* W1T, const float* b1,
                         const float* ln, const float* w2, const float* b2, float* ew, hipStream_t st);

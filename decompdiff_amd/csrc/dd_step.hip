@@ -129,7 +129,7 @@ __global__ void k_advance(int32_t* step_counter) { *step_counter += 1; }
 // One workgroup (64 threads) per sample; NL <= 64.
 __global__ __launch_bounds__(64) void k_drift_armsca(const float* __restrict__ pos, const int32_t* __restrict__ decomp,
                                                      int B, int NL, float min_d, float max_d, float* __restrict__ grad,
-                                                     int accumulate) {
+                                                     int accumulate, int norm_B) {
   __shared__ float px[DD_NL_MAX], py[DD_NL_MAX], pz[DD_NL_MAX];
   __shared__ int arm[DD_NL_MAX];
   __shared__ float gx[DD_NL_MAX], gy[DD_NL_MAX], gz[DD_NL_MAX];
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64) void k_drift_armsca(const float* __restrict__ p
         float coef = 0.f;
         if (min_d - best > 0.f) coef -= 1.f;
         if (best - max_d > 0.f) coef += 1.f;
-        coef /= ((float)n_arms * (float)B);
+        coef /= ((float)n_arms * (float)norm_B);          // the loss is averaged over the caller's whole batch
         if (coef != 0.f) {
           float dx = px[ba] - px[bs], dy = py[ba] - py[bs], dz = pz[ba] - pz[bs];
           float inv = 1.0f / best;
@@ -245,14 +245,21 @@ int launch_advance(int32_t* ctr, hipStream_t st) {
 
 }  // namespace dd
 
+namespace dd {
+int launch_drift_armsca(const float* lig_pos, const int32_t* decomp_index, int B, int NL, float min_d, float max_d,
+                        float* grad, int accumulate, int norm_B, hipStream_t st) {
+  hipLaunchKernelGGL(k_drift_armsca, dim3(B), dim3(64), 0, st, lig_pos, decomp_index, B, NL, min_d, max_d, grad, accumulate,
+                     norm_B > 0 ? norm_B : B);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+}  // namespace dd
+
 extern "C" int dd_drift_armsca(const float* lig_pos, const int32_t* decomp_index, int B, int NL, float min_d,
                                float max_d, float* grad, int accumulate, void* stream) {
   if (!lig_pos || !decomp_index || !grad || B <= 0 || NL <= 0) return DD_ERR_BAD_ARG;
   if (NL > DD_NL_MAX) return DD_ERR_UNSUPPORTED_SHAPE;
-  hipLaunchKernelGGL(dd::k_drift_armsca, dim3(B), dim3(64), 0, (hipStream_t)stream, lig_pos, decomp_index, B, NL, min_d,
-                     max_d, grad, accumulate);
-  DD_CHECK_LAUNCH();
-  return DD_OK;
+  return dd::launch_drift_armsca(lig_pos, decomp_index, B, NL, min_d, max_d, grad, accumulate, B, (hipStream_t)stream);
 }
 
 extern "C" int dd_drift_clash(const float* lig_pos, const float* offset, const float* full_protein_pos, int B, int NL,

@@ -36,6 +36,7 @@ class DDSampler(ctypes.Structure):
         ("lig_pos", c_void_p), ("lig_v", c_void_p), ("lig_bond", c_void_p), ("step_counter", c_void_p),
         ("drift_armsca", c_int32), ("armsca_min_d", c_float), ("armsca_max_d", c_float), ("armsca_scale", c_int32),
         ("drift_clash", c_int32), ("clash_sigma", c_float), ("clash_gamma", c_float), ("clash_scale", c_int32),
+        ("drift_norm_batch", c_int32),
         ("u_v", c_void_p), ("u_b", c_void_p), ("eps", c_void_p), ("seed", c_uint64),
         ("traj_pos", c_void_p), ("traj_v", c_void_p), ("traj_bond", c_void_p), ("traj_v0", c_void_p),
         ("traj_vt", c_void_p), ("traj_bt", c_void_p),
@@ -50,6 +51,9 @@ class DDWsView(ctypes.Structure):
 
 
 PROF_CATS = ["misc", "gemm", "assemble", "attn_NE", "attn_NB", "attn_BL", "attn_PE", "attn_PB", "step"]
+
+
+ABI_VERSION = 2          # include/decompdiff_hip.h: layout of struct dd_sampler
 
 
 class HipLibraryError(RuntimeError):
@@ -75,6 +79,8 @@ def load():
     lib.dd_status_string.restype = c_char_p
     lib.dd_status_string.argtypes = [c_int]
     lib.dd_abi_version.restype = c_int
+    if lib.dd_abi_version() != ABI_VERSION:
+        raise HipLibraryError(f"{LIB_PATH} has ABI version {lib.dd_abi_version()}, this package needs {ABI_VERSION}: rebuild it")
     lib.dd_workspace_floats.restype = c_size_t
     lib.dd_workspace_floats.argtypes = [c_int, c_int, c_int, c_int]
     lib.dd_knn.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]

@@ -166,6 +166,94 @@ class DecompScorePosNet3D(nn.Module):
             self._packed_key = key
         return self._packed
 
+
+    # ------------------------------------------------------------------------------------------
+    # Ragged batches (samples with different atom counts).  Every sample's chain is independent of the
+    # rest of its batch (all graph ops of the reference are segmented by `batch`; tests/test_gpu_parity.py checks that
+    # the kernels keep this bit for bit), so a ragged batch is run as one dense launch sequence per group of samples
+    # with equal (protein, ligand, prior, full-protein) sizes and the results are scattered back into batch order.
+    @staticmethod
+    def _is_ragged(batch_protein, batch_ligand) -> bool:
+        if batch_protein.numel() == 0 or batch_ligand.numel() == 0:
+            return False
+        B = int(batch_protein.max().item()) + 1
+        cp = torch.bincount(batch_protein, minlength=B)
+        cl = torch.bincount(batch_ligand, minlength=B)
+        return bool((cp != cp[0]).any().item() or (cl != cl[0]).any().item())
+
+    def _sample_ragged(self, kw, ligand_atom_mask, num_steps, center_pos_mode, energy_drift_opt, noise, seed, keep_traj,
+                       use_graph):
+        if ligand_atom_mask is not None:
+            raise NotImplementedError("ligand_atom_mask (partially fixed ligands) is not part of the shipped sampling path")
+        dev = kw["protein_pos"].device
+        bp, bl, bpr = kw["batch_protein"], kw["batch_ligand"], kw["batch_prior"]
+        for name, t in (("batch_protein", bp), ("batch_ligand", bl), ("batch_prior", bpr)):
+            if t.numel() > 1 and bool((t[1:] < t[:-1]).any().item()):
+                raise NotImplementedError(f"{name} must be sorted (PyG Batch order)")
+        B = int(bp.max().item()) + 1
+        cnt = lambda t: torch.bincount(t.cpu(), minlength=B).tolist()
+        n_p, n_l, n_pr = cnt(bp), cnt(bl), cnt(bpr)
+        n_b = [n * (n - 1) for n in n_l]
+        if kw["ligand_fc_bond_index"] is None or kw["init_ligand_fc_bond_type"] is None:
+            raise NotImplementedError("the uni_o2_bond path needs the fully connected ligand bond graph")
+        if kw["init_ligand_fc_bond_type"].numel() != sum(n_b):
+            raise NotImplementedError("ligand_fc_bond_index must be the dst-major fully connected graph ('fc' mode)")
+        if kw["batch_ligand_bond"] is not None and cnt(kw["batch_ligand_bond"]) != n_b:
+            raise NotImplementedError("batch_ligand_bond does not match the fully connected bond graph")
+        has_full = kw["full_protein_pos"] is not None and kw["full_batch_protein"] is not None
+        n_f = cnt(kw["full_batch_protein"]) if has_full else [0] * B
+        off = lambda c: [0] + list(np.cumsum(c))
+        o_p, o_l, o_pr, o_b, o_f = off(n_p), off(n_l), off(n_pr), off(n_b), off(n_f)
+        groups: Dict[tuple, list] = {}
+        for b in range(B):
+            groups.setdefault((n_p[b], n_l[b], n_pr[b], n_f[b]), []).append(b)
+        n_lig, n_bond = sum(n_l), sum(n_b)
+        out = {"pos": torch.empty(n_lig, 3, device=dev), "v": torch.empty(n_lig, dtype=torch.long, device=dev),
+               "bond": torch.empty(n_bond, dtype=torch.long, device=dev)}
+        traj: Dict[str, Optional[torch.Tensor]] = {k: None for k in ("pos_traj", "v_traj", "bond_traj", "v0_traj", "vt_traj", "bt_traj")}
+        rng = lambda o, c, ids: torch.cat([torch.arange(o[b], o[b] + c[b]) for b in ids])
+        for gi, ((np_, nl_, npr_, nf_), ids) in enumerate(sorted(groups.items(), key=lambda kv: kv[1][0])):
+            G = len(ids)
+            r_p, r_l, r_pr, r_b = rng(o_p, n_p, ids), rng(o_l, n_l, ids), rng(o_pr, n_pr, ids), rng(o_b, n_b, ids)
+            d_p, d_l, d_pr, d_b = r_p.to(dev), r_l.to(dev), r_pr.to(dev), r_b.to(dev)
+            ar = lambda n: torch.arange(G, device=dev).repeat_interleave(n)
+            k_of_row_l = torch.arange(G).repeat_interleave(nl_).to(dev)          # sample slot of each ligand row
+            old_lig0 = torch.tensor([o_l[b] for b in ids], device=dev)
+            old_pr0 = torch.tensor([o_pr[b] for b in ids], device=dev)
+            sub = dict(
+                protein_pos=kw["protein_pos"][d_p], protein_v=kw["protein_v"][d_p], batch_protein=ar(np_),
+                protein_group_idx=None, init_ligand_pos=kw["init_ligand_pos"][d_l], init_ligand_v=kw["init_ligand_v"][d_l],
+                ligand_v_aux=kw["ligand_v_aux"][d_l], batch_ligand=ar(nl_), ligand_group_idx=None,
+                prior_centers=kw["prior_centers"][d_pr], prior_stds=kw["prior_stds"][d_pr],
+                prior_num_atoms=kw["prior_num_atoms"][d_pr] if kw["prior_num_atoms"] is not None else None,
+                batch_prior=ar(npr_), prior_group_idx=None,
+                ligand_decomp_batch=kw["ligand_decomp_batch"].to(dev)[d_l] - old_pr0[k_of_row_l] + k_of_row_l * npr_,
+                ligand_decomp_index=kw["ligand_decomp_index"][d_l] if kw["ligand_decomp_index"] is not None else None,
+                ligand_fc_bond_index=kw["ligand_fc_bond_index"].to(dev)[:, d_b]
+                - old_lig0.repeat_interleave(nl_ * (nl_ - 1))[None, :] + (torch.arange(G, device=dev) * nl_).repeat_interleave(nl_ * (nl_ - 1))[None, :],
+                init_ligand_fc_bond_type=kw["init_ligand_fc_bond_type"][d_b], batch_ligand_bond=ar(nl_ * (nl_ - 1)))
+            if has_full:
+                d_f = rng(o_f, n_f, ids).to(dev)
+                sub["full_protein_pos"] = kw["full_protein_pos"].to(dev)[d_f]
+                sub["full_batch_protein"] = ar(nf_)
+            sub_noise = None
+            if noise is not None:
+                sub_noise = {"u_v": noise["u_v"][:, r_l], "u_b": noise["u_b"][:, r_b], "eps": noise["eps"][:, r_l]}
+            r = self.sample_diffusion(num_steps=num_steps, center_pos_mode=center_pos_mode, energy_drift_opt=energy_drift_opt,
+                                      noise=sub_noise, seed=seed + 7919 * gi, keep_traj=keep_traj, use_graph=use_graph,
+                                      _drift_norm_batch=B, **sub)      # (the armsca loss is averaged over the whole batch)
+            out["pos"][d_l], out["v"][d_l], out["bond"][d_b] = r["pos"], r["v"], r["bond"]
+            if keep_traj and num_steps > 0:
+                for k, rows, n_tot in (("pos_traj", r_l, n_lig), ("v_traj", r_l, n_lig), ("v0_traj", r_l, n_lig),
+                                       ("vt_traj", r_l, n_lig), ("bond_traj", r_b, n_bond), ("bt_traj", r_b, n_bond)):
+                    st = torch.stack(r[k])                                         # [T, rows of this group, ...]
+                    if traj[k] is None:
+                        traj[k] = torch.empty((st.shape[0], n_tot) + tuple(st.shape[2:]), dtype=st.dtype)
+                    traj[k][:, rows] = st
+        for k in traj:
+            out[k] = list(traj[k].unbind(0)) if traj[k] is not None else []
+        return out
+
     # ------------------------------------------------------------------------------------------
     def _dense_inputs(self, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, ligand_v_aux, batch_ligand,
                       ligand_fc_bond_index, ligand_bond_type, ligand_atom_mask):
@@ -208,7 +296,7 @@ class DecompScorePosNet3D(nn.Module):
                     bond=ligand_bond_type.detach().to(torch.int32).contiguous())
 
     def _make_sampler(self, d, pw, n_steps, t_start, noise, keep_traj, drift, atom_std, offset, decomp_index,
-                      full_protein_pos, seed):
+                      full_protein_pos, seed, drift_norm_batch=0):
         lib = hip_lib.load()
         dev = d["protein_pos"].device
         B, NP, NL = d["B"], d["NP"], d["NL"]
@@ -282,6 +370,7 @@ class DecompScorePosNet3D(nn.Module):
                                           "(center_prox raises in the reference; mmff_min is RDKit/CPU)")
             else:
                 raise ValueError(dr["type"])
+        s.drift_norm_batch = int(drift_norm_batch)
         return s, bufs, pw
 
     def _side_stream(self, dev):
@@ -336,7 +425,7 @@ class DecompScorePosNet3D(nn.Module):
                          num_steps=None, center_pos_mode=None,
                          energy_drift_opt=None,
                          full_protein_pos=None, full_batch_protein=None,
-                         noise=None, seed=0, keep_traj=True, use_graph=True):
+                         noise=None, seed=0, keep_traj=True, use_graph=True, _drift_norm_batch=0):
         """Reverse diffusion (reference: models/decompdiff.py:552-703), same arguments and return
         keys.  Extra keyword-only knobs (all optional, reference call sites never pass them):
 
@@ -351,6 +440,17 @@ class DecompScorePosNet3D(nn.Module):
             raise ValueError(self.model_mean_type)
         if num_steps is None:
             num_steps = self.num_timesteps
+        if self._is_ragged(batch_protein, batch_ligand):
+            return self._sample_ragged(
+                dict(protein_pos=protein_pos, protein_v=protein_v, batch_protein=batch_protein,
+                     protein_group_idx=protein_group_idx, init_ligand_pos=init_ligand_pos, init_ligand_v=init_ligand_v,
+                     ligand_v_aux=ligand_v_aux, batch_ligand=batch_ligand, ligand_group_idx=ligand_group_idx,
+                     prior_centers=prior_centers, prior_stds=prior_stds, prior_num_atoms=prior_num_atoms,
+                     batch_prior=batch_prior, prior_group_idx=prior_group_idx, ligand_decomp_batch=ligand_decomp_batch,
+                     ligand_decomp_index=ligand_decomp_index, ligand_fc_bond_index=ligand_fc_bond_index,
+                     init_ligand_fc_bond_type=init_ligand_fc_bond_type, batch_ligand_bond=batch_ligand_bond,
+                     full_protein_pos=full_protein_pos, full_batch_protein=full_batch_protein),
+                ligand_atom_mask, num_steps, center_pos_mode, energy_drift_opt, noise, seed, keep_traj, use_graph)
         d = self._dense_inputs(protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, ligand_v_aux,
                                batch_ligand, ligand_fc_bond_index, init_ligand_fc_bond_type, ligand_atom_mask)
         dev = d["protein_pos"].device
@@ -380,7 +480,7 @@ class DecompScorePosNet3D(nn.Module):
             raise ValueError("num_steps exceeds num_timesteps")
         pw = self._packed_weights()
         s, bufs, _ = self._make_sampler(d, pw, num_steps, t_start, noise, keep_traj, energy_drift_opt, atom_std,
-                                        offset.contiguous(), decomp, fpp, seed)
+                                        offset.contiguous(), decomp, fpp, seed, _drift_norm_batch)
         lib = hip_lib.load()
         fn = lib.dd_sample_steps_graph if use_graph else lib.dd_sample_steps
         # the loop runs on a dedicated HIP stream (the legacy default stream cannot be captured into a hipGraph)

@@ -220,6 +220,40 @@ def build_sampling_batch(pocket: Pocket, n_data: int, num_bond_classes: int = 5,
     return out
 
 
+def concat_sampling_batches(batches) -> Dict[str, Optional[torch.Tensor]]:
+    """Collate several ``build_sampling_batch`` results (different pockets / ligand sizes) into ONE flat batch, the way
+    PyG's ``Batch.from_data_list`` does for the reference (utils/data.py:389-446: sample ids are renumbered, index
+    fields are incremented by the running atom / prior-row counts).  The result is a *ragged* batch."""
+    out: Dict[str, Optional[torch.Tensor]] = {}
+    n_s = n_lig = n_prior = 0
+    cat: Dict[str, list] = {}
+    for b in batches:
+        ns = int(b["batch_protein"].max()) + 1
+        inc = {"batch_protein": n_s, "batch_ligand": n_s, "batch_prior": n_s, "batch_ligand_bond": n_s,
+               "full_batch_protein": n_s, "ligand_fc_bond_index": n_lig, "ligand_decomp_batch": n_prior,
+               "ligand_group_idx": n_prior}
+        for k, v in b.items():
+            if not torch.is_tensor(v):
+                continue
+            cat.setdefault(k, []).append(v + inc[k] if k in inc else v)
+        n_s += ns
+        n_lig += b["batch_ligand"].numel()
+        n_prior += b["batch_prior"].numel()
+    for k, vs in cat.items():
+        out[k] = torch.cat(vs, 1 if k == "ligand_fc_bond_index" else 0)
+    out["ligand_atom_mask"] = None
+    return out
+
+
+def ragged_demo_batch(seed: int) -> Dict[str, Optional[torch.Tensor]]:
+    """A small ragged batch (two pocket / ligand sizes, groups interleaved: 1 + 2 + 1 samples) — the input of the
+    ``traj10_ragged`` golden fixture (oracle/make_golden.py) and of the tests that replay it."""
+    pa = make_pocket_tiny(11, num_protein=48, arm_atoms=(3, 2), scaffold_atoms=3)       # NL = 8
+    pb = make_pocket_tiny(12, num_protein=40, arm_atoms=(2, 2), scaffold_atoms=2)       # NL = 6
+    torch.manual_seed(seed)
+    return concat_sampling_batches([build_sampling_batch(p, n) for p, n in ((pa, 1), (pb, 2), (pa, 1))])
+
+
 def draw_step_noise(num_steps: int, n_ligand: int, n_bond: int, num_classes: int = NUM_ATOM_CLASSES,
                     num_bond_classes: int = 5):
     """Pre-draw the per-step noise exactly as the reference loop consumes it.

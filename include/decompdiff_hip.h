@@ -98,6 +98,8 @@ typedef struct dd_sampler {
   /* drift (configs/sampling_drift.yml:31-37) */
   int32_t drift_armsca; float armsca_min_d, armsca_max_d; int32_t armsca_scale;
   int32_t drift_clash;  float clash_sigma, clash_gamma;    int32_t clash_scale;
+  int32_t drift_norm_batch;        /* batch size the armsca loss is averaged over (guidance_funcs.py:78); 0 = B.
+                                      Set when a larger (e.g. ragged) batch is run in several dense groups. */
   /* noise: injected (reference draw order, decompdiff.py:620,633,680) or Philox when NULL */
   const float* u_v;                /* [n_steps,B*NL,8]  uniforms for atom types   */
   const float* u_b;                /* [n_steps,B*Eb,5]  uniforms for bond types   */

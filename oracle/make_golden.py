@@ -232,6 +232,26 @@ def gen_traj(ref, sd, cfg, name, pocket, n_data, num_steps, drift, seed, every=1
     print(f"[{name}] {num_steps} steps: reference {t_ref:.1f}s, oracle {t_or:.1f}s, oracle maxabs diff = {w:g}")
 
 
+def gen_traj_ragged(ref, sd, cfg, name, num_steps, drift, seed):
+    """Ragged batch: the reference handles different atom counts per sample natively."""
+    batch = synth.ragged_demo_batch(seed)
+    state = torch.get_rng_state()
+    r = run_ref_sampling(ref, batch, num_steps, drift)
+    torch.set_rng_state(state)
+    noise = synth.draw_step_noise(num_steps, batch["init_ligand_pos"].size(0), batch["init_ligand_fc_bond_type"].size(0))
+    ro = run_oracle_sampling(sd, cfg, batch, num_steps, drift, noise)
+    w = max(maxabs(r["pos"], ro["pos"]), maxabs(r["v"], ro["v"]), maxabs(r["bond"], ro["bond"]))
+    out = np_inputs(batch)
+    out.update(traj_arrays(r))
+    out["seed"], out["num_steps"] = np.array(seed), np.array(num_steps)
+    out["drift"] = np.array(json.dumps(drift))
+    out["noise_checksum"] = np.array([float(noise["u_v"].double().sum()), float(noise["u_b"].double().sum()),
+                                      float(noise["eps"].double().sum())])
+    out["oracle_vs_reference_maxabs"] = np.array(w)
+    np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **out)
+    print(f"[{name}] {num_steps} steps, ragged batch: oracle maxabs diff = {w:g}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-long", action="store_true", help="skip the 1000-step trajectory (~10 min)")
@@ -254,6 +274,8 @@ def main():
     if want("traj20"):
         gen_traj(ref, sd, cfg, "traj20_plain", synth.make_pocket_small(2), 2, 20, None, 2021)
         gen_traj(ref, sd, cfg, "traj20_drift", synth.make_pocket_small(2), 2, 20, DRIFT, 2022, std_scale=[1.0, 0.85])
+    if want("ragged"):
+        gen_traj_ragged(ref, sd, cfg, "traj10_ragged", 10, DRIFT, 2023)
     if want("traj1000") and not args.skip_long:
         gen_traj(ref, sd, cfg, "traj1000_plain", synth.make_pocket_small(3), 1, 1000, None, 2021, every=50)
 

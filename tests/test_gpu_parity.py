@@ -431,6 +431,27 @@ def test_harness_batches_and_unbatching():
             k += 1
 
 
+def test_ragged_batch_golden():
+    """samples with different atom counts in one batch (fixture from the reference).  The HIP path
+    runs one dense group per distinct size and scatters the results back into batch order."""
+    g = GU.load("traj10_ragged")
+    b = GU.batch_from_npz(g)
+    T = int(g["num_steps"])
+    batch = synth.ragged_demo_batch(int(g["seed"]))
+    noise = synth.draw_step_noise(T, batch["init_ligand_pos"].size(0), batch["init_ligand_fc_bond_type"].size(0))
+    assert np.array_equal(GU.checksum(noise), g["noise_checksum"])
+    drift = json.loads(str(g["drift"]))
+    r = _sample_hip(model(0), b, T, drift, noise)
+    tp = torch.stack(r["pos_traj"]).numpy()
+    per_step = np.abs(tp.astype(np.float64) - g["traj_pos"]).reshape(T, -1).max(1)
+    nv = int((torch.stack(r["v_traj"]).numpy() != g["traj_v"]).sum())
+    nb = int((torch.stack(r["bond_traj"]).numpy() != g["traj_bond"]).sum())
+    print(f"ragged: per-step max pos err first/last {per_step[0]:.3g}/{per_step[-1]:.3g}; type mismatches v={nv} bond={nb}")
+    assert maxabs(r["pos"], g["out_pos"]) < POS_TOL
+    assert nv == 0 and nb == 0
+    assert np.array_equal(r["v"].cpu().numpy(), g["out_v"]) and np.array_equal(r["bond"].cpu().numpy(), g["out_bond"])
+
+
 def test_unsupported_inputs_fail_loudly():
     g = GU.load("forward_small")
     b = GU.batch_from_npz(g)

@@ -173,3 +173,21 @@ def test_knn_graph_semantics():
     # fewer than k candidates -> all of them
     ei2 = ops.knn_graph(x[:4], k=5)
     assert ei2.shape == (2, 4 * 3)
+
+
+def test_trajectory_ragged_batch():
+    """Ragged batch (different protein / ligand sizes per sample): the oracle follows the reference's
+    segmented ops, fixture generated by the reference itself (oracle/make_golden.py --only ragged)."""
+    g = GU.load("traj10_ragged")
+    batch = synth.ragged_demo_batch(int(g["seed"]))
+    noise = synth.draw_step_noise(int(g["num_steps"]), batch["init_ligand_pos"].size(0), batch["init_ligand_fc_bond_type"].size(0))
+    assert np.array_equal(GU.checksum(noise), g["noise_checksum"])
+    stored = GU.batch_from_npz(g)
+    for k, v in stored.items():
+        if torch.is_tensor(v):
+            assert torch.equal(v, batch[k].to(v.dtype)), k
+    cfg, sd = GU.weights(0)
+    r = OD.sample_diffusion(sd, cfg, num_steps=int(g["num_steps"]), energy_drift_opt=json.loads(str(g["drift"])), noise=noise, **batch)
+    assert np.array_equal(g["out_pos"], r["pos"].numpy())
+    assert np.array_equal(g["out_v"], r["v"].numpy()) and np.array_equal(g["out_bond"], r["bond"].numpy())
+    assert np.array_equal(g["traj_pos"], torch.stack(r["pos_traj"]).numpy())
