@@ -625,7 +625,7 @@ namespace dd { extern int g_gemm_ksplit; extern int g_attn_waves; extern int g_a
 extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 0) return dd_debug_set_fusion(value);
   if (key == 1) { dd::g_gemm_ksplit = value ? 1 : 0; return DD_OK; }
-  if (key == 3) { dd::g_attn_persist = value; return DD_OK; }
+  if (key == 3) { dd::g_attn_persist = value ? 1 : 0; return DD_OK; }
   if (key == 6) { dd::g_mlp_fused = value ? 1 : 0; return DD_OK; }
   if (key == 5) { if (value != 2 && value != 4 && value != 8) return DD_ERR_BAD_ARG; dd::g_pos_waves = value; return DD_OK; }
   if (key == 4) { dd::g_assemble_persist = value ? 1 : 0; return DD_OK; }

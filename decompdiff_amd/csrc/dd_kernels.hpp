@@ -64,7 +64,6 @@ struct AttnArgs {
   const float *W2vT, *b2v; // node modes
   const float* W2v;        // node modes, tiled kernel: [128 o][128 c]
   int* work_counter;       // persistent workgroups: next segment to process (zeroed before the launch)
-  int persist_batches;     // persistent workgroups fetch NW segments per trip, barrier-synchronised
   const float *W2v16, *b2v16;  // pos modes
   float* out;
   const float* dxe;        // PB: result of PE

@@ -354,6 +354,27 @@ def test_launch_variants_agree():
         assert max(maxabs(outs[mode][k], g["out_" + k]) for k in outs[1]) < POS_TOL
 
 
+def test_runtime_options_agree():
+    """dd_debug_set_option variants (scheduling / kernel alternatives kept for A/B measurements) give the same forward."""
+    g = GU.load("forward_small")
+    b = GU.batch_from_npz(g)
+    lib = hip_lib.load()
+    defaults = {1: 1, 3: 1, 4: 1, 5: 4, 6: 0}
+    ref = {k: v.clone() for k, v in _forward_hip(model(0), b).items()}
+    try:
+        for key, val in ((1, 0), (3, 0), (4, 0), (5, 8), (5, 2), (6, 1)):
+            assert lib.dd_debug_set_option(key, val) == 0
+            o = _forward_hip(model(0), b)
+            torch.cuda.synchronize()
+            errs = {k: maxabs(o[k], ref[k]) for k in ref}
+            print(f"option {key}={val} vs default:", {k: f"{v:.3g}" for k, v in errs.items()})
+            assert max(errs.values()) < 2e-5
+            lib.dd_debug_set_option(key, defaults[key])
+    finally:
+        for key, val in defaults.items():
+            lib.dd_debug_set_option(key, val)
+
+
 def test_philox_noise_mode_is_deterministic_and_sane():
     pocket = synth.make_pocket_small(5)
     torch.manual_seed(1)
@@ -429,6 +450,28 @@ def test_harness_batches_and_unbatching():
             assert np.array_equal(out["pred_bond_type"][k], r["bond"][s * Eb:(s + 1) * Eb].numpy())
             assert maxabs(out["pred_pos_traj"][k][-1], r["pos_traj"][-1][s * NL:(s + 1) * NL]) < POS_TOL
             k += 1
+
+
+def test_drift_scale_option_vs_oracle():
+    """`scale: True` of a drift term multiplies its gradient by pos_score_coef[t] (decompdiff.py:656-657,667-668).
+    Not used by the shipped config, so there is no reference fixture: checked against the oracle (bit-exact restatement
+    of the reference on every fixture that exists) on injected noise, mid-chain where the coefficient is not tiny."""
+    cfg, sd = GU.weights(0)
+    pocket = synth.make_pocket(41, 80, (3, 3), 4, num_full_protein=200)
+    torch.manual_seed(9)
+    b = synth.build_sampling_batch(pocket, 2, per_sample_std_scale=[1.0, 0.8])
+    steps, t_start = 3, 600
+    noise = synth.draw_step_noise(steps, b["init_ligand_pos"].size(0), b["init_ligand_fc_bond_type"].size(0))
+    drift = [dict(type="armsca_prox", min_d=1.2, max_d=1.9, scale=True), dict(type="clash", sigma=2, gamma=4, scale=True)]
+    want = OD.sample_diffusion(sd, cfg, num_steps=steps, energy_drift_opt=drift, noise=noise, t_start=t_start, **b)
+    plain = OD.sample_diffusion(sd, cfg, num_steps=steps, energy_drift_opt=[dict(d, scale=False) for d in drift], noise=noise,
+                                t_start=t_start, **b)
+    got = _sample_hip(model(0), b, steps, drift, noise, t_start)
+    err = maxabs(got["pos"], want["pos"])
+    print(f"drift scale: pos err {err:.3g}; effect of the option on the result {maxabs(want['pos'], plain['pos']):.3g}")
+    assert maxabs(want["pos"], plain["pos"]) > 1e-3        # the option matters in this case
+    assert err < POS_TOL
+    assert torch.equal(got["v"].cpu(), want["v"]) and torch.equal(got["bond"].cpu(), want["bond"])
 
 
 def test_ragged_batch_golden():
