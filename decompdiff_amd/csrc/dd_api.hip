@@ -102,6 +102,7 @@ struct ProfScope {
 // projection GEMMs); fork/join through events, which stream capture turns into graph edges
 static hipStream_t g_side = nullptr, g_side2 = nullptr;   // g_side2: query MLPs of the node / bond sub-layers
 static hipEvent_t g_ev_qa_fork[8], g_ev_qa_join[8], g_ev_qb_fork[8];
+static int g_step_fused = 1;                   // dd_debug_set_option(7, v): rows + coordinates + counter in one launch
 static int g_mlp_fused = 0;                    // dd_debug_set_option(6, v): fused 2-layer query MLPs beside the projections
 static hipEvent_t g_ev_fork[9], g_ev_join[9];   // [0..7] per layer, [8] graph construction at the head of a forward
 static int g_overlap = 1;                     // measured in-process A/B: -3.5 % step time
@@ -439,16 +440,21 @@ static int heads_and_step(const dd_sampler* s, hipStream_t st) {
     DD_TRYP(DD_PROF_STEP, dd_drift_clash(s->lig_pos, s->offset, s->full_protein_pos, B, NL, s->NF, s->clash_sigma, s->clash_gamma, w.gc, 0, st));
     gc = w.gc;
   }
-  DD_TRYP(DD_PROF_STEP, launch_step_rows(r, st));
-  DD_TRYP(DD_PROF_STEP, launch_step_rows(rb, st));
   StepPosArgs p;
   memset(&p, 0, sizeof(p));
   p.B = B; p.NL = NL; p.T = s->T; p.t_start = s->t_start; p.step_counter = s->step_counter;
   p.x0 = s->pred_pos; p.xt = s->lig_pos; p.tab_pos = s->tab_pos; p.tab_score = s->tab_score;
   p.atom_std = s->atom_std; p.offset = s->offset; p.grad_a = ga; p.scale_a = s->armsca_scale; p.grad_c = gc;
   p.scale_c = s->clash_scale; p.eps = s->eps; p.seed = s->seed; p.traj_pos = s->traj_pos;
-  DD_TRYP(DD_PROF_STEP, launch_step_pos(p, st));
-  DD_TRYP(DD_PROF_STEP, launch_advance(s->step_counter, st));
+  if (g_step_fused) {
+    DD_TRYP(DD_PROF_STEP, launch_step_all(rb, r, p, st));
+    DD_TRYP(DD_PROF_STEP, launch_advance(s->step_counter, st));
+  } else {
+    DD_TRYP(DD_PROF_STEP, launch_step_rows(r, st));
+    DD_TRYP(DD_PROF_STEP, launch_step_rows(rb, st));
+    DD_TRYP(DD_PROF_STEP, launch_step_pos(p, st));
+    DD_TRYP(DD_PROF_STEP, launch_advance(s->step_counter, st));
+  }
   return DD_OK;
 }
 
@@ -626,6 +632,7 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 0) return dd_debug_set_fusion(value);
   if (key == 1) { dd::g_gemm_ksplit = value ? 1 : 0; return DD_OK; }
   if (key == 3) { dd::g_attn_persist = value ? 1 : 0; return DD_OK; }
+  if (key == 7) { dd::g_step_fused = value ? 1 : 0; return DD_OK; }
   if (key == 6) { dd::g_mlp_fused = value ? 1 : 0; return DD_OK; }
   if (key == 5) { if (value != 2 && value != 4 && value != 8) return DD_ERR_BAD_ARG; dd::g_pos_waves = value; return DD_OK; }
   if (key == 4) { dd::g_assemble_persist = value ? 1 : 0; return DD_OK; }

@@ -112,5 +112,6 @@ struct StepPosArgs {
 int launch_step_rows(const StepRowsArgs& a, hipStream_t st);
 int launch_step_pos(const StepPosArgs& a, hipStream_t st);
 int launch_advance(int32_t* ctr, hipStream_t st);
+int launch_step_all(const StepRowsArgs& rb, const StepRowsArgs& rv, const StepPosArgs& p, hipStream_t st);
 
 }  // namespace dd

@@ -222,6 +222,134 @@ __global__ __launch_bounds__(256) void k_drift_clash(const float* __restrict__ p
   }
 }
 
+
+// ---------------------------------------------------------------------------------- one launch per reverse step
+// Bond rows, atom rows and the coordinate update are independent given the head activations, so they share one
+// launch (block ranges); the step counter is advanced by a 1-thread launch behind it (a last-block ticket was
+// tried: ~1800 atomics on one address serialise to 45 us).  A row is one wave: the
+// second head Linear uses the whole wave, the per-class posterior / Gumbel arithmetic runs one class per lane with
+// the cross-class sums taken in class order through v_readlane (bit-identical to the serial k_step_rows).
+template <int NC>
+__device__ __forceinline__ void step_row(const StepRowsArgs& a, const long row, const int lane, const int step) {
+  const int t = a.t_start - step;
+  float2 hv = *reinterpret_cast<const float2*>(a.hid + row * 128 + 2 * lane);
+  hv.x = (hv.x > 20.f ? hv.x : log1pf(expf(hv.x))) - 0.6931471805599453f;
+  hv.y = (hv.y > 20.f ? hv.y : log1pf(expf(hv.y))) - 0.6931471805599453f;
+  float logit[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const float2 w = *reinterpret_cast<const float2*>(a.W2 + c * 128 + 2 * lane);
+    logit[c] = wave_sum(fmaf(hv.y, w.y, hv.x * w.x)) + a.b2[c];
+  }
+  const int c = lane < NC ? lane : NC - 1;               // lanes >= NC shadow the last class (results unused)
+  float mine = logit[0], mx = logit[0];
+#pragma unroll
+  for (int k = 1; k < NC; ++k) { mine = (c == k) ? logit[k] : mine; mx = fmaxf(mx, logit[k]); }
+  const float e = expf(mine - mx);
+  float se = 0.f;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) se += lane_bcast(e, k);
+  const float lse = mx + logf(se);
+  const int tm1 = t - 1 < 0 ? 0 : t - 1;
+  const float la_t = a.tab[t], l1ma_t = a.tab[a.T + t];
+  const float lca = a.tab[2 * a.T + tm1], l1mca = a.tab[3 * a.T + tm1];
+  const float log_prior = -logf((float)NC);
+  const int cur = a.state[row];
+  const float lv0 = mine - lse;
+  const float lvt = (c == cur) ? 0.f : -69.07755278982137f;      // log(clamp(onehot, 1e-30))
+  const float q0 = log_add_exp(lv0 + lca, l1mca + log_prior);    // q(v_{t-1} | v0)
+  const float q1 = log_add_exp(lvt + la_t, l1ma_t + log_prior);  // q(v_t | v_{t-1})
+  const float un = q0 + q1;
+  float umax = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) umax = fmaxf(umax, lane_bcast(un, k));
+  const float ue = expf(un - umax);
+  float us = 0.f;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) us += lane_bcast(ue, k);
+  const float ulse = umax + logf(us);
+  float u;
+  if (a.uniforms) {
+    u = a.uniforms[((long)step * a.rows + row) * NC + c];
+  } else {
+    Philox ph(a.seed);
+    uint32_t r[4], r2[4];
+    ph.gen((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)step, a.stream_id, r);
+    ph.gen((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)step, a.stream_id | 0x100u, r2);
+    uint32_t bits = r[0];
+#pragma unroll
+    for (int k = 1; k < NC; ++k) bits = (c == k) ? (k < 4 ? r[k] : r2[k - 4]) : bits;
+    u = u01(bits);
+  }
+  const float lp = un - ulse;
+  const float sc = -logf(-logf(u + 1e-30f) + 1e-30f) + lp;      // Gumbel-argmax (transitions.py:78-84)
+  int best = 0;
+  float bestv = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const float sk = lane_bcast(sc, k);
+    if (sk > bestv) { bestv = sk; best = k; }
+  }
+  if (lane < NC) {
+    if (a.logits_out) a.logits_out[row * NC + c] = mine;
+    if (a.traj_recon) a.traj_recon[((long)step * a.rows + row) * NC + c] = lv0;
+    if (a.traj_prob) a.traj_prob[((long)step * a.rows + row) * NC + c] = lp;
+  }
+  if (lane == 0) {
+    a.state[row] = best;
+    if (a.traj_state) a.traj_state[(long)step * a.rows + row] = best;
+  }
+}
+
+__device__ __forceinline__ void step_pos_elem(const StepPosArgs& a, const int idx, const int step) {
+  const int n = a.B * a.NL * 3;
+  if (idx >= n) return;
+  const int t = a.t_start - step;
+  const int atom = idx / 3, c = idx % 3, b = atom / a.NL;
+  const float xt = a.xt[idx];
+  float mean = a.tab_pos[t] * a.x0[idx] + a.tab_pos[a.T + t] * xt;
+  float g = 0.f;
+  if (a.grad_a) g += a.scale_a ? a.grad_a[idx] * a.tab_score[t] : a.grad_a[idx];
+  if (a.grad_c) g += a.scale_c ? a.grad_c[idx] * a.tab_score[t] : a.grad_c[idx];
+  mean -= g;
+  float e;
+  if (a.eps) {
+    e = a.eps[(long)step * n + idx];
+  } else {
+    Philox ph(a.seed);
+    uint32_t r[4];
+    ph.gen((uint32_t)idx, 0u, (uint32_t)step, 7u, r);
+    const float u1 = fmaxf(u01(r[0]), 5.9604645e-8f), u2 = u01(r[1]);
+    e = sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+  }
+  const float nz = t == 0 ? 0.f : 1.f;
+  const float nxt = mean + nz * expf(0.5f * a.tab_pos[2 * a.T + t]) * e * a.atom_std[idx];
+  a.xt[idx] = nxt;
+  if (a.traj_pos) a.traj_pos[(long)step * n + idx] = nxt + a.offset[b * 3 + c];
+}
+
+__global__ __launch_bounds__(256) void k_step_all(const StepRowsArgs rb, const StepRowsArgs rv, const StepPosArgs p, int nb_b, int nb_v) {
+  const int blk = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int step = *rb.step_counter;
+  if (blk < nb_b) {
+    const long row = (long)blk * 4 + wave;
+    if (row < rb.rows) step_row<DD_NUM_B>(rb, row, lane, step);
+  } else if (blk < nb_b + nb_v) {
+    const long row = (long)(blk - nb_b) * 4 + wave;
+    if (row < rv.rows) step_row<DD_NUM_V>(rv, row, lane, step);
+  } else {
+    step_pos_elem(p, (blk - nb_b - nb_v) * 256 + threadIdx.x, step);
+  }
+}
+
+int launch_step_all(const StepRowsArgs& rb, const StepRowsArgs& rv, const StepPosArgs& p, hipStream_t st) {
+  if (rb.NC != DD_NUM_B || rv.NC != DD_NUM_V) return DD_ERR_UNSUPPORTED_SHAPE;
+  const int nb_b = (rb.rows + 3) / 4, nb_v = (rv.rows + 3) / 4, nb_p = (p.B * p.NL * 3 + 255) / 256;
+  hipLaunchKernelGGL(k_step_all, dim3(nb_b + nb_v + nb_p), dim3(256), 0, st, rb, rv, p, nb_b, nb_v);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
 int launch_step_rows(const StepRowsArgs& a, hipStream_t st) {
   if (a.rows <= 0) return DD_OK;
   dim3 grid((a.rows + 3) / 4);

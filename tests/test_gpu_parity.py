@@ -359,7 +359,7 @@ def test_runtime_options_agree():
     g = GU.load("forward_small")
     b = GU.batch_from_npz(g)
     lib = hip_lib.load()
-    defaults = {1: 1, 3: 1, 4: 1, 5: 4, 6: 0}
+    defaults = {1: 1, 3: 1, 4: 1, 5: 4, 6: 0, 7: 1}
     ref = {k: v.clone() for k, v in _forward_hip(model(0), b).items()}
     try:
         for key, val in ((1, 0), (3, 0), (4, 0), (5, 8), (5, 2), (6, 1)):
