@@ -152,10 +152,10 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
   const bool overlap = fused && g_overlap && g_prof == nullptr && s->num_layers <= 8;
   if (overlap) DD_TRY(ensure_side_stream());
 
-  if (hipMemsetAsync(w.counters, 0, 64 * sizeof(int32_t), st) != hipSuccess) return DD_ERR_HIP;
-  // embeddings + context (decompdiff.py:219-297)
-  DD_TRYP(DD_PROF_MISC, launch_embed_nodes(s->protein_h, s->protein_pos, s->lig_pos, s->lig_v, s->lig_aux, GW(DD_G_W_lemb),
-                            GW(DD_G_b_lemb), B, NP, NL, w.h, w.xa, w.xb, st));
+  // embeddings + context (decompdiff.py:219-297) and the zeroed work counters: one launch
+  DD_TRYP(DD_PROF_MISC, launch_embed_all(s->protein_h, s->protein_pos, s->lig_pos, s->lig_v, s->lig_aux, GW(DD_G_W_lemb),
+                                         GW(DD_G_b_lemb), B, NP, NL, w.h, w.xa, w.xb, s->lig_bond, (long)B * Eb, GW(DD_G_W_bemb),
+                                         GW(DD_G_b_bemb), w.hb, w.counters, st));
   // graph (uni_transformer_edge.py:404-427): only the attention kernels need it, so with two streams it is built
   // beside the bond embedding and the first layer's projections
   bool head_join = false;
@@ -173,8 +173,6 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
       head_join = true;
     }
   }
-  DD_TRYP(DD_PROF_MISC, launch_embed_bonds(s->lig_bond, (long)B * Eb, GW(DD_G_W_bemb), GW(DD_G_b_bemb), w.hb, st));
-
   int pending_join = -1;
   for (int l = 0; l < s->num_layers && fused; ++l) {
     const int nE = (int)(B * Eb);

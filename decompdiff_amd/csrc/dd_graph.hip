@@ -145,6 +145,48 @@ __global__ void k_embed_bonds(const int32_t* __restrict__ bond, long rows, const
   hb[idx] = Wb[c * 5 + bond[e]] + bb[c];
 }
 
+
+// One launch at the head of a step: node embedding / context, bond embedding, and the per-forward work counters
+// of the persistent kernels (64 ints) set to zero.
+__global__ __launch_bounds__(256) void k_embed_all(const float* __restrict__ protein_h, const float* __restrict__ protein_pos,
+                                                   const float* __restrict__ lig_pos, const int32_t* __restrict__ lig_v,
+                                                   const float* __restrict__ lig_aux, const float* __restrict__ Wl,
+                                                   const float* __restrict__ bl, int B, int NP, int NL, float* __restrict__ h,
+                                                   float* __restrict__ xa, float* __restrict__ xb,
+                                                   const int32_t* __restrict__ bond, long bond_rows,
+                                                   const float* __restrict__ Wb, const float* __restrict__ bb,
+                                                   float* __restrict__ hb, int32_t* __restrict__ counters, int node_blocks) {
+  if (blockIdx.x == 0 && threadIdx.x < 64 && counters) counters[threadIdx.x] = 0;
+  if ((int)blockIdx.x < node_blocks) {
+    const int N = NP + NL;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * N * 128) return;
+    const int c = idx & 127;
+    const long node = idx >> 7;
+    const int b = node / N, n = node % N;
+    float val;
+    if (n < NP) {
+      val = protein_h[((long)b * NP + n) * 128 + c];
+    } else {
+      const long a = (long)b * NL + (n - NP);
+      const float* w = Wl + c * 10;
+      val = w[lig_v[a]] + w[8] * lig_aux[2 * a] + w[9] * lig_aux[2 * a + 1] + bl[c];
+    }
+    h[idx] = val;
+    if (c < 3) {
+      const float p = n < NP ? protein_pos[((long)b * NP + n) * 3 + c] : lig_pos[((long)b * NL + (n - NP)) * 3 + c];
+      xa[node * 3 + c] = p;
+      xb[node * 3 + c] = p;
+    }
+  } else {
+    const long idx = (long)(blockIdx.x - node_blocks) * 256 + threadIdx.x;
+    if (idx >= bond_rows * 128) return;
+    const int c = idx & 127;
+    const long e = idx >> 7;
+    hb[idx] = Wb[c * 5 + bond[e]] + bb[c];
+  }
+}
+
 // --------------------------------------------------------------------------- bond-layer assemble
 // For bond edge e = (src s -> dst t) of sample b (dst-major id e = t*(NL-1) + s'):
 //   Ek[e] = PB.k_hb[e] + Wg1k . G(d_e) + PL[s].k_hk + PL[t].k_hj        (b1 folded into PB bias)
@@ -330,6 +372,17 @@ int launch_embed_nodes(const float* protein_h, const float* protein_pos, const f
   long n = (long)B * (NP + NL) * 128;
   hipLaunchKernelGGL(k_embed_nodes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, protein_h, protein_pos, lig_pos,
                      lig_v, lig_aux, Wl, bl, B, NP, NL, h, xa, xb);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+int launch_embed_all(const float* protein_h, const float* protein_pos, const float* lig_pos, const int32_t* lig_v,
+                     const float* lig_aux, const float* Wl, const float* bl, int B, int NP, int NL, float* h, float* xa, float* xb,
+                     const int32_t* bond, long bond_rows, const float* Wb, const float* bb, float* hb, int32_t* counters,
+                     hipStream_t st) {
+  const long nn = (long)B * (NP + NL) * 128, nb = bond_rows * 128;
+  const int node_blocks = (int)((nn + 255) / 256), bond_blocks = (int)((nb + 255) / 256);
+  hipLaunchKernelGGL(k_embed_all, dim3(node_blocks + bond_blocks), dim3(256), 0, st, protein_h, protein_pos, lig_pos, lig_v, lig_aux,
+                     Wl, bl, B, NP, NL, h, xa, xb, bond, bond_rows, Wb, bb, hb, counters, node_blocks);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }

@@ -31,6 +31,10 @@ int launch_gemm128(const GemmArgs& a, hipStream_t st);
 // up to 4 independent projections in one launch (small ones ride along with the big ones)
 int launch_gemm128_batch(const GemmArgs* jobs, int njobs, hipStream_t st);
 
+int launch_embed_all(const float* protein_h, const float* protein_pos, const float* lig_pos, const int32_t* lig_v,
+                     const float* lig_aux, const float* Wl, const float* bl, int B, int NP, int NL, float* h, float* xa, float* xb,
+                     const int32_t* bond, long bond_rows, const float* Wb, const float* bb, float* hb, int32_t* counters,
+                     hipStream_t st);
 int launch_drift_armsca(const float* lig_pos, const int32_t* decomp_index, int B, int NL, float min_d, float max_d,
                         float* grad, int accumulate, int norm_B, hipStream_t st);
 int launch_knn(const float* x, int B, int N, int K, int32_t* nbr, hipStream_t st);
