@@ -103,12 +103,19 @@ struct ProfScope {
 static hipStream_t g_side = nullptr, g_side2 = nullptr;   // g_side2: query MLPs of the node / bond sub-layers
 static hipEvent_t g_ev_qa_fork[8], g_ev_qa_join[8], g_ev_qb_fork[8];
 static int g_step_fused = 1;                   // dd_debug_set_option(7, v): rows + coordinates + counter in one launch
+static int g_sched = 1;                        // dd_debug_set_option(8, v): 1 = next layer's projections ahead on the side stream,
+                                               // 0 = coordinate sub-layers on the side stream
 static int g_mlp_fused = 0;                    // dd_debug_set_option(6, v): fused 2-layer query MLPs beside the projections
 static hipEvent_t g_ev_fork[9], g_ev_join[9];   // [0..7] per layer, [8] graph construction at the head of a forward
+static int g_side_low_priority = [] { const char* e = getenv("DD_SIDE_PRIO"); return (e && e[0] == '0') ? 0 : 1; }();
 static int g_overlap = 1;                     // measured in-process A/B: -3.5 % step time
 static int ensure_side_stream() {
   if (g_side) return DD_OK;
-  if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) return DD_ERR_HIP;
+  {
+    int lo = 0, hi = 0;                                  // lowest priority: side work fills CUs the main chain leaves idle
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; (void)hipGetLastError(); }
+    if (hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, g_side_low_priority ? lo : 0) != hipSuccess) return DD_ERR_HIP;
+  }
   if (hipStreamCreateWithFlags(&g_side2, hipStreamNonBlocking) != hipSuccess) return DD_ERR_HIP;
   for (int i = 0; i < 8; ++i)
     if (hipEventCreateWithFlags(&g_ev_qa_fork[i], hipEventDisableTiming) != hipSuccess ||
@@ -200,14 +207,18 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
         DD_TRYP(DD_PROF_GEMM, launch_mlp2_batch(q, 3, st));
       }
     }
-    // ---- projections of the old h / h_bond: one launch (the q blocks are the last columns: skipped when fused above)
-    {
+    // ---- projections of the old h / h_bond: one launch (the q blocks are the last columns: skipped when fused above).
+    //      With the projection-ahead schedule this launch was already issued on the side stream right after the
+    //      previous layer's lin_node (it needs h and h_bond only) and is joined before its first consumer.
+    auto launch_batch1 = [&](int ll, hipStream_t sx) -> int {
       GemmArgs j[3] = {
-          gemm_args(w.h, B * N, 0, 128, B * N, LW(l, DD_W_n1), LW(l, DD_b_n1), nullptr, w.P, B * N, 0, 640, mlpf ? 512 : 640, 0),
-          gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(l, DD_W_l1), LW(l, DD_b_l1), nullptr, w.PL, B * NL, 0, 1280, mlpf ? 1152 : 1280, 0),
-          gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b1), LW(l, DD_b_b1), nullptr, w.PB, nE, 0, 640, mlpf ? 512 : 640, 0)};
-      DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, 3, st));
-    }
+          gemm_args(w.h, B * N, 0, 128, B * N, LW(ll, DD_W_n1), LW(ll, DD_b_n1), nullptr, w.P, B * N, 0, 640, mlpf ? 512 : 640, 0),
+          gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(ll, DD_W_l1), LW(ll, DD_b_l1), nullptr, w.PL, B * NL, 0, 1280, mlpf ? 1152 : 1280, 0),
+          gemm_args(w.hb, nE, 0, 128, nE, LW(ll, DD_W_b1), LW(ll, DD_b_b1), nullptr, w.PB, nE, 0, 640, mlpf ? 512 : 640, 0)};
+      return launch_gemm128_batch(j, 3, sx);
+    };
+    const bool ahead = overlap && g_sched == 1;
+    if (!(ahead && l > 0)) DD_TRYP(DD_PROF_GEMM, launch_batch1(l, st));
     if (pending_join >= 0) {
       if (hipStreamWaitEvent(st, g_ev_join[pending_join], 0) != hipSuccess) return DD_ERR_HIP;
       pending_join = -1;
@@ -216,6 +227,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
       if (hipStreamWaitEvent(st, g_ev_join[8], 0) != hipSuccess) return DD_ERR_HIP;
       head_join = false;
     }
+    if (ahead && l > 0 && hipStreamWaitEvent(st, g_ev_join[l], 0) != hipSuccess) return DD_ERR_HIP;   // projections of this layer
     DD_TRYP(DD_PROF_ASSEMBLE, launch_bl_assemble(xcur, w.PB, w.PL, LW(l, DD_BL_Wg1k), LW(l, DD_BL_Wg1v), LW(l, DD_BL_Wg2k),
                                                   LW(l, DD_BL_Wg2v), B, NP, NL, w.Ek, w.Ev, mlpf ? nullptr : w.q1bl, w.Rk, w.Rv, st));
     if (!mlpf) {
@@ -256,6 +268,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
       g.X2 = w.Anb; g.x2_N = N; g.x2_NP = NP;
       DD_TRYP(DD_PROF_GEMM, launch_gemm128(g, st));
     }
+    if (ahead && l + 1 < s->num_layers && hipEventRecord(g_ev_fork[l + 1], st) != hipSuccess) return DD_ERR_HIP;   // h, h_bond final
     // ---- query MLPs of the two coordinate sub-layers: fused, on the stream the sub-layers themselves run on
     if (mlpf) {
       Mlp2Job q[2];
@@ -267,7 +280,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
       q[0].ln = LW(l, DD_PE_lnq); q[0].W2 = LW(l, DD_PE_W2q); q[0].b2 = LW(l, DD_PE_b2q); q[0].Y = w.ql;
       q[1].W1a = LW(l, DD_W_l2) + 896 * 128; q[1].b1 = LW(l, DD_b_l2) + 896;
       q[1].ln = LW(l, DD_PB_lnq); q[1].W2 = LW(l, DD_PB_W2q); q[1].b2 = LW(l, DD_PB_b2q); q[1].Y = w.ql2;
-      if (overlap) {
+      if (overlap && !ahead) {
         if (hipEventRecord(g_ev_qb_fork[l], st) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_qb_fork[l], 0) != hipSuccess) return DD_ERR_HIP;
         DD_TRY(launch_mlp2_batch(q, 2, g_side));        // (the pos launch follows on the same stream)
       } else {
@@ -301,7 +314,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
       pb.ke = w.PB2; pb.ve = w.PB2 + 128; pb.ld_ke = pb.ld_ve = 256;
       pb.q = w.ql2; pb.lnk = LW(l, DD_PB_lnk); pb.lnv = LW(l, DD_PB_lnv);
       pb.W2k = LW(l, DD_PB_W2k); pb.W2v16 = LW(l, DD_PB_W2v); pb.b2v16 = LW(l, DD_PB_b2v); pb.out = w.dxb; pb.x_next = nullptr;
-      if (overlap) {
+      if (overlap && !ahead) {
         // fork: the coordinate sub-layers run on the side stream and are joined before the next consumer of x
         if (hipEventRecord(g_ev_fork[l], st) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_fork[l], 0) != hipSuccess) return DD_ERR_HIP;
         int rc = launch_attn2_pos(pe, pb, g_side);
@@ -313,6 +326,11 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
         DD_TRYP(DD_PROF_ATTN_PE, launch_attn2_pos(pe, pb, st));
         DD_TRYP(DD_PROF_MISC, launch_xupdate(xcur, w.dxe, w.dxb, B, NP, NL, xnext, st));
       }
+    }
+    if (ahead && l + 1 < s->num_layers) {                // (recorded after the main-stream nodes on purpose)
+      if (hipStreamWaitEvent(g_side, g_ev_fork[l + 1], 0) != hipSuccess) return DD_ERR_HIP;
+      DD_TRY(launch_batch1(l + 1, g_side));
+      if (hipEventRecord(g_ev_join[l + 1], g_side) != hipSuccess) return DD_ERR_HIP;
     }
     float* t = xcur; xcur = xnext; xnext = t;
   }
@@ -630,6 +648,7 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 0) return dd_debug_set_fusion(value);
   if (key == 1) { dd::g_gemm_ksplit = value ? 1 : 0; return DD_OK; }
   if (key == 3) { dd::g_attn_persist = value ? 1 : 0; return DD_OK; }
+  if (key == 8) { dd::g_sched = value ? 1 : 0; return DD_OK; }
   if (key == 7) { dd::g_step_fused = value ? 1 : 0; return DD_OK; }
   if (key == 6) { dd::g_mlp_fused = value ? 1 : 0; return DD_OK; }
   if (key == 5) { if (value != 2 && value != 4 && value != 8) return DD_ERR_BAD_ARG; dd::g_pos_waves = value; return DD_OK; }
