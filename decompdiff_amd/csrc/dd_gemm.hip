@@ -164,41 +164,51 @@ __device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx
   const int row0 = bx * GT, col0 = by * GT;
   const bool xplain = a.x_rows_per_b >= a.rows;
   float4 xv[4], wv[4];
-  auto fetch = [&](int half) {
+  auto fetch_x = [&](int half, float4 (&dst)[4]) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int i = tid + k * 256;
       const int r = i >> 4, c4 = half * 64 + (i & 15) * 4;
-      const int gr = row0 + r, gc = col0 + r;
-      xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      wv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int gr = row0 + r;
+      dst[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (gr < a.rows) {
         const float* src = a.X + row_offset(gr, a.x_rows_per_b, a.x_stride_b, a.ldx, xplain) + c4;
-        xv[k] = *reinterpret_cast<const float4*>(src);
+        dst[k] = *reinterpret_cast<const float4*>(src);
         if (a.X2 != nullptr) {
           const int bb = gr / a.x2_N, n = gr % a.x2_N;
           if (n >= a.x2_NP) {
             const float4 t = *reinterpret_cast<const float4*>(a.X2 + ((long)bb * (a.x2_N - a.x2_NP) + (n - a.x2_NP)) * 128 + c4);
-            xv[k].x += t.x; xv[k].y += t.y; xv[k].z += t.z; xv[k].w += t.w;
+            dst[k].x += t.x; dst[k].y += t.y; dst[k].z += t.z; dst[k].w += t.w;
           }
         }
       }
-      if (gc < a.ncols) wv[k] = *reinterpret_cast<const float4*>(a.W + (long)gc * 128 + c4);
     }
   };
-  auto commit = [&]() {
+  auto fetch_w = [&](int half, float4 (&dst)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + k * 256;
+      const int r = i >> 4, c4 = half * 64 + (i & 15) * 4;
+      const int gc = col0 + r;
+      dst[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gc < a.ncols) dst[k] = *reinterpret_cast<const float4*>(a.W + (long)gc * 128 + c4);
+    }
+  };
+  auto fetch = [&](int half) { fetch_x(half, xv); fetch_w(half, wv); };
+  auto commit2 = [&](const float4 (&xs)[4], const float4 (&ws)[4]) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int i = tid + k * 256;
       const int r = i >> 4, c4 = (i & 15) * 4;
       float2* d = reinterpret_cast<float2*>(&Xh[r * GPH + c4]);
-      d[0] = make_float2(xv[k].x, xv[k].y);
-      d[1] = make_float2(xv[k].z, xv[k].w);
+      d[0] = make_float2(xs[k].x, xs[k].y);
+      d[1] = make_float2(xs[k].z, xs[k].w);
       float2* e = reinterpret_cast<float2*>(&Wh[r * GPH + c4]);
-      e[0] = make_float2(wv[k].x, wv[k].y);
-      e[1] = make_float2(wv[k].z, wv[k].w);
+      e[0] = make_float2(ws[k].x, ws[k].y);
+      e[1] = make_float2(ws[k].z, ws[k].w);
     }
   };
+  auto commit = [&]() { commit2(xv, wv); };
   const int wr = wave >> 1, wc = wave & 1;
   const int li = lane & 31, hh = lane >> 5;
   const float* xa = &Xh[(wr * 32 + li) * GPH + 2 * hh];
@@ -209,11 +219,52 @@ __device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx
   long long* dbg = a.dbg ? a.dbg + ((long)by * gridDim.x + bx) * 8 : nullptr;
 #define GSTAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
   GSTAMP(0);
-  fetch(0);
-  commit();
-  __syncthreads();
-  GSTAMP(1);
-  fetch(1);
+  if (a.ln != nullptr) {
+    // LayerNorm+ReLU prologue (MLP hidden activation): both K-halves of the rows are fetched first; a row's 128 channels
+    // sit in one 16-lane DPP row (4 + 4 channels per lane), so mean / variance are 4-step row reductions
+    float4 x1[4];
+    fetch_x(0, xv);
+    fetch_x(1, x1);
+    fetch_w(0, wv);
+    const int cl = (tid & 15) * 4;
+    const float4 g0 = *reinterpret_cast<const float4*>(a.ln + cl), g1 = *reinterpret_cast<const float4*>(a.ln + 64 + cl);
+    const float4 b0 = *reinterpret_cast<const float4*>(a.ln + 128 + cl), b1 = *reinterpret_cast<const float4*>(a.ln + 192 + cl);
+    auto row_sum = [](float v) {
+      v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); v += dpp_mov<0x140>(v);
+      return v;
+    };
+    auto norm4 = [](float4& v, float mean, float rstd, const float4& g, const float4& b) {
+      v.x = fmaxf(fmaf((v.x - mean) * rstd, g.x, b.x), 0.f);
+      v.y = fmaxf(fmaf((v.y - mean) * rstd, g.y, b.y), 0.f);
+      v.z = fmaxf(fmaf((v.z - mean) * rstd, g.z, b.z), 0.f);
+      v.w = fmaxf(fmaf((v.w - mean) * rstd, g.w, b.w), 0.f);
+    };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float s = ((xv[k].x + xv[k].y) + (xv[k].z + xv[k].w)) + ((x1[k].x + x1[k].y) + (x1[k].z + x1[k].w));
+      const float mean = row_sum(s) * (1.0f / 128.0f);
+      float q = 0.f;
+      { const float d0 = xv[k].x - mean, d1 = xv[k].y - mean, d2 = xv[k].z - mean, d3 = xv[k].w - mean;
+        q = fmaf(d0, d0, d1 * d1) + fmaf(d2, d2, d3 * d3); }
+      { const float d0 = x1[k].x - mean, d1 = x1[k].y - mean, d2 = x1[k].z - mean, d3 = x1[k].w - mean;
+        q += fmaf(d0, d0, d1 * d1) + fmaf(d2, d2, d3 * d3); }
+      const float rstd = __builtin_amdgcn_rsqf(row_sum(q) * (1.0f / 128.0f) + 1e-5f);
+      norm4(xv[k], mean, rstd, g0, b0);
+      norm4(x1[k], mean, rstd, g1, b1);
+    }
+    commit();
+    __syncthreads();
+    GSTAMP(1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xv[k] = x1[k];
+    fetch_w(1, wv);
+  } else {
+    fetch(0);
+    commit();
+    __syncthreads();
+    GSTAMP(1);
+    fetch(1);
+  }
 #pragma unroll 8
   for (int kk = 0; kk < 16; ++kk) {
     float2 av = *reinterpret_cast<const float2*>(xa + 4 * kk);
@@ -453,7 +504,8 @@ int launch_gemm128_batch(const GemmArgs* jobs, int njobs, hipStream_t st) {
   if (total <= 0) return DD_OK;
   bool any_ln = false;
   for (int i = 0; i < njobs; ++i) any_ln = any_ln || jobs[i].ln != nullptr;
-  if (any_ln || !g_gemm_ksplit) hipLaunchKernelGGL(k_gemm128_batch<false>, dim3(total), dim3(256), 0, st, gb);
+  (void)any_ln;                                        // (the K-split tile handles the LayerNorm prologue as well)
+  if (!g_gemm_ksplit) hipLaunchKernelGGL(k_gemm128_batch<false>, dim3(total), dim3(256), 0, st, gb);
   else hipLaunchKernelGGL(k_gemm128_batch<true>, dim3(total), dim3(256), 0, st, gb);
   DD_CHECK_LAUNCH();
   return DD_OK;
@@ -462,7 +514,7 @@ int launch_gemm128_batch(const GemmArgs* jobs, int njobs, hipStream_t st) {
 int launch_gemm128(const GemmArgs& a, hipStream_t st) {
   if (a.rows <= 0 || a.ncols <= 0) return DD_OK;
   dim3 grid((a.rows + GT - 1) / GT, (a.ncols + GT - 1) / GT);
-  if (a.ln != nullptr || !g_gemm_ksplit) hipLaunchKernelGGL(k_gemm128, grid, dim3(256), 0, st, a);
+  if (!g_gemm_ksplit) hipLaunchKernelGGL(k_gemm128, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(k_gemm128_ks, grid, dim3(256), 0, st, a);
   DD_CHECK_LAUNCH();
   return DD_OK;
