@@ -229,7 +229,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
     }
     if (ahead && l > 0 && hipStreamWaitEvent(st, g_ev_join[l], 0) != hipSuccess) return DD_ERR_HIP;   // projections of this layer
     DD_TRYP(DD_PROF_ASSEMBLE, launch_bl_assemble(xcur, w.PB, w.PL, LW(l, DD_BL_Wg1k), LW(l, DD_BL_Wg1v), LW(l, DD_BL_Wg2k),
-                                                  LW(l, DD_BL_Wg2v), B, NP, NL, w.Ek, w.Ev, mlpf ? nullptr : w.q1bl, w.Rk, w.Rv, st));
+                                                  LW(l, DD_BL_Wg2v), LW(l, DD_BL_Wgp), B, NP, NL, w.Ek, w.Ev, mlpf ? nullptr : w.q1bl, w.Rk, w.Rv, st));
     if (!mlpf) {
       // ---- queries (second Linear of the q MLPs, LayerNorm+ReLU prologue): one launch
       GemmArgs j[3] = {
@@ -342,7 +342,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
     DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.hb, (int)(B * Eb), 0, 128, (int)(B * Eb), LW(l, DD_W_b1), LW(l, DD_b_b1), nullptr, w.PB,
                            (int)(B * Eb), 0, 640, 640, 0}, st));
     DD_TRYP(DD_PROF_ASSEMBLE, launch_bl_assemble(xcur, w.PB, w.PL, LW(l, DD_BL_Wg1k), LW(l, DD_BL_Wg1v), LW(l, DD_BL_Wg2k),
-                                                  LW(l, DD_BL_Wg2v), B, NP, NL, w.Ek, w.Ev, w.q1bl, w.Rk, w.Rv, st));
+                                                  LW(l, DD_BL_Wg2v), LW(l, DD_BL_Wgp), B, NP, NL, w.Ek, w.Ev, w.q1bl, w.Rk, w.Rv, st));
     // ---- queries: second Linear of the q MLPs (LayerNorm+ReLU prologue)
     DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.P + 512, B * N, 0, 640, B * N, LW(l, DD_NE_W2q), LW(l, DD_NE_b2q), LW(l, DD_NE_lnq), w.qn,
                            B * N, 0, 128, 128, 0}, st));
@@ -652,7 +652,7 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 7) { dd::g_step_fused = value ? 1 : 0; return DD_OK; }
   if (key == 6) { dd::g_mlp_fused = value ? 1 : 0; return DD_OK; }
   if (key == 5) { if (value != 2 && value != 4 && value != 8) return DD_ERR_BAD_ARG; dd::g_pos_waves = value; return DD_OK; }
-  if (key == 4) { dd::g_assemble_persist = value ? 1 : 0; return DD_OK; }
+  if (key == 4) { if (value < 0 || value > 2) return DD_ERR_BAD_ARG; dd::g_assemble_persist = value; return DD_OK; }
   if (key == 2) { if (value != 8) return DD_ERR_BAD_ARG; dd::g_attn_waves = value; return DD_OK; }
   return DD_ERR_BAD_ARG;
 }

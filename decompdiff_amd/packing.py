@@ -54,6 +54,7 @@ LAYER_SLOTS = [
     "BL_Wg2k", "BL_Wg2v",    # [20,128]  G(d_ji) columns
     "BL_Wak", "BL_Wav",      # [13,128]  angle-code columns
     "BL_lnk", "BL_lnv", "BL_lnq", "BL_W2q", "BL_b2q", "BL_W2k", "BL_W2vT", "BL_b2v", "BL_W2v",
+    "BL_Wgp",                # [4,20,128] Wg1k | Wg1v | Wg2k | Wg2v in the MFMA A-operand layout (assemble kernel)
     "BL_Wakp", "BL_Wavp",    # [12,128] angle-code columns, MFMA A-operand layout, duplicate codes merged (see _ANGLE_MERGE)
     # --- lin_node --------------------------------------------------------------------------
     "W_lin", "b_lin",
@@ -158,6 +159,7 @@ def pack_layer(sd: Dict[str, torch.Tensor], prefix: str) -> "OrderedDict[str, to
     out["BL_W2q"], out["BL_b2q"], out["BL_W2k"] = bq[3], bq[4], bk[3]
     out["BL_W2vT"], out["BL_b2v"] = bv[3].t().contiguous(), bv[4]
     out["BL_W2v"] = bv[3]
+    out["BL_Wgp"] = torch.stack([_mfma_rows(out[k], 20) for k in ("BL_Wg1k", "BL_Wg1v", "BL_Wg2k", "BL_Wg2v")], 0)
     out["BL_Wakp"], out["BL_Wavp"] = _angle_rows(out["BL_Wak"]), _angle_rows(out["BL_Wav"])
 
     out["W_lin"], out["b_lin"] = sd[f"{prefix}.lin_node.weight"], sd[f"{prefix}.lin_node.bias"]

@@ -50,7 +50,7 @@ typedef enum dd_wslot {
   DD_NE_Ak, DD_NE_Av, DD_NE_lnk, DD_NE_lnv, DD_NE_lnq, DD_NE_W2q, DD_NE_b2q, DD_NE_W2k, DD_NE_W2vT, DD_NE_b2v, DD_NE_W2v, DD_NE_Akp, DD_NE_Avp,
   DD_NB_lnk, DD_NB_lnv, DD_NB_lnq, DD_NB_W2q, DD_NB_b2q, DD_NB_W2k, DD_NB_W2vT, DD_NB_b2v, DD_NB_W2v,
   DD_BL_Wg1k, DD_BL_Wg1v, DD_BL_Wg2k, DD_BL_Wg2v, DD_BL_Wak, DD_BL_Wav,
-  DD_BL_lnk, DD_BL_lnv, DD_BL_lnq, DD_BL_W2q, DD_BL_b2q, DD_BL_W2k, DD_BL_W2vT, DD_BL_b2v, DD_BL_W2v, DD_BL_Wakp, DD_BL_Wavp,
+  DD_BL_lnk, DD_BL_lnv, DD_BL_lnq, DD_BL_W2q, DD_BL_b2q, DD_BL_W2k, DD_BL_W2vT, DD_BL_b2v, DD_BL_W2v, DD_BL_Wgp, DD_BL_Wakp, DD_BL_Wavp,
   DD_W_lin, DD_b_lin,
   DD_W_n2, DD_b_n2, DD_W_l2, DD_b_l2, DD_W_b2, DD_b_b2,
   DD_PE_Ak, DD_PE_Av, DD_PE_lnk, DD_PE_lnv, DD_PE_lnq, DD_PE_W2q, DD_PE_b2q, DD_PE_W2k, DD_PE_W2v, DD_PE_b2v, DD_PE_Akp, DD_PE_Avp,
