@@ -333,72 +333,33 @@ typedef float f32x4a __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_bl_assemble3(const float* __restrict__ x, const float* __restrict__ PB,
                                                       const float* __restrict__ PL, const float* __restrict__ Wgp /*[4,20,128]*/,
                                                       int B, int NP, int NL, float* __restrict__ Ek, float* __restrict__ Ev,
-                                                      float* __restrict__ q1, float* __restrict__ Rk, float* __restrict__ Rv) {
-  __shared__ __attribute__((aligned(16))) float tab[4 * DD_NGAUSS * 128];
-  {
-    float4 tmp[10];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) tmp[i] = reinterpret_cast<const float4*>(Wgp)[threadIdx.x + i * 256];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) reinterpret_cast<float4*>(tab)[threadIdx.x + i * 256] = tmp[i];
+                                                      float* __restrict__ q1, float* __restrict__ Rk, float* __restrict__ Rv,
+                                                      int blocks_per_output) {
+  // workgroup = (output q: Ek, Ev, Rk, Rv, q1; four consecutive 16-bond tiles, one per wave): 5x the parallelism of a
+  // tile-per-wave split over all outputs (only 435 tiles exist at B=8), and only that output's 10 KB table is staged
+  __shared__ __attribute__((aligned(16))) float tab[DD_NGAUSS * 128];
+  const int q = blockIdx.x / blocks_per_output;
+  if (q < 4) {
+    const float4* src = reinterpret_cast<const float4*>(Wgp + q * DD_NGAUSS * 128);
+    for (int i = threadIdx.x; i < DD_NGAUSS * 32; i += 256) reinterpret_cast<float4*>(tab)[i] = src[i];
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, mm = lane & 15, cg = lane >> 4;
   const int Eb = NL * (NL - 1), N = NP + NL;
   const long nrows = (long)B * Eb;
-  const long ntiles = (nrows + 15) / 16;
-  for (long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntiles; tile += (long)gridDim.x * 4) {
-    const long e_raw = tile * 16 + mm;
-    const bool valid = e_raw < nrows;
-    const long e_glob = valid ? e_raw : nrows - 1;
-    const int b = e_glob / Eb, e = e_glob % Eb;
-    const int t = e / (NL - 1), sp = e % (NL - 1);
-    const int s = sp + (sp >= t ? 1 : 0);
-    const float* xl = x + ((long)b * N + NP) * 3;
-    const float dx = xl[3 * t] - xl[3 * s], dy = xl[3 * t + 1] - xl[3 * s + 1], dz = xl[3 * t + 2] - xl[3 * s + 2];
-    const float d = sqrtf(dx * dx + dy * dy + dz * dz);
-    float F[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) F[k] = gauss_feat(d, 4 * k + cg);
-    const float* pb = PB + e_glob * 640 + 4 * cg;
-    const float* ps = PL + ((long)b * NL + s) * 1280 + 4 * cg;
-    const float* pt = PL + ((long)b * NL + t) * 1280 + 4 * cg;
-    auto ld4 = [](const float* p) { return *reinterpret_cast<const float4*>(p); };
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {                      // Ek, Ev, Rk, Rv
-      f32x4a acc[8];
-#pragma unroll
-      for (int nt = 0; nt < 8; ++nt) {
-        if (q < 2) {
-          const float4 a0 = ld4(pb + 256 + 128 * q + 16 * nt);          // k_hb | v_hb
-          const float4 a1 = ld4(ps + 640 + 256 * q + 16 * nt);          // k_hk | v_hk
-          const float4 a2 = ld4(pt + 768 + 256 * q + 16 * nt);          // k_hj | v_hj
-          acc[nt] = f32x4a{(a0.x + a1.x) + a2.x, (a0.y + a1.y) + a2.y, (a0.z + a1.z) + a2.z, (a0.w + a1.w) + a2.w};
-        } else {
-          acc[nt] = f32x4a{0.f, 0.f, 0.f, 0.f};
-        }
-      }
-      const float* tb = tab + q * DD_NGAUSS * 128 + cg * 128 + mm * 4;
-#pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        const float4 w0 = *reinterpret_cast<const float4*>(tb + k * 512);
-        const float4 w1 = *reinterpret_cast<const float4*>(tb + k * 512 + 64);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, F[k], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, F[k], acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, F[k], acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, F[k], acc[3], 0, 0, 0);
-        acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, F[k], acc[4], 0, 0, 0);
-        acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, F[k], acc[5], 0, 0, 0);
-        acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, F[k], acc[6], 0, 0, 0);
-        acc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, F[k], acc[7], 0, 0, 0);
-      }
-      float* dst = (q == 0 ? Ek : (q == 1 ? Ev : (q == 2 ? Rk : Rv))) + e_glob * 128 + 4 * cg;
-      if (valid) {
-#pragma unroll
-        for (int nt = 0; nt < 8; ++nt)
-          *reinterpret_cast<float4*>(dst + 16 * nt) = make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]);
-      }
-    }
+  const long tile = (long)(blockIdx.x % blocks_per_output) * 4 + (threadIdx.x >> 6);
+  if (tile * 16 >= nrows) return;
+  const long e_raw = tile * 16 + mm;
+  const bool valid = e_raw < nrows;
+  const long e_glob = valid ? e_raw : nrows - 1;
+  const int b = e_glob / Eb, e = e_glob % Eb;
+  const int t = e / (NL - 1), sp = e % (NL - 1);
+  const int s = sp + (sp >= t ? 1 : 0);
+  const float* pb = PB + e_glob * 640 + 4 * cg;
+  const float* ps = PL + ((long)b * NL + s) * 1280 + 4 * cg;
+  const float* pt = PL + ((long)b * NL + t) * 1280 + 4 * cg;
+  auto ld4 = [](const float* p) { return *reinterpret_cast<const float4*>(p); };
+  if (q == 4) {                                        // q1 = q_hb[e] + q_hi[t]
     if (q1 != nullptr && valid) {
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) {
@@ -406,6 +367,43 @@ __global__ __launch_bounds__(256) void k_bl_assemble3(const float* __restrict__ 
         *reinterpret_cast<float4*>(q1 + e_glob * 128 + 4 * cg + 16 * nt) = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
       }
     }
+    return;
+  }
+  f32x4a acc[8];
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) {
+    if (q < 2) {
+      const float4 a0 = ld4(pb + 256 + 128 * q + 16 * nt);          // k_hb | v_hb
+      const float4 a1 = ld4(ps + 640 + 256 * q + 16 * nt);          // k_hk | v_hk
+      const float4 a2 = ld4(pt + 768 + 256 * q + 16 * nt);          // k_hj | v_hj
+      acc[nt] = f32x4a{(a0.x + a1.x) + a2.x, (a0.y + a1.y) + a2.y, (a0.z + a1.z) + a2.z, (a0.w + a1.w) + a2.w};
+    } else {
+      acc[nt] = f32x4a{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const float* xl = x + ((long)b * N + NP) * 3;
+  const float dx = xl[3 * t] - xl[3 * s], dy = xl[3 * t + 1] - xl[3 * s + 1], dz = xl[3 * t + 2] - xl[3 * s + 2];
+  const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+  const float* tb = tab + cg * 128 + mm * 4;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const float fk = gauss_feat(d, 4 * k + cg);
+    const float4 w0 = *reinterpret_cast<const float4*>(tb + k * 512);
+    const float4 w1 = *reinterpret_cast<const float4*>(tb + k * 512 + 64);
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, fk, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, fk, acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, fk, acc[2], 0, 0, 0);
+    acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, fk, acc[3], 0, 0, 0);
+    acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, fk, acc[4], 0, 0, 0);
+    acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, fk, acc[5], 0, 0, 0);
+    acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, fk, acc[6], 0, 0, 0);
+    acc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, fk, acc[7], 0, 0, 0);
+  }
+  float* dst = (q == 0 ? Ek : (q == 1 ? Ev : (q == 2 ? Rk : Rv))) + e_glob * 128 + 4 * cg;
+  if (valid) {
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+      *reinterpret_cast<float4*>(dst + 16 * nt) = make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]);
   }
 }
 
@@ -483,9 +481,10 @@ int launch_bl_assemble(const float* x, const float* PB, const float* PL, const f
                        float* q1, float* Rk, float* Rv, hipStream_t st) {
   long rows = (long)B * NL * (NL - 1);
   if (g_assemble_persist == 2 && Wgp != nullptr) {
-    const long tiles = (rows + 15) / 16, want = (tiles + 3) / 4;      // one 16-bond tile per wave and trip
-    hipLaunchKernelGGL(k_bl_assemble3, dim3((unsigned)(want < 512 ? (want > 0 ? want : 1) : 512)), dim3(256), 0, st, x, PB, PL, Wgp, B,
-                       NP, NL, Ek, Ev, q1, Rk, Rv);
+    const long tiles = (rows + 15) / 16;
+    const int bpo = (int)((tiles + 3) / 4);                            // blocks per output (4 tiles each)
+    hipLaunchKernelGGL(k_bl_assemble3, dim3((unsigned)(bpo * (q1 ? 5 : 4))), dim3(256), 0, st, x, PB, PL, Wgp, B, NP, NL, Ek, Ev, q1,
+                       Rk, Rv, bpo);
   } else if (g_assemble_persist) {
     const long want = (rows + 7) / 8;                      // >= 2 bonds per wave
     hipLaunchKernelGGL(k_bl_assemble2, dim3((unsigned)(want < 512 ? (want > 0 ? want : 1) : 512)), dim3(256), 0, st, x, PB, PL, Wg1k,
