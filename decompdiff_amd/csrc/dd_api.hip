@@ -105,6 +105,7 @@ static hipEvent_t g_ev_qa_fork[8], g_ev_qa_join[8], g_ev_qb_fork[8];
 static int g_step_fused = 1;                   // dd_debug_set_option(7, v): rows + coordinates + counter in one launch
 static int g_sched = 1;                        // dd_debug_set_option(8, v): 1 = next layer's projections ahead on the side stream,
                                                // 0 = coordinate sub-layers on the side stream
+static int g_q_in_pos = 1;                     // dd_debug_set_option(9, v): coordinate query MLPs' second layer inside attn_pos
 static int g_mlp_fused = 0;                    // dd_debug_set_option(6, v): fused 2-layer query MLPs beside the projections
 static hipEvent_t g_ev_fork[9], g_ev_join[9];   // [0..7] per layer, [8] graph construction at the head of a forward
 static int g_side_low_priority = [] { const char* e = getenv("DD_SIDE_PRIO"); return (e && e[0] == '0') ? 0 : 1; }();
@@ -295,7 +296,8 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
           gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(l, DD_W_l2), LW(l, DD_b_l2), nullptr, w.PL2, B * NL, 0, 1024, mlpf ? 896 : 1024, 0)};
       DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, 3, st));
     }
-    if (!mlpf) {
+    const bool q_in_pos = g_q_in_pos && !mlpf;           // second layer of the coordinate query MLPs inside attn_pos
+    if (!mlpf && !q_in_pos) {
       GemmArgs j[2] = {
           gemm_args(w.PL2 + 256, B * NL, 0, 1024, B * NL, LW(l, DD_PE_W2q), LW(l, DD_PE_b2q), LW(l, DD_PE_lnq), w.ql, B * NL, 0, 128, 128, 0),
           gemm_args(w.PL2 + 896, B * NL, 0, 1024, B * NL, LW(l, DD_PB_W2q), LW(l, DD_PB_b2q), LW(l, DD_PB_lnq), w.ql2, B * NL, 0, 128, 128, 0)};
@@ -314,6 +316,10 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
       pb.ke = w.PB2; pb.ve = w.PB2 + 128; pb.ld_ke = pb.ld_ve = 256;
       pb.q = w.ql2; pb.lnk = LW(l, DD_PB_lnk); pb.lnv = LW(l, DD_PB_lnv);
       pb.W2k = LW(l, DD_PB_W2k); pb.W2v16 = LW(l, DD_PB_W2v); pb.b2v16 = LW(l, DD_PB_b2v); pb.out = w.dxb; pb.x_next = nullptr;
+      if (q_in_pos) {
+        pe.qhid = w.PL2 + 256; pe.ld_qhid = 1024; pe.lnq = LW(l, DD_PE_lnq); pe.W2q = LW(l, DD_PE_W2qT); pe.b2q = LW(l, DD_PE_b2q);
+        pb.qhid = w.PL2 + 896; pb.ld_qhid = 1024; pb.lnq = LW(l, DD_PB_lnq); pb.W2q = LW(l, DD_PB_W2qT); pb.b2q = LW(l, DD_PB_b2q);
+      }
       if (overlap && !ahead) {
         // fork: the coordinate sub-layers run on the side stream and are joined before the next consumer of x
         if (hipEventRecord(g_ev_fork[l], st) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_fork[l], 0) != hipSuccess) return DD_ERR_HIP;
@@ -648,6 +654,7 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 0) return dd_debug_set_fusion(value);
   if (key == 1) { dd::g_gemm_ksplit = value ? 1 : 0; return DD_OK; }
   if (key == 3) { dd::g_attn_persist = value ? 1 : 0; return DD_OK; }
+  if (key == 9) { dd::g_q_in_pos = value ? 1 : 0; return DD_OK; }
   if (key == 8) { dd::g_sched = value ? 1 : 0; return DD_OK; }
   if (key == 7) { dd::g_step_fused = value ? 1 : 0; return DD_OK; }
   if (key == 6) { dd::g_mlp_fused = value ? 1 : 0; return DD_OK; }

@@ -364,6 +364,39 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
   float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
   if (PERSIST && it > 0) {
     q0 = qn0; q1 = qn1;                                // requested during the previous trip's epilogue
+  } else if (POS && a.W2q != nullptr) {
+    // coordinate modes: the query MLP's second layer runs here (q = W2q . relu(LN(hidden)) + b2q, one 128x128
+    // mat-vec per segment) instead of as a 16-tile GEMM launch on the critical chain.  Lane l owns outputs 2l, 2l+1.
+    float* sc = smem + L::TOTAL + wave * 256;
+    if (active) {
+      float2 hv = *reinterpret_cast<const float2*>(a.qhid + drow * a.ld_qhid + 2 * lane);
+      ln_relu2(hv.x, hv.y, a.lnq[2 * lane], a.lnq[2 * lane + 1], a.lnq[128 + 2 * lane], a.lnq[128 + 2 * lane + 1]);
+      *reinterpret_cast<float2*>(sc + 2 * lane) = hv;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (active) {
+      const float2* wT = reinterpret_cast<const float2*>(a.W2q) + lane;      // W2q^T [k][o]: row k is one coalesced 512 B read
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll 4
+      for (int k4 = 0; k4 < 32; ++k4) {                 // 64 row reads in flight per trip: the mat-vec is latency-bound
+        const float4 z = *reinterpret_cast<const float4*>(sc + 4 * k4);
+        const float2 u0 = wT[(4 * k4 + 0) * 64], u1 = wT[(4 * k4 + 1) * 64], u2 = wT[(4 * k4 + 2) * 64], u3 = wT[(4 * k4 + 3) * 64];
+        a0 = fmaf(u0.x, z.x, a0); a1 = fmaf(u0.y, z.x, a1);
+        a0 = fmaf(u1.x, z.y, a0); a1 = fmaf(u1.y, z.y, a1);
+        a0 = fmaf(u2.x, z.z, a0); a1 = fmaf(u2.y, z.z, a1);
+        a0 = fmaf(u3.x, z.w, a0); a1 = fmaf(u3.y, z.w, a1);
+      }
+      *reinterpret_cast<float2*>(sc + 128 + 2 * lane) = make_float2(a0 + a.b2q[2 * lane], a1 + a.b2q[2 * lane + 1]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (active) {
+      q0 = *reinterpret_cast<const float4*>(sc + 128 + mm * 8);
+      q1 = *reinterpret_cast<const float4*>(sc + 128 + mm * 8 + 4);
+    }
   } else if (active) {
     q0 = *reinterpret_cast<const float4*>(a.q + (long)seg * 128 + mm * 8);
     q1 = *reinterpret_cast<const float4*>(a.q + (long)seg * 128 + mm * 8 + 4);
@@ -765,7 +798,7 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
 
 template <int MODE, int MAXT, int NW>
 __global__ __launch_bounds__(NW * 64) void k_attn2(const AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[Lds<MODE>::TOTAL];
+  __shared__ __attribute__((aligned(16))) float smem[Lds<MODE>::TOTAL + ((MODE == M_PE || MODE == M_PB) ? NW * 256 : 0)];
   attn2_body<MODE, MAXT, NW>(a, blockIdx.x, smem);
 }
 
@@ -789,7 +822,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn2_node(const AttnArgs ne, const
 // Same for the two coordinate sub-layers (both write their own delta buffer; x is updated afterwards).
 template <int MAXT, int NW>
 __global__ __launch_bounds__(NW * 64) void k_attn2_pos(const AttnArgs pe, const AttnArgs pb, int n_pe) {
-  constexpr int SZ = imax(Lds<M_PE>::TOTAL, Lds<M_PB>::TOTAL);
+  constexpr int SZ = imax(Lds<M_PE>::TOTAL, Lds<M_PB>::TOTAL) + NW * 256;   // + per-wave scratch of the in-kernel query MLP
   __shared__ __attribute__((aligned(16))) float smem[SZ];
   const int blk = blockIdx.x;
   if (blk < n_pe) attn2_body<M_PE, 2, NW>(pe, blk, smem);

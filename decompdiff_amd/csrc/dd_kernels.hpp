@@ -67,6 +67,8 @@ struct AttnArgs {
   const float* W2k;        // [128,128]
   const float *W2vT, *b2v; // node modes
   const float* W2v;        // node modes, tiled kernel: [128 o][128 c]
+  // coordinate modes, optional: second layer of the query MLP evaluated in the kernel (q is then ignored)
+  const float *qhid, *lnq, *W2q, *b2q; int ld_qhid;   // hidden pre-activation rows [B*NL, ld_qhid], LN [2,128], W2q^T [128 k,128 o], [128]
   int* work_counter;       // persistent workgroups: next segment to process (zeroed before the launch)
   const float *W2v16, *b2v16;  // pos modes
   float* out;

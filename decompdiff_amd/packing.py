@@ -66,8 +66,9 @@ LAYER_SLOTS = [
     "PE_Ak", "PE_Av", "PE_lnk", "PE_lnv", "PE_lnq", "PE_W2q", "PE_b2q", "PE_W2k",
     "PE_W2v", "PE_b2v",      # [16,128],[16]
     "PE_Akp", "PE_Avp",      # [4,24,128]
+    "PE_W2qT",               # [128(k),128(o)] (query MLP second layer evaluated inside the coordinate kernel)
     # --- pos_layer_with_bond (PB) ----------------------------------------------------------
-    "PB_lnk", "PB_lnv", "PB_lnq", "PB_W2q", "PB_b2q", "PB_W2k", "PB_W2v", "PB_b2v",
+    "PB_lnk", "PB_lnv", "PB_lnq", "PB_W2q", "PB_b2q", "PB_W2k", "PB_W2v", "PB_b2v", "PB_W2qT",
 ]
 GLOBAL_SLOTS = [
     "W_pemb", "b_pemb",      # [128,29]/[128]  protein_atom_emb padded to 128 rows (row 127 = node indicator 0)
@@ -179,9 +180,11 @@ def pack_layer(sd: Dict[str, torch.Tensor], prefix: str) -> "OrderedDict[str, to
     out["PE_W2q"], out["PE_b2q"], out["PE_W2k"] = xq[3], xq[4], xk[3]
     out["PE_W2v"], out["PE_b2v"] = xv[3], xv[4]
     out["PE_Akp"], out["PE_Avp"] = _mfma_rows(out["PE_Ak"], 24), _mfma_rows(out["PE_Av"], 24)
+    out["PE_W2qT"] = xq[3].t().contiguous()
     out["PB_lnk"], out["PB_lnv"], out["PB_lnq"] = yk[2], yv[2], yq[2]
     out["PB_W2q"], out["PB_b2q"], out["PB_W2k"] = yq[3], yq[4], yk[3]
     out["PB_W2v"], out["PB_b2v"] = yv[3], yv[4]
+    out["PB_W2qT"] = yq[3].t().contiguous()
     assert list(out.keys()) == LAYER_SLOTS
     return out
 

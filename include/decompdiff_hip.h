@@ -53,8 +53,8 @@ typedef enum dd_wslot {
   DD_BL_lnk, DD_BL_lnv, DD_BL_lnq, DD_BL_W2q, DD_BL_b2q, DD_BL_W2k, DD_BL_W2vT, DD_BL_b2v, DD_BL_W2v, DD_BL_Wgp, DD_BL_Wakp, DD_BL_Wavp,
   DD_W_lin, DD_b_lin,
   DD_W_n2, DD_b_n2, DD_W_l2, DD_b_l2, DD_W_b2, DD_b_b2,
-  DD_PE_Ak, DD_PE_Av, DD_PE_lnk, DD_PE_lnv, DD_PE_lnq, DD_PE_W2q, DD_PE_b2q, DD_PE_W2k, DD_PE_W2v, DD_PE_b2v, DD_PE_Akp, DD_PE_Avp,
-  DD_PB_lnk, DD_PB_lnv, DD_PB_lnq, DD_PB_W2q, DD_PB_b2q, DD_PB_W2k, DD_PB_W2v, DD_PB_b2v,
+  DD_PE_Ak, DD_PE_Av, DD_PE_lnk, DD_PE_lnv, DD_PE_lnq, DD_PE_W2q, DD_PE_b2q, DD_PE_W2k, DD_PE_W2v, DD_PE_b2v, DD_PE_Akp, DD_PE_Avp, DD_PE_W2qT,
+  DD_PB_lnk, DD_PB_lnv, DD_PB_lnq, DD_PB_W2q, DD_PB_b2q, DD_PB_W2k, DD_PB_W2v, DD_PB_b2v, DD_PB_W2qT,
   DD_NUM_LAYER_SLOTS
 } dd_wslot;
 
