@@ -156,8 +156,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int bx, const
 // image (4 workgroups/CU instead of 2); the second half's global loads are in flight while the first half is
 // multiplied.  Same MFMA order per output element as gemm_tile (k ascending), hence bit-identical results.
 constexpr int GPH = 66;       // LDS pitch of a K-half tile: (66*row) mod 64 = 2*row -> conflict-free ds_read_b64
-__device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx, const int by) {
-  __shared__ __attribute__((aligned(16))) float smh[2 * GT * GPH];
+__device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx, const int by, float* smh /*>= 2*GT*GPH floats*/) {
   float* Xh = smh;
   float* Wh = smh + GT * GPH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -463,12 +462,175 @@ int launch_mlp2_batch(const Mlp2Job* jobs, int njobs, hipStream_t st) {
   return DD_OK;
 }
 
-__global__ __launch_bounds__(256) void k_gemm128(GemmArgs a) { gemm_tile(a, blockIdx.x, blockIdx.y); }
-__global__ __launch_bounds__(256) void k_gemm128_ks(GemmArgs a) { gemm_tile_ksplit(a, blockIdx.x, blockIdx.y); }
 
-struct GemmBatch { GemmArgs job[4]; int end[4]; int nbx[4]; int njobs; };
+// ------------------------------------------------------------------------------------------ 128 x 128 tile
+// Large jobs (>= 1024 rows, >= 128 columns): one workgroup = 128 rows x 128 columns, every wave a 64 x 64 quadrant
+// (four 32x32 accumulators: 8 MFMAs per 4 LDS operand reads).  K = 128 goes through one 34.8 KB LDS buffer in four
+// chunks of 32; the next chunk's global loads fly while the current one multiplies.  Four times the MFMA work of the
+// 64 x 64 tile per workgroup for about the same fixed cost (fetch latency, barriers, epilogue), same LDS class
+// (4 workgroups/CU).  LayerNorm prologue: a first pass over the rows leaves (mean, rstd) per row in LDS, the chunk
+// commits apply it.  Same k-ascending MFMA order per output element as the 64 x 64 tiles.
+constexpr int BT = 128, BK = 32, BP = 34;            // tile, K chunk, LDS pitch of a chunk row
+constexpr int BIG_LDS = 2 * BT * BP + 2 * BT;          // floats
+__device__ __forceinline__ void gemm_tile128(const GemmArgs& a, const int bx, const int by, float* smb /*>= BIG_LDS floats*/) {
+  float* Xc = smb;
+  float* Wc = smb + BT * BP;
+  float* stats = smb + 2 * BT * BP;                      // [128][2] mean, rstd (LayerNorm jobs)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = bx * BT, col0 = by * BT;
+  const bool xplain = a.x_rows_per_b >= a.rows;
+  if (a.ln != nullptr) {
+    // rows (tid >> 5) + 8k, channels 4 * (tid & 31) .. +3: a row = one half wave
+    const int c4 = (tid & 31) * 4;
+    auto half_sum = [](float v) {
+      v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); v += dpp_mov<0x140>(v);
+      return swap16_sum(v, v);
+    };
+    float4 xv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int gr = row0 + (tid >> 5) + 8 * k;
+      xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gr < a.rows) xv[k] = *reinterpret_cast<const float4*>(a.X + row_offset(gr, a.x_rows_per_b, a.x_stride_b, a.ldx, xplain) + c4);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float mean = half_sum((xv[k].x + xv[k].y) + (xv[k].z + xv[k].w)) * (1.0f / 128.0f);
+      const float dx = xv[k].x - mean, dy = xv[k].y - mean, dz = xv[k].z - mean, dw = xv[k].w - mean;
+      const float var = half_sum(fmaf(dx, dx, dy * dy) + fmaf(dz, dz, dw * dw)) * (1.0f / 128.0f);
+      if ((tid & 31) == 0) {
+        stats[2 * ((tid >> 5) + 8 * k)] = mean;
+        stats[2 * ((tid >> 5) + 8 * k) + 1] = __builtin_amdgcn_rsqf(var + 1e-5f);
+      }
+    }
+    __syncthreads();
+  }
+  float4 xr[4], wr4[4];
+  auto fetch = [&](int ch) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + k * 256;
+      const int r = i >> 3, c4 = ch * BK + (i & 7) * 4;
+      const int gr = row0 + r, gc = col0 + r;
+      xr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      wr4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gr < a.rows) xr[k] = *reinterpret_cast<const float4*>(a.X + row_offset(gr, a.x_rows_per_b, a.x_stride_b, a.ldx, xplain) + c4);
+      if (gc < a.ncols) wr4[k] = *reinterpret_cast<const float4*>(a.W + (long)gc * 128 + c4);
+    }
+  };
+  auto commit = [&](int ch) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + k * 256;
+      const int r = i >> 3, cl = (i & 7) * 4;
+      float4 v = xr[k];
+      if (a.ln != nullptr) {
+        const float2 st = *reinterpret_cast<const float2*>(stats + 2 * r);
+        const float4 g = *reinterpret_cast<const float4*>(a.ln + ch * BK + cl);
+        const float4 b = *reinterpret_cast<const float4*>(a.ln + 128 + ch * BK + cl);
+        v.x = fmaxf(fmaf((v.x - st.x) * st.y, g.x, b.x), 0.f);
+        v.y = fmaxf(fmaf((v.y - st.x) * st.y, g.y, b.y), 0.f);
+        v.z = fmaxf(fmaf((v.z - st.x) * st.y, g.z, b.z), 0.f);
+        v.w = fmaxf(fmaf((v.w - st.x) * st.y, g.w, b.w), 0.f);
+      }
+      float2* d = reinterpret_cast<float2*>(&Xc[r * BP + cl]);
+      d[0] = make_float2(v.x, v.y);
+      d[1] = make_float2(v.z, v.w);
+      float2* e = reinterpret_cast<float2*>(&Wc[r * BP + cl]);
+      e[0] = make_float2(wr4[k].x, wr4[k].y);
+      e[1] = make_float2(wr4[k].z, wr4[k].w);
+    }
+  };
+  const int wrow = wave >> 1, wcol = wave & 1, li = lane & 31, hh = lane >> 5;
+  const float* xa = &Xc[(wrow * 64 + li) * BP + 2 * hh];
+  const float* wb = &Wc[(wcol * 64 + li) * BP + 2 * hh];
+  f32x16 acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
+  fetch(0);
+#pragma unroll 1
+  for (int ch = 0; ch < 128 / BK; ++ch) {
+    if (ch > 0) __syncthreads();                         // previous chunk consumed
+    commit(ch);
+    __syncthreads();
+    if (ch + 1 < 128 / BK) fetch(ch + 1);
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      const float2 a0 = *reinterpret_cast<const float2*>(xa + 4 * kk);
+      const float2 a1 = *reinterpret_cast<const float2*>(xa + 32 * BP + 4 * kk);
+      const float2 b0 = *reinterpret_cast<const float2*>(wb + 4 * kk);
+      const float2 b1 = *reinterpret_cast<const float2*>(wb + 32 * BP + 4 * kk);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc[3], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b1.y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc[3], 0, 0, 0);
+    }
+  }
+  // ---- epilogue: two passes of 64 rows x 128 columns through the chunk buffers (pitch 132), 16-byte row pieces out
+  const bool yplain = a.y_rows_per_b >= a.rows;
+  const bool vec_ok = ((a.ldy & 3) == 0) && ((a.y_stride_b & 3) == 0) && ((reinterpret_cast<size_t>(a.Y) & 15) == 0);
+  float* Os = smb;                                       // 64 x 132 = 8448 floats <= 2 * 128 * 34
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+    if (wrow == pass) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rb = (q >> 1) * 32, cb = wcol * 64 + (q & 1) * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Os[(rb + (r & 3) + 8 * (r >> 2) + 4 * hh) * 132 + cb + li] = acc[q][r];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = tid + k * 256;
+      const int r = i >> 5, c4 = (i & 31) * 4;
+      const int gr = row0 + pass * 64 + r, gc = col0 + c4;
+      if (gr >= a.rows || gc >= a.ncols) continue;
+      const float4 v = *reinterpret_cast<const float4*>(&Os[r * 132 + c4]);
+      float o[4] = {v.x, v.y, v.z, v.w};
+      float* dst = a.Y + row_offset(gr, a.y_rows_per_b, a.y_stride_b, a.ldy, yplain) + gc;
+      if (vec_ok && gc + 3 < a.ncols) {
+        if (a.bias) { const float4 bb = *reinterpret_cast<const float4*>(a.bias + gc); o[0] += bb.x; o[1] += bb.y; o[2] += bb.z; o[3] += bb.w; }
+        if (a.accumulate) { const float4 old = *reinterpret_cast<const float4*>(dst); o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w; }
+        *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (gc + e < a.ncols) {
+            float x = o[e] + (a.bias ? a.bias[gc + e] : 0.f);
+            if (a.accumulate) x += dst[e];
+            dst[e] = x;
+          }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gemm128(GemmArgs a) { gemm_tile(a, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void k_gemm128_ks(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float sm[2 * GT * GPH];
+  gemm_tile_ksplit(a, blockIdx.x, blockIdx.y, sm);
+}
+
+struct GemmBatch { GemmArgs job[4]; int end[4]; int nbx[4]; int big[4]; int njobs; };
+template <bool KS>
+__device__ __forceinline__ void gemm_job(const GemmArgs& a, int lb, int nbx, int big, float* sm) {
+  if (KS && big) gemm_tile128(a, lb % nbx, lb / nbx, sm);
+  else if (KS) gemm_tile_ksplit(a, lb % nbx, lb / nbx, sm);
+  else gemm_tile(a, lb % nbx, lb / nbx);
+}
 template <bool KS>
 __global__ __launch_bounds__(256) void k_gemm128_batch(GemmBatch gb) {
+  __shared__ __attribute__((aligned(16))) float sm[KS ? BIG_LDS : 4];   // one buffer for both K-split tile shapes (>= 2*GT*GPH)
+  static_assert(BIG_LDS >= 2 * GT * GPH, "shared LDS buffer too small");
   int j = 0, base = 0;
   const int blk = blockIdx.x;
 #pragma unroll
@@ -476,14 +638,24 @@ __global__ __launch_bounds__(256) void k_gemm128_batch(GemmBatch gb) {
     if (j == i && blk >= gb.end[i] && i + 1 < gb.njobs) { base = gb.end[i]; j = i + 1; }
   const int lb = blk - base;
   // block-uniform job selection; explicit cases keep the job arguments in SGPRs
-  if (j == 0) { if (KS) gemm_tile_ksplit(gb.job[0], lb % gb.nbx[0], lb / gb.nbx[0]); else gemm_tile(gb.job[0], lb % gb.nbx[0], lb / gb.nbx[0]); }
-  else if (j == 1) { if (KS) gemm_tile_ksplit(gb.job[1], lb % gb.nbx[1], lb / gb.nbx[1]); else gemm_tile(gb.job[1], lb % gb.nbx[1], lb / gb.nbx[1]); }
-  else if (j == 2) { if (KS) gemm_tile_ksplit(gb.job[2], lb % gb.nbx[2], lb / gb.nbx[2]); else gemm_tile(gb.job[2], lb % gb.nbx[2], lb / gb.nbx[2]); }
-  else { if (KS) gemm_tile_ksplit(gb.job[3], lb % gb.nbx[3], lb / gb.nbx[3]); else gemm_tile(gb.job[3], lb % gb.nbx[3], lb / gb.nbx[3]); }
+  if (j == 0) gemm_job<KS>(gb.job[0], lb, gb.nbx[0], gb.big[0], sm);
+  else if (j == 1) gemm_job<KS>(gb.job[1], lb, gb.nbx[1], gb.big[1], sm);
+  else if (j == 2) gemm_job<KS>(gb.job[2], lb, gb.nbx[2], gb.big[2], sm);
+  else gemm_job<KS>(gb.job[3], lb, gb.nbx[3], gb.big[3], sm);
+}
+__global__ __launch_bounds__(256) void k_gemm128_big(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float sm[BIG_LDS];
+  gemm_tile128(a, blockIdx.x, blockIdx.y, sm);
 }
 
 long long* g_gemm_dbg = nullptr;
 int g_gemm_ksplit = 1;   // dd_debug_set_option(1, v): K-split tiles for jobs without a LayerNorm prologue
+
+int g_gemm_big = 0;      // dd_debug_set_option(10, v): 128 x 128 tiles for the large jobs (measured slower at these sizes:
+                         // too few workgroups, 4 serial K chunks per workgroup; 6960x640: 27.8 vs 22.0 us)
+static bool use_big_tile(const GemmArgs& a) {
+  return g_gemm_big && g_gemm_ksplit && a.rows >= 1024 && a.ncols >= 128 && a.X2 == nullptr && a.dbg == nullptr;
+}
 
 int launch_gemm128_batch(const GemmArgs* jobs, int njobs, hipStream_t st) {
   if (njobs <= 0 || njobs > 4) return DD_ERR_BAD_ARG;
@@ -493,11 +665,14 @@ int launch_gemm128_batch(const GemmArgs* jobs, int njobs, hipStream_t st) {
   for (int i = 0; i < 4; ++i) {
     if (i < njobs) {
       gb.job[i] = jobs[i];
-      gb.nbx[i] = (jobs[i].rows + GT - 1) / GT;
-      total += gb.nbx[i] * ((jobs[i].ncols + GT - 1) / GT);
+      const int big = use_big_tile(jobs[i]) ? 1 : 0, t = big ? BT : GT;
+      gb.big[i] = big;
+      gb.nbx[i] = (jobs[i].rows + t - 1) / t;
+      total += gb.nbx[i] * ((jobs[i].ncols + t - 1) / t);
     } else {
       gb.job[i] = jobs[0];
       gb.nbx[i] = 1;
+      gb.big[i] = 0;
     }
     gb.end[i] = total;
   }
@@ -513,6 +688,11 @@ int launch_gemm128_batch(const GemmArgs* jobs, int njobs, hipStream_t st) {
 
 int launch_gemm128(const GemmArgs& a, hipStream_t st) {
   if (a.rows <= 0 || a.ncols <= 0) return DD_OK;
+  if (use_big_tile(a)) {
+    hipLaunchKernelGGL(k_gemm128_big, dim3((a.rows + BT - 1) / BT, (a.ncols + BT - 1) / BT), dim3(256), 0, st, a);
+    DD_CHECK_LAUNCH();
+    return DD_OK;
+  }
   dim3 grid((a.rows + GT - 1) / GT, (a.ncols + GT - 1) / GT);
   if (!g_gemm_ksplit) hipLaunchKernelGGL(k_gemm128, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(k_gemm128_ks, grid, dim3(256), 0, st, a);
