@@ -623,14 +623,15 @@ __global__ __launch_bounds__(256) void k_gemm128_ks(GemmArgs a) {
 struct GemmBatch { GemmArgs job[4]; int end[4]; int nbx[4]; int big[4]; int njobs; };
 template <bool KS>
 __device__ __forceinline__ void gemm_job(const GemmArgs& a, int lb, int nbx, int big, float* sm) {
-  if (KS && big) gemm_tile128(a, lb % nbx, lb / nbx, sm);
-  else if (KS) gemm_tile_ksplit(a, lb % nbx, lb / nbx, sm);
+  (void)big;                                           // (the 128 x 128 tile is only reachable through dd_gemm128: keeping
+                                                       //  it out of this kernel keeps the code small -- with it inlined four
+                                                       //  times the projection launch ran 50 % slower)
+  if (KS) gemm_tile_ksplit(a, lb % nbx, lb / nbx, sm);
   else gemm_tile(a, lb % nbx, lb / nbx);
 }
 template <bool KS>
 __global__ __launch_bounds__(256) void k_gemm128_batch(GemmBatch gb) {
-  __shared__ __attribute__((aligned(16))) float sm[KS ? BIG_LDS : 4];   // one buffer for both K-split tile shapes (>= 2*GT*GPH)
-  static_assert(BIG_LDS >= 2 * GT * GPH, "shared LDS buffer too small");
+  __shared__ __attribute__((aligned(16))) float sm[KS ? 2 * GT * GPH : 4];
   int j = 0, base = 0;
   const int blk = blockIdx.x;
 #pragma unroll
@@ -665,7 +666,7 @@ int launch_gemm128_batch(const GemmArgs* jobs, int njobs, hipStream_t st) {
   for (int i = 0; i < 4; ++i) {
     if (i < njobs) {
       gb.job[i] = jobs[i];
-      const int big = use_big_tile(jobs[i]) ? 1 : 0, t = big ? BT : GT;
+      const int big = 0, t = GT;
       gb.big[i] = big;
       gb.nbx[i] = (jobs[i].rows + t - 1) / t;
       total += gb.nbx[i] * ((jobs[i].ncols + t - 1) / t);
