@@ -638,11 +638,10 @@ __global__ __launch_bounds__(256) void k_gemm128_batch(GemmBatch gb) {
   for (int i = 0; i < 3; ++i)
     if (j == i && blk >= gb.end[i] && i + 1 < gb.njobs) { base = gb.end[i]; j = i + 1; }
   const int lb = blk - base;
-  // block-uniform job selection; explicit cases keep the job arguments in SGPRs
-  if (j == 0) gemm_job<KS>(gb.job[0], lb, gb.nbx[0], gb.big[0], sm);
-  else if (j == 1) gemm_job<KS>(gb.job[1], lb, gb.nbx[1], gb.big[1], sm);
-  else if (j == 2) gemm_job<KS>(gb.job[2], lb, gb.nbx[2], gb.big[2], sm);
-  else gemm_job<KS>(gb.job[3], lb, gb.nbx[3], gb.big[3], sm);
+  // block-uniform job selection through a uniform index into the kernel arguments (scalar loads): ONE copy of the tile
+  // code.  (One inlined copy per job made this kernel 70 KB -- more than the 64 KB instruction cache two CUs share.)
+  const GemmArgs a = gb.job[j];
+  gemm_job<KS>(a, lb, gb.nbx[j], gb.big[j], sm);
 }
 __global__ __launch_bounds__(256) void k_gemm128_big(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float sm[BIG_LDS];
