@@ -103,8 +103,9 @@ struct ProfScope {
 static hipStream_t g_side = nullptr, g_side2 = nullptr;   // g_side2: query MLPs of the node / bond sub-layers
 static hipEvent_t g_ev_qa_fork[8], g_ev_qa_join[8], g_ev_qb_fork[8];
 static int g_step_fused = 1;                   // dd_debug_set_option(7, v): rows + coordinates + counter in one launch
-static int g_sched = 1;                        // dd_debug_set_option(8, v): 1 = next layer's projections ahead on the side stream,
-                                               // 0 = coordinate sub-layers on the side stream
+static int g_sched = 0;                        // dd_debug_set_option(8, v): 0 = coordinate sub-layers on the side stream (default:
+                                               // fastest in the last in-process A/B), 1 = next layer's projections ahead on the
+                                               // side stream, 2 = the same in two launches (bond part forked at the node attention)
 static int g_q_in_pos = 1;                     // dd_debug_set_option(9, v): coordinate query MLPs' second layer inside attn_pos
 static int g_mlp_fused = 0;                    // dd_debug_set_option(6, v): fused 2-layer query MLPs beside the projections
 static hipEvent_t g_ev_fork[9], g_ev_join[9];   // [0..7] per layer, [8] graph construction at the head of a forward
@@ -218,7 +219,20 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
           gemm_args(w.hb, nE, 0, 128, nE, LW(ll, DD_W_b1), LW(ll, DD_b_b1), nullptr, w.PB, nE, 0, 640, mlpf ? 512 : 640, 0)};
       return launch_gemm128_batch(j, 3, sx);
     };
-    const bool ahead = overlap && g_sched == 1;
+    // (schedule 2) the same projections in two launches: the bond part only needs h_bond, final once the node
+    // attention is done; the node parts need h (lin_node)
+    auto launch_batch1_part = [&](int ll, int part, hipStream_t sx) -> int {
+      if (part == 0) {
+        GemmArgs j[1] = {gemm_args(w.hb, nE, 0, 128, nE, LW(ll, DD_W_b1), LW(ll, DD_b_b1), nullptr, w.PB, nE, 0, 640, mlpf ? 512 : 640, 0)};
+        return launch_gemm128_batch(j, 1, sx);
+      }
+      GemmArgs j[2] = {
+          gemm_args(w.h, B * N, 0, 128, B * N, LW(ll, DD_W_n1), LW(ll, DD_b_n1), nullptr, w.P, B * N, 0, 640, mlpf ? 512 : 640, 0),
+          gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(ll, DD_W_l1), LW(ll, DD_b_l1), nullptr, w.PL, B * NL, 0, 1280, mlpf ? 1152 : 1280, 0)};
+      return launch_gemm128_batch(j, 2, sx);
+    };
+    const bool ahead = overlap && g_sched >= 1;
+    const bool ahead_split = overlap && g_sched == 2;
     if (!(ahead && l > 0)) DD_TRYP(DD_PROF_GEMM, launch_batch1(l, st));
     if (pending_join >= 0) {
       if (hipStreamWaitEvent(st, g_ev_join[pending_join], 0) != hipSuccess) return DD_ERR_HIP;
@@ -263,6 +277,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
       bl.work_counter = (l < 64) ? w.counters + l : nullptr;
       DD_TRYP(DD_PROF_ATTN_BL, launch_attn2_node(ne, nb, bl, st));
     }
+    if (ahead_split && l + 1 < s->num_layers && hipEventRecord(g_ev_qa_fork[l + 1], st) != hipSuccess) return DD_ERR_HIP;   // h_bond final
     // ---- h += lin_node(A + A_nb on ligand rows)
     {
       GemmArgs g = gemm_args(w.A, B * N, 0, 128, B * N, LW(l, DD_W_lin), LW(l, DD_b_lin), nullptr, w.h, B * N, 0, 128, 128, 1);
@@ -334,8 +349,15 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
       }
     }
     if (ahead && l + 1 < s->num_layers) {                // (recorded after the main-stream nodes on purpose)
-      if (hipStreamWaitEvent(g_side, g_ev_fork[l + 1], 0) != hipSuccess) return DD_ERR_HIP;
-      DD_TRY(launch_batch1(l + 1, g_side));
+      if (ahead_split) {
+        if (hipStreamWaitEvent(g_side, g_ev_qa_fork[l + 1], 0) != hipSuccess) return DD_ERR_HIP;
+        DD_TRY(launch_batch1_part(l + 1, 0, g_side));
+        if (hipStreamWaitEvent(g_side, g_ev_fork[l + 1], 0) != hipSuccess) return DD_ERR_HIP;
+        DD_TRY(launch_batch1_part(l + 1, 1, g_side));
+      } else {
+        if (hipStreamWaitEvent(g_side, g_ev_fork[l + 1], 0) != hipSuccess) return DD_ERR_HIP;
+        DD_TRY(launch_batch1(l + 1, g_side));
+      }
       if (hipEventRecord(g_ev_join[l + 1], g_side) != hipSuccess) return DD_ERR_HIP;
     }
     float* t = xcur; xcur = xnext; xnext = t;
@@ -656,7 +678,7 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 3) { dd::g_attn_persist = value ? 1 : 0; return DD_OK; }
   if (key == 10) { dd::g_gemm_big = value ? 1 : 0; return DD_OK; }
   if (key == 9) { dd::g_q_in_pos = value ? 1 : 0; return DD_OK; }
-  if (key == 8) { dd::g_sched = value ? 1 : 0; return DD_OK; }
+  if (key == 8) { if (value < 0 || value > 2) return DD_ERR_BAD_ARG; dd::g_sched = value; return DD_OK; }
   if (key == 7) { dd::g_step_fused = value ? 1 : 0; return DD_OK; }
   if (key == 6) { dd::g_mlp_fused = value ? 1 : 0; return DD_OK; }
   if (key == 5) { if (value != 2 && value != 4 && value != 8) return DD_ERR_BAD_ARG; dd::g_pos_waves = value; return DD_OK; }
