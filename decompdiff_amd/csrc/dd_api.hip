@@ -106,6 +106,8 @@ static int g_step_fused = 1;                   // dd_debug_set_option(7, v): row
 static int g_sched = 0;                        // dd_debug_set_option(8, v): 0 = coordinate sub-layers on the side stream (default:
                                                // fastest in the last in-process A/B), 1 = next layer's projections ahead on the
                                                // side stream, 2 = the same in two launches (bond part forked at the node attention)
+static int g_xup_in_pos = 0;                   // dd_debug_set_option(11, v): x update inside the coordinate launch (last workgroup);
+                                               // measured 1 % slower than the separate 3-block launch, off
 static int g_q_in_pos = 1;                     // dd_debug_set_option(9, v): coordinate query MLPs' second layer inside attn_pos
 static int g_mlp_fused = 0;                    // dd_debug_set_option(6, v): fused 2-layer query MLPs beside the projections
 static hipEvent_t g_ev_fork[9], g_ev_join[9];   // [0..7] per layer, [8] graph construction at the head of a forward
@@ -331,6 +333,8 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
       pb.ke = w.PB2; pb.ve = w.PB2 + 128; pb.ld_ke = pb.ld_ve = 256;
       pb.q = w.ql2; pb.lnk = LW(l, DD_PB_lnk); pb.lnv = LW(l, DD_PB_lnv);
       pb.W2k = LW(l, DD_PB_W2k); pb.W2v16 = LW(l, DD_PB_W2v); pb.b2v16 = LW(l, DD_PB_b2v); pb.out = w.dxb; pb.x_next = nullptr;
+      const bool xup_in_pos = g_xup_in_pos != 0;           // x update by the last workgroup of the coordinate launch
+      if (xup_in_pos) { pe.work_counter = w.counters + 32 + (l & 15); pe.x_next = xnext; }
       if (q_in_pos) {
         pe.qhid = w.PL2 + 256; pe.ld_qhid = 1024; pe.lnq = LW(l, DD_PE_lnq); pe.W2q = LW(l, DD_PE_W2qT); pe.b2q = LW(l, DD_PE_b2q);
         pb.qhid = w.PL2 + 896; pb.ld_qhid = 1024; pb.lnq = LW(l, DD_PB_lnq); pb.W2q = LW(l, DD_PB_W2qT); pb.b2q = LW(l, DD_PB_b2q);
@@ -339,13 +343,13 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
         // fork: the coordinate sub-layers run on the side stream and are joined before the next consumer of x
         if (hipEventRecord(g_ev_fork[l], st) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_fork[l], 0) != hipSuccess) return DD_ERR_HIP;
         int rc = launch_attn2_pos(pe, pb, g_side);
-        if (rc == DD_OK) rc = launch_xupdate(xcur, w.dxe, w.dxb, B, NP, NL, xnext, g_side);
+        if (rc == DD_OK && !xup_in_pos) rc = launch_xupdate(xcur, w.dxe, w.dxb, B, NP, NL, xnext, g_side);
         if (rc != DD_OK) return rc;
         if (hipEventRecord(g_ev_join[l], g_side) != hipSuccess) return DD_ERR_HIP;
         pending_join = l;
       } else {
         DD_TRYP(DD_PROF_ATTN_PE, launch_attn2_pos(pe, pb, st));
-        DD_TRYP(DD_PROF_MISC, launch_xupdate(xcur, w.dxe, w.dxb, B, NP, NL, xnext, st));
+        if (!xup_in_pos) DD_TRYP(DD_PROF_MISC, launch_xupdate(xcur, w.dxe, w.dxb, B, NP, NL, xnext, st));
       }
     }
     if (ahead && l + 1 < s->num_layers) {                // (recorded after the main-stream nodes on purpose)
@@ -676,6 +680,7 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 0) return dd_debug_set_fusion(value);
   if (key == 1) { dd::g_gemm_ksplit = value ? 1 : 0; return DD_OK; }
   if (key == 3) { dd::g_attn_persist = value ? 1 : 0; return DD_OK; }
+  if (key == 11) { dd::g_xup_in_pos = value ? 1 : 0; return DD_OK; }
   if (key == 10) { dd::g_gemm_big = value ? 1 : 0; return DD_OK; }
   if (key == 9) { dd::g_q_in_pos = value ? 1 : 0; return DD_OK; }
   if (key == 8) { if (value < 0 || value > 2) return DD_ERR_BAD_ARG; dd::g_sched = value; return DD_OK; }

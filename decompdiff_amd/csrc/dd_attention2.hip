@@ -827,6 +827,28 @@ __global__ __launch_bounds__(NW * 64) void k_attn2_pos(const AttnArgs pe, const 
   const int blk = blockIdx.x;
   if (blk < n_pe) attn2_body<M_PE, 2, NW>(pe, blk, smem);
   else attn2_body<M_PB, MAXT, NW>(pb, blk - n_pe, smem);
+  // x update (x += (dx_edge + dx_bond) on the ligand rows, uni_transformer_edge.py:285) by the workgroup that finishes
+  // last: ~120 workgroups, so the ticket costs nothing and a launch on the critical chain is saved
+  if (pe.work_counter == nullptr) return;
+  __shared__ int s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    s_last = atomicAdd(pe.work_counter, 1) == (int)gridDim.x - 1 ? 1 : 0;
+  }
+  __syncthreads();
+  if (s_last) {
+    __threadfence();
+    const int n = pe.B * pe.NL * 3, N = pe.NP + pe.NL;
+    const volatile float* dxe = pe.out;
+    const volatile float* dxb = pb.out;
+    for (int idx = threadIdx.x; idx < n; idx += NW * 64) {
+      const int b = idx / (pe.NL * 3), r = idx % (pe.NL * 3);
+      const long xi = ((long)b * N + pe.NP) * 3 + r;
+      pe.x_next[xi] = pe.x[xi] + dxe[idx] + dxb[idx];
+    }
+    if (threadIdx.x == 0) *pe.work_counter = 0;
+  }
 }
 
 template <int MODE, int MAXT, int NW>
