@@ -100,6 +100,8 @@ struct ProfScope {
 
 // second stream for the coordinate sub-layers (they only feed the NEXT layer's geometry, so they overlap its
 // projection GEMMs); fork/join through events, which stream capture turns into graph edges
+extern int g_gemm_ksplit;                      // dd_gemm.hip
+static bool g_gemm_ksplit_on() { return g_gemm_ksplit != 0; }   // (the addend form above lives in the K-split tile)
 static hipStream_t g_side = nullptr, g_side2 = nullptr;   // g_side2: query MLPs of the node / bond sub-layers
 static hipEvent_t g_ev_qa_fork[8], g_ev_qa_join[8], g_ev_qb_fork[8];
 static int g_step_fused = 1;                   // dd_debug_set_option(7, v): rows + coordinates + counter in one launch
@@ -108,6 +110,7 @@ static int g_sched = 0;                        // dd_debug_set_option(8, v): 0 =
                                                // side stream, 2 = the same in two launches (bond part forked at the node attention)
 static int g_xup_in_pos = 0;                   // dd_debug_set_option(11, v): x update inside the coordinate launch (last workgroup);
                                                // measured 1 % slower than the separate 3-block launch, off
+static int g_q1_in_gemm = 1;                   // dd_debug_set_option(12, v): bond-layer query hidden row summed inside the query GEMM
 static int g_q_in_pos = 1;                     // dd_debug_set_option(9, v): coordinate query MLPs' second layer inside attn_pos
 static int g_mlp_fused = 0;                    // dd_debug_set_option(6, v): fused 2-layer query MLPs beside the projections
 static hipEvent_t g_ev_fork[9], g_ev_join[9];   // [0..7] per layer, [8] graph construction at the head of a forward
@@ -236,6 +239,29 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
     const bool ahead = overlap && g_sched >= 1;
     const bool ahead_split = overlap && g_sched == 2;
     if (!(ahead && l > 0)) DD_TRYP(DD_PROF_GEMM, launch_batch1(l, st));
+    // ---- queries (second Linear of the q MLPs, LayerNorm+ReLU prologue): one launch.  The bond-layer hidden row is
+    //      q_hb[bond] + q_hi[dst atom], summed while the GEMM stages its rows, so this launch depends on the projections
+    //      only and runs before the coordinates of the previous layer are joined.
+    const bool q1_in_gemm = g_q1_in_gemm && !mlpf && g_gemm_ksplit_on();
+    auto launch_b2 = [&]() -> int {
+      GemmArgs j[3] = {
+          gemm_args(w.q1bl, nE, 0, 128, nE, LW(l, DD_BL_W2q), LW(l, DD_BL_b2q), LW(l, DD_BL_lnq), w.qb, nE, 0, 128, 128, 0),
+          gemm_args(w.P + 512, B * N, 0, 640, B * N, LW(l, DD_NE_W2q), LW(l, DD_NE_b2q), LW(l, DD_NE_lnq), w.qn, B * N, 0, 128, 128, 0),
+          gemm_args(w.PL + 512, B * NL, 0, 1280, B * NL, LW(l, DD_NB_W2q), LW(l, DD_NB_b2q), LW(l, DD_NB_lnq), w.qlnb, B * NL, 0, 128, 128, 0)};
+      if (q1_in_gemm) {
+        j[0] = gemm_args(w.PB + 512, nE, 0, 640, nE, LW(l, DD_BL_W2q), LW(l, DD_BL_b2q), LW(l, DD_BL_lnq), w.qb, nE, 0, 128, 128, 0);
+        j[0].X2 = w.PL + 1152; j[0].x2_N = NL; j[0].x2_Eb = (int)Eb; j[0].x2_NLm1 = NL - 1; j[0].x2_ld = 1280;
+      }
+      return launch_gemm128_batch(j, 3, st);
+    };
+    bool b1_joined = false;
+    if (q1_in_gemm) {
+      if (ahead && l > 0) {                              // (schedules 1/2: this layer's projections ran on the side stream)
+        if (hipStreamWaitEvent(st, g_ev_join[l], 0) != hipSuccess) return DD_ERR_HIP;
+        b1_joined = true;
+      }
+      DD_TRYP(DD_PROF_GEMM, launch_b2());
+    }
     if (pending_join >= 0) {
       if (hipStreamWaitEvent(st, g_ev_join[pending_join], 0) != hipSuccess) return DD_ERR_HIP;
       pending_join = -1;
@@ -244,17 +270,13 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
       if (hipStreamWaitEvent(st, g_ev_join[8], 0) != hipSuccess) return DD_ERR_HIP;
       head_join = false;
     }
-    if (ahead && l > 0 && hipStreamWaitEvent(st, g_ev_join[l], 0) != hipSuccess) return DD_ERR_HIP;   // projections of this layer
+    if (ahead && l > 0 && !b1_joined && hipStreamWaitEvent(st, g_ev_join[l], 0) != hipSuccess) return DD_ERR_HIP;   // projections of this layer
     DD_TRYP(DD_PROF_ASSEMBLE, launch_bl_assemble(xcur, w.PB, w.PL, LW(l, DD_BL_Wg1k), LW(l, DD_BL_Wg1v), LW(l, DD_BL_Wg2k),
-                                                  LW(l, DD_BL_Wg2v), LW(l, DD_BL_Wgp), B, NP, NL, w.Ek, w.Ev, mlpf ? nullptr : w.q1bl, w.Rk, w.Rv, st));
-    if (!mlpf) {
-      // ---- queries (second Linear of the q MLPs, LayerNorm+ReLU prologue): one launch
-      GemmArgs j[3] = {
-          gemm_args(w.q1bl, nE, 0, 128, nE, LW(l, DD_BL_W2q), LW(l, DD_BL_b2q), LW(l, DD_BL_lnq), w.qb, nE, 0, 128, 128, 0),
-          gemm_args(w.P + 512, B * N, 0, 640, B * N, LW(l, DD_NE_W2q), LW(l, DD_NE_b2q), LW(l, DD_NE_lnq), w.qn, B * N, 0, 128, 128, 0),
-          gemm_args(w.PL + 512, B * NL, 0, 1280, B * NL, LW(l, DD_NB_W2q), LW(l, DD_NB_b2q), LW(l, DD_NB_lnq), w.qlnb, B * NL, 0, 128, 128, 0)};
-      DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, 3, st));
-    } else if (overlap) {
+                                                  LW(l, DD_BL_Wg2v), LW(l, DD_BL_Wgp), B, NP, NL, w.Ek, w.Ev,
+                                                  (mlpf || q1_in_gemm) ? nullptr : w.q1bl, w.Rk, w.Rv, st));
+    if (!mlpf && !q1_in_gemm) {
+      DD_TRYP(DD_PROF_GEMM, launch_b2());
+    } else if (mlpf && overlap) {
       if (hipStreamWaitEvent(st, g_ev_qa_join[l], 0) != hipSuccess) return DD_ERR_HIP;
     }
     // ---- node_layer_with_edge + node_layer_with_bond + bond_layer: one launch
@@ -680,6 +702,7 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 0) return dd_debug_set_fusion(value);
   if (key == 1) { dd::g_gemm_ksplit = value ? 1 : 0; return DD_OK; }
   if (key == 3) { dd::g_attn_persist = value ? 1 : 0; return DD_OK; }
+  if (key == 12) { dd::g_q1_in_gemm = value ? 1 : 0; return DD_OK; }
   if (key == 11) { dd::g_xup_in_pos = value ? 1 : 0; return DD_OK; }
   if (key == 10) { dd::g_gemm_big = value ? 1 : 0; return DD_OK; }
   if (key == 9) { dd::g_q_in_pos = value ? 1 : 0; return DD_OK; }

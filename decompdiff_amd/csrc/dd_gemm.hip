@@ -173,7 +173,11 @@ __device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx
       if (gr < a.rows) {
         const float* src = a.X + row_offset(gr, a.x_rows_per_b, a.x_stride_b, a.ldx, xplain) + c4;
         dst[k] = *reinterpret_cast<const float4*>(src);
-        if (a.X2 != nullptr) {
+        if (a.X2 != nullptr && a.x2_Eb > 0) {              // bond row -> row of its destination atom
+          const long r2 = (long)(gr / a.x2_Eb) * a.x2_N + (gr % a.x2_Eb) / a.x2_NLm1;
+          const float4 t = *reinterpret_cast<const float4*>(a.X2 + r2 * a.x2_ld + c4);
+          dst[k].x += t.x; dst[k].y += t.y; dst[k].z += t.z; dst[k].w += t.w;
+        } else if (a.X2 != nullptr) {
           const int bb = gr / a.x2_N, n = gr % a.x2_N;
           if (n >= a.x2_NP) {
             const float4 t = *reinterpret_cast<const float4*>(a.X2 + ((long)bb * (a.x2_N - a.x2_NP) + (n - a.x2_NP)) * 128 + c4);

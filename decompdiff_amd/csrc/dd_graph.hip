@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void k_bl_assemble(const float* __restrict__ x
   a = *reinterpret_cast<const float2*>(pt + 1152); q.x += a.x; q.y += a.y;
   *reinterpret_cast<float2*>(Ek + e_glob * 128 + 2 * lane) = k;
   *reinterpret_cast<float2*>(Ev + e_glob * 128 + 2 * lane) = v;
-  *reinterpret_cast<float2*>(q1 + e_glob * 128 + 2 * lane) = q;
+  if (q1) *reinterpret_cast<float2*>(q1 + e_glob * 128 + 2 * lane) = q;
   *reinterpret_cast<float2*>(Rk + e_glob * 128 + 2 * lane) = rk;
   *reinterpret_cast<float2*>(Rv + e_glob * 128 + 2 * lane) = rv;
 }

@@ -10,13 +10,16 @@ struct GemmArgs {
   float* Y; int y_rows_per_b; long y_stride_b; int ldy; int ncols; int accumulate;
   // optional second addend for X rows that are ligand nodes: X[b*N + n] += X2[b*NL + n - NP] (n >= NP)
   const float* X2; int x2_N, x2_NP;
+  // x2_Eb > 0 selects the other addend form: X row r is a bond edge, X2 row = its destination atom
+  //   X[r] += X2[((r / x2_Eb) * x2_N + (r % x2_Eb) / x2_NLm1) * x2_ld]      (x2_N = ligand atoms per sample here)
+  int x2_Eb, x2_NLm1, x2_ld;
   long long* dbg;          // profiling aid: s_memtime phase stamps, 8 per workgroup (single launches only)
 };
 inline GemmArgs gemm_args(const float* X, int x_rows_per_b, long x_stride_b, int ldx, int rows, const float* W,
                           const float* bias, const float* ln, float* Y, int y_rows_per_b, long y_stride_b, int ldy,
                           int ncols, int accumulate) {
   GemmArgs g{X, x_rows_per_b, x_stride_b, ldx, rows, W, bias, ln, Y, y_rows_per_b, y_stride_b, ldy, ncols, accumulate,
-             nullptr, 0, 0, nullptr};
+             nullptr, 0, 0, 0, 0, 0, nullptr};
   return g;
 }
 // fused query MLP (dd_gemm.hip): Y = W2 . relu(LN(W1a . X1[r] (+ W1b . X2[dst atom of bond r]) + b1)) + b2
