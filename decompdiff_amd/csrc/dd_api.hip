@@ -110,6 +110,7 @@ static int g_sched = 0;                        // dd_debug_set_option(8, v): 0 =
                                                // side stream, 2 = the same in two launches (bond part forked at the node attention)
 static int g_xup_in_pos = 0;                   // dd_debug_set_option(11, v): x update inside the coordinate launch (last workgroup);
                                                // measured 1 % slower than the separate 3-block launch, off
+static int g_fused_max_nl = 64;                // dd_debug_set_option(13, v): largest ligand handled by the fused launches
 static int g_q1_in_gemm = 1;                   // dd_debug_set_option(12, v): bond-layer query hidden row summed inside the query GEMM
 static int g_q_in_pos = 1;                     // dd_debug_set_option(9, v): coordinate query MLPs' second layer inside attn_pos
 static int g_mlp_fused = 0;                    // dd_debug_set_option(6, v): fused 2-layer query MLPs beside the projections
@@ -162,7 +163,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
   float* xcur = w.xa;
   float* xnext = w.xb;
   const long hN = (long)N * 128;
-  const bool fused = g_fuse && !g_use_v1 && NL <= 33 && g_dbg_clock == nullptr;
+  const bool fused = g_fuse && !g_use_v1 && NL <= g_fused_max_nl && g_dbg_clock == nullptr;
   const bool overlap = fused && g_overlap && g_prof == nullptr && s->num_layers <= 8;
   if (overlap) DD_TRY(ensure_side_stream());
 
@@ -570,7 +571,7 @@ extern "C" int dd_workspace_view(const dd_sampler* s, dd_ws_view* out) {
   dd::Workspace w = dd::carve(s->workspace, s->B, s->NP, s->NL, s->K);
   out->x = (s->num_layers & 1) ? w.xb : w.xa;
   out->h = w.h; out->hb = w.hb; out->ew = w.ew; out->A = w.A; out->nbr = w.nbr;
-  out->Anb = (dd::g_fuse && !dd::g_use_v1 && s->NL <= 33) ? w.Anb : nullptr;
+  out->Anb = (dd::g_fuse && !dd::g_use_v1 && s->NL <= dd::g_fused_max_nl) ? w.Anb : nullptr;
   return DD_OK;
 }
 
@@ -702,6 +703,7 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 0) return dd_debug_set_fusion(value);
   if (key == 1) { dd::g_gemm_ksplit = value ? 1 : 0; return DD_OK; }
   if (key == 3) { dd::g_attn_persist = value ? 1 : 0; return DD_OK; }
+  if (key == 13) { dd::g_fused_max_nl = value; return DD_OK; }
   if (key == 12) { dd::g_q1_in_gemm = value ? 1 : 0; return DD_OK; }
   if (key == 11) { dd::g_xup_in_pos = value ? 1 : 0; return DD_OK; }
   if (key == 10) { dd::g_gemm_big = value ? 1 : 0; return DD_OK; }

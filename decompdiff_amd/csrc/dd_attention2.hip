@@ -881,7 +881,7 @@ int launch_attn2(int mode, const AttnArgs& a, hipStream_t st) {
 
 // Fused launches (ligands with <= 33 atoms).  Returns DD_ERR_UNSUPPORTED_SHAPE for larger ligands; the caller then
 // falls back to one launch per sub-layer.
-template <int NW>
+template <int NW, int MAXT>
 static int launch_node_nw(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs& bl, hipStream_t st) {
   using namespace v2;
   const int N = ne.NP + ne.NL;
@@ -898,25 +898,27 @@ static int launch_node_nw(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs
     }
     if (n_bl > n_cu) n_bl = n_cu;                      // one workgroup per CU (LDS-limited)
   }
-  hipLaunchKernelGGL((k_attn2_node<2, NW>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, bl, n_ne, n_nb, persist);
+  hipLaunchKernelGGL((k_attn2_node<MAXT, NW>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, bl, n_ne, n_nb, persist);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
 int launch_attn2_node(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs& bl, hipStream_t st) {
-  if (ne.NL > 33) return DD_ERR_UNSUPPORTED_SHAPE;
-  return launch_node_nw<8>(ne, nb, bl, st);             // (12- and 16-wave workgroups were tried: register spills)
+  if (ne.NL > 65) return DD_ERR_UNSUPPORTED_SHAPE;
+  if (ne.NL > 33) return launch_node_nw<8, 4>(ne, nb, bl, st);    // up to 64 members per segment: 4 tiles
+  return launch_node_nw<8, 2>(ne, nb, bl, st);             // (12- and 16-wave workgroups were tried: register spills)
 }
 template <int NW>
 static int launch_pos_nw(const AttnArgs& pe, const AttnArgs& pb, hipStream_t st) {
   using namespace v2;
   const int n = (pe.B * pe.NL + NW - 1) / NW;
-  hipLaunchKernelGGL((k_attn2_pos<2, NW>), dim3(2 * n), dim3(NW * 64), 0, st, pe, pb, n);
+  if (pe.NL > 33) hipLaunchKernelGGL((k_attn2_pos<4, NW>), dim3(2 * n), dim3(NW * 64), 0, st, pe, pb, n);
+  else hipLaunchKernelGGL((k_attn2_pos<2, NW>), dim3(2 * n), dim3(NW * 64), 0, st, pe, pb, n);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
 int g_pos_waves = 4;         // waves per workgroup of the fused coordinate launch: 2, 4 or 8
 int launch_attn2_pos(const AttnArgs& pe, const AttnArgs& pb, hipStream_t st) {
-  if (pe.NL > 33) return DD_ERR_UNSUPPORTED_SHAPE;
+  if (pe.NL > 65) return DD_ERR_UNSUPPORTED_SHAPE;
   if (g_pos_waves == 2) return launch_pos_nw<2>(pe, pb, st);
   if (g_pos_waves == 4) return launch_pos_nw<4>(pe, pb, st);
   return launch_pos_nw<8>(pe, pb, st);
