@@ -94,3 +94,29 @@ def sample_diffusion_ligand_decomp(model, pocket: synth.Pocket, num_samples: int
         time_list.append(time.time() - t1)
     out["time_list"] = time_list
     return out
+
+
+def to_result_records(out: Dict[str, list], ligand_filename: Optional[str] = None, reconstruct=None) -> List[dict]:
+    """Per-sample records in the layout of the reference's ``result.pt`` (scripts/sample_diffusion_decomp.py:416-457,
+    609-619): ``mol, smiles, pred_pos, pred_v, pred_pos_traj, pred_v_traj, decomp_mask, pred_bond_index (list),
+    pred_bond_type`` (+ ``ligand_filename``), so that ``evaluate_mol_from_meta_full.py`` can consume them unchanged.
+
+    Molecule reconstruction is RDKit/OpenBabel CPU chemistry outside the sampling hot path: pass the
+    reference's ``reconstruct_from_generated_with_bond``-style callable as ``reconstruct(pred_pos, pred_v,
+    pred_bond_index, pred_bond_type) -> (mol, smiles)`` where those packages exist; without it ``mol`` is ``None`` and
+    ``smiles`` empty, exactly what the reference stores when reconstruction fails (:440-443).
+    """
+    records = []
+    for i in range(len(out["pred_pos"])):
+        bond_index = np.asarray(out["pred_bond_index"][i]).tolist()
+        mol, smiles = None, ""
+        if reconstruct is not None:
+            mol, smiles = reconstruct(out["pred_pos"][i], out["pred_v"][i], bond_index, out["pred_bond_type"][i])
+        rec = {"mol": mol, "smiles": smiles, "pred_pos": out["pred_pos"][i], "pred_v": out["pred_v"][i],
+               "pred_pos_traj": out["pred_pos_traj"][i], "pred_v_traj": out["pred_v_traj"][i],
+               "decomp_mask": out["decomp_mask"][i], "pred_bond_index": bond_index,
+               "pred_bond_type": out["pred_bond_type"][i]}
+        if ligand_filename is not None:
+            rec["ligand_filename"] = ligand_filename
+        records.append(rec)
+    return records

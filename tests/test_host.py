@@ -136,3 +136,19 @@ def test_harness_batch_builder_layout():
     d = torch.cdist(torch.from_numpy(pocket.protein_pos), torch.from_numpy(pocket.protein_pos)) + 10 * torch.eye(NP)
     assert float(d.min()) > 1.19
     assert np.allclose(pocket.protein_pos, np.round(pocket.protein_pos, 3), atol=1e-6)
+
+
+def test_result_records_layout():
+    """harness.to_result_records: the reference's result.pt keys (sample_diffusion_decomp.py:444-456), no GPU needed."""
+    from decompdiff_amd.harness import to_result_records
+    NL, Eb, T = 4, 12, 3
+    out = {"pred_pos": [np.zeros((NL, 3))] * 2, "pred_v": [np.zeros(NL, dtype=np.int64)] * 2,
+           "pred_pos_traj": [np.zeros((T, NL, 3))] * 2, "pred_v_traj": [np.zeros((T, NL), dtype=np.int64)] * 2,
+           "pred_bond_index": [np.zeros((2, Eb), dtype=np.int64)] * 2, "pred_bond_type": [np.zeros(Eb, dtype=np.int64)] * 2,
+           "decomp_mask": [np.array([0, 0, 1, -1])] * 2}
+    recs = to_result_records(out, ligand_filename="x/y.sdf", reconstruct=lambda p, v, bi, bt: ("MOL", "C"))
+    assert len(recs) == 2
+    assert set(recs[0]) == {"mol", "smiles", "pred_pos", "pred_v", "pred_pos_traj", "pred_v_traj", "decomp_mask",
+                            "pred_bond_index", "pred_bond_type", "ligand_filename"}
+    assert recs[0]["mol"] == "MOL" and recs[0]["smiles"] == "C" and isinstance(recs[0]["pred_bond_index"], list)
+    assert to_result_records(out)[1]["mol"] is None and to_result_records(out)[1]["smiles"] == ""
