@@ -267,10 +267,6 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
       if (hipStreamWaitEvent(st, g_ev_join[pending_join], 0) != hipSuccess) return DD_ERR_HIP;
       pending_join = -1;
     }
-    if (head_join) {
-      if (hipStreamWaitEvent(st, g_ev_join[8], 0) != hipSuccess) return DD_ERR_HIP;
-      head_join = false;
-    }
     if (ahead && l > 0 && !b1_joined && hipStreamWaitEvent(st, g_ev_join[l], 0) != hipSuccess) return DD_ERR_HIP;   // projections of this layer
     DD_TRYP(DD_PROF_ASSEMBLE, launch_bl_assemble(xcur, w.PB, w.PL, LW(l, DD_BL_Wg1k), LW(l, DD_BL_Wg1v), LW(l, DD_BL_Wg2k),
                                                   LW(l, DD_BL_Wg2v), LW(l, DD_BL_Wgp), B, NP, NL, w.Ek, w.Ev,
@@ -279,6 +275,10 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
       DD_TRYP(DD_PROF_GEMM, launch_b2());
     } else if (mlpf && overlap) {
       if (hipStreamWaitEvent(st, g_ev_qa_join[l], 0) != hipSuccess) return DD_ERR_HIP;
+    }
+    if (head_join) {                                     // kNN graph + edge weights: first needed by the node attention
+      if (hipStreamWaitEvent(st, g_ev_join[8], 0) != hipSuccess) return DD_ERR_HIP;
+      head_join = false;
     }
     // ---- node_layer_with_edge + node_layer_with_bond + bond_layer: one launch
     {
