@@ -14,8 +14,39 @@ namespace dd {
 // N <= 1024).  Key = (bits(d2) << 32) | index is monotone in (d2, index) because d2 >= 0, so
 // K rounds of wave-min give neighbours in ascending (distance, index) — the same total order
 // the oracle's stable sort uses.  d2 = (dx*dx + dy*dy) + dz*dz with no FMA contraction.
-constexpr int KNN_CAND = DD_N_MAX / 64;
+// The wave-min runs on DPP / permlane-swap exchanges of the two key halves (no LDS round trips), and the per-lane
+// candidate count is a template parameter (ceil(N / 64), not the maximum 16).
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_mov_u(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+__device__ __forceinline__ void key_min(unsigned& hi, unsigned& lo, unsigned oh, unsigned ol) {
+  const bool take = oh < hi || (oh == hi && ol < lo);
+  hi = take ? oh : hi;
+  lo = take ? ol : lo;
+}
+__device__ __forceinline__ void wave_min_key(unsigned& hi, unsigned& lo) {
+  key_min(hi, lo, dpp_mov_u<0xB1>(hi), dpp_mov_u<0xB1>(lo));
+  key_min(hi, lo, dpp_mov_u<0x4E>(hi), dpp_mov_u<0x4E>(lo));
+  key_min(hi, lo, dpp_mov_u<0x141>(hi), dpp_mov_u<0x141>(lo));
+  key_min(hi, lo, dpp_mov_u<0x140>(hi), dpp_mov_u<0x140>(lo));
+  {
+    auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    unsigned h0 = rh[0], h1 = rh[1], l0 = rl[0], l1 = rl[1];
+    key_min(h0, l0, h1, l1);
+    hi = h0; lo = l0;
+  }
+  {
+    auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    unsigned h0 = rh[0], h1 = rh[1], l0 = rl[0], l1 = rl[1];
+    key_min(h0, l0, h1, l1);
+    hi = h0; lo = l0;
+  }
+}
 
+template <int CAND>
 __global__ __launch_bounds__(256) void k_knn(const float* __restrict__ x, int B, int N, int K, int32_t* __restrict__ nbr) {
   const int lane = threadIdx.x & 63;
   const int centre = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -23,31 +54,26 @@ __global__ __launch_bounds__(256) void k_knn(const float* __restrict__ x, int B,
   const int b = centre / N, i = centre % N;
   const float* xb = x + (long)b * N * 3;
   const float cx = xb[3 * i], cy = xb[3 * i + 1], cz = xb[3 * i + 2];
-  unsigned long long key[KNN_CAND];
+  unsigned khi[CAND], klo[CAND];                         // key = (bits(d2), index): d2 >= 0, so unsigned order = float order
 #pragma unroll
-  for (int t = 0; t < KNN_CAND; ++t) {
-    int c = lane + 64 * t;
-    unsigned long long k = ~0ull;
+  for (int t = 0; t < CAND; ++t) {
+    const int c = lane + 64 * t;
+    khi[t] = ~0u; klo[t] = ~0u;
     if (c < N && c != i) {
       float dx = __fsub_rn(cx, xb[3 * c]), dy = __fsub_rn(cy, xb[3 * c + 1]), dz = __fsub_rn(cz, xb[3 * c + 2]);
       float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-      k = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)c;
+      khi[t] = __float_as_uint(d2); klo[t] = (unsigned)c;
     }
-    key[t] = k;
   }
   for (int s = 0; s < K; ++s) {
-    unsigned long long best = key[0];
+    unsigned bh = khi[0], bl = klo[0];
 #pragma unroll
-    for (int t = 1; t < KNN_CAND; ++t) best = key[t] < best ? key[t] : best;
+    for (int t = 1; t < CAND; ++t) key_min(bh, bl, khi[t], klo[t]);
+    wave_min_key(bh, bl);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      unsigned long long other = __shfl_xor(best, o, 64);
-      best = other < best ? other : best;
-    }
-#pragma unroll
-    for (int t = 0; t < KNN_CAND; ++t)
-      if (key[t] == best) key[t] = ~0ull;
-    if (lane == 0) nbr[(long)centre * K + s] = (int32_t)(best & 0xffffffffull);
+    for (int t = 0; t < CAND; ++t)
+      if (khi[t] == bh && klo[t] == bl) { khi[t] = ~0u; klo[t] = ~0u; }
+    if (lane == 0) nbr[(long)centre * K + s] = (int32_t)bl;
   }
 }
 
@@ -438,7 +464,13 @@ int launch_xupdate(const float* x, const float* dxe, const float* dxb, int B, in
 }
 
 int launch_knn(const float* x, int B, int N, int K, int32_t* nbr, hipStream_t st) {
-  hipLaunchKernelGGL(k_knn, dim3((B * N + 3) / 4), dim3(256), 0, st, x, B, N, K, nbr);
+  const dim3 grid((B * N + 3) / 4), block(256);
+  const int cand = (N + 63) / 64;
+  if (cand <= 2) hipLaunchKernelGGL(k_knn<2>, grid, block, 0, st, x, B, N, K, nbr);
+  else if (cand <= 4) hipLaunchKernelGGL(k_knn<4>, grid, block, 0, st, x, B, N, K, nbr);
+  else if (cand <= 6) hipLaunchKernelGGL(k_knn<6>, grid, block, 0, st, x, B, N, K, nbr);
+  else if (cand <= 11) hipLaunchKernelGGL(k_knn<11>, grid, block, 0, st, x, B, N, K, nbr);
+  else hipLaunchKernelGGL(k_knn<DD_N_MAX / 64>, grid, block, 0, st, x, B, N, K, nbr);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
