@@ -111,18 +111,22 @@ static int g_sched = 0;                        // dd_debug_set_option(8, v): 0 =
 static int g_xup_in_pos = 0;                   // dd_debug_set_option(11, v): x update inside the coordinate launch (last workgroup);
                                                // measured 1 % slower than the separate 3-block launch, off
 static int g_fused_max_nl = 64;                // dd_debug_set_option(13, v): largest ligand handled by the fused launches
+static int g_defer_pos = 0;                    // dd_debug_set_option(14, v): record the coordinate launch after the next layer's GEMMs
+                                               // (keeps the GEMM chain on the main queue; measured 1.3 % slower: the coordinate
+                                               // launch then starves behind the projections' workgroups)
 static int g_q1_in_gemm = 1;                   // dd_debug_set_option(12, v): bond-layer query hidden row summed inside the query GEMM
 static int g_q_in_pos = 1;                     // dd_debug_set_option(9, v): coordinate query MLPs' second layer inside attn_pos
 static int g_mlp_fused = 0;                    // dd_debug_set_option(6, v): fused 2-layer query MLPs beside the projections
 static hipEvent_t g_ev_fork[9], g_ev_join[9];   // [0..7] per layer, [8] graph construction at the head of a forward
-static int g_side_low_priority = [] { const char* e = getenv("DD_SIDE_PRIO"); return (e && e[0] == '0') ? 0 : 1; }();
+// DD_SIDE_PRIO: 1 (default) lowest priority for the side stream, 0 default priority, 2 highest
+static int g_side_low_priority = [] { const char* e = getenv("DD_SIDE_PRIO"); return (e && e[0] == '0') ? 0 : ((e && e[0] == '2') ? 2 : 1); }();
 static int g_overlap = 1;                     // measured in-process A/B: -3.5 % step time
 static int ensure_side_stream() {
   if (g_side) return DD_OK;
   {
     int lo = 0, hi = 0;                                  // lowest priority: side work fills CUs the main chain leaves idle
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; (void)hipGetLastError(); }
-    if (hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, g_side_low_priority ? lo : 0) != hipSuccess) return DD_ERR_HIP;
+    if (hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, g_side_low_priority == 1 ? lo : (g_side_low_priority == 2 ? hi : 0)) != hipSuccess) return DD_ERR_HIP;
   }
   if (hipStreamCreateWithFlags(&g_side2, hipStreamNonBlocking) != hipSuccess) return DD_ERR_HIP;
   for (int i = 0; i < 8; ++i)
@@ -189,6 +193,22 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
     }
   }
   int pending_join = -1;
+  // (schedule 0) the coordinate launch of layer l is *recorded* after the next layer's projection / query GEMMs: the graph
+  // runtime keeps the first-recorded successor of a node on the same hardware queue, and the branch that pays the
+  // 10-12 us of cross-queue fork + join latency must be the short one (coordinates), not the GEMM chain
+  struct DeferredPos { bool armed; AttnArgs pe, pb; float *xcur, *xnext; int layer; bool xup; } dpos;
+  dpos.armed = false;
+  auto flush_pos = [&]() -> int {
+    if (!dpos.armed) return DD_OK;
+    dpos.armed = false;
+    if (hipStreamWaitEvent(g_side, g_ev_fork[dpos.layer], 0) != hipSuccess) return DD_ERR_HIP;
+    int rc = launch_attn2_pos(dpos.pe, dpos.pb, g_side);
+    if (rc == DD_OK && !dpos.xup) rc = launch_xupdate(dpos.xcur, w.dxe, w.dxb, B, NP, NL, dpos.xnext, g_side);
+    if (rc != DD_OK) return rc;
+    if (hipEventRecord(g_ev_join[dpos.layer], g_side) != hipSuccess) return DD_ERR_HIP;
+    pending_join = dpos.layer;
+    return DD_OK;
+  };
   for (int l = 0; l < s->num_layers && fused; ++l) {
     const int nE = (int)(B * Eb);
     const bool mlpf = g_mlp_fused != 0;
@@ -263,6 +283,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
       }
       DD_TRYP(DD_PROF_GEMM, launch_b2());
     }
+    DD_TRY(flush_pos());                                 // previous layer's coordinate launch (side stream)
     if (pending_join >= 0) {
       if (hipStreamWaitEvent(st, g_ev_join[pending_join], 0) != hipSuccess) return DD_ERR_HIP;
       pending_join = -1;
@@ -364,12 +385,9 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
       }
       if (overlap && !ahead) {
         // fork: the coordinate sub-layers run on the side stream and are joined before the next consumer of x
-        if (hipEventRecord(g_ev_fork[l], st) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_fork[l], 0) != hipSuccess) return DD_ERR_HIP;
-        int rc = launch_attn2_pos(pe, pb, g_side);
-        if (rc == DD_OK && !xup_in_pos) rc = launch_xupdate(xcur, w.dxe, w.dxb, B, NP, NL, xnext, g_side);
-        if (rc != DD_OK) return rc;
-        if (hipEventRecord(g_ev_join[l], g_side) != hipSuccess) return DD_ERR_HIP;
-        pending_join = l;
+        if (hipEventRecord(g_ev_fork[l], st) != hipSuccess) return DD_ERR_HIP;
+        dpos.armed = true; dpos.pe = pe; dpos.pb = pb; dpos.xcur = xcur; dpos.xnext = xnext; dpos.layer = l; dpos.xup = xup_in_pos;
+        if (!g_defer_pos) DD_TRY(flush_pos());
       } else {
         DD_TRYP(DD_PROF_ATTN_PE, launch_attn2_pos(pe, pb, st));
         if (!xup_in_pos) DD_TRYP(DD_PROF_MISC, launch_xupdate(xcur, w.dxe, w.dxb, B, NP, NL, xnext, st));
@@ -470,6 +488,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
         gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, GW(DD_G_VH_W1), GW(DD_G_VH_b1), nullptr, w.qn, B * NL, 0, 128, 128, 0)};
     DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, 2, st));   // (v-head hidden -> qn: ql may still be read by the overlapped pos sub-layer)
   }
+  DD_TRY(flush_pos());                                   // last layer's coordinate launch (recorded after the head GEMMs)
   if (pending_join >= 0) {
     if (hipStreamWaitEvent(st, g_ev_join[pending_join], 0) != hipSuccess) return DD_ERR_HIP;
     pending_join = -1;
@@ -703,6 +722,7 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 0) return dd_debug_set_fusion(value);
   if (key == 1) { dd::g_gemm_ksplit = value ? 1 : 0; return DD_OK; }
   if (key == 3) { dd::g_attn_persist = value ? 1 : 0; return DD_OK; }
+  if (key == 14) { dd::g_defer_pos = value ? 1 : 0; return DD_OK; }
   if (key == 13) { dd::g_fused_max_nl = value; return DD_OK; }
   if (key == 12) { dd::g_q1_in_gemm = value ? 1 : 0; return DD_OK; }
   if (key == 11) { dd::g_xup_in_pos = value ? 1 : 0; return DD_OK; }
