@@ -20,30 +20,23 @@ template <int CTRL>
 __device__ __forceinline__ unsigned dpp_mov_u(unsigned v) {
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
-__device__ __forceinline__ void key_min(unsigned& hi, unsigned& lo, unsigned oh, unsigned ol) {
-  const bool take = oh < hi || (oh == hi && ol < lo);
-  hi = take ? oh : hi;
-  lo = take ? ol : lo;
-}
-__device__ __forceinline__ void wave_min_key(unsigned& hi, unsigned& lo) {
-  key_min(hi, lo, dpp_mov_u<0xB1>(hi), dpp_mov_u<0xB1>(lo));
-  key_min(hi, lo, dpp_mov_u<0x4E>(hi), dpp_mov_u<0x4E>(lo));
-  key_min(hi, lo, dpp_mov_u<0x141>(hi), dpp_mov_u<0x141>(lo));
-  key_min(hi, lo, dpp_mov_u<0x140>(hi), dpp_mov_u<0x140>(lo));
+// wave-wide minimum of an unsigned value: 4 DPP steps + 2 permlane swaps, one v_min_u32 each
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+  v = min(v, dpp_mov_u<0xB1>(v));
+  v = min(v, dpp_mov_u<0x4E>(v));
+  v = min(v, dpp_mov_u<0x141>(v));
+  v = min(v, dpp_mov_u<0x140>(v));
   {
-    auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-    auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-    unsigned h0 = rh[0], h1 = rh[1], l0 = rl[0], l1 = rl[1];
-    key_min(h0, l0, h1, l1);
-    hi = h0; lo = l0;
+    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    v = min(r0, r1);
   }
   {
-    auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-    unsigned h0 = rh[0], h1 = rh[1], l0 = rl[0], l1 = rl[1];
-    key_min(h0, l0, h1, l1);
-    hi = h0; lo = l0;
+    auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    v = min(r0, r1);
   }
+  return v;
 }
 
 template <int CAND>
@@ -65,15 +58,21 @@ __global__ __launch_bounds__(256) void k_knn(const float* __restrict__ x, int B,
       khi[t] = __float_as_uint(d2); klo[t] = (unsigned)c;
     }
   }
+  // K rounds: minimum distance first (32-bit), then the lowest index among the candidates at that distance -- the
+  // (d2, index) lexicographic minimum with two cheap 32-bit wave reductions instead of one 64-bit one
   for (int s = 0; s < K; ++s) {
-    unsigned bh = khi[0], bl = klo[0];
+    unsigned bh = khi[0];
 #pragma unroll
-    for (int t = 1; t < CAND; ++t) key_min(bh, bl, khi[t], klo[t]);
-    wave_min_key(bh, bl);
+    for (int t = 1; t < CAND; ++t) bh = min(bh, khi[t]);
+    const unsigned mh = wave_min_u32(bh);
+    unsigned bl = ~0u;
+#pragma unroll
+    for (int t = 0; t < CAND; ++t) bl = min(bl, khi[t] == mh ? klo[t] : ~0u);
+    const unsigned ml = wave_min_u32(bl);
 #pragma unroll
     for (int t = 0; t < CAND; ++t)
-      if (khi[t] == bh && klo[t] == bl) { khi[t] = ~0u; klo[t] = ~0u; }
-    if (lane == 0) nbr[(long)centre * K + s] = (int32_t)bl;
+      if (khi[t] == mh && klo[t] == ml) { khi[t] = ~0u; klo[t] = ~0u; }
+    if (lane == 0) nbr[(long)centre * K + s] = (int32_t)ml;
   }
 }
 
