@@ -715,13 +715,14 @@ extern "C" int dd_debug_set_fusion(int mode) {
   return DD_OK;
 }
 
-namespace dd { extern int g_gemm_ksplit; extern int g_attn_waves; extern int g_attn_persist; extern int g_assemble_persist; extern int g_pos_waves; extern int g_gemm_big; }
+namespace dd { extern int g_gemm_ksplit; extern int g_attn_waves; extern int g_attn_persist; extern int g_assemble_persist; extern int g_pos_waves; extern int g_gemm_big; extern int g_ew_mfma; }
 // Measurement aid: runtime switches for A/B timing inside one process.  key 0: attention launch structure (same
 // values as dd_debug_set_fusion), key 1: K-split projection GEMM tiles (1 = on).
 extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 0) return dd_debug_set_fusion(value);
   if (key == 1) { dd::g_gemm_ksplit = value ? 1 : 0; return DD_OK; }
   if (key == 3) { dd::g_attn_persist = value ? 1 : 0; return DD_OK; }
+  if (key == 15) { dd::g_ew_mfma = value ? 1 : 0; return DD_OK; }
   if (key == 14) { dd::g_defer_pos = value ? 1 : 0; return DD_OK; }
   if (key == 13) { dd::g_fused_max_nl = value; return DD_OK; }
   if (key == 12) { dd::g_q1_in_gemm = value ? 1 : 0; return DD_OK; }

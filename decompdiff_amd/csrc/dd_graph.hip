@@ -117,6 +117,75 @@ __global__ __launch_bounds__(256) void k_edge_weights(const float* __restrict__ 
   }
 }
 
+
+// Matrix-core variant (default): one wave per node, 16 neighbours per tile in the attention kernels' k-pass layout
+// (lane = (member mm, channel group cg), 32 hidden channels per lane).  hidden = b1 + W1 . G(d) is 5 k-steps of
+// v_mfma_f32_16x16x4_f32 with the weights as A operands held in 40 registers; LayerNorm + ReLU and the 128 -> 1
+// output layer reduce over the 4 lanes of a member with permlane swaps.
+typedef float f32x4e __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_edge_weights2(const float* __restrict__ x, const int32_t* __restrict__ nbr, int B,
+                                                       int N, int K, const float* __restrict__ W1T,
+                                                       const float* __restrict__ b1, const float* __restrict__ ln,
+                                                       const float* __restrict__ w2, const float* __restrict__ b2,
+                                                       float* __restrict__ ew) {
+  const int lane = threadIdx.x & 63, mm = lane & 15, cg = lane >> 4;
+  const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (node >= B * N) return;
+  const int b = node / N, i = node % N;
+  const float* xb = x + (long)b * N * 3;
+  const float cx = xb[3 * i], cy = xb[3 * i + 1], cz = xb[3 * i + 2];
+  float Wa[5][8];                                        // A operands: W1T[4s + cg][16nt + mm]
+#pragma unroll
+  for (int s = 0; s < 5; ++s)
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) Wa[s][nt] = W1T[(4 * s + cg) * 128 + 16 * nt + mm];
+  float4 bb[8], gm[8], bt[8], ww[8];                     // channels 16nt + 4cg .. +3
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) {
+    bb[nt] = *reinterpret_cast<const float4*>(b1 + 16 * nt + 4 * cg);
+    gm[nt] = *reinterpret_cast<const float4*>(ln + 16 * nt + 4 * cg);
+    bt[nt] = *reinterpret_cast<const float4*>(ln + 128 + 16 * nt + 4 * cg);
+    ww[nt] = *reinterpret_cast<const float4*>(w2 + 16 * nt + 4 * cg);
+  }
+  const float bias2 = b2[0];
+  auto quad = [](float v) { v = swap16_sum(v, v); return swap32_sum(v, v); };
+  for (int t0 = 0; t0 < K; t0 += 16) {
+    const int m = t0 + mm;
+    const int j = nbr[(long)node * K + (m < K ? m : K - 1)];
+    const float dx = cx - xb[3 * j], dy = cy - xb[3 * j + 1], dz = cz - xb[3 * j + 2];
+    const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+    f32x4e acc[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) acc[nt] = f32x4e{bb[nt].x, bb[nt].y, bb[nt].z, bb[nt].w};
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      const float fk = gauss_feat(d, 4 * s + cg);
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wa[s][nt], fk, acc[nt], 0, 0, 0);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) sum += (acc[nt][0] + acc[nt][1]) + (acc[nt][2] + acc[nt][3]);
+    const float mean = quad(sum) * (1.0f / 128.0f);
+    float var = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { acc[nt][r] -= mean; var = fmaf(acc[nt][r], acc[nt][r], var); }
+    const float rstd = __builtin_amdgcn_rsqf(quad(var) * (1.0f / 128.0f) + 1e-5f);
+    float dot = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+      dot = fmaf(fmaxf(fmaf(acc[nt][0] * rstd, gm[nt].x, bt[nt].x), 0.f), ww[nt].x, dot);
+      dot = fmaf(fmaxf(fmaf(acc[nt][1] * rstd, gm[nt].y, bt[nt].y), 0.f), ww[nt].y, dot);
+      dot = fmaf(fmaxf(fmaf(acc[nt][2] * rstd, gm[nt].z, bt[nt].z), 0.f), ww[nt].z, dot);
+      dot = fmaf(fmaxf(fmaf(acc[nt][3] * rstd, gm[nt].w, bt[nt].w), 0.f), ww[nt].w, dot);
+    }
+    const float logit = quad(dot) + bias2;
+    if (cg == 0 && m < K) ew[(long)node * K + m] = 1.0f / (1.0f + expf(-logit));
+  }
+}
+
 // -------------------------------------------------------------------------------- embeddings
 // protein_h[r, c] = sum_f W[c, f] * feat[r, f] + b[c]     (W padded to 128 rows: row 127 = 0, b[127] = 0)
 __global__ void k_embed_protein(const float* __restrict__ feat, int rows, const float* __restrict__ W,
@@ -473,9 +542,12 @@ int launch_knn(const float* x, int B, int N, int K, int32_t* nbr, hipStream_t st
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
+int g_ew_mfma = 1;           // dd_debug_set_option(15, v): matrix-core edge-weight kernel
+
 int launch_edge_weights(const float* x, const int32_t* nbr, int B, int N, int K, const float* W1T, const float* b1,
                         const float* ln, const float* w2, const float* b2, float* ew, hipStream_t st) {
-  hipLaunchKernelGGL(k_edge_weights, dim3((B * N + 3) / 4), dim3(256), 0, st, x, nbr, B, N, K, W1T, b1, ln, w2, b2, ew);
+  if (g_ew_mfma) hipLaunchKernelGGL(k_edge_weights2, dim3((B * N + 3) / 4), dim3(256), 0, st, x, nbr, B, N, K, W1T, b1, ln, w2, b2, ew);
+  else hipLaunchKernelGGL(k_edge_weights, dim3((B * N + 3) / 4), dim3(256), 0, st, x, nbr, B, N, K, W1T, b1, ln, w2, b2, ew);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
