@@ -114,6 +114,7 @@ static int g_fused_max_nl = 64;                // dd_debug_set_option(13, v): la
 static int g_defer_pos = 0;                    // dd_debug_set_option(14, v): record the coordinate launch after the next layer's GEMMs
                                                // (keeps the GEMM chain on the main queue; measured 1.3 % slower: the coordinate
                                                // launch then starves behind the projections' workgroups)
+static int g_lin_with_pb2 = 1;                 // dd_debug_set_option(16, v): bond projections of the coordinate sub-layer ride with lin_node
 static int g_q1_in_gemm = 1;                   // dd_debug_set_option(12, v): bond-layer query hidden row summed inside the query GEMM
 static int g_q_in_pos = 1;                     // dd_debug_set_option(9, v): coordinate query MLPs' second layer inside attn_pos
 static int g_mlp_fused = 0;                    // dd_debug_set_option(6, v): fused 2-layer query MLPs beside the projections
@@ -328,7 +329,14 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
     {
       GemmArgs g = gemm_args(w.A, B * N, 0, 128, B * N, LW(l, DD_W_lin), LW(l, DD_b_lin), nullptr, w.h, B * N, 0, 128, 128, 1);
       g.X2 = w.Anb; g.x2_N = N; g.x2_NP = NP;
-      DD_TRYP(DD_PROF_GEMM, launch_gemm128(g, st));
+      if (g_lin_with_pb2) {
+        // the bond projections of the coordinate sub-layer only need the new h_bond: they share this launch, so that
+        // the launch behind lin_node (projections of the new h) is a third of its former size
+        GemmArgs j[2] = {g, gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b2), LW(l, DD_b_b2), nullptr, w.PB2, nE, 0, 256, 256, 0)};
+        DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, 2, st));
+      } else {
+        DD_TRYP(DD_PROF_GEMM, launch_gemm128(g, st));
+      }
     }
     if (ahead && l + 1 < s->num_layers && hipEventRecord(g_ev_fork[l + 1], st) != hipSuccess) return DD_ERR_HIP;   // h, h_bond final
     // ---- query MLPs of the two coordinate sub-layers: fused, on the stream the sub-layers themselves run on
@@ -352,10 +360,10 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
     // ---- projections of the new h / h_bond: one launch
     {
       GemmArgs j[3] = {
-          gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b2), LW(l, DD_b_b2), nullptr, w.PB2, nE, 0, 256, 256, 0),
           gemm_args(w.h, B * N, 0, 128, B * N, LW(l, DD_W_n2), LW(l, DD_b_n2), nullptr, w.P2, B * N, 0, 256, 256, 0),
-          gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(l, DD_W_l2), LW(l, DD_b_l2), nullptr, w.PL2, B * NL, 0, 1024, mlpf ? 896 : 1024, 0)};
-      DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, 3, st));
+          gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(l, DD_W_l2), LW(l, DD_b_l2), nullptr, w.PL2, B * NL, 0, 1024, mlpf ? 896 : 1024, 0),
+          gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b2), LW(l, DD_b_b2), nullptr, w.PB2, nE, 0, 256, 256, 0)};
+      DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, g_lin_with_pb2 ? 2 : 3, st));
     }
     const bool q_in_pos = g_q_in_pos && !mlpf;           // second layer of the coordinate query MLPs inside attn_pos
     if (!mlpf && !q_in_pos) {
@@ -722,6 +730,7 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 0) return dd_debug_set_fusion(value);
   if (key == 1) { dd::g_gemm_ksplit = value ? 1 : 0; return DD_OK; }
   if (key == 3) { dd::g_attn_persist = value ? 1 : 0; return DD_OK; }
+  if (key == 16) { dd::g_lin_with_pb2 = value ? 1 : 0; return DD_OK; }
   if (key == 15) { dd::g_ew_mfma = value ? 1 : 0; return DD_OK; }
   if (key == 14) { dd::g_defer_pos = value ? 1 : 0; return DD_OK; }
   if (key == 13) { dd::g_fused_max_nl = value; return DD_OK; }
