@@ -1,23 +1,24 @@
-// Fused segment attention, tiled variant (v2): 16 members per tile, matrix cores for the
-// per-head contractions.
+// Fused segment attention, tiled variant (v2): 16 members per tile, matrix cores for every contraction.
 //
-// Same math and interface as dd_attention.hip (see there for the algebra); the work inside a
-// wavefront is laid out for v_mfma_f32_16x16x4_f32 instead of one member at a time:
+// Same math and interface as dd_attention.hip (see there for the algebra).  One wavefront owns one softmax segment;
+// all per-segment state lives in registers, LDS only holds read-only weight images shared by the workgroup.
 //
-//   lane l = (mm = l & 15, cg = l >> 4)   holds member mm of the current 16-member tile and the 32
-//   hidden channels  c(nt, r) = 16*nt + 4*cg + r  (nt < 8, r < 4; register kk = 4*nt + r).
+// k pass -- lane l = (mm = l & 15, cg = l >> 4) holds member mm of the current 16-member tile and the 32 hidden
+// channels c(nt, r) = 16*nt + 4*cg + r (nt < 8, r < 4; register 4*nt + r):
+//   * gathered projection rows summed in registers (requested one tile ahead);
+//   * type (x) Gaussian / angular part of the first Linear: MFMA with the table as A operand (channel-permuted LDS
+//     image packed on the host) and the per-lane features as B -> lands in this very layout;
+//   * LayerNorm + ReLU on the VALU, row reductions over the 4 lanes of a member with v_permlane{16,32}_swap;
+//   * scores S[m][h] = sum_c z_k[m][c] * Q~[h][c]: 32 MFMAs per tile (A = z from the registers above, B = Q~ held in
+//     32 VGPRs per segment), exact fp32 (k-ordered fmaf chain);  softmax over the segment in registers.
+// v pass -- member-major layout: lane (mm, cg) holds members 4*cg + r and channels 16*nt + mm.  The same table MFMAs
+//   with swapped operands deliver the activation in exactly the layout the aggregation
+//   Z~[h][c] = sum_m aw[m][h] * z_v[m][c] consumes as an A operand, with aw straight from the softmax registers as B.
+//   No transposes, no LDS scratch.  (Coordinate modes keep the k-pass layout: v16[m][h] = z_v[m] . W2xv[h].)
+// Epilogue -- W2v . Z~ from a head-permuted LDS image, reduce-scatter over the 4 lanes of a head with two swaps.
 //
-//   * pre-activation / LayerNorm / ReLU: VALU, 32 channels per lane, row reductions over the 4
-//     lanes of a member with v_permlane{16,32}_swap (no LDS, no 64-lane butterflies);
-//   * scores   S[m][h] = sum_c z_k[m][c] * Q~[h][c]      : 32 MFMAs per tile (A = z straight from the
-//     registers above, B = Q~ held in 32 VGPRs per segment), exact fp32 (k-ordered fmaf chain);
-//   * softmax over the members of the segment: registers + 2 swaps per reduction;
-//   * aggregation Z~[h][c] = sum_m aw[m][h] * z_v[m][c]   : 32 MFMAs per tile (A = z_v transposed
-//     through a 5 KB LDS tile, B = alpha*w after an in-register 4x4 lane transpose);
-//   * pos layers: v16[m][h] = z_v[m] . W2xv[h]            : 32 MFMAs per tile, consumed in registers.
-//
-// This removes the per-member 16-value cross-lane reductions and broadcasts of v1 (its dominant
-// instruction count) and moves ~4k MACs per member from the VALU to the otherwise idle MFMA pipe.
+// LDS plans (per mode, struct Lds), persistent bond-layer workgroups, the prefetch pipeline and the launch shapes are
+// described at their definitions below and in DESIGN.md section 5.
 #include <type_traits>
 
 #include "dd_kernels.hpp"
@@ -29,7 +30,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace v2 {
 
 constexpr int WPITCH = 132;                    // pitch of the head-permuted W2k image
-constexpr int WB_FLOATS = 128 * WPITCH;        // 67.6 KB weight buffer (W2k -> Gaussian tables -> W2v^T)
+constexpr int WB_FLOATS = 128 * WPITCH;        // 67.6 KB: one head-permuted 128 x 128 weight image (W2k or W2v)
 constexpr int TABP = 24 * 128;                 // Gaussian table stride per edge type (21 rows + 3 zero rows)
 // sum / max over the 4 lanes {l, l^16, l^32, l^48}
 __device__ __forceinline__ float quad_sum(float v) { v = swap16_sum(v, v); return swap32_sum(v, v); }
