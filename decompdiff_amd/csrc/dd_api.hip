@@ -115,6 +115,7 @@ static int g_defer_pos = 0;                    // dd_debug_set_option(14, v): re
                                                // (keeps the GEMM chain on the main queue; measured 1.3 % slower: the coordinate
                                                // launch then starves behind the projections' workgroups)
 static int g_lin_with_pb2 = 1;                 // dd_debug_set_option(16, v): bond projections of the coordinate sub-layer ride with lin_node
+static int g_pb_early = 1;                     // dd_debug_set_option(17, v): next layer's bond projections in the lin_node launch
 static int g_q1_in_gemm = 1;                   // dd_debug_set_option(12, v): bond-layer query hidden row summed inside the query GEMM
 static int g_q_in_pos = 1;                     // dd_debug_set_option(9, v): coordinate query MLPs' second layer inside attn_pos
 static int g_mlp_fused = 0;                    // dd_debug_set_option(6, v): fused 2-layer query MLPs beside the projections
@@ -260,7 +261,9 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
     };
     const bool ahead = overlap && g_sched >= 1;
     const bool ahead_split = overlap && g_sched == 2;
-    if (!(ahead && l > 0)) DD_TRYP(DD_PROF_GEMM, launch_batch1(l, st));
+    const bool pb_early = g_pb_early && g_lin_with_pb2 && !ahead;   // next layer's bond projections ride with lin_node
+    if (pb_early && l > 0) DD_TRYP(DD_PROF_GEMM, launch_batch1_part(l, 1, st));
+    else if (!(ahead && l > 0)) DD_TRYP(DD_PROF_GEMM, launch_batch1(l, st));
     // ---- queries (second Linear of the q MLPs, LayerNorm+ReLU prologue): one launch.  The bond-layer hidden row is
     //      q_hb[bond] + q_hi[dst atom], summed while the GEMM stages its rows, so this launch depends on the projections
     //      only and runs before the coordinates of the previous layer are joined.
@@ -332,8 +335,12 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
       if (g_lin_with_pb2) {
         // the bond projections of the coordinate sub-layer only need the new h_bond: they share this launch, so that
         // the launch behind lin_node (projections of the new h) is a third of its former size
-        GemmArgs j[2] = {g, gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b2), LW(l, DD_b_b2), nullptr, w.PB2, nE, 0, 256, 256, 0)};
-        DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, 2, st));
+        GemmArgs j[3] = {g, gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b2), LW(l, DD_b_b2), nullptr, w.PB2, nE, 0, 256, 256, 0),
+                         gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b2), LW(l, DD_b_b2), nullptr, w.PB2, nE, 0, 256, 256, 0)};
+        const bool more = pb_early && l + 1 < s->num_layers;
+        if (more)                                          // ... and so do the next layer's bond projections (h_bond is final)
+          j[2] = gemm_args(w.hb, nE, 0, 128, nE, LW(l + 1, DD_W_b1), LW(l + 1, DD_b_b1), nullptr, w.PB, nE, 0, 640, mlpf ? 512 : 640, 0);
+        DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, more ? 3 : 2, st));
       } else {
         DD_TRYP(DD_PROF_GEMM, launch_gemm128(g, st));
       }
@@ -730,6 +737,7 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 0) return dd_debug_set_fusion(value);
   if (key == 1) { dd::g_gemm_ksplit = value ? 1 : 0; return DD_OK; }
   if (key == 3) { dd::g_attn_persist = value ? 1 : 0; return DD_OK; }
+  if (key == 17) { dd::g_pb_early = value ? 1 : 0; return DD_OK; }
   if (key == 16) { dd::g_lin_with_pb2 = value ? 1 : 0; return DD_OK; }
   if (key == 15) { dd::g_ew_mfma = value ? 1 : 0; return DD_OK; }
   if (key == 14) { dd::g_defer_pos = value ? 1 : 0; return DD_OK; }
