@@ -1,6 +1,8 @@
 // C ABI orchestration: workspace carving, the score-network forward (launch sequence of
 // models/decompdiff.py:213-351 + uni_transformer_edge.py:259-287,394-443) and the reverse loop
 // (decompdiff.py:575-689), eager or as a replayed hipGraph.
+#include <thread>
+#include <vector>
 #include <stdlib.h>
 #include <string.h>
 
@@ -681,6 +683,65 @@ extern "C" int dd_sample_steps_graph(const dd_sampler* s, int n_steps, void* str
   if (hipStreamSynchronize(st) != hipSuccess) rc = DD_ERR_HIP;
   (void)hipGraphExecDestroy(exec);
   (void)hipGraphDestroy(graph);
+  return rc;
+}
+
+extern "C" int dd_sample_steps_graph_multi(const dd_sampler* const* ss, int n, int n_steps, void* const* streams) {
+  if (!ss || !streams || n <= 0 || n > 64 || n_steps < 0) return DD_ERR_BAD_ARG;
+  for (int i = 0; i < n; ++i) {
+    const dd_sampler* s = ss[i];
+    if (!s || !streams[i] || !s->step_counter || !s->tab_pos || !s->tab_v || !s->tab_b || !s->atom_std || !s->offset ||
+        !s->pred_pos)
+      return DD_ERR_BAD_ARG;
+    for (int j = 0; j < i; ++j)
+      if (streams[j] == streams[i] || ss[j]->workspace == s->workspace) return DD_ERR_BAD_ARG;
+    int rc = dd::check_shapes(s);
+    if (rc != DD_OK) return rc;
+  }
+  if (n_steps == 0) return DD_OK;
+  hipGraph_t graph[64] = {};
+  hipGraphExec_t exec[64] = {};
+  int rc = DD_OK;
+  // the side streams / events used inside a step are shared, which is fine: they only shape each graph while it
+  // is being captured, one chain at a time; the replays below do not touch them
+  for (int i = 0; i < n && rc == DD_OK; ++i) {
+    hipStream_t st = (hipStream_t)streams[i];
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { rc = DD_ERR_HIP; break; }
+    int rs = one_step(ss[i], st);
+    hipError_t e = hipStreamEndCapture(st, &graph[i]);
+    if (rs != DD_OK || e != hipSuccess || !graph[i]) { rc = rs != DD_OK ? rs : DD_ERR_HIP; break; }
+    if (hipGraphInstantiate(&exec[i], graph[i], nullptr, nullptr, 0) != hipSuccess) rc = DD_ERR_HIP;
+  }
+  if (rc == DD_OK) {
+    static const int threaded = [] { const char* e = getenv("DD_MULTI_THREADS"); return e ? atoi(e) : 1; }();
+    if (threaded) {
+      // one host thread per chain: replaying a graph of ~60 kernel nodes costs the host about as much time as a small
+      // chain takes on the GPU, so a single launching thread would be the bottleneck
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      std::vector<std::thread> th;
+      std::vector<int> trc(n, DD_OK);
+      for (int i = 0; i < n; ++i)
+        th.emplace_back([&, i] {
+          if (hipSetDevice(dev) != hipSuccess) { trc[i] = DD_ERR_HIP; return; }
+          for (int k = 0; k < n_steps; ++k)
+            if (hipGraphLaunch(exec[i], (hipStream_t)streams[i]) != hipSuccess) { trc[i] = DD_ERR_HIP; return; }
+        });
+      for (auto& t : th) t.join();
+      for (int i = 0; i < n; ++i) if (trc[i] != DD_OK) rc = trc[i];
+    } else {
+      for (int k = 0; k < n_steps && rc == DD_OK; ++k)
+        for (int i = 0; i < n; ++i)
+          if (hipGraphLaunch(exec[i], (hipStream_t)streams[i]) != hipSuccess) { rc = DD_ERR_HIP; break; }
+    }
+  }
+  for (int i = 0; i < n; ++i)
+    if (hipStreamSynchronize((hipStream_t)streams[i]) != hipSuccess) rc = rc == DD_OK ? DD_ERR_HIP : rc;
+  for (int i = 0; i < n; ++i) {
+    if (exec[i]) (void)hipGraphExecDestroy(exec[i]);
+    if (graph[i]) (void)hipGraphDestroy(graph[i]);
+  }
+  if (rc != DD_OK) (void)hipGetLastError();
   return rc;
 }
 

@@ -12,6 +12,7 @@ results.  Nothing here computes the network on the CPU — CPU tensors raise.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -182,7 +183,7 @@ class DecompScorePosNet3D(nn.Module):
         return bool((cp != cp[0]).any().item() or (cl != cl[0]).any().item())
 
     def _sample_ragged(self, kw, ligand_atom_mask, num_steps, center_pos_mode, energy_drift_opt, noise, seed, keep_traj,
-                       use_graph):
+                       use_graph, concurrent=None):
         if ligand_atom_mask is not None:
             raise NotImplementedError("ligand_atom_mask (partially fixed ligands) is not part of the shipped sampling path")
         dev = kw["protein_pos"].device
@@ -212,6 +213,7 @@ class DecompScorePosNet3D(nn.Module):
                "bond": torch.empty(n_bond, dtype=torch.long, device=dev)}
         traj: Dict[str, Optional[torch.Tensor]] = {k: None for k in ("pos_traj", "v_traj", "bond_traj", "v0_traj", "vt_traj", "bt_traj")}
         rng = lambda o, c, ids: torch.cat([torch.arange(o[b], o[b] + c[b]) for b in ids])
+        prepared = []
         for gi, ((np_, nl_, npr_, nf_), ids) in enumerate(sorted(groups.items(), key=lambda kv: kv[1][0])):
             G = len(ids)
             r_p, r_l, r_pr, r_b = rng(o_p, n_p, ids), rng(o_l, n_l, ids), rng(o_pr, n_pr, ids), rng(o_b, n_b, ids)
@@ -239,9 +241,26 @@ class DecompScorePosNet3D(nn.Module):
             sub_noise = None
             if noise is not None:
                 sub_noise = {"u_v": noise["u_v"][:, r_l], "u_b": noise["u_b"][:, r_b], "eps": noise["eps"][:, r_l]}
-            r = self.sample_diffusion(num_steps=num_steps, center_pos_mode=center_pos_mode, energy_drift_opt=energy_drift_opt,
-                                      noise=sub_noise, seed=seed + 7919 * gi, keep_traj=keep_traj, use_graph=use_graph,
-                                      _drift_norm_batch=B, **sub)      # (the armsca loss is averaged over the whole batch)
+            if self._is_ragged(sub["batch_protein"], sub["batch_ligand"]):
+                raise AssertionError("group is not dense")
+            chain = self._prepare_chain(
+                sub["protein_pos"], sub["protein_v"], sub["batch_protein"], sub["init_ligand_pos"], sub["init_ligand_v"],
+                sub["ligand_v_aux"], sub["batch_ligand"], sub["prior_stds"], sub["ligand_decomp_batch"],
+                sub["ligand_decomp_index"], None, sub["ligand_fc_bond_index"], sub["init_ligand_fc_bond_type"], num_steps,
+                center_pos_mode, energy_drift_opt, sub.get("full_protein_pos"), sub.get("full_batch_protein"), sub_noise,
+                seed + 7919 * gi, keep_traj, B)                    # (the armsca loss is averaged over the whole batch)
+            prepared.append((chain, d_l, d_b, r_l, r_b))
+        if concurrent is None:
+            # measured on MI355X (tools/ragged_bench.py): with the runtime's default 4 hardware queues the
+            # groups' graphs get in each other's way (0.7x); with GPU_MAX_HW_QUEUES=3 running them together gains 1.4x
+            concurrent = os.environ.get("DD_RAGGED_CONCURRENT", "0") == "1"
+        if concurrent:
+            self._run_chains([p[0] for p in prepared], num_steps, use_graph)
+        else:
+            for p in prepared:
+                self._run_chains([p[0]], num_steps, use_graph)
+        for chain, d_l, d_b, r_l, r_b in prepared:
+            r = self._collect_chain(chain, num_steps, keep_traj)
             out["pos"][d_l], out["v"][d_l], out["bond"][d_b] = r["pos"], r["v"], r["bond"]
             if keep_traj and num_steps > 0:
                 for k, rows, n_tot in (("pos_traj", r_l, n_lig), ("v_traj", r_l, n_lig), ("v0_traj", r_l, n_lig),
@@ -380,6 +399,15 @@ class DecompScorePosNet3D(nn.Module):
             self._stream = st
         return st
 
+    def _stream_pool(self, dev, n):
+        pool = getattr(self, "_streams", None)
+        if pool is None or (pool and pool[0].device != dev):
+            pool = []
+        while len(pool) < n:
+            pool.append(torch.cuda.Stream(device=dev))
+        self._streams = pool
+        return pool[:n]
+
     def _global_offsets(self, pw):
         n = int(self.config.num_layers) * len(packing.LAYER_SLOTS)
         return {k: int(pw["offsets"][n + i]) for i, k in enumerate(packing.GLOBAL_SLOTS)}
@@ -451,6 +479,21 @@ class DecompScorePosNet3D(nn.Module):
                      init_ligand_fc_bond_type=init_ligand_fc_bond_type, batch_ligand_bond=batch_ligand_bond,
                      full_protein_pos=full_protein_pos, full_batch_protein=full_batch_protein),
                 ligand_atom_mask, num_steps, center_pos_mode, energy_drift_opt, noise, seed, keep_traj, use_graph)
+        chain = self._prepare_chain(protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, ligand_v_aux,
+                                    batch_ligand, prior_stds, ligand_decomp_batch, ligand_decomp_index, ligand_atom_mask,
+                                    ligand_fc_bond_index, init_ligand_fc_bond_type, num_steps, center_pos_mode,
+                                    energy_drift_opt, full_protein_pos, full_batch_protein, noise, seed, keep_traj,
+                                    _drift_norm_batch)
+        self._run_chains([chain], num_steps, use_graph)
+        out = self._collect_chain(chain, num_steps, keep_traj)
+        self._last = (chain["s"], chain["bufs"])
+        return out
+
+    def _prepare_chain(self, protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, ligand_v_aux,
+                       batch_ligand, prior_stds, ligand_decomp_batch, ligand_decomp_index, ligand_atom_mask,
+                       ligand_fc_bond_index, init_ligand_fc_bond_type, num_steps, center_pos_mode, energy_drift_opt,
+                       full_protein_pos, full_batch_protein, noise, seed, keep_traj, drift_norm_batch):
+        """Validate one dense batch, centre it, allocate its state / workspace and fill the ``dd_sampler`` struct."""
         d = self._dense_inputs(protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, ligand_v_aux,
                                batch_ligand, ligand_fc_bond_index, init_ligand_fc_bond_type, ligand_atom_mask)
         dev = d["protein_pos"].device
@@ -480,16 +523,42 @@ class DecompScorePosNet3D(nn.Module):
             raise ValueError("num_steps exceeds num_timesteps")
         pw = self._packed_weights()
         s, bufs, _ = self._make_sampler(d, pw, num_steps, t_start, noise, keep_traj, energy_drift_opt, atom_std,
-                                        offset.contiguous(), decomp, fpp, seed, _drift_norm_batch)
+                                        offset.contiguous(), decomp, fpp, seed, drift_norm_batch)
+        return dict(s=s, bufs=bufs, offset=offset, B=B, NL=NL, dev=dev)
+
+    def _run_chains(self, chains, num_steps, use_graph):
+        """Advance every prepared chain by ``num_steps``.  One chain: the captured step graph replayed on a dedicated
+        stream (the legacy default stream cannot be captured).  Several chains (the equal-size groups of a ragged batch):
+        one graph and one stream each, replayed round-robin so the groups overlap on the GPU."""
         lib = hip_lib.load()
-        fn = lib.dd_sample_steps_graph if use_graph else lib.dd_sample_steps
-        # the loop runs on a dedicated HIP stream (the legacy default stream cannot be captured into a hipGraph)
-        side = self._side_stream(dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            hip_lib.check(fn(ctypes.byref(s), int(num_steps), hip_lib.stream_ptr(dev)),
-                          "dd_sample_steps_graph" if use_graph else "dd_sample_steps")
-        torch.cuda.current_stream(dev).wait_stream(side)
+        dev = chains[0]["dev"]
+        cur = torch.cuda.current_stream(dev)
+        if len(chains) == 1 or not use_graph:
+            fn = lib.dd_sample_steps_graph if use_graph else lib.dd_sample_steps
+            side = self._side_stream(dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for c in chains:
+                    hip_lib.check(fn(ctypes.byref(c["s"]), int(num_steps), hip_lib.stream_ptr(dev)),
+                                  "dd_sample_steps_graph" if use_graph else "dd_sample_steps")
+            cur.wait_stream(side)
+            return
+        if len(chains) > 64:                            # dd_sample_steps_graph_multi takes at most 64 chains
+            self._run_chains(chains[:64], num_steps, use_graph)
+            self._run_chains(chains[64:], num_steps, use_graph)
+            return
+        pool = self._stream_pool(dev, len(chains))
+        for st in pool:
+            st.wait_stream(cur)
+        n = len(chains)
+        ss = (ctypes.POINTER(hip_lib.DDSampler) * n)(*[ctypes.pointer(c["s"]) for c in chains])
+        sts = (ctypes.c_void_p * n)(*[st.cuda_stream for st in pool])
+        hip_lib.check(lib.dd_sample_steps_graph_multi(ss, n, int(num_steps), sts), "dd_sample_steps_graph_multi")
+        for st in pool:
+            cur.wait_stream(st)
+
+    def _collect_chain(self, chain, num_steps, keep_traj):
+        bufs, B, NL, offset = chain["bufs"], chain["B"], chain["NL"], chain["offset"]
         ligand_pos = bufs["lig_pos"].view(B, NL, 3) + offset[:, None, :]
         out = {
             "pos": ligand_pos.reshape(B * NL, 3),
@@ -507,5 +576,4 @@ class DecompScorePosNet3D(nn.Module):
         else:
             for k in ("pos_traj", "v_traj", "bond_traj", "v0_traj", "vt_traj", "bt_traj"):
                 out[k] = []
-        self._last = (s, bufs)
         return out

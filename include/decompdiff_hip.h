@@ -160,6 +160,14 @@ int dd_sample_steps(const dd_sampler* s, int n_steps, void* stream);
 /* Same loop with one step captured into a hipGraph and replayed n_steps times. */
 int dd_sample_steps_graph(const dd_sampler* s, int n_steps, void* stream);
 
+/* n independent chains advanced together: chain i's step graph is captured on streams[i] (HOST array of n distinct,
+ * non-default streams) and the n graphs are replayed round-robin, so chains with different sizes (the sub-batches of
+ * a heterogeneous PyG batch: sample_diffusion_decomp.py:300-326 collates samples with different ligand sizes when
+ * num_atoms_mode is 'prior' / 'old' / 'stat') share the GPU instead of running back to back.  Every chain needs its
+ * own workspace and state buffers.  Waits for all streams before returning. */
+int dd_sample_steps_graph_multi(const dd_sampler* const* s /*HOST [n]*/, int n, int n_steps,
+                                void* const* streams /*HOST [n]*/);
+
 /* Drift guidance gradients at x_t (utils/guidance_funcs.py:24-78), analytic. grad [B,NL,3]. */
 int dd_drift_armsca(const float* lig_pos, const int32_t* decomp_index, int B, int NL, float min_d, float max_d,
                     float* grad, int accumulate, void* stream);

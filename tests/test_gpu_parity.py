@@ -495,6 +495,24 @@ def test_ragged_batch_golden():
     assert np.array_equal(r["v"].cpu().numpy(), g["out_v"]) and np.array_equal(r["bond"].cpu().numpy(), g["out_bond"])
 
 
+def test_ragged_groups_together_equals_one_by_one(monkeypatch):
+    """DD_RAGGED_CONCURRENT=1 advances the groups of a ragged batch together (dd_sample_steps_graph_multi: one graph,
+    one stream and one launching thread per group); every group keeps its own state and workspace, so the result must
+    be bit-identical to running the groups one after the other (device Philox noise)."""
+    g = GU.load("traj10_ragged")
+    b = GU.batch_from_npz(g)
+    m = model(0)
+    drift = json.loads(str(g["drift"]))
+    outs = []
+    for conc in ("0", "1"):
+        monkeypatch.setenv("DD_RAGGED_CONCURRENT", conc)
+        outs.append(_sample_hip(m, b, 25, drift, None))
+    for k in ("pos", "v", "bond"):
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    for k in ("pos_traj", "v_traj", "bond_traj", "v0_traj", "vt_traj", "bt_traj"):
+        assert torch.equal(torch.stack(outs[0][k]), torch.stack(outs[1][k])), k
+
+
 def test_unsupported_inputs_fail_loudly():
     g = GU.load("forward_small")
     b = GU.batch_from_npz(g)
