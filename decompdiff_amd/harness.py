@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 from . import synth
+from .pocket_data import PocketData, build_batch
 
 
 def unbatch_traj(traj: List[torch.Tensor], n_data: int, cum: np.ndarray, dtype=None) -> List[np.ndarray]:
@@ -36,11 +37,17 @@ def unbatch_traj(traj: List[torch.Tensor], n_data: int, cum: np.ndarray, dtype=N
 
 
 @torch.no_grad()
-def sample_diffusion_ligand_decomp(model, pocket: synth.Pocket, num_samples: int, batch_size: int = 16,
+def sample_diffusion_ligand_decomp(model, pocket, num_samples: int, batch_size: int = 16,
                                    device="cuda:0", num_steps: Optional[int] = None, center_pos_mode: str = "protein",
                                    energy_drift_opt=None, per_sample_std_scale=None, noise_fn=None, seed: int = 0,
-                                   use_graph: bool = True) -> Dict[str, list]:
+                                   use_graph: bool = True, prior_mode: str = "ref_prior", num_atoms_mode: str = "ref",
+                                   arms_natoms_config=None, scaffold_natoms_config=None, natoms_sampler=None,
+                                   atom_prior_probs=None, bond_prior_probs=None) -> Dict[str, list]:
     """Sample ``num_samples`` ligands for one pocket in batches of ``batch_size``.
+
+    ``pocket`` is a :class:`synth.Pocket` (synthetic, ``ref_prior``-style batches with equal sizes) or a
+    :class:`pocket_data.PocketData` (the reference's ``data`` fields; every ``prior_mode`` / ``num_atoms_mode`` of
+    scripts/sample_diffusion_decomp.py:78-298, including the modes whose samples differ in size).
 
     ``noise_fn(batch_index, n_ligand_atoms, n_bonds, num_steps)`` may return pre-drawn reference-order noise for
     a batch (parity mode); otherwise the device Philox generator is used with ``seed + batch_index``.
@@ -49,24 +56,31 @@ def sample_diffusion_ligand_decomp(model, pocket: synth.Pocket, num_samples: int
                            "pred_bond_index", "pred_bond_type", "pred_b_traj", "pred_bt_traj", "decomp_mask")}
     time_list = []
     num_batch = int(np.ceil(num_samples / batch_size))
-    NL = pocket.num_ligand_atoms
-    Eb = NL * (NL - 1)
     for i in range(num_batch):
         n_data = batch_size if i < num_batch - 1 else num_samples - batch_size * (num_batch - 1)
-        scale = None
-        if per_sample_std_scale is not None:
-            scale = list(per_sample_std_scale[i * batch_size: i * batch_size + n_data])
-        batch = synth.build_sampling_batch(pocket, n_data, num_bond_classes=model.num_bond_classes,
-                                           num_classes=model.num_classes, per_sample_std_scale=scale)
+        if isinstance(pocket, PocketData):
+            batch, n_atoms, _ = build_batch(pocket, n_data, prior_mode=prior_mode, num_atoms_mode=num_atoms_mode,
+                                            num_classes=model.num_classes, num_bond_classes=model.num_bond_classes,
+                                            arms_natoms_config=arms_natoms_config,
+                                            scaffold_natoms_config=scaffold_natoms_config, natoms_sampler=natoms_sampler,
+                                            atom_prior_probs=atom_prior_probs, bond_prior_probs=bond_prior_probs)
+        else:
+            scale = None
+            if per_sample_std_scale is not None:
+                scale = list(per_sample_std_scale[i * batch_size: i * batch_size + n_data])
+            batch = synth.build_sampling_batch(pocket, n_data, num_bond_classes=model.num_bond_classes,
+                                               num_classes=model.num_classes, per_sample_std_scale=scale)
+            n_atoms = [pocket.num_ligand_atoms] * n_data
+        n_bonds = [n * (n - 1) for n in n_atoms]
         steps = model.num_timesteps if num_steps is None else num_steps
-        noise = noise_fn(i, n_data * NL, n_data * Eb, steps) if noise_fn is not None else None
+        noise = noise_fn(i, sum(n_atoms), sum(n_bonds), steps) if noise_fn is not None else None
         dev_batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        extra = dict(noise=noise, seed=seed + i, use_graph=use_graph) if _accepts_extras(model) else {}
         t1 = time.time()
         r = model.sample_diffusion(num_steps=num_steps, center_pos_mode=center_pos_mode,
-                                   energy_drift_opt=energy_drift_opt, noise=noise, seed=seed + i,
-                                   use_graph=use_graph, **dev_batch)
-        cum_atoms = np.arange(n_data + 1) * NL
-        cum_bonds = np.arange(n_data + 1) * Eb
+                                   energy_drift_opt=energy_drift_opt, **extra, **dev_batch)
+        cum_atoms = np.cumsum([0] + n_atoms)                                   # (:367)
+        cum_bonds = np.cumsum([0] + n_bonds)                                   # (:390-393)
         pos = r["pos"].cpu().numpy().astype(np.float64)
         v = r["v"].cpu().numpy()
         bond = r["bond"].cpu().numpy()
@@ -94,6 +108,15 @@ def sample_diffusion_ligand_decomp(model, pocket: synth.Pocket, num_samples: int
         time_list.append(time.time() - t1)
     out["time_list"] = time_list
     return out
+
+
+def _accepts_extras(model) -> bool:
+    """The HIP model takes ``noise / seed / use_graph``; a model with the bare reference signature does not."""
+    import inspect
+    try:
+        return "use_graph" in inspect.signature(model.sample_diffusion).parameters
+    except (TypeError, ValueError):
+        return False
 
 
 def to_result_records(out: Dict[str, list], ligand_filename: Optional[str] = None, reconstruct=None) -> List[dict]:

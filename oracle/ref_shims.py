@@ -97,12 +97,112 @@ class EasyDict(dict):
         self[k] = v
 
 
-class _Data:  # placeholder so `class ProteinLigandData(Data)` can be defined at import
-    def __init__(self, *a, **k):
-        pass
+class _Data:
+    """Minimal ``torch_geometric.data.Data``: an attribute/key store with PyG's documented collate hooks
+    (``__inc__``: ``'batch' in key`` -> max+1, ``'index' in key`` -> num_nodes, else 0; ``__cat_dim__``: -1 for
+    ``'index'`` keys, else 0).  The reference's ``ProteinLigandData`` (utils/data.py:343-446) subclasses it and
+    overrides ``__inc__`` for its own keys — those overrides are what the harness fixtures pin."""
+
+    def __init__(self, *a, **kw):
+        object.__setattr__(self, "_store", {})
+        for k, v in kw.items():
+            self._store[k] = v
+
+    def __getattr__(self, k):
+        try:
+            return object.__getattribute__(self, "_store")[k]
+        except KeyError:
+            raise AttributeError(k) from None
+
+    def __setattr__(self, k, v):
+        self._store[k] = v
+
+    def __getitem__(self, k):
+        return self._store[k]
+
+    def __setitem__(self, k, v):
+        self._store[k] = v
+
+    def __contains__(self, k):
+        return k in self._store
+
+    def keys(self):
+        return list(self._store.keys())
+
+    @property
+    def num_nodes(self):
+        return None
+
+    def clone(self):
+        import copy
+        out = self.__class__()
+        for k, v in self._store.items():
+            out._store[k] = v.clone() if torch.is_tensor(v) else copy.deepcopy(v)
+        return out
+
+    def to(self, device):
+        for k, v in list(self._store.items()):
+            if torch.is_tensor(v):
+                self._store[k] = v.to(device)
+        return self
 
     def __inc__(self, key, value, *a, **k):
+        if "batch" in key and torch.is_tensor(value):
+            return int(value.max()) + 1
+        if "index" in key or key == "face":
+            return self.num_nodes
         return 0
+
+    def __cat_dim__(self, key, value, *a, **k):
+        return -1 if ("index" in key or key == "face") else 0
+
+
+class _Batch(_Data):
+    """``Batch.from_data_list`` (documented PyG collate): tensors are concatenated along ``__cat_dim__`` after adding
+    the running sum of the items' ``__inc__``; python numbers become a tensor, everything else a list; each
+    ``follow_batch`` key gets a ``<key>_batch`` assignment vector."""
+
+    @classmethod
+    def from_data_list(cls, data_list, follow_batch=None, exclude_keys=None):
+        out = cls()
+        exclude = set(exclude_keys or [])
+        for key in data_list[0].keys():
+            if key in exclude:
+                continue
+            vals = [d[key] for d in data_list]
+            v0 = vals[0]
+            if torch.is_tensor(v0):
+                cat_dim = data_list[0].__cat_dim__(key, v0)
+                inc_total, pieces, sizes = 0, [], []
+                for d, v in zip(data_list, vals):
+                    if v.dim() == 0:
+                        v = v.unsqueeze(0)
+                    if not (isinstance(inc_total, int) and inc_total == 0):
+                        v = v + inc_total
+                    pieces.append(v)
+                    sizes.append(v.size(cat_dim))
+                    inc = d.__inc__(key, d[key])
+                    if torch.is_tensor(inc):
+                        inc = int(inc)
+                    inc_total = inc_total + (inc or 0)
+                out[key] = torch.cat(pieces, dim=cat_dim)
+                if follow_batch and key in follow_batch:
+                    out[key + "_batch"] = torch.repeat_interleave(torch.arange(len(vals)), torch.tensor(sizes))
+            elif isinstance(v0, (int, float)) and not isinstance(v0, bool):
+                out[key] = torch.tensor(vals)
+            else:
+                out[key] = vals
+        return out
+
+
+class _Compose:
+    def __init__(self, transforms):
+        self.transforms = list(transforms)
+
+    def __call__(self, data):
+        for t in self.transforms:
+            data = t(data)
+        return data
 
 
 def _module(name, **attrs):
@@ -125,9 +225,9 @@ def install():
     tg = _module("torch_geometric")
     tg.nn = _module("torch_geometric.nn", knn_graph=ops.knn_graph, radius_graph=_not_available,
                     radius=_not_available, knn=_not_available)
-    tg.data = _module("torch_geometric.data", Data=_Data, Batch=_Data)
+    tg.data = _module("torch_geometric.data", Data=_Data, Batch=_Batch)
     tg.loader = _module("torch_geometric.loader", DataLoader=_Data)
-    tg.transforms = _module("torch_geometric.transforms", Compose=_Data)
+    tg.transforms = _module("torch_geometric.transforms", Compose=_Compose)
     _module("torch_sparse", SparseTensor=SparseTensor)
     _module("easydict", EasyDict=EasyDict)
     for name in ["rdkit", "rdkit.Chem", "rdkit.Chem.rdchem", "rdkit.Chem.AllChem", "rdkit.Chem.Lipinski",

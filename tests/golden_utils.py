@@ -44,3 +44,89 @@ def noise_for(seed, pocket_builder, n_data, num_steps, std_scale=None):
 def checksum(noise):
     return np.array([float(noise["u_v"].double().sum()), float(noise["u_b"].double().sum()),
                      float(noise["eps"].double().sum())])
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# harness fixtures (tests/golden/harness_*.npz): shared by oracle/make_harness_golden.py (which runs the reference's
+# own harness around RecordingModel) and tests/test_harness_golden.py (which runs ours around the same model)
+# ----------------------------------------------------------------------------------------------------------------
+class RecordingModel:
+    """Stands in for DecompScorePosNet3D inside the sampling harness: records the keyword arguments and returns a
+    deterministic function of the initial state with the shapes of the real result (2 'steps')."""
+    num_bond_classes = 5
+    num_classes = 8
+    bond_diffusion = True
+    num_timesteps = 1000
+
+    def __init__(self):
+        self.calls = []
+
+    def sample_diffusion(self, **kw):
+        self.calls.append({k: (v.detach().clone().cpu() if torch.is_tensor(v) else v) for k, v in kw.items()})
+        pos0, v0, b0 = kw["init_ligand_pos"].cpu(), kw["init_ligand_v"].cpu(), kw["init_ligand_fc_bond_type"].cpu()
+        T = 2
+        one_hot = lambda t, k: torch.nn.functional.one_hot(t, k).float()
+        r = {"pos": pos0 * 0.5 + 1.0, "v": (v0 + 1) % 8, "bond": (b0 + 2) % 5,
+             "pos_traj": [pos0 * (0.25 * (i + 1)) for i in range(T)], "v_traj": [(v0 + i) % 8 for i in range(T)],
+             "v0_traj": [one_hot((v0 + i) % 8, 8) * 0.5 for i in range(T)],
+             "vt_traj": [one_hot((v0 + 2 * i) % 8, 8) * 0.25 for i in range(T)],
+             "bond_traj": [(b0 + i) % 5 for i in range(T)], "bt_traj": [one_hot((b0 + i) % 5, 5) * 0.75 for i in range(T)]}
+        return r
+
+
+class LinearCountModel:
+    """A scikit-learn style regressor for the ``stat`` atom-count mode: predict(x) = w * x.sum(1) + b."""
+
+    def __init__(self, w, b):
+        self.w, self.b = float(w), float(b)
+
+    def predict(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        return self.w * x.reshape(len(x), -1).sum(1) + self.b
+
+
+STAT_MODELS = {"arm_model": (0.002, 3.0), "armstd_model": (0.1, 0.5), "sca_model": (0.001, 4.0), "scastd_model": (0.08, 0.6)}
+# layout of the reference's arm/scaffold_num_config.pkl (synthetic content): 9 bounds, 10 (counts, probabilities) bins
+NUM_CONFIG = {"bounds": [float(b) for b in np.linspace(12.0, 20.0, 9)],
+              "bins": [(tuple(range(2 + i, 6 + i)), (0.1, 0.4, 0.3, 0.2)) for i in range(10)]}
+
+
+def harness_cases():
+    base = dict(num_samples=5, batch_size=3, seed=7, pocket_seed=3)
+    return [dict(base, name="ref_prior", prior_mode="ref_prior", num_atoms_mode="ref"),
+            dict(base, name="beta_v2", prior_mode="beta_prior", num_atoms_mode="v2"),
+            dict(base, name="beta_v2_noscaffold", prior_mode="beta_prior", num_atoms_mode="v2", with_scaffold=False),
+            dict(base, name="beta_old", prior_mode="beta_prior", num_atoms_mode="old"),
+            # (the reference's `stat` sampler only broadcasts for 3 arms: utils/prior.py:188 zips [1,A] distances with [A,3] stds)
+            dict(base, name="beta_stat", prior_mode="beta_prior", num_atoms_mode="stat", stat_models=STAT_MODELS, num_arms=3),
+            dict(base, name="subpocket_ref", prior_mode="subpocket", num_atoms_mode="ref"),
+            dict(base, name="subpocket_ref_large", prior_mode="subpocket", num_atoms_mode="ref_large"),
+            dict(base, name="subpocket_prior", prior_mode="subpocket", num_atoms_mode="prior")]
+
+
+def make_pocket_fields(seed, beta=False, with_scaffold=True, num_arms=2):
+    """A small synthetic pocket `data` item (60 protein atoms, 2 arms [+ scaffold]) with the fields the reference's
+    harness and transforms read."""
+    rng = np.random.default_rng([seed, 991])
+    NP, NF = 60, 90
+    pos = rng.normal(size=(NP, 3)); pos = pos / np.linalg.norm(pos, axis=1, keepdims=True) * rng.uniform(4, 10, (NP, 1))
+    pos = np.round(pos, 3).astype(np.float32)
+    A = num_arms
+    centers = np.array([[3.0, 0.5, 0.0], [-2.5, 1.0, 1.5], [0.5, 3.0, -2.0]][:A] + [[0.0, -1.0, -0.5]], dtype=np.float32)
+    sizes = [3, 1, 2][:A] + [5 if with_scaffold else 0]
+    mask = np.concatenate([np.full(n, a) for a, n in zip(list(range(A)) + [-1], sizes)]).astype(np.int64)
+    lig = np.concatenate([centers[i] + 0.8 * rng.normal(size=(n, 3)) for i, n in enumerate(sizes)]).astype(np.float32)
+    stds = [0.9, 0.7, 0.8][:A] + [1.3]
+    t = torch.from_numpy
+    arms_prior = [(sizes[a], t(centers[a]), torch.eye(3) * stds[a] ** 2) for a in range(A)]
+    scaffold_prior = []
+    if with_scaffold:
+        cov = torch.tensor(stds[A] ** 2) if beta else torch.eye(3) * stds[A] ** 2
+        scaffold_prior = [(sizes[A], t(centers[A]), cov)]
+    masks = np.stack([np.linalg.norm(pos - centers[a], axis=1) < 7.0 for a in range(A)])
+    full = np.round(rng.normal(size=(NF, 3)) * 8, 3).astype(np.float32)
+    return dict(protein_pos=t(pos), protein_element=t(rng.choice([1, 6, 7, 8, 16, 34], NP, p=[.0, .63, .17, .18, .01, .01]).astype(np.int64)),
+                protein_is_backbone=t(rng.random(NP) < 0.5), protein_atom_to_aa_type=t(rng.integers(0, 20, NP).astype(np.int64)),
+                pocket_atom_masks=t(masks), ligand_atom_mask=t(mask), ligand_pos=t(lig), num_arms=A,
+                num_scaffold=1 if with_scaffold else 0, arms_prior=arms_prior, scaffold_prior=scaffold_prior,
+                full_protein_pos=t(full))

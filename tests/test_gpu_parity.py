@@ -495,6 +495,38 @@ def test_ragged_batch_golden():
     assert np.array_equal(r["v"].cpu().numpy(), g["out_v"]) and np.array_equal(r["bond"].cpu().numpy(), g["out_bond"])
 
 
+def test_harness_ragged_mode_vs_oracle():
+    """End to end through the PyG-free harness in a mode whose samples differ in size (beta_prior / 'old':
+    sample_diffusion_decomp.py:233-260): the batch built by pocket_data.build_batch (pinned against the reference's
+    harness in tests/test_harness_golden.py) is sampled by the HIP path and by the oracle on the same injected noise."""
+    from decompdiff_amd import harness
+    from decompdiff_amd.pocket_data import PocketData, build_batch
+    cfg, sd = GU.weights(0)
+    f = GU.make_pocket_fields(5, beta=True)
+    pocket = PocketData(**{k: f[k] for k in ("protein_pos", "protein_element", "protein_is_backbone", "protein_atom_to_aa_type",
+                                             "pocket_atom_masks", "num_arms", "num_scaffold", "arms_prior", "scaffold_prior",
+                                             "ligand_atom_mask", "ligand_pos", "full_protein_pos")})
+    steps, drift = 3, GU.DRIFT
+    torch.manual_seed(21)
+    kw, n_atoms, _ = build_batch(pocket, 3, prior_mode="beta_prior", num_atoms_mode="old")
+    assert len(set(n_atoms)) > 1
+    noise = synth.draw_step_noise(steps, sum(n_atoms), sum(n * (n - 1) for n in n_atoms))
+    want = OD.sample_diffusion(sd, cfg, num_steps=steps, energy_drift_opt=drift, noise=noise, **kw)
+    torch.manual_seed(21)
+    out = harness.sample_diffusion_ligand_decomp(model(0), pocket, num_samples=3, batch_size=3, device="cuda:0", num_steps=steps,
+                                                 energy_drift_opt=drift, prior_mode="beta_prior", num_atoms_mode="old",
+                                                 noise_fn=lambda i, na, nb, st: noise)
+    cum = np.cumsum([0] + n_atoms)
+    err = max(np.abs(out["pred_pos"][k] - want["pos"][cum[k]:cum[k + 1]].double().numpy()).max() for k in range(3))
+    print(f"ragged harness mode: ligand sizes {n_atoms}, pos err {err:.3g}")
+    assert err < POS_TOL
+    for k in range(3):
+        assert np.array_equal(out["pred_v"][k], want["v"][cum[k]:cum[k + 1]].numpy())
+        assert out["pred_pos_traj"][k].shape == (steps, n_atoms[k], 3)
+    recs = harness.to_result_records(out, ligand_filename="x.sdf")
+    assert len(recs) == 3 and recs[1]["pred_bond_type"].shape == (n_atoms[1] * (n_atoms[1] - 1),)
+
+
 def test_ragged_groups_together_equals_one_by_one(monkeypatch):
     """DD_RAGGED_CONCURRENT=1 advances the groups of a ragged batch together (dd_sample_steps_graph_multi: one graph,
     one stream and one launching thread per group); every group keeps its own state and workspace, so the result must
