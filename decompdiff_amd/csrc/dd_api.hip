@@ -686,6 +686,53 @@ extern "C" int dd_sample_steps_graph(const dd_sampler* s, int n_steps, void* str
   return rc;
 }
 
+namespace { struct StepGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; }; }
+
+extern "C" int dd_graph_create(const dd_sampler* s, int steps_per_graph, void* stream, void** graph_out) {
+  if (!s || !graph_out || steps_per_graph < 1 || steps_per_graph > 64 || !s->step_counter || !s->tab_pos || !s->tab_v ||
+      !s->tab_b || !s->atom_std || !s->offset || !s->pred_pos)
+    return DD_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (st == nullptr) return DD_ERR_BAD_ARG;      // the legacy default stream cannot be captured
+  int rc = dd::check_shapes(s);
+  if (rc != DD_OK) return rc;
+  StepGraph* g = new StepGraph();
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    delete g;
+    return DD_ERR_HIP;
+  }
+  for (int i = 0; i < steps_per_graph && rc == DD_OK; ++i) rc = one_step(s, st);
+  hipError_t e = hipStreamEndCapture(st, &g->graph);
+  if (rc == DD_OK && (e != hipSuccess || !g->graph)) rc = DD_ERR_HIP;
+  if (rc == DD_OK && hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0) != hipSuccess) rc = DD_ERR_HIP;
+  if (rc != DD_OK) {
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    (void)hipGetLastError();
+    delete g;
+    return rc;
+  }
+  *graph_out = g;
+  return DD_OK;
+}
+
+extern "C" int dd_graph_launch(void* graph, int n_graphs, void* stream) {
+  StepGraph* g = (StepGraph*)graph;
+  if (!g || !g->exec || n_graphs < 0 || !stream) return DD_ERR_BAD_ARG;
+  for (int i = 0; i < n_graphs; ++i)
+    if (hipGraphLaunch(g->exec, (hipStream_t)stream) != hipSuccess) { (void)hipGetLastError(); return DD_ERR_HIP; }
+  return DD_OK;
+}
+
+extern "C" int dd_graph_destroy(void* graph) {
+  StepGraph* g = (StepGraph*)graph;
+  if (!g) return DD_ERR_BAD_ARG;
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
+  delete g;
+  return DD_OK;
+}
+
 extern "C" int dd_sample_steps_graph_multi(const dd_sampler* const* ss, int n, int n_steps, void* const* streams) {
   if (!ss || !streams || n <= 0 || n > 64 || n_steps < 0) return DD_ERR_BAD_ARG;
   for (int i = 0; i < n; ++i) {

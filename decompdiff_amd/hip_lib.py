@@ -20,6 +20,7 @@ LIB_PATH = os.environ.get("DD_HIP_LIB") or os.path.join(_HERE, "lib", "libdecomp
 EXPORTED_SYMBOLS = [
     "dd_status_string", "dd_abi_version", "dd_workspace_floats", "dd_knn", "dd_edge_weights", "dd_gemm128",
     "dd_embed_protein", "dd_forward", "dd_sample_steps", "dd_sample_steps_graph", "dd_sample_steps_graph_multi",
+    "dd_graph_create", "dd_graph_launch", "dd_graph_destroy",
     "dd_drift_armsca",
     "dd_drift_clash", "dd_workspace_view", "dd_profile_step", "dd_debug_set_clock_buffer", "dd_debug_set_fusion", "dd_debug_set_option",
 ]
@@ -92,6 +93,9 @@ def load():
     lib.dd_forward.argtypes = [POINTER(DDSampler), c_void_p]
     lib.dd_sample_steps.argtypes = [POINTER(DDSampler), c_int, c_void_p]
     lib.dd_sample_steps_graph.argtypes = [POINTER(DDSampler), c_int, c_void_p]
+    lib.dd_graph_create.argtypes = [POINTER(DDSampler), c_int, c_void_p, POINTER(c_void_p)]
+    lib.dd_graph_launch.argtypes = [c_void_p, c_int, c_void_p]
+    lib.dd_graph_destroy.argtypes = [c_void_p]
     lib.dd_sample_steps_graph_multi.argtypes = [POINTER(POINTER(DDSampler)), c_int, c_int, POINTER(c_void_p)]
     lib.dd_drift_armsca.argtypes = [c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_int, c_void_p]
     lib.dd_drift_clash.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p,

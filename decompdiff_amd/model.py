@@ -533,6 +533,9 @@ class DecompScorePosNet3D(nn.Module):
         lib = hip_lib.load()
         dev = chains[0]["dev"]
         cur = torch.cuda.current_stream(dev)
+        if (len(chains) == 1 and use_graph and num_steps > 0 and "traj_pos" in chains[0]["bufs"]
+                and os.environ.get("DD_TRAJ_STREAMING", "1") != "0"):
+            return self._run_chain_streaming(chains[0], num_steps)
         if len(chains) == 1 or not use_graph:
             fn = lib.dd_sample_steps_graph if use_graph else lib.dd_sample_steps
             side = self._side_stream(dev)
@@ -557,6 +560,86 @@ class DecompScorePosNet3D(nn.Module):
         for st in pool:
             cur.wait_stream(st)
 
+    _TRAJ_KEYS = ("traj_pos", "traj_v", "traj_bond", "traj_v0", "traj_vt", "traj_bt")
+
+    def _run_chain_streaming(self, chain, num_steps):
+        """One chain, trajectories kept: the step graph is replayed in chunks and every finished chunk of the six
+        trajectory buffers is drained to the host (device -> pinned staging on a copy stream -> the result tensors,
+        with the int32 -> int64 widening in that last host copy) while the GPU is already working on the next chunk,
+        instead of one big blocking copy after the loop (scripts/sample_diffusion_decomp.py:361-364 reads them on the CPU).
+        The host copies are numpy, i.e. single-threaded, on purpose: a torch CPU op spins up every core of the box and
+        the HIP runtime's own threads then fall behind — measured 2.4 ms/step instead of 1.38 with 16-step chunks."""
+        lib = hip_lib.load()
+        dev, bufs, s = chain["dev"], chain["bufs"], chain["s"]
+        cur = torch.cuda.current_stream(dev)
+        side = self._side_stream(dev)
+        copy_st = getattr(self, "_copy_stream", None)
+        if copy_st is None or copy_st.device != dev:
+            copy_st = self._copy_stream = torch.cuda.Stream(device=dev)
+        keys = self._TRAJ_KEYS
+        per_step = sum(bufs[k][0].numel() * bufs[k].element_size() for k in keys)
+        # ~24 MB per chunk: the last chunk is the only one whose drain is not hidden (a few ms)
+        chunk = int(os.environ.get("DD_TRAJ_CHUNK", "0")) or max(8, min(128, (24 << 20) // max(per_step, 1)))
+        sig = (str(dev), chunk, tuple((k, tuple(bufs[k].shape[1:]), bufs[k].dtype) for k in keys))
+        cache = getattr(self, "_staging", None)
+        if cache is None or cache[0] != sig:
+            slots = [{k: torch.empty((chunk,) + tuple(bufs[k].shape[1:]), dtype=bufs[k].dtype).pin_memory() for k in keys}
+                     for _ in range(2)]
+            cache = self._staging = (sig, slots)
+        slots = cache[1]
+        widen = {"traj_v": torch.int64, "traj_bond": torch.int64}
+        final = {k: torch.empty(tuple(bufs[k].shape), dtype=widen.get(k, bufs[k].dtype)) for k in keys}
+        side.wait_stream(cur)
+        graph = ctypes.c_void_p()
+        hip_lib.check(lib.dd_graph_create(ctypes.byref(s), 1, side.cuda_stream, ctypes.byref(graph)), "dd_graph_create")
+
+        dbg = int(os.environ.get("DD_TRAJ_DEBUG", "0"))
+        final_np = {k: v.numpy() for k, v in final.items()}
+        slots_np = [{k: v.numpy() for k, v in sl.items()} for sl in slots]
+
+        def drain(item):
+            lo, hi, slot, done = item
+            if not dbg & 8:
+                done.synchronize()
+            if dbg & 2:
+                return
+            if dbg & 16:
+                for k in keys:
+                    final[k][lo:hi].copy_(slots[slot][k][:hi - lo])
+                return
+            for k in keys:                             # single-threaded on purpose (see the docstring)
+                np.copyto(final_np[k][lo:hi], slots_np[slot][k][:hi - lo], casting="same_kind")
+
+        pending = []
+        try:
+            for c, lo in enumerate(range(0, num_steps, chunk)):
+                hi = min(num_steps, lo + chunk)
+                hip_lib.check(lib.dd_graph_launch(graph, hi - lo, side.cuda_stream), "dd_graph_launch")
+                ev = torch.cuda.Event()
+                ev.record(side)
+                copy_st.wait_event(ev)
+                with torch.cuda.stream(copy_st):
+                    for k in keys:
+                        if not dbg & 1:
+                            slots[c % 2][k][:hi - lo].copy_(bufs[k][lo:hi], non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(copy_st)
+                pending.append((lo, hi, c % 2, done))
+                if c == 0 and not dbg & 4:
+                    tail = ((num_steps - 1) // chunk) * chunk
+                    for k in keys:                     # first touch of the pages the un-hidden last drain writes
+                        final_np[k][tail:].fill(0)
+                if len(pending) == 2:
+                    drain(pending.pop(0))
+            while pending:
+                drain(pending.pop(0))
+        finally:
+            side.synchronize()
+            copy_st.synchronize()
+            lib.dd_graph_destroy(graph)
+        cur.wait_stream(side)
+        chain["traj_cpu"] = final
+
     def _collect_chain(self, chain, num_steps, keep_traj):
         bufs, B, NL, offset = chain["bufs"], chain["B"], chain["NL"], chain["offset"]
         ligand_pos = bufs["lig_pos"].view(B, NL, 3) + offset[:, None, :]
@@ -566,7 +649,7 @@ class DecompScorePosNet3D(nn.Module):
             "bond": bufs["lig_bond"].long(),
         }
         if keep_traj and num_steps > 0:
-            cpu = {k: bufs[k].cpu() for k in ("traj_pos", "traj_v", "traj_bond", "traj_v0", "traj_vt", "traj_bt")}
+            cpu = chain.get("traj_cpu") or {k: bufs[k].cpu() for k in self._TRAJ_KEYS}
             out["pos_traj"] = list(cpu["traj_pos"].unbind(0))
             out["v_traj"] = list(cpu["traj_v"].long().unbind(0))
             out["bond_traj"] = list(cpu["traj_bond"].long().unbind(0))

@@ -160,6 +160,15 @@ int dd_sample_steps(const dd_sampler* s, int n_steps, void* stream);
 /* Same loop with one step captured into a hipGraph and replayed n_steps times. */
 int dd_sample_steps_graph(const dd_sampler* s, int n_steps, void* stream);
 
+/* The same, split so that a host can interleave its own work (e.g. draining trajectory chunks to the host on a copy
+ * stream) with the replays: create captures `steps_per_graph` (>= 1) consecutive steps of chain `s` on `stream` into one
+ * executable graph; launch replays it n_graphs times on `stream` without waiting; destroy waits for nothing — the
+ * caller synchronises the stream first.  The dd_sampler and every buffer it points to must stay alive and unchanged
+ * until the graph is destroyed. */
+int dd_graph_create(const dd_sampler* s, int steps_per_graph, void* stream, void** graph_out /*HOST*/);
+int dd_graph_launch(void* graph, int n_graphs, void* stream);
+int dd_graph_destroy(void* graph);
+
 /* n independent chains advanced together: chain i's step graph is captured on streams[i] (HOST array of n distinct,
  * non-default streams) and the n graphs are replayed round-robin, so chains with different sizes (the sub-batches of
  * a heterogeneous PyG batch: sample_diffusion_decomp.py:300-326 collates samples with different ligand sizes when
