@@ -177,10 +177,11 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{'configs[1]' if args.workload == 'small' else 'C-large (configs[4] size)'}: single pocket ref_prior, {NP} protein + {NL} ligand atoms, batch={args.batch} "
-                                   f"per GPU, {'drift guidance, ' if args.drift else ''}trajectories recorded and copied to host",
+                                   f"per GPU, {'drift guidance, ' if args.drift else ''}trajectories recorded and streamed to the host",
                        "batch_per_gpu": args.batch, "sample_steps_per_s": round(steps_per_s * args.batch, 2),
                        "parallelism": f"{world} independent pocket batches (no data-path collective)",
-                       "launch": "eager" if args.eager else "hipGraph replay", "noise": "device Philox"},
+                       "launch": "eager" if args.eager else "hipGraph replay", "noise": "device Philox",
+                       "node_launch_split_cus": int(lib.dd_debug_node_split(args.batch, NP, NL, min(cfg.knn, NP + NL - 1)))},
             "roofline": roofline, "cpu_baseline": cpu, "per_rank": meta,
         }
         if cpu:

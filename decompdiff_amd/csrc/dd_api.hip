@@ -630,6 +630,63 @@ extern "C" int dd_forward(const dd_sampler* s, void* stream) {
   return DD_OK;
 }
 
+namespace dd {
+extern int g_node_split_trial;
+int node_split_lookup(int B, int NP, int NL, int K);
+void node_split_store(int B, int NP, int NL, int K, int n_bl);
+bool node_split_applies(int B, int NL, int n_cu);
+}
+
+// One-off measurement per (B, NP, NL, K): how many CUs the persistent bond-layer workgroups of the fused node launch
+// keep (see launch_node_nw).  Times whole forward passes on `st` (eager, min of 4) for a coarse and then a fine set of
+// splits; ~60 ms, before the first graph of a shape is captured.  The passes only write the workspace and pred_*.
+static int autotune_node_split(const dd_sampler* s, hipStream_t st) {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return DD_ERR_HIP;
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const bool fused = dd::g_fuse && !dd::g_use_v1 && s->NL <= dd::g_fused_max_nl && dd::g_dbg_clock == nullptr;
+  if (!fused || !dd::node_split_applies(s->B, s->NL, n_cu) || dd::node_split_lookup(s->B, s->NP, s->NL, s->K) >= 0) return DD_OK;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return DD_ERR_HIP;
+  int rc = DD_OK;
+  auto time_split = [&](int n_bl, float& best) {
+    dd::g_node_split_trial = n_bl;
+    best = 1e30f;
+    for (int rep = 0; rep < 5 && rc == DD_OK; ++rep) {
+      if (hipEventRecord(e0, st) != hipSuccess) { rc = DD_ERR_HIP; break; }
+      rc = dd::forward_impl(s, st);
+      if (rc != DD_OK) break;
+      float ms = 0.f;
+      if (hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+          hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = DD_ERR_HIP; break; }
+      if (rep > 0 && ms < best) best = ms;                 // (the first pass of a setting warms caches)
+    }
+  };
+  int best_n = 0;
+  float best_t = 0.f, t = 0.f;
+  time_split(0, best_t);
+  const int lo = n_cu / 4, hi = n_cu - n_cu / 8;
+  for (int n = lo; n <= hi && rc == DD_OK; n += 16) {
+    time_split(n, t);
+    if (t < best_t) { best_t = t; best_n = n; }
+  }
+  if (best_n > 0)
+    for (int n : {best_n - 8, best_n + 8}) {
+      if (rc != DD_OK || n < 16 || n > n_cu - 16) continue;
+      time_split(n, t);
+      if (t < best_t) { best_t = t; best_n = n; }
+    }
+  dd::g_node_split_trial = -1;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc == DD_OK) dd::node_split_store(s->B, s->NP, s->NL, s->K, best_n);
+  return rc;
+}
+
 static int one_step(const dd_sampler* s, hipStream_t st) {
   int rc = dd::forward_impl(s, st);
   if (rc != DD_OK) return rc;
@@ -659,6 +716,8 @@ extern "C" int dd_sample_steps_graph(const dd_sampler* s, int n_steps, void* str
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   if (st == nullptr) return DD_ERR_BAD_ARG;      // the legacy default stream cannot be captured
+  rc = autotune_node_split(s, st);
+  if (rc != DD_OK) return rc;
   if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
     (void)hipGetLastError();                     // do not leave a sticky error behind for the caller
     return DD_ERR_HIP;
@@ -695,6 +754,8 @@ extern "C" int dd_graph_create(const dd_sampler* s, int steps_per_graph, void* s
   hipStream_t st = (hipStream_t)stream;
   if (st == nullptr) return DD_ERR_BAD_ARG;      // the legacy default stream cannot be captured
   int rc = dd::check_shapes(s);
+  if (rc != DD_OK) return rc;
+  rc = autotune_node_split(s, st);
   if (rc != DD_OK) return rc;
   StepGraph* g = new StepGraph();
   if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
@@ -753,6 +814,8 @@ extern "C" int dd_sample_steps_graph_multi(const dd_sampler* const* ss, int n, i
   // is being captured, one chain at a time; the replays below do not touch them
   for (int i = 0; i < n && rc == DD_OK; ++i) {
     hipStream_t st = (hipStream_t)streams[i];
+    rc = autotune_node_split(ss[i], st);
+    if (rc != DD_OK) break;
     if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { rc = DD_ERR_HIP; break; }
     int rs = one_step(ss[i], st);
     hipError_t e = hipStreamEndCapture(st, &graph[i]);
@@ -838,13 +901,16 @@ extern "C" int dd_debug_set_fusion(int mode) {
   return DD_OK;
 }
 
-namespace dd { extern int g_gemm_ksplit; extern int g_attn_waves; extern int g_attn_persist; extern int g_assemble_persist; extern int g_pos_waves; extern int g_gemm_big; extern int g_ew_mfma; }
+namespace dd { extern int g_gemm_ksplit; extern int g_attn_waves; extern int g_attn_persist; extern int g_assemble_persist; extern int g_pos_waves; extern int g_gemm_big; extern int g_ew_mfma; extern int g_bl_first; }
 // Measurement aid: runtime switches for A/B timing inside one process.  key 0: attention launch structure (same
 // values as dd_debug_set_fusion), key 1: K-split projection GEMM tiles (1 = on).
+extern "C" int dd_debug_node_split(int B, int NP, int NL, int K) { return dd::node_split_lookup(B, NP, NL, K); }
+
 extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 0) return dd_debug_set_fusion(value);
   if (key == 1) { dd::g_gemm_ksplit = value ? 1 : 0; return DD_OK; }
   if (key == 3) { dd::g_attn_persist = value ? 1 : 0; return DD_OK; }
+  if (key == 18) { if (value < 0 || value > 1024) return DD_ERR_BAD_ARG; dd::g_bl_first = value; return DD_OK; }
   if (key == 17) { dd::g_pb_early = value ? 1 : 0; return DD_OK; }
   if (key == 16) { dd::g_lin_with_pb2 = value ? 1 : 0; return DD_OK; }
   if (key == 15) { dd::g_ew_mfma = value ? 1 : 0; return DD_OK; }

@@ -19,6 +19,7 @@
 //
 // LDS plans (per mode, struct Lds), persistent bond-layer workgroups, the prefetch pipeline and the launch shapes are
 // described at their definitions below and in DESIGN.md section 5.
+#include <vector>
 #include <type_traits>
 
 #include "dd_kernels.hpp"
@@ -811,10 +812,19 @@ constexpr int imax(int a, int b) { return a > b ? a : b; }
 // within one segment of each other.
 template <int MAXT, int NW>
 __global__ __launch_bounds__(NW * 64) void k_attn2_node(const AttnArgs ne, const AttnArgs nb, const AttnArgs bl, int n_ne, int n_nb,
-                                                        int persist) {
+                                                        int persist, int n_bl_first) {
   constexpr int SZ = imax(imax(Lds<M_NE>::TOTAL, Lds<M_NB>::TOTAL), Lds<M_BL>::TOTAL) + 4;
   __shared__ __attribute__((aligned(16))) float smem[SZ];
-  const int blk = blockIdx.x;
+  int blk = blockIdx.x;
+  // n_bl_first > 0: the persistent bond-layer workgroups come first in dispatch order and keep their CUs for the whole
+  // launch, the node blocks cycle through the remaining CUs -- both parts then end together (see launch_node_nw)
+  if (n_bl_first > 0) {
+    if (blk < n_bl_first) { attn2_body<M_BL, MAXT, NW, true>(bl, blk, smem); return; }
+    blk -= n_bl_first;
+    if (blk < n_ne) attn2_body<M_NE, 2, NW>(ne, blk, smem);
+    else attn2_body<M_NB, MAXT, NW>(nb, blk - n_ne, smem);
+    return;
+  }
   if (blk < n_ne) attn2_body<M_NE, 2, NW>(ne, blk, smem);
   else if (blk < n_ne + n_nb) attn2_body<M_NB, MAXT, NW>(nb, blk - n_ne, smem);
   else if (persist) attn2_body<M_BL, MAXT, NW, true>(bl, blk - n_ne - n_nb, smem);
@@ -864,6 +874,25 @@ static int launch_mode(const AttnArgs& a, int nseg, hipStream_t st) {
 
 int g_attn_waves = 8;        // waves (= segments) per workgroup of the fused node launch
 int g_attn_persist = 1;      // bond_layer workgroups of the fused launch are persistent (global batch counter)
+int g_bl_first = 1;          // bond-layer workgroups first in the node launch: 0 off, 1 measured split per shape, n>1 that many
+int g_node_split_trial = -1; // >= 0 while autotune_node_split is timing a candidate (0 = node blocks first)
+namespace {
+struct NodeSplit { int B, NP, NL, K, n_bl; };
+std::vector<NodeSplit> g_node_splits;
+}
+int node_split_lookup(int B, int NP, int NL, int K) {          // -1: not measured yet, 0: node blocks first, n: n bond-layer WGs first
+  for (const NodeSplit& e : g_node_splits)
+    if (e.B == B && e.NP == NP && e.NL == NL && e.K == K) return e.n_bl;
+  return -1;
+}
+void node_split_store(int B, int NP, int NL, int K, int n_bl) {
+  for (NodeSplit& e : g_node_splits)
+    if (e.B == B && e.NP == NP && e.NL == NL && e.K == K) { e.n_bl = n_bl; return; }
+  g_node_splits.push_back(NodeSplit{B, NP, NL, K, n_bl});
+}
+bool node_split_applies(int B, int NL, int n_cu) {             // the bond layer has at least one trip per CU
+  return g_attn_persist && g_bl_first == 1 && (B * NL * (NL - 1) + 7) / 8 >= n_cu;
+}
 
 int launch_attn2(int mode, const AttnArgs& a, hipStream_t st) {
   using namespace v2;
@@ -898,8 +927,21 @@ static int launch_node_nw(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs
       n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     if (n_bl > n_cu) n_bl = n_cu;                      // one workgroup per CU (LDS-limited)
+    if (g_bl_first > 0 && n_bl == n_cu) {
+      // The bond-layer workgroups first, on a fixed share of the CUs, the node blocks cycling through the rest: both
+      // parts run in whole "rounds" (a node block ~23 us, a bond-layer trip ~17 us at NL = 30), so the best share is a
+      // step function of the shape -- it is measured once per shape (dd_api.hip::autotune_node_split), not modelled.
+      int want = g_bl_first > 1 ? g_bl_first : (g_node_split_trial >= 0 ? g_node_split_trial : node_split_lookup(ne.B, ne.NP, ne.NL, ne.K));
+      if (want > 0) {
+        n_bl = want < 16 ? 16 : (want > n_cu - 16 ? n_cu - 16 : want);
+        hipLaunchKernelGGL((k_attn2_node<MAXT, NW>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, bl, n_ne, n_nb, persist,
+                           n_bl);
+        DD_CHECK_LAUNCH();
+        return DD_OK;
+      }
+    }
   }
-  hipLaunchKernelGGL((k_attn2_node<MAXT, NW>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, bl, n_ne, n_nb, persist);
+  hipLaunchKernelGGL((k_attn2_node<MAXT, NW>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, bl, n_ne, n_nb, persist, 0);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }

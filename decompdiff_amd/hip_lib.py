@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "dd_embed_protein", "dd_forward", "dd_sample_steps", "dd_sample_steps_graph", "dd_sample_steps_graph_multi",
     "dd_graph_create", "dd_graph_launch", "dd_graph_destroy",
     "dd_drift_armsca",
-    "dd_drift_clash", "dd_workspace_view", "dd_profile_step", "dd_debug_set_clock_buffer", "dd_debug_set_fusion", "dd_debug_set_option",
+    "dd_drift_clash", "dd_workspace_view", "dd_profile_step", "dd_debug_set_clock_buffer", "dd_debug_set_fusion", "dd_debug_set_option", "dd_debug_node_split",
 ]
 
 
@@ -104,6 +104,7 @@ def load():
     lib.dd_debug_set_clock_buffer.argtypes = [c_void_p, c_int]
     lib.dd_debug_set_fusion.argtypes = [c_int]
     lib.dd_debug_set_option.argtypes = [c_int, c_int]
+    lib.dd_debug_node_split.argtypes = [c_int, c_int, c_int, c_int]
     lib.dd_profile_step.argtypes = [POINTER(DDSampler), c_int, POINTER(c_float), c_void_p]
     for name in EXPORTED_SYMBOLS:
         if name not in ("dd_status_string", "dd_workspace_floats"):

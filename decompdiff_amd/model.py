@@ -591,7 +591,10 @@ class DecompScorePosNet3D(nn.Module):
         final = {k: torch.empty(tuple(bufs[k].shape), dtype=widen.get(k, bufs[k].dtype)) for k in keys}
         side.wait_stream(cur)
         graph = ctypes.c_void_p()
-        hip_lib.check(lib.dd_graph_create(ctypes.byref(s), 1, side.cuda_stream, ctypes.byref(graph)), "dd_graph_create")
+        spg = int(os.environ.get("DD_STEPS_PER_GRAPH", "1"))
+        if spg < 1 or num_steps % spg or chunk % spg:
+            spg = 1
+        hip_lib.check(lib.dd_graph_create(ctypes.byref(s), spg, side.cuda_stream, ctypes.byref(graph)), "dd_graph_create")
 
         dbg = int(os.environ.get("DD_TRAJ_DEBUG", "0"))
         final_np = {k: v.numpy() for k, v in final.items()}
@@ -614,7 +617,7 @@ class DecompScorePosNet3D(nn.Module):
         try:
             for c, lo in enumerate(range(0, num_steps, chunk)):
                 hi = min(num_steps, lo + chunk)
-                hip_lib.check(lib.dd_graph_launch(graph, hi - lo, side.cuda_stream), "dd_graph_launch")
+                hip_lib.check(lib.dd_graph_launch(graph, (hi - lo) // spg, side.cuda_stream), "dd_graph_launch")
                 ev = torch.cuda.Event()
                 ev.record(side)
                 copy_st.wait_event(ev)

@@ -203,6 +203,9 @@ int dd_debug_set_fusion(int mode);
 /* Measurement aid: runtime switches for A/B timing in one process (key 0: as dd_debug_set_fusion; key 1: K-split
  * projection GEMM tiles on/off).  Results are identical for every setting up to fp32 summation order. */
 int dd_debug_set_option(int key, int value);
+/* Measured split of the fused node launch for a shape (dd_debug_set_option key 18 = 1): number of CUs kept by the
+ * persistent bond-layer workgroups, 0 = node blocks first, -1 = not measured yet. */
+int dd_debug_node_split(int B, int NP, int NL, int K);
 
 /* Debug/test access to intermediate buffers of the last dd_forward (pointers into workspace). */
 typedef struct dd_ws_view {

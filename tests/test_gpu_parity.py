@@ -359,10 +359,10 @@ def test_runtime_options_agree():
     g = GU.load("forward_small")
     b = GU.batch_from_npz(g)
     lib = hip_lib.load()
-    defaults = {1: 1, 3: 1, 4: 2, 5: 4, 6: 0, 7: 1, 8: 0, 9: 1, 10: 0, 11: 0, 12: 1, 14: 0, 15: 1, 16: 1, 17: 1}
+    defaults = {1: 1, 3: 1, 4: 2, 5: 4, 6: 0, 7: 1, 8: 0, 9: 1, 10: 0, 11: 0, 12: 1, 14: 0, 15: 1, 16: 1, 17: 1, 18: 1}
     ref = {k: v.clone() for k, v in _forward_hip(model(0), b).items()}
     try:
-        for key, val in ((1, 0), (3, 0), (4, 0), (4, 1), (5, 8), (5, 2), (6, 1), (8, 1), (8, 2), (9, 0), (10, 1), (11, 1), (12, 0), (14, 1), (15, 0), (16, 0), (17, 0)):
+        for key, val in ((1, 0), (3, 0), (4, 0), (4, 1), (5, 8), (5, 2), (6, 1), (8, 1), (8, 2), (9, 0), (10, 1), (11, 1), (12, 0), (14, 1), (15, 0), (16, 0), (17, 0), (18, 0), (18, 96)):
             assert lib.dd_debug_set_option(key, val) == 0
             o = _forward_hip(model(0), b)
             torch.cuda.synchronize()
@@ -373,6 +373,28 @@ def test_runtime_options_agree():
     finally:
         for key, val in defaults.items():
             lib.dd_debug_set_option(key, val)
+
+
+def test_node_split_variants_bit_identical():
+    """Option 18: how the CUs of the fused node launch are split between the persistent bond-layer workgroups and the
+    node blocks (0 = node blocks first, 1 = split measured once per shape before the first graph capture, n = fixed).
+    Every segment is computed by one wave whatever workgroup picks it up, so the chain must not change by a bit.  Needs
+    a batch with at least one bond-layer trip per CU (B = 8 of the shipped size) for the split to apply."""
+    lib = hip_lib.load()
+    pocket = synth.make_pocket_small(2)
+    torch.manual_seed(4)
+    b = synth.build_sampling_batch(pocket, 8)
+    outs = {}
+    try:
+        for val in (0, 1, 160, 40):
+            assert lib.dd_debug_set_option(18, val) == 0
+            outs[val] = _sample_hip(model(0), b, 3, None, None, seed=77)
+    finally:
+        lib.dd_debug_set_option(18, 1)
+    for val in (1, 160, 40):
+        for k in ("pos", "v", "bond"):
+            assert torch.equal(outs[0][k], outs[val][k]), (val, k)
+        assert torch.equal(torch.stack(outs[0]["pos_traj"]), torch.stack(outs[val]["pos_traj"])), val
 
 
 def test_philox_noise_mode_is_deterministic_and_sane():

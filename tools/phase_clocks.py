@@ -9,7 +9,7 @@ m = DecompScorePosNet3D(cfg, 29, 10, 8); sd = m.state_dict(); sd.update(synth.sy
 pocket = synth.make_pocket_small(0); torch.manual_seed(0)
 b = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synth.build_sampling_batch(pocket, 8).items()}
 lib = hip_lib.load()
-names = ["stage W2k", "Q~", "codes", "sync+stage A1", "pass1 tiles", "softmax", "stage A2", "pass2 tiles", "stage W2vT+zt", "epilogue"]
+names = ["stage weights/tables", "query + Q~ fold", "angle codes", "stage W2v (NE/PE)", "pass1 tiles", "softmax", "-", "pass2 tiles", "-", "epilogue"]
 for mode, nm in enumerate(["NE", "NB", "BL", "PE", "PB"]):
     buf = torch.zeros(4096, 16, dtype=torch.int64, device=dev)
     lib.dd_debug_set_clock_buffer(ctypes.c_void_p(buf.data_ptr()), mode)
