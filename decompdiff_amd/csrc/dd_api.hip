@@ -107,9 +107,12 @@ static bool g_gemm_ksplit_on() { return g_gemm_ksplit != 0; }   // (the addend f
 static hipStream_t g_side = nullptr, g_side2 = nullptr;   // g_side2: query MLPs of the node / bond sub-layers
 static hipEvent_t g_ev_qa_fork[8], g_ev_qa_join[8], g_ev_qb_fork[8];
 static int g_step_fused = 1;                   // dd_debug_set_option(7, v): rows + coordinates + counter in one launch
-static int g_sched = 0;                        // dd_debug_set_option(8, v): 0 = coordinate sub-layers on the side stream (default:
-                                               // fastest in the last in-process A/B), 1 = next layer's projections ahead on the
-                                               // side stream, 2 = the same in two launches (bond part forked at the node attention)
+extern int g_assemble_persist;                 // (dd_graph.hip) 2 = matrix-core assemble kernel
+static int g_xup_in_asm = 1;                   // dd_debug_set_option(19, v): x += dx applied by the next layer's assemble launch
+static int g_sched = 3;                        // dd_debug_set_option(8, v): 0 = coordinate sub-layers on the side stream,
+                                               // 1 = next layer's projections ahead on the side stream, 2 = the same in two
+                                               // launches (bond part forked at the node attention), 3 (default, -3 % in the
+                                               // in-process A/B) = 2 + the next layer's query GEMMs on the side stream too
 static int g_xup_in_pos = 0;                   // dd_debug_set_option(11, v): x update inside the coordinate launch (last workgroup);
                                                // measured 1 % slower than the separate 3-block launch, off
 static int g_fused_max_nl = 64;                // dd_debug_set_option(13, v): largest ligand handled by the fused launches
@@ -213,6 +216,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
     pending_join = dpos.layer;
     return DD_OK;
   };
+  const float* xup_prev = nullptr;                       // != nullptr: x of the previous layer, its update still pending
   for (int l = 0; l < s->num_layers && fused; ++l) {
     const int nE = (int)(B * Eb);
     const bool mlpf = g_mlp_fused != 0;
@@ -262,7 +266,8 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
       return launch_gemm128_batch(j, 2, sx);
     };
     const bool ahead = overlap && g_sched >= 1;
-    const bool ahead_split = overlap && g_sched == 2;
+    const bool ahead_split = overlap && g_sched >= 2;
+    const bool ahead_b2 = overlap && g_sched == 3 && !mlpf && g_q1_in_gemm && g_gemm_ksplit_on();
     const bool pb_early = g_pb_early && g_lin_with_pb2 && !ahead;   // next layer's bond projections ride with lin_node
     if (pb_early && l > 0) DD_TRYP(DD_PROF_GEMM, launch_batch1_part(l, 1, st));
     else if (!(ahead && l > 0)) DD_TRYP(DD_PROF_GEMM, launch_batch1(l, st));
@@ -270,24 +275,26 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
     //      q_hb[bond] + q_hi[dst atom], summed while the GEMM stages its rows, so this launch depends on the projections
     //      only and runs before the coordinates of the previous layer are joined.
     const bool q1_in_gemm = g_q1_in_gemm && !mlpf && g_gemm_ksplit_on();
-    auto launch_b2 = [&]() -> int {
+    auto launch_b2 = [&](int ll, hipStream_t sx) -> int {
       GemmArgs j[3] = {
-          gemm_args(w.q1bl, nE, 0, 128, nE, LW(l, DD_BL_W2q), LW(l, DD_BL_b2q), LW(l, DD_BL_lnq), w.qb, nE, 0, 128, 128, 0),
-          gemm_args(w.P + 512, B * N, 0, 640, B * N, LW(l, DD_NE_W2q), LW(l, DD_NE_b2q), LW(l, DD_NE_lnq), w.qn, B * N, 0, 128, 128, 0),
-          gemm_args(w.PL + 512, B * NL, 0, 1280, B * NL, LW(l, DD_NB_W2q), LW(l, DD_NB_b2q), LW(l, DD_NB_lnq), w.qlnb, B * NL, 0, 128, 128, 0)};
+          gemm_args(w.q1bl, nE, 0, 128, nE, LW(ll, DD_BL_W2q), LW(ll, DD_BL_b2q), LW(ll, DD_BL_lnq), w.qb, nE, 0, 128, 128, 0),
+          gemm_args(w.P + 512, B * N, 0, 640, B * N, LW(ll, DD_NE_W2q), LW(ll, DD_NE_b2q), LW(ll, DD_NE_lnq), w.qn, B * N, 0, 128, 128, 0),
+          gemm_args(w.PL + 512, B * NL, 0, 1280, B * NL, LW(ll, DD_NB_W2q), LW(ll, DD_NB_b2q), LW(ll, DD_NB_lnq), w.qlnb, B * NL, 0, 128, 128, 0)};
       if (q1_in_gemm) {
-        j[0] = gemm_args(w.PB + 512, nE, 0, 640, nE, LW(l, DD_BL_W2q), LW(l, DD_BL_b2q), LW(l, DD_BL_lnq), w.qb, nE, 0, 128, 128, 0);
+        j[0] = gemm_args(w.PB + 512, nE, 0, 640, nE, LW(ll, DD_BL_W2q), LW(ll, DD_BL_b2q), LW(ll, DD_BL_lnq), w.qb, nE, 0, 128, 128, 0);
         j[0].X2 = w.PL + 1152; j[0].x2_N = NL; j[0].x2_Eb = (int)Eb; j[0].x2_NLm1 = NL - 1; j[0].x2_ld = 1280;
       }
-      return launch_gemm128_batch(j, 3, st);
+      return launch_gemm128_batch(j, 3, sx);
     };
+    // (schedule 3) the query GEMMs of this layer already ran on the side stream behind its projections
+    const bool b2_ahead = ahead_b2 && q1_in_gemm && l > 0;
     bool b1_joined = false;
-    if (q1_in_gemm) {
+    if (q1_in_gemm && !b2_ahead) {
       if (ahead && l > 0) {                              // (schedules 1/2: this layer's projections ran on the side stream)
         if (hipStreamWaitEvent(st, g_ev_join[l], 0) != hipSuccess) return DD_ERR_HIP;
         b1_joined = true;
       }
-      DD_TRYP(DD_PROF_GEMM, launch_b2());
+      DD_TRYP(DD_PROF_GEMM, launch_b2(l, st));
     }
     DD_TRY(flush_pos());                                 // previous layer's coordinate launch (side stream)
     if (pending_join >= 0) {
@@ -295,11 +302,14 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
       pending_join = -1;
     }
     if (ahead && l > 0 && !b1_joined && hipStreamWaitEvent(st, g_ev_join[l], 0) != hipSuccess) return DD_ERR_HIP;   // projections of this layer
+    // (a deferred coordinate update of the previous layer is applied here: xcur's ligand rows are written by this launch)
     DD_TRYP(DD_PROF_ASSEMBLE, launch_bl_assemble(xcur, w.PB, w.PL, LW(l, DD_BL_Wg1k), LW(l, DD_BL_Wg1v), LW(l, DD_BL_Wg2k),
                                                   LW(l, DD_BL_Wg2v), LW(l, DD_BL_Wgp), B, NP, NL, w.Ek, w.Ev,
-                                                  (mlpf || q1_in_gemm) ? nullptr : w.q1bl, w.Rk, w.Rv, st));
+                                                  (mlpf || q1_in_gemm) ? nullptr : w.q1bl, w.Rk, w.Rv, st, xup_prev, w.dxe, w.dxb,
+                                                  xup_prev ? xcur : nullptr));
+    xup_prev = nullptr;
     if (!mlpf && !q1_in_gemm) {
-      DD_TRYP(DD_PROF_GEMM, launch_b2());
+      DD_TRYP(DD_PROF_GEMM, launch_b2(l, st));
     } else if (mlpf && overlap) {
       if (hipStreamWaitEvent(st, g_ev_qa_join[l], 0) != hipSuccess) return DD_ERR_HIP;
     }
@@ -395,6 +405,8 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
       pb.q = w.ql2; pb.lnk = LW(l, DD_PB_lnk); pb.lnv = LW(l, DD_PB_lnv);
       pb.W2k = LW(l, DD_PB_W2k); pb.W2v16 = LW(l, DD_PB_W2v); pb.b2v16 = LW(l, DD_PB_b2v); pb.out = w.dxb; pb.x_next = nullptr;
       const bool xup_in_pos = g_xup_in_pos != 0;           // x update by the last workgroup of the coordinate launch
+      // ... or by the next layer's assemble launch, the first consumer of the new x (one launch less on the chain)
+      const bool xup_in_asm = g_xup_in_asm && !xup_in_pos && g_assemble_persist == 2 && l + 1 < s->num_layers;
       if (xup_in_pos) { pe.work_counter = w.counters + 32 + (l & 15); pe.x_next = xnext; }
       if (q_in_pos) {
         pe.qhid = w.PL2 + 256; pe.ld_qhid = 1024; pe.lnq = LW(l, DD_PE_lnq); pe.W2q = LW(l, DD_PE_W2qT); pe.b2q = LW(l, DD_PE_b2q);
@@ -403,12 +415,13 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
       if (overlap && !ahead) {
         // fork: the coordinate sub-layers run on the side stream and are joined before the next consumer of x
         if (hipEventRecord(g_ev_fork[l], st) != hipSuccess) return DD_ERR_HIP;
-        dpos.armed = true; dpos.pe = pe; dpos.pb = pb; dpos.xcur = xcur; dpos.xnext = xnext; dpos.layer = l; dpos.xup = xup_in_pos;
+        dpos.armed = true; dpos.pe = pe; dpos.pb = pb; dpos.xcur = xcur; dpos.xnext = xnext; dpos.layer = l; dpos.xup = xup_in_pos || xup_in_asm;
         if (!g_defer_pos) DD_TRY(flush_pos());
       } else {
         DD_TRYP(DD_PROF_ATTN_PE, launch_attn2_pos(pe, pb, st));
-        if (!xup_in_pos) DD_TRYP(DD_PROF_MISC, launch_xupdate(xcur, w.dxe, w.dxb, B, NP, NL, xnext, st));
+        if (!xup_in_pos && !xup_in_asm) DD_TRYP(DD_PROF_MISC, launch_xupdate(xcur, w.dxe, w.dxb, B, NP, NL, xnext, st));
       }
+      if (xup_in_asm) xup_prev = xcur;
     }
     if (ahead && l + 1 < s->num_layers) {                // (recorded after the main-stream nodes on purpose)
       if (ahead_split) {
@@ -416,6 +429,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
         DD_TRY(launch_batch1_part(l + 1, 0, g_side));
         if (hipStreamWaitEvent(g_side, g_ev_fork[l + 1], 0) != hipSuccess) return DD_ERR_HIP;
         DD_TRY(launch_batch1_part(l + 1, 1, g_side));
+        if (ahead_b2) DD_TRY(launch_b2(l + 1, g_side));
       } else {
         if (hipStreamWaitEvent(g_side, g_ev_fork[l + 1], 0) != hipSuccess) return DD_ERR_HIP;
         DD_TRY(launch_batch1(l + 1, g_side));
@@ -910,6 +924,7 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 0) return dd_debug_set_fusion(value);
   if (key == 1) { dd::g_gemm_ksplit = value ? 1 : 0; return DD_OK; }
   if (key == 3) { dd::g_attn_persist = value ? 1 : 0; return DD_OK; }
+  if (key == 19) { dd::g_xup_in_asm = value ? 1 : 0; return DD_OK; }
   if (key == 18) { if (value < 0 || value > 1024) return DD_ERR_BAD_ARG; dd::g_bl_first = value; return DD_OK; }
   if (key == 17) { dd::g_pb_early = value ? 1 : 0; return DD_OK; }
   if (key == 16) { dd::g_lin_with_pb2 = value ? 1 : 0; return DD_OK; }
@@ -920,7 +935,7 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 11) { dd::g_xup_in_pos = value ? 1 : 0; return DD_OK; }
   if (key == 10) { dd::g_gemm_big = value ? 1 : 0; return DD_OK; }
   if (key == 9) { dd::g_q_in_pos = value ? 1 : 0; return DD_OK; }
-  if (key == 8) { if (value < 0 || value > 2) return DD_ERR_BAD_ARG; dd::g_sched = value; return DD_OK; }
+  if (key == 8) { if (value < 0 || value > 3) return DD_ERR_BAD_ARG; dd::g_sched = value; return DD_OK; }
   if (key == 7) { dd::g_step_fused = value ? 1 : 0; return DD_OK; }
   if (key == 6) { dd::g_mlp_fused = value ? 1 : 0; return DD_OK; }
   if (key == 5) { if (value != 2 && value != 4 && value != 8) return DD_ERR_BAD_ARG; dd::g_pos_waves = value; return DD_OK; }

@@ -428,7 +428,20 @@ __global__ __launch_bounds__(256) void k_bl_assemble3(const float* __restrict__ 
                                                       const float* __restrict__ PL, const float* __restrict__ Wgp /*[4,20,128]*/,
                                                       int B, int NP, int NL, float* __restrict__ Ek, float* __restrict__ Ev,
                                                       float* __restrict__ q1, float* __restrict__ Rk, float* __restrict__ Rv,
-                                                      int blocks_per_output) {
+                                                      int blocks_per_output, const float* __restrict__ xprev,
+                                                      const float* __restrict__ dxe, const float* __restrict__ dxb,
+                                                      float* __restrict__ xout) {
+  // Deferred coordinate update (xprev != nullptr): the previous layer's x += dx_edge + dx_bond (uni_transformer_edge.py:285)
+  // has not been applied yet -- every lane forms its two ligand positions from xprev + deltas (same association as
+  // k_xupdate, so bit-identical) and workgroup 0 writes the updated rows for the kernels that follow.
+  if (xprev != nullptr && blockIdx.x == 0) {
+    const int n = B * NL * 3;
+    for (int idx = threadIdx.x; idx < n; idx += 256) {
+      const int bb = idx / (NL * 3), r = idx % (NL * 3);
+      const long xi = ((long)bb * (NP + NL) + NP) * 3 + r;
+      xout[xi] = xprev[xi] + dxe[idx] + dxb[idx];
+    }
+  }
   // workgroup = (output q: Ek, Ev, Rk, Rv, q1; four consecutive 16-bond tiles, one per wave): 5x the parallelism of a
   // tile-per-wave split over all outputs (only 435 tiles exist at B=8), and only that output's 10 KB table is staged
   __shared__ __attribute__((aligned(16))) float tab[DD_NGAUSS * 128];
@@ -475,8 +488,18 @@ __global__ __launch_bounds__(256) void k_bl_assemble3(const float* __restrict__ 
       acc[nt] = f32x4a{0.f, 0.f, 0.f, 0.f};
     }
   }
-  const float* xl = x + ((long)b * N + NP) * 3;
-  const float dx = xl[3 * t] - xl[3 * s], dy = xl[3 * t + 1] - xl[3 * s + 1], dz = xl[3 * t + 2] - xl[3 * s + 2];
+  float dx, dy, dz;
+  if (xprev != nullptr) {
+    const float* xl = xprev + ((long)b * N + NP) * 3;
+    const float* de = dxe + (long)b * NL * 3;
+    const float* db = dxb + (long)b * NL * 3;
+    dx = (xl[3 * t] + de[3 * t] + db[3 * t]) - (xl[3 * s] + de[3 * s] + db[3 * s]);
+    dy = (xl[3 * t + 1] + de[3 * t + 1] + db[3 * t + 1]) - (xl[3 * s + 1] + de[3 * s + 1] + db[3 * s + 1]);
+    dz = (xl[3 * t + 2] + de[3 * t + 2] + db[3 * t + 2]) - (xl[3 * s + 2] + de[3 * s + 2] + db[3 * s + 2]);
+  } else {
+    const float* xl = x + ((long)b * N + NP) * 3;
+    dx = xl[3 * t] - xl[3 * s]; dy = xl[3 * t + 1] - xl[3 * s + 1]; dz = xl[3 * t + 2] - xl[3 * s + 2];
+  }
   const float d = sqrtf(dx * dx + dy * dy + dz * dz);
   const float* tb = tab + cg * 128 + mm * 4;
 #pragma unroll
@@ -581,13 +604,15 @@ int g_assemble_persist = 2;   // dd_debug_set_option(4, v): 2 = matrix-core kern
 
 int launch_bl_assemble(const float* x, const float* PB, const float* PL, const float* Wg1k, const float* Wg1v,
                        const float* Wg2k, const float* Wg2v, const float* Wgp, int B, int NP, int NL, float* Ek, float* Ev,
-                       float* q1, float* Rk, float* Rv, hipStream_t st) {
+                       float* q1, float* Rk, float* Rv, hipStream_t st, const float* xprev, const float* dxe, const float* dxb,
+                       float* xout) {
   long rows = (long)B * NL * (NL - 1);
+  if (xprev != nullptr && !(g_assemble_persist == 2 && Wgp != nullptr)) return DD_ERR_BAD_ARG;   // only the MFMA kernel defers
   if (g_assemble_persist == 2 && Wgp != nullptr) {
     const long tiles = (rows + 15) / 16;
     const int bpo = (int)((tiles + 3) / 4);                            // blocks per output (4 tiles each)
     hipLaunchKernelGGL(k_bl_assemble3, dim3((unsigned)(bpo * (q1 ? 5 : 4))), dim3(256), 0, st, x, PB, PL, Wgp, B, NP, NL, Ek, Ev, q1,
-                       Rk, Rv, bpo);
+                       Rk, Rv, bpo, xprev, dxe, dxb, xout);
   } else if (g_assemble_persist) {
     const long want = (rows + 7) / 8;                      // >= 2 bonds per wave
     hipLaunchKernelGGL(k_bl_assemble2, dim3((unsigned)(want < 512 ? (want > 0 ? want : 1) : 512)), dim3(256), 0, st, x, PB, PL, Wg1k,

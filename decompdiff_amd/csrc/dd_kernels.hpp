@@ -49,7 +49,8 @@ int launch_embed_nodes(const float* protein_h, const float* protein_pos, const f
 int launch_embed_bonds(const int32_t* bond, long rows, const float* Wb, const float* bb, float* hb, hipStream_t st);
 int launch_bl_assemble(const float* x, const float* PB, const float* PL, const float* Wg1k, const float* Wg1v,
                        const float* Wg2k, const float* Wg2v, const float* Wgp, int B, int NP, int NL, float* Ek, float* Ev,
-                       float* q1, float* Rk, float* Rv, hipStream_t st);
+                       float* q1, float* Rk, float* Rv, hipStream_t st, const float* xprev = nullptr, const float* dxe = nullptr,
+                       const float* dxb = nullptr, float* xout = nullptr);
 int launch_extract_ligand(const float* x, int B, int NP, int NL, float* out, hipStream_t st);
 
 enum { M_NE = 0, M_NB = 1, M_BL = 2, M_PE = 3, M_PB = 4 };
