@@ -71,6 +71,10 @@ def algorithmic_flops_bond_layer(B, NL):
 def main():
     args = parse()
     world, rank, local_rank = ddist.env_world()
+    if world > 1:
+        # torch CPU ops spin up every host core; with one process per GPU that starves the HIP runtime threads of the
+        # other ranks (Trajectories) -- give each rank its share of the host
+        torch.set_num_threads(max(1, min(16, (os.cpu_count() or 16) // (2 * world))))
     distributed = ddist.init_from_env(backend="nccl")      # RCCL on ROCm; no-op for a single process
     if not distributed:
         torch.cuda.set_device(0)
