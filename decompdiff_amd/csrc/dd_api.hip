@@ -108,6 +108,8 @@ static hipStream_t g_side = nullptr, g_side2 = nullptr;   // g_side2: query MLPs
 static hipEvent_t g_ev_qa_fork[8], g_ev_qa_join[8], g_ev_qb_fork[8];
 static int g_step_fused = 1;                   // dd_debug_set_option(7, v): rows + coordinates + counter in one launch
 extern int g_assemble_persist;                 // (dd_graph.hip) 2 = matrix-core assemble kernel
+static int g_step_fold = 1;                    // dd_debug_set_option(20, v): step boundary folded (counter advanced by the forward's
+                                               // first launch; last x update + x0 extraction inside the step kernel)
 static int g_xup_in_asm = 1;                   // dd_debug_set_option(19, v): x += dx applied by the next layer's assemble launch
 static int g_sched = 3;                        // dd_debug_set_option(8, v): 0 = coordinate sub-layers on the side stream,
                                                // 1 = next layer's projections ahead on the side stream, 2 = the same in two
@@ -161,7 +163,14 @@ static int attn_dispatch(int mode, const AttnArgs& a0, hipStream_t st) {
   return g_use_v1 ? launch_attn(mode, a, st) : launch_attn2(mode, a, st);
 }
 
-static int forward_impl(const dd_sampler* s, hipStream_t st) {
+// What one_step hands from the forward to the step kernels when the step boundary is folded (option 20).
+struct StepFold {
+  bool advance = false;                  // in: let the forward's first launch advance the step counter
+  bool fold_tail = false;                // in: leave the last coordinate update + x0 extraction to the step kernel
+  const float* xprev = nullptr;          // out: != nullptr when the tail was deferred
+};
+
+static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nullptr) {
   DD_TRY(check_shapes(s));
   const int B = s->B, NP = s->NP, NL = s->NL, K = s->K, N = NP + NL;
   const long Eb = (long)NL * (NL - 1);
@@ -181,7 +190,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
   // embeddings + context (decompdiff.py:219-297) and the zeroed work counters: one launch
   DD_TRYP(DD_PROF_MISC, launch_embed_all(s->protein_h, s->protein_pos, s->lig_pos, s->lig_v, s->lig_aux, GW(DD_G_W_lemb),
                                          GW(DD_G_b_lemb), B, NP, NL, w.h, w.xa, w.xb, s->lig_bond, (long)B * Eb, GW(DD_G_W_bemb),
-                                         GW(DD_G_b_bemb), w.hb, w.counters, st));
+                                         GW(DD_G_b_bemb), w.hb, w.counters, st, (fold && fold->advance) ? s->step_counter : nullptr));
   // graph (uni_transformer_edge.py:404-427): only the attention kernels need it, so with two streams it is built
   // beside the bond embedding and the first layer's projections
   bool head_join = false;
@@ -406,7 +415,8 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
       pb.W2k = LW(l, DD_PB_W2k); pb.W2v16 = LW(l, DD_PB_W2v); pb.b2v16 = LW(l, DD_PB_b2v); pb.out = w.dxb; pb.x_next = nullptr;
       const bool xup_in_pos = g_xup_in_pos != 0;           // x update by the last workgroup of the coordinate launch
       // ... or by the next layer's assemble launch, the first consumer of the new x (one launch less on the chain)
-      const bool xup_in_asm = g_xup_in_asm && !xup_in_pos && g_assemble_persist == 2 && l + 1 < s->num_layers;
+      const bool xup_in_asm = !xup_in_pos && ((g_xup_in_asm && g_assemble_persist == 2 && l + 1 < s->num_layers) ||
+                                              (fold && fold->fold_tail && l + 1 == s->num_layers));   // (... or by the step kernel)
       if (xup_in_pos) { pe.work_counter = w.counters + 32 + (l & 15); pe.x_next = xnext; }
       if (q_in_pos) {
         pe.qhid = w.PL2 + 256; pe.ld_qhid = 1024; pe.lnq = LW(l, DD_PE_lnq); pe.W2q = LW(l, DD_PE_W2qT); pe.b2q = LW(l, DD_PE_b2q);
@@ -526,11 +536,15 @@ static int forward_impl(const dd_sampler* s, hipStream_t st) {
   }
   // x0-hat = ligand rows of the final x
   if (!s->pred_pos) return DD_ERR_BAD_ARG;
+  if (xup_prev != nullptr) {                             // folded tail: the step kernel applies the update and extracts
+    fold->xprev = xup_prev;
+    return DD_OK;
+  }
   DD_TRYP(DD_PROF_MISC, launch_extract_ligand(xcur, B, NP, NL, s->pred_pos, st));
   return DD_OK;
 }
 
-static int heads_and_step(const dd_sampler* s, hipStream_t st) {
+static int heads_and_step(const dd_sampler* s, hipStream_t st, const StepFold* fold = nullptr) {
   const int B = s->B, NL = s->NL;
   const long Eb = (long)NL * (NL - 1);
   Workspace w = carve(s->workspace, B, s->NP, NL, s->K);
@@ -541,6 +555,7 @@ static int heads_and_step(const dd_sampler* s, hipStream_t st) {
   memset(&r, 0, sizeof(r));
   r.hid = w.qn; r.W2 = GW(DD_G_VH_W2); r.b2 = GW(DD_G_VH_b2); r.rows = B * NL; r.NC = DD_NUM_V; r.rows_per_sample = NL;
   r.tab = s->tab_v; r.T = s->T; r.t_start = s->t_start; r.step_counter = s->step_counter;
+  r.counter_bias = (fold && fold->advance) ? 1 : 0;
   r.state = s->lig_v; r.uniforms = s->u_v; r.seed = s->seed; r.stream_id = 1;
   r.logits_out = s->pred_v; r.traj_recon = s->traj_v0; r.traj_prob = s->traj_vt; r.traj_state = s->traj_v;
   StepRowsArgs rb = r;
@@ -564,17 +579,20 @@ static int heads_and_step(const dd_sampler* s, hipStream_t st) {
   StepPosArgs p;
   memset(&p, 0, sizeof(p));
   p.B = B; p.NL = NL; p.T = s->T; p.t_start = s->t_start; p.step_counter = s->step_counter;
+  p.counter_bias = r.counter_bias; p.NP = s->NP;
+  if (fold && fold->xprev) { p.x0_prev = fold->xprev; p.x0_dxe = w.dxe; p.x0_dxb = w.dxb; p.x0_out = s->pred_pos; }
   p.x0 = s->pred_pos; p.xt = s->lig_pos; p.tab_pos = s->tab_pos; p.tab_score = s->tab_score;
   p.atom_std = s->atom_std; p.offset = s->offset; p.grad_a = ga; p.scale_a = s->armsca_scale; p.grad_c = gc;
   p.scale_c = s->clash_scale; p.eps = s->eps; p.seed = s->seed; p.traj_pos = s->traj_pos;
+  const bool advanced = fold && fold->advance;
   if (g_step_fused) {
     DD_TRYP(DD_PROF_STEP, launch_step_all(rb, r, p, st));
-    DD_TRYP(DD_PROF_STEP, launch_advance(s->step_counter, st));
+    if (!advanced) DD_TRYP(DD_PROF_STEP, launch_advance(s->step_counter, st));
   } else {
     DD_TRYP(DD_PROF_STEP, launch_step_rows(r, st));
     DD_TRYP(DD_PROF_STEP, launch_step_rows(rb, st));
     DD_TRYP(DD_PROF_STEP, launch_step_pos(p, st));
-    DD_TRYP(DD_PROF_STEP, launch_advance(s->step_counter, st));
+    if (!advanced) DD_TRYP(DD_PROF_STEP, launch_advance(s->step_counter, st));
   }
   return DD_OK;
 }
@@ -708,9 +726,11 @@ static int autotune_node_split(const dd_sampler* s, hipStream_t st) {
 }
 
 static int one_step(const dd_sampler* s, hipStream_t st) {
-  int rc = dd::forward_impl(s, st);
+  dd::StepFold fold;
+  fold.advance = fold.fold_tail = dd::g_step_fold != 0;
+  int rc = dd::forward_impl(s, st, &fold);
   if (rc != DD_OK) return rc;
-  return dd::heads_and_step(s, st);
+  return dd::heads_and_step(s, st, &fold);
 }
 
 extern "C" int dd_sample_steps(const dd_sampler* s, int n_steps, void* stream) {
@@ -930,6 +950,7 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 0) return dd_debug_set_fusion(value);
   if (key == 1) { dd::g_gemm_ksplit = value ? 1 : 0; return DD_OK; }
   if (key == 3) { dd::g_attn_persist = value ? 1 : 0; return DD_OK; }
+  if (key == 20) { dd::g_step_fold = value ? 1 : 0; return DD_OK; }
   if (key == 19) { dd::g_xup_in_asm = value ? 1 : 0; return DD_OK; }
   if (key == 18) { if (value < 0 || value > 1024) return DD_ERR_BAD_ARG; dd::g_bl_first = value; return DD_OK; }
   if (key == 17) { dd::g_pb_early = value ? 1 : 0; return DD_OK; }

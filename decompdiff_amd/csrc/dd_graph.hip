@@ -249,8 +249,12 @@ __global__ __launch_bounds__(256) void k_embed_all(const float* __restrict__ pro
                                                    float* __restrict__ xa, float* __restrict__ xb,
                                                    const int32_t* __restrict__ bond, long bond_rows,
                                                    const float* __restrict__ Wb, const float* __restrict__ bb,
-                                                   float* __restrict__ hb, int32_t* __restrict__ counters, int node_blocks) {
+                                                   float* __restrict__ hb, int32_t* __restrict__ counters, int node_blocks,
+                                                   int32_t* __restrict__ advance) {
   if (blockIdx.x == 0 && threadIdx.x < 64 && counters) counters[threadIdx.x] = 0;
+  // the step index moves on with the first launch of a step's forward (nothing before the step kernels reads it): the
+  // step kernels use *advance - 1, and no one-thread launch sits at the end of a step
+  if (blockIdx.x == 0 && threadIdx.x == 64 && advance) *advance += 1;
   if ((int)blockIdx.x < node_blocks) {
     const int N = NP + NL;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -586,11 +590,11 @@ int launch_embed_nodes(const float* protein_h, const float* protein_pos, const f
 int launch_embed_all(const float* protein_h, const float* protein_pos, const float* lig_pos, const int32_t* lig_v,
                      const float* lig_aux, const float* Wl, const float* bl, int B, int NP, int NL, float* h, float* xa, float* xb,
                      const int32_t* bond, long bond_rows, const float* Wb, const float* bb, float* hb, int32_t* counters,
-                     hipStream_t st) {
+                     hipStream_t st, int32_t* advance) {
   const long nn = (long)B * (NP + NL) * 128, nb = bond_rows * 128;
   const int node_blocks = (int)((nn + 255) / 256), bond_blocks = (int)((nb + 255) / 256);
   hipLaunchKernelGGL(k_embed_all, dim3(node_blocks + bond_blocks), dim3(256), 0, st, protein_h, protein_pos, lig_pos, lig_v, lig_aux,
-                     Wl, bl, B, NP, NL, h, xa, xb, bond, bond_rows, Wb, bb, hb, counters, node_blocks);
+                     Wl, bl, B, NP, NL, h, xa, xb, bond, bond_rows, Wb, bb, hb, counters, node_blocks, advance);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }

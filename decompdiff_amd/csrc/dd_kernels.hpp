@@ -37,7 +37,7 @@ int launch_gemm128_batch(const GemmArgs* jobs, int njobs, hipStream_t st);
 int launch_embed_all(const float* protein_h, const float* protein_pos, const float* lig_pos, const int32_t* lig_v,
                      const float* lig_aux, const float* Wl, const float* bl, int B, int NP, int NL, float* h, float* xa, float* xb,
                      const int32_t* bond, long bond_rows, const float* Wb, const float* bb, float* hb, int32_t* counters,
-                     hipStream_t st);
+                     hipStream_t st, int32_t* advance = nullptr);
 int launch_drift_armsca(const float* lig_pos, const int32_t* decomp_index, int B, int NL, float min_d, float max_d,
                         float* grad, int accumulate, int norm_B, hipStream_t st);
 int launch_knn(const float* x, int B, int N, int K, int32_t* nbr, hipStream_t st);
@@ -96,6 +96,7 @@ struct StepRowsArgs {
   const float* tab;        // [4][T] log_alphas, log_1m_alphas, log_cumprod, log_1m_cumprod
   int T, t_start;
   const int32_t* step_counter;
+  int counter_bias;        // step index = *step_counter - counter_bias (1 when the forward's first launch advanced it)
   int32_t* state;          // [rows] current class, updated in place
   const float* uniforms;   // [n_steps, rows, NC] or NULL
   uint64_t seed; uint32_t stream_id;
@@ -107,7 +108,11 @@ struct StepRowsArgs {
 struct StepPosArgs {
   int B, NL, T, t_start;
   const int32_t* step_counter;
+  int counter_bias;
   const float* x0;          // [B*NL,3] predicted x0 (centred)
+  // deferred tail of the forward: x0 = x0_prev[ligand rows] + x0_dxe + x0_dxb (the last layer's coordinate update,
+  // same association as k_xupdate), also stored to x0_out; x0 is ignored then
+  const float* x0_prev; const float* x0_dxe; const float* x0_dxb; float* x0_out; int NP;
   float* xt;                // [B*NL,3] current positions, updated in place
   const float* tab_pos;     // [3][T] c0, ct, logvar
   const float* tab_score;   // [T]

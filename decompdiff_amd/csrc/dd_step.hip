@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void k_step_rows(const StepRowsArgs a) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.rows) return;
-  const int step = *a.step_counter;
+  const int step = *a.step_counter - a.counter_bias;
   const int t = a.t_start - step;
   // ShiftedSoftplus (common.py:66-72): softplus(x) - log 2, torch threshold 20
   float2 hv = *reinterpret_cast<const float2*>(a.hid + row * 128 + 2 * lane);
@@ -96,11 +96,19 @@ __global__ void k_step_pos(const StepPosArgs a) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = a.B * a.NL * 3;
   if (idx >= n) return;
-  const int step = *a.step_counter;
+  const int step = *a.step_counter - a.counter_bias;
   const int t = a.t_start - step;
   const int atom = idx / 3, c = idx % 3, b = atom / a.NL;
   const float xt = a.xt[idx];
-  float mean = a.tab_pos[t] * a.x0[idx] + a.tab_pos[a.T + t] * xt;
+  float x0;
+  if (a.x0_prev != nullptr) {
+    const int r = idx % (a.NL * 3);
+    x0 = a.x0_prev[((long)b * (a.NP + a.NL) + a.NP) * 3 + r] + a.x0_dxe[idx] + a.x0_dxb[idx];
+    a.x0_out[idx] = x0;
+  } else {
+    x0 = a.x0[idx];
+  }
+  float mean = a.tab_pos[t] * x0 + a.tab_pos[a.T + t] * xt;
   float g = 0.f;
   if (a.grad_a) g += a.scale_a ? a.grad_a[idx] * a.tab_score[t] : a.grad_a[idx];
   if (a.grad_c) g += a.scale_c ? a.grad_c[idx] * a.tab_score[t] : a.grad_c[idx];
@@ -307,7 +315,15 @@ __device__ __forceinline__ void step_pos_elem(const StepPosArgs& a, const int id
   const int t = a.t_start - step;
   const int atom = idx / 3, c = idx % 3, b = atom / a.NL;
   const float xt = a.xt[idx];
-  float mean = a.tab_pos[t] * a.x0[idx] + a.tab_pos[a.T + t] * xt;
+  float x0;
+  if (a.x0_prev != nullptr) {
+    const int r = idx % (a.NL * 3);
+    x0 = a.x0_prev[((long)b * (a.NP + a.NL) + a.NP) * 3 + r] + a.x0_dxe[idx] + a.x0_dxb[idx];
+    a.x0_out[idx] = x0;
+  } else {
+    x0 = a.x0[idx];
+  }
+  float mean = a.tab_pos[t] * x0 + a.tab_pos[a.T + t] * xt;
   float g = 0.f;
   if (a.grad_a) g += a.scale_a ? a.grad_a[idx] * a.tab_score[t] : a.grad_a[idx];
   if (a.grad_c) g += a.scale_c ? a.grad_c[idx] * a.tab_score[t] : a.grad_c[idx];
@@ -330,7 +346,7 @@ __device__ __forceinline__ void step_pos_elem(const StepPosArgs& a, const int id
 
 __global__ __launch_bounds__(256) void k_step_all(const StepRowsArgs rb, const StepRowsArgs rv, const StepPosArgs p, int nb_b, int nb_v) {
   const int blk = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int step = *rb.step_counter;
+  const int step = *rb.step_counter - rb.counter_bias;
   if (blk < nb_b) {
     const long row = (long)blk * 4 + wave;
     if (row < rb.rows) step_row<DD_NUM_B>(rb, row, lane, step);

@@ -359,7 +359,7 @@ def test_runtime_options_agree():
     g = GU.load("forward_small")
     b = GU.batch_from_npz(g)
     lib = hip_lib.load()
-    defaults = {1: 1, 3: 1, 4: 2, 5: 4, 6: 0, 7: 1, 8: 3, 9: 1, 10: 0, 11: 0, 12: 1, 14: 0, 15: 1, 16: 1, 17: 1, 18: 1, 19: 1}
+    defaults = {1: 1, 3: 1, 4: 2, 5: 4, 6: 0, 7: 1, 8: 3, 9: 1, 10: 0, 11: 0, 12: 1, 14: 0, 15: 1, 16: 1, 17: 1, 18: 1, 19: 1, 20: 1}
     ref = {k: v.clone() for k, v in _forward_hip(model(0), b).items()}
     try:
         for key, val in ((1, 0), (3, 0), (4, 0), (4, 1), (5, 8), (5, 2), (6, 1), (8, 1), (8, 2), (8, 3), (9, 0), (10, 1), (11, 1), (12, 0), (14, 1), (15, 0), (16, 0), (17, 0), (18, 0), (18, 96), (19, 0), (8, 0)):
@@ -395,6 +395,30 @@ def test_node_split_variants_bit_identical():
         for k in ("pos", "v", "bond"):
             assert torch.equal(outs[0][k], outs[val][k]), (val, k)
         assert torch.equal(torch.stack(outs[0]["pos_traj"]), torch.stack(outs[val]["pos_traj"])), val
+
+
+def test_step_fold_bit_identical():
+    """Option 20 folds the step boundary (the forward's first launch advances the step counter; the last coordinate
+    update and the x0 extraction happen inside the step kernel with the association of the separate kernels): the chain,
+    its trajectories and the pred_* outputs must not change by a bit, with drift, in graph and eager mode."""
+    lib = hip_lib.load()
+    pocket = synth.make_pocket_small(3)
+    torch.manual_seed(5)
+    b = synth.build_sampling_batch(pocket, 2)
+    outs = {}
+    try:
+        for val in (0, 1):
+            for graph in (True, False):
+                assert lib.dd_debug_set_option(20, val) == 0
+                outs[(val, graph)] = _sample_hip(model(0), b, 6, GU.DRIFT, None, seed=11, use_graph=graph)
+    finally:
+        lib.dd_debug_set_option(20, 1)
+    ref = outs[(0, True)]
+    for key, o in outs.items():
+        for k in ("pos", "v", "bond"):
+            assert torch.equal(ref[k], o[k]), (key, k)
+        for k in ("pos_traj", "v_traj", "bond_traj", "v0_traj", "vt_traj", "bt_traj"):
+            assert torch.equal(torch.stack(ref[k]), torch.stack(o[k])), (key, k)
 
 
 def test_philox_noise_mode_is_deterministic_and_sane():
