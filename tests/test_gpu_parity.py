@@ -211,9 +211,13 @@ def test_forward_intermediates_vs_dense_spec():
     assert errs["ew"] < 1e-5 and errs["h"] < 1e-4 and errs["hb"] < 1e-4 and errs["x"] < POS_TOL and errs["A"] < 1e-4
 
 
-@pytest.mark.parametrize("np_,arms,sca,B", [(600, (15, 15), 30, 1), (40, (2, 2), 2, 3), (20, (1, 1), 1, 2), (120, (5, 0), 3, 2)])
+@pytest.mark.parametrize("np_,arms,sca,B", [(600, (15, 15), 30, 1), (40, (2, 2), 2, 3), (20, (1, 1), 1, 2), (120, (5, 0), 3, 2),
+                                            (60, (6, 5), 6, 2), (60, (6, 6), 6, 2), (100, (11, 11), 11, 2), (100, (11, 11), 12, 1),
+                                            (150, (15, 15), 15, 1), (80, (21, 21), 22, 1)])
 def test_forward_vs_oracle_other_shapes(np_, arms, sca, B):
-    """C-large, tiny graphs with fewer than 32 candidates (K = N-1), NL = 3, an empty arm."""
+    """C-large, tiny graphs with fewer than 32 candidates (K = N-1), NL = 3, an empty arm, and the tile boundaries of the
+    segment kernels: NL = 17 / 18 (15 / 16 triplet members: one tile), 33 / 34 (last size of the 2-tile kernels / first
+    of the 4-tile ones), 45 (3 of 4 tiles used), 64 (largest supported ligand)."""
     cfg, sd = GU.weights(0)
     arms = tuple(a for a in arms)
     pocket = synth.make_pocket(11, np_, arms, sca, num_full_protein=np_ + 10)
@@ -331,6 +335,28 @@ def test_graph_replay_equals_eager_launches():
     # and the run is repeatable bit for bit (no atomics, fixed reduction order)
     r3 = _sample_hip(model(0), b, 5, None, n5, use_graph=True)
     assert torch.equal(r1["pos"], r3["pos"]) and torch.equal(torch.stack(r1["vt_traj"]), torch.stack(r3["vt_traj"]))
+
+
+def test_chain_mid_size_ligand_vs_oracle():
+    """A ligand between the two kernel families (NL = 45: 4-tile kernels with 3 tiles used) in a batch large enough for
+    the measured CU split of the node launch to apply: 2 reverse steps with drift against the oracle on injected noise,
+    graph replay == eager launches."""
+    cfg, sd = GU.weights(0)
+    pocket = synth.make_pocket(23, 150, (15, 15), 15, num_full_protein=300)
+    torch.manual_seed(13)
+    b = synth.build_sampling_batch(pocket, 3)
+    steps = 2
+    noise = synth.draw_step_noise(steps, b["init_ligand_pos"].size(0), b["init_ligand_fc_bond_type"].size(0))
+    want = OD.sample_diffusion(sd, cfg, num_steps=steps, energy_drift_opt=GU.DRIFT, noise=noise, **b)
+    got = _sample_hip(model(0), b, steps, GU.DRIFT, noise, use_graph=True)
+    eager = _sample_hip(model(0), b, steps, GU.DRIFT, noise, use_graph=False)
+    split = hip_lib.load().dd_debug_node_split(3, 150, 45, 32)
+    err = maxabs(got["pos"], want["pos"])
+    print(f"NL=45 B=3 chain: pos err {err:.3g}; measured node-launch split {split} CUs")
+    assert split >= 0                                   # the measurement ran for this shape
+    assert err < POS_TOL
+    assert torch.equal(got["v"].cpu(), want["v"]) and torch.equal(got["bond"].cpu(), want["bond"])
+    assert torch.equal(got["pos"], eager["pos"]) and torch.equal(got["bond"], eager["bond"])
 
 
 def test_launch_variants_agree():
