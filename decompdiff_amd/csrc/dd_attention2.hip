@@ -30,8 +30,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace v2 {
 
-constexpr int WPITCH = 132;                    // pitch of the head-permuted W2k image
-constexpr int WB_FLOATS = 128 * WPITCH;        // 67.6 KB: one head-permuted 128 x 128 weight image (W2k or W2v)
+// Pitch of the head-permuted W2k / W2v images.  The fold and the epilogue read them with ds_read_b128 at
+// (d*16 + mm) * WPITCH + 16*nt + 4*cg; a b128 read is served in four 16-lane groups, each holding 8 values of mm with
+// one cg and the complementary 8 with the next cg, so the 16-byte bank slot (mm * WPITCH/4 + cg) mod 16 must be
+// injective over such a group: WPITCH/4 = 2 (mod 16) is, 33 (pitch 132) collides once per group (measured: 35 % of
+// all LDS cycles were bank conflicts).
+constexpr int WPITCH = 136;
+constexpr int WB_FLOATS = 128 * WPITCH;        // 69.6 KB: one head-permuted 128 x 128 weight image (W2k or W2v)
 constexpr int TABP = 24 * 128;                 // Gaussian table stride per edge type (21 rows + 3 zero rows)
 // sum / max over the 4 lanes {l, l^16, l^32, l^48}
 __device__ __forceinline__ float quad_sum(float v) { v = swap16_sum(v, v); return swap32_sum(v, v); }
@@ -40,7 +45,7 @@ __device__ __forceinline__ float quad_max(float v) { return swap32_max(swap16_ma
 // ---- cooperative staging (all loads of a thread issued before its LDS stores) -------------------
 template <int NT>
 __device__ __forceinline__ void stage_w2k_permuted(float* WB, const float* __restrict__ W2k) {
-  // global row r = h*8 + d  ->  LDS row d*16 + h (pitch 132): the 16 heads of a d land in 16 different bank slots
+  // global row r = h*8 + d  ->  LDS row d*16 + h (pitch WPITCH, see there)
   constexpr int PER = (4096 + NT - 1) / NT;
   float4 tmp[PER];
 #pragma unroll
@@ -448,7 +453,7 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
     // The 8 query values rotate through r0 so that no dynamic register indexing is needed.
     float r0 = q0.x, r1 = q0.y, r2 = q0.z, r3 = q0.w, r4 = q1.x, r5 = q1.y, r6 = q1.z, r7 = q1.w;
 #pragma nounroll
-    for (int d = 0; d < 8; ++d) {
+    for (int d = 0; d < 8; ++d) {                        // (unrolled by 2: fewer spills, but 2 % slower end to end)
       const float qv = r0;
       r0 = r1; r1 = r2; r2 = r3; r3 = r4; r4 = r5; r5 = r6; r6 = r7; r7 = qv;
       const float* wr = WB + (d * 16 + mm) * WPITCH + 4 * cg;

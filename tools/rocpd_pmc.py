@@ -13,10 +13,13 @@ def table(path):
     tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
     T = lambda p: [t for t in tabs if t.startswith(p)][0]
     pe, ip, kd, ks = T("rocpd_pmc_event_"), T("rocpd_info_pmc_"), T("rocpd_kernel_dispatch_"), T("rocpd_info_kernel_symbol_")
+    # a counter has one row per hardware instance (XCD x SE ...) and dispatch: sum the instances of a dispatch first,
+    # then average over the dispatches of a (kernel, grid)
     rows = cur.execute(
-        f"select s.kernel_name, d.grid_size_x / d.workgroup_size_x, i.name, count(*), avg(p.value), min(p.value), max(p.value)"
+        f"select kname, wgs, cname, count(*), avg(v), min(v), max(v) from ("
+        f" select s.kernel_name as kname, d.grid_size_x / d.workgroup_size_x as wgs, i.name as cname, sum(p.value) as v"
         f" from {pe} p join {ip} i on p.pmc_id = i.id join {kd} d on d.event_id = p.event_id join {ks} s on d.kernel_id = s.id"
-        f" group by s.kernel_name, d.grid_size_x, i.name order by 5 desc").fetchall()
+        f" group by p.event_id, i.name) group by kname, wgs, cname order by 1, 2, 3").fetchall()
     return rows
 
 
