@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Compare two builds of the library on ONE box: alternating subprocesses, each timing the shipped workload.
-usage: python tools/ab_builds.py libA.so libB.so [rounds]   (paths relative to the repo root)
+usage: python tools/ab_builds.py libA.so libB.so [libC.so ...] [rounds]   (paths relative to the repo root)
 
 Note: packed-weight slot layouts must be compatible with the Python package for both builds.
 """
@@ -20,7 +20,7 @@ def run(steps):
 run(20)
 print(min(run(200) for _ in range(3)))
 '''
-libs = sys.argv[1:3]; rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+args = sys.argv[1:]; rounds = int(args.pop()) if args and args[-1].isdigit() else 3; libs = args
 res = {l: [] for l in libs}
 for r in range(rounds):
     for l in libs:
