@@ -941,7 +941,7 @@ extern "C" int dd_debug_set_fusion(int mode) {
   return DD_OK;
 }
 
-namespace dd { extern int g_gemm_ksplit; extern int g_attn_waves; extern int g_attn_persist; extern int g_assemble_persist; extern int g_pos_waves; extern int g_gemm_big; extern int g_ew_mfma; extern int g_bl_first; }
+namespace dd { extern int g_gemm_ksplit; extern int g_attn_waves; extern int g_attn_persist; extern int g_assemble_persist; extern int g_pos_waves; extern int g_gemm_big; extern int g_ew_mfma; extern int g_bl_first; extern int g_gemm_xcd; }
 // Measurement aid: runtime switches for A/B timing inside one process.  key 0: attention launch structure (same
 // values as dd_debug_set_fusion), key 1: K-split projection GEMM tiles (1 = on).
 extern "C" int dd_debug_node_split(int B, int NP, int NL, int K) { return dd::node_split_lookup(B, NP, NL, K); }
@@ -950,6 +950,7 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 0) return dd_debug_set_fusion(value);
   if (key == 1) { dd::g_gemm_ksplit = value ? 1 : 0; return DD_OK; }
   if (key == 3) { dd::g_attn_persist = value ? 1 : 0; return DD_OK; }
+  if (key == 21) { dd::g_gemm_xcd = value ? 1 : 0; return DD_OK; }
   if (key == 20) { dd::g_step_fold = value ? 1 : 0; return DD_OK; }
   if (key == 19) { dd::g_xup_in_asm = value ? 1 : 0; return DD_OK; }
   if (key == 18) { if (value < 0 || value > 1024) return DD_ERR_BAD_ARG; dd::g_bl_first = value; return DD_OK; }

@@ -625,13 +625,22 @@ __global__ __launch_bounds__(256) void k_gemm128_ks(GemmArgs a) {
 }
 
 struct GemmBatch { GemmArgs job[4]; int end[4]; int nbx[4]; int big[4]; int njobs; };
+// `nby` > 0 selects the XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so
+// with the plain order (row block fastest) the 64 x 128 input block of a row block is pulled into every L2 once per
+// column tile.  Here a job's block range starts at a multiple of 8, XCD x = lb % 8 owns the row blocks x, x + 8, ...
+// and walks their column tiles back to back: an input block is filled into one L2 once (the weights, 0.3 MB, are
+// L2-resident everywhere).  Blocks past the last row block of an XCD exit.
 template <bool KS>
-__device__ __forceinline__ void gemm_job(const GemmArgs& a, int lb, int nbx, int big, float* sm) {
-  (void)big;                                           // (the 128 x 128 tile is only reachable through dd_gemm128: keeping
-                                                       //  it out of this kernel keeps the code small -- with it inlined four
-                                                       //  times the projection launch ran 50 % slower)
-  if (KS) gemm_tile_ksplit(a, lb % nbx, lb / nbx, sm);
-  else gemm_tile(a, lb % nbx, lb / nbx);
+__device__ __forceinline__ void gemm_job(const GemmArgs& a, int lb, int nbx, int nby, float* sm) {
+  int bx = lb % nbx, by = lb / nbx;
+  if (nby > 0) {
+    const int k = lb >> 3;
+    bx = (lb & 7) + 8 * (k / nby);
+    by = k % nby;
+    if (bx >= nbx) return;
+  }
+  if (KS) gemm_tile_ksplit(a, bx, by, sm);
+  else gemm_tile(a, bx, by);
 }
 template <bool KS>
 __global__ __launch_bounds__(256) void k_gemm128_batch(GemmBatch gb) {
@@ -661,6 +670,8 @@ static bool use_big_tile(const GemmArgs& a) {
   return g_gemm_big && g_gemm_ksplit && a.rows >= 1024 && a.ncols >= 128 && a.X2 == nullptr && a.dbg == nullptr;
 }
 
+int g_gemm_xcd = 1;      // dd_debug_set_option(21, v): XCD-aware tile order in the batched projection launches
+
 int launch_gemm128_batch(const GemmArgs* jobs, int njobs, hipStream_t st) {
   if (njobs <= 0 || njobs > 4) return DD_ERR_BAD_ARG;
   GemmBatch gb;
@@ -669,10 +680,12 @@ int launch_gemm128_batch(const GemmArgs* jobs, int njobs, hipStream_t st) {
   for (int i = 0; i < 4; ++i) {
     if (i < njobs) {
       gb.job[i] = jobs[i];
-      const int big = 0, t = GT;
-      gb.big[i] = big;
+      const int t = GT;
       gb.nbx[i] = (jobs[i].rows + t - 1) / t;
-      total += gb.nbx[i] * ((jobs[i].ncols + t - 1) / t);
+      const int nby = (jobs[i].ncols + t - 1) / t;
+      const bool xcd = g_gemm_xcd && gb.nbx[i] >= 16 && nby >= 2;        // (nothing to share with one column tile)
+      gb.big[i] = xcd ? nby : 0;
+      total += xcd ? 8 * ((gb.nbx[i] + 7) / 8) * nby : gb.nbx[i] * nby;
     } else {
       gb.job[i] = jobs[0];
       gb.nbx[i] = 1;

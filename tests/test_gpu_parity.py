@@ -385,10 +385,10 @@ def test_runtime_options_agree():
     g = GU.load("forward_small")
     b = GU.batch_from_npz(g)
     lib = hip_lib.load()
-    defaults = {1: 1, 3: 1, 4: 2, 5: 4, 6: 0, 7: 1, 8: 3, 9: 1, 10: 0, 11: 0, 12: 1, 14: 0, 15: 1, 16: 1, 17: 1, 18: 1, 19: 1, 20: 1}
+    defaults = {1: 1, 3: 1, 4: 2, 5: 4, 6: 0, 7: 1, 8: 3, 9: 1, 10: 0, 11: 0, 12: 1, 14: 0, 15: 1, 16: 1, 17: 1, 18: 1, 19: 1, 20: 1, 21: 1}
     ref = {k: v.clone() for k, v in _forward_hip(model(0), b).items()}
     try:
-        for key, val in ((1, 0), (3, 0), (4, 0), (4, 1), (5, 8), (5, 2), (6, 1), (8, 1), (8, 2), (8, 3), (9, 0), (10, 1), (11, 1), (12, 0), (14, 1), (15, 0), (16, 0), (17, 0), (18, 0), (18, 96), (19, 0), (8, 0)):
+        for key, val in ((1, 0), (3, 0), (4, 0), (4, 1), (5, 8), (5, 2), (6, 1), (8, 1), (8, 2), (8, 3), (9, 0), (10, 1), (11, 1), (12, 0), (14, 1), (15, 0), (16, 0), (17, 0), (18, 0), (18, 96), (19, 0), (8, 0), (21, 0)):
             assert lib.dd_debug_set_option(key, val) == 0
             o = _forward_hip(model(0), b)
             torch.cuda.synchronize()
