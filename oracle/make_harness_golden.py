@@ -89,7 +89,9 @@ def main():
         results = mod.sample_diffusion_ligand_decomp(
             model, data, init_transform=init_transform, num_samples=case["num_samples"], batch_size=case["batch_size"],
             device="cpu", prior_mode=case["prior_mode"], num_steps=2, center_pos_mode="protein",
-            num_atoms_mode=case["num_atoms_mode"], atom_prior_probs=None, bond_prior_probs=None,
+            num_atoms_mode=case["num_atoms_mode"],
+            atom_prior_probs=np.array(case["atom_probs"]) if "atom_probs" in case else None,
+            bond_prior_probs=np.array(case["bond_probs"]) if "bond_probs" in case else None,
             arms_natoms_config=arm_cfg, scaffold_natoms_config=sca_cfg, natoms_config=natoms_path,
             atom_enc_mode="add_aromatic", bond_fc_mode="fc", energy_drift_opt=None)
         if natoms_path:

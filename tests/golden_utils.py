@@ -101,7 +101,11 @@ def harness_cases():
             dict(base, name="beta_stat", prior_mode="beta_prior", num_atoms_mode="stat", stat_models=STAT_MODELS, num_arms=3),
             dict(base, name="subpocket_ref", prior_mode="subpocket", num_atoms_mode="ref"),
             dict(base, name="subpocket_ref_large", prior_mode="subpocket", num_atoms_mode="ref_large"),
-            dict(base, name="subpocket_prior", prior_mode="subpocket", num_atoms_mode="prior")]
+            dict(base, name="subpocket_prior", prior_mode="subpocket", num_atoms_mode="prior"),
+            # initial types drawn from prior probabilities (torch.multinomial) instead of the uniform Gumbel draw
+            # (scripts/sample_diffusion_decomp.py:136-143,304-308: FeaturizeLigandAtom(prior_types=True))
+            dict(base, name="ref_prior_typeprobs", prior_mode="ref_prior", num_atoms_mode="ref",
+                 atom_probs=[0.3, 0.05, 0.2, 0.05, 0.2, 0.1, 0.05, 0.05], bond_probs=[0.6, 0.25, 0.1, 0.03, 0.02])]
 
 
 def make_pocket_fields(seed, beta=False, with_scaffold=True, num_arms=2):

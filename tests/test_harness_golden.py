@@ -35,7 +35,9 @@ def test_harness_matches_reference(case):
     out = harness.sample_diffusion_ligand_decomp(
         model, _pocket(case), num_samples=case["num_samples"], batch_size=case["batch_size"], device="cpu", num_steps=2,
         center_pos_mode="protein", prior_mode=case["prior_mode"], num_atoms_mode=case["num_atoms_mode"],
-        arms_natoms_config=GU.NUM_CONFIG, scaffold_natoms_config=GU.NUM_CONFIG, natoms_sampler=sampler)
+        arms_natoms_config=GU.NUM_CONFIG, scaffold_natoms_config=GU.NUM_CONFIG, natoms_sampler=sampler,
+        atom_prior_probs=np.array(case["atom_probs"]) if "atom_probs" in case else None,
+        bond_prior_probs=np.array(case["bond_probs"]) if "bond_probs" in case else None)
     assert len(model.calls) == int(g["n_batches"])
     for bi, kw in enumerate(model.calls):
         ref_keys = {k[len(f"b{bi}_"):] for k in g.files if k.startswith(f"b{bi}_")}
