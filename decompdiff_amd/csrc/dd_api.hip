@@ -627,7 +627,7 @@ extern "C" const char* dd_status_string(int status) {
   return "unknown status";
 }
 
-extern "C" int dd_abi_version(void) { return 2; }
+extern "C" int dd_abi_version(void) { return 3; }   // 3: tab_v / tab_b carry the class log-prior after the four schedule rows
 
 extern "C" size_t dd_workspace_floats(int B, int NP, int NL, int K) {
   if (B <= 0 || NP < 0 || NL <= 0 || K <= 0) return 0;

@@ -93,7 +93,7 @@ struct StepRowsArgs {
   const float* W2;         // [NC,128]
   const float* b2;         // [NC]
   int rows, NC, rows_per_sample;
-  const float* tab;        // [4][T] log_alphas, log_1m_alphas, log_cumprod, log_1m_cumprod
+  const float* tab;        // [4][T] log_alphas, log_1m_alphas, log_cumprod, log_1m_cumprod, then [NC] log prior
   int T, t_start;
   const int32_t* step_counter;
   int counter_bias;        // step index = *step_counter - counter_bias (1 when the forward's first launch advanced it)

@@ -46,12 +46,13 @@ __global__ __launch_bounds__(256) void k_step_rows(const StepRowsArgs a) {
   const int tm1 = t - 1 < 0 ? 0 : t - 1;
   const float la_t = a.tab[t], l1ma_t = a.tab[a.T + t];
   const float lca = a.tab[2 * a.T + tm1], l1mca = a.tab[3 * a.T + tm1];
-  const float log_prior = -logf((float)NC);
+  const float* log_prior_tab = a.tab + 4 * a.T;         // [NC] log prior (uniform: -log NC), DiscreteTransition.prior_probs
   const int cur = a.state[row];
   float un[NC];
   float umax = -INFINITY;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
+    const float log_prior = log_prior_tab[c];
     const float lv0 = logit[c] - lse;
     const float lvt = (c == cur) ? 0.f : -69.07755278982137f;    // log(clamp(onehot, 1e-30))
     const float q0 = log_add_exp(lv0 + lca, l1mca + log_prior);  // q(v_{t-1} | v0)
@@ -261,7 +262,7 @@ __device__ __forceinline__ void step_row(const StepRowsArgs& a, const long row, 
   const int tm1 = t - 1 < 0 ? 0 : t - 1;
   const float la_t = a.tab[t], l1ma_t = a.tab[a.T + t];
   const float lca = a.tab[2 * a.T + tm1], l1mca = a.tab[3 * a.T + tm1];
-  const float log_prior = -logf((float)NC);
+  const float log_prior = a.tab[4 * a.T + c];            // log prior of this lane's class (uniform: -log NC)
   const int cur = a.state[row];
   const float lv0 = mine - lse;
   const float lvt = (c == cur) ? 0.f : -69.07755278982137f;      // log(clamp(onehot, 1e-30))

@@ -55,7 +55,7 @@ class DDWsView(ctypes.Structure):
 PROF_CATS = ["misc", "gemm", "assemble", "attn_NE", "attn_NB", "attn_BL", "attn_PE", "attn_PB", "step"]
 
 
-ABI_VERSION = 2          # include/decompdiff_hip.h: layout of struct dd_sampler
+ABI_VERSION = 3          # include/decompdiff_hip.h: layout of struct dd_sampler and of the tables it points to
 
 
 class HipLibraryError(RuntimeError):

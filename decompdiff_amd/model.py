@@ -157,10 +157,11 @@ class DecompScorePosNet3D(nn.Module):
                                    self.posterior_logvar]).detach().float().contiguous()
             tv = self.atom_type_trans
             tb = self.bond_type_trans
-            tab_v = torch.stack([tv.log_alphas_v, tv.log_one_minus_alphas_v, tv.log_alphas_cumprod_v,
-                                 tv.log_one_minus_alphas_cumprod_v]).detach().float().contiguous()
-            tab_b = torch.stack([tb.log_alphas_v, tb.log_one_minus_alphas_v, tb.log_alphas_cumprod_v,
-                                 tb.log_one_minus_alphas_cumprod_v]).detach().float().contiguous()
+            # [4][T] schedule rows followed by the [K] class log-prior (uniform unless prior_*_types were given)
+            tab_v = torch.cat([tv.log_alphas_v, tv.log_one_minus_alphas_v, tv.log_alphas_cumprod_v,
+                               tv.log_one_minus_alphas_cumprod_v, tv.prior_probs.reshape(-1)]).detach().float().contiguous()
+            tab_b = torch.cat([tb.log_alphas_v, tb.log_one_minus_alphas_v, tb.log_alphas_cumprod_v,
+                               tb.log_one_minus_alphas_cumprod_v, tb.prior_probs.reshape(-1)]).detach().float().contiguous()
             self._packed = dict(arena=arena.to(dev), offsets=offsets.numpy().astype(np.int64).copy(),
                                 tab_pos=tab_pos.to(dev), tab_v=tab_v.to(dev), tab_b=tab_b.to(dev),
                                 tab_score=self.pos_score_coef.detach().float().contiguous().to(dev))

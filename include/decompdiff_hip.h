@@ -79,8 +79,9 @@ typedef struct dd_sampler {
   const float* weights;            /* packed arena */
   const int64_t* slot_off;         /* HOST: offsets (floats) [num_layers*DD_NUM_LAYER_SLOTS + DD_NUM_GLOBAL_SLOTS] */
   const float* tab_pos;            /* [3][T]: posterior_mean_c0_coef, posterior_mean_ct_coef, posterior_logvar */
-  const float* tab_v;              /* [4][T]: log_alphas_v, log_one_minus_alphas_v, log_alphas_cumprod_v, log_one_minus_alphas_cumprod_v (atoms) */
-  const float* tab_b;              /* [4][T]: same for bonds */
+  const float* tab_v;              /* [4][T]: log_alphas_v, log_one_minus_alphas_v, log_alphas_cumprod_v, log_one_minus_alphas_cumprod_v (atoms),
+                                      followed by [8] log prior_probs (DiscreteTransition.prior_probs, transitions.py:114-120; uniform = -log 8) */
+  const float* tab_b;              /* [4][T] + [5]: same for bonds */
   const float* tab_score;          /* [T]: pos_score_coef (drift 'scale' option) */
   /* static inputs */
   const float* protein_pos;        /* [B,NP,3] centred (center_pos, decompdiff.py:20-32) */

@@ -67,15 +67,17 @@ def position_tables(cfg):
     return t
 
 
-def categorical_tables(cfg, num_classes):
-    """DiscreteTransition.__init__ (transitions.py:98-120), uniform prior."""
+def categorical_tables(cfg, num_classes, prior_probs=None):
+    """DiscreteTransition.__init__ (transitions.py:98-120); ``prior_probs`` None = uniform prior (:114-116), else the
+    class probabilities whose clipped log becomes the prior (:118-120)."""
     assert cfg.v_beta_schedule == "cosine"
     la = np.log(cosine_alphas(cfg.num_diffusion_timesteps, cfg.v_beta_s))
     lca = np.cumsum(la)
     l1m = lambda a: np.log(1 - np.exp(a) + 1e-40)                     # transitions.py:87
     return dict(log_alphas_v=f32(la), log_one_minus_alphas_v=f32(l1m(la)),
                 log_alphas_cumprod_v=f32(lca), log_one_minus_alphas_cumprod_v=f32(l1m(lca)),
-                prior_probs=f32(-np.log(num_classes).repeat(num_classes)[None, :]))
+                prior_probs=f32(-np.log(num_classes).repeat(num_classes)[None, :]) if prior_probs is None
+                else f32(np.log(np.asarray(prior_probs, dtype=np.float64).clip(min=1e-30))))
 
 
 # -------------------------------------------------------------------------- transitions
@@ -150,7 +152,8 @@ def sample_diffusion(sd, cfg, *, protein_pos, protein_v, batch_protein, init_lig
                      ligand_fc_bond_index, init_ligand_fc_bond_type, batch_ligand_bond,
                      num_steps=None, center_pos_mode="protein", energy_drift_opt=None,
                      full_protein_pos=None, full_batch_protein=None, ligand_atom_mask=None,
-                     num_classes=8, noise=None, keep_traj=True, step_hook=None, t_start=None, **unused):
+                     num_classes=8, noise=None, keep_traj=True, step_hook=None, t_start=None,
+                     prior_atom_types=None, prior_bond_types=None, **unused):
     """DecompScorePosNet3D.sample_diffusion for model_mean_type='C0' (decompdiff.py:552-703).
 
     Extra keyword arguments of the reference signature that the shipped path never reads
@@ -161,8 +164,8 @@ def sample_diffusion(sd, cfg, *, protein_pos, protein_v, batch_protein, init_lig
     """
     assert cfg.model_mean_type == "C0"
     pt = position_tables(cfg)
-    vt = categorical_tables(cfg, num_classes)
-    bt = categorical_tables(cfg, cfg.num_bond_classes)
+    vt = categorical_tables(cfg, num_classes, prior_atom_types)          # (decompdiff.py:137-144)
+    bt = categorical_tables(cfg, cfg.num_bond_classes, prior_bond_types)
     T = cfg.num_diffusion_timesteps
     if num_steps is None:
         num_steps = T

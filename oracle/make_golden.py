@@ -36,6 +36,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 FWD_KEYS = ["protein_pos", "protein_v", "batch_protein", "protein_group_idx", "init_ligand_pos", "init_ligand_v",
             "batch_ligand", "ligand_group_idx", "prior_centers", "prior_stds", "batch_prior", "prior_group_idx",
             "ligand_fc_bond_index", "init_ligand_fc_bond_type"]
+GU_PRIOR_ATOM = [0.30, 0.05, 0.20, 0.05, 0.20, 0.10, 0.05, 0.05]
+GU_PRIOR_BOND = [0.60, 0.25, 0.10, 0.03, 0.02]
 DRIFT = [dict(type="armsca_prox", min_d=1.2, max_d=1.9), dict(type="clash", sigma=2, gamma=4)]  # sampling_drift.yml:31-37
 
 
@@ -156,9 +158,9 @@ def run_ref_sampling(ref, batch, num_steps, drift, t_start=None):
     return r
 
 
-def run_oracle_sampling(sd, cfg, batch, num_steps, drift, noise, t_start=None):
+def run_oracle_sampling(sd, cfg, batch, num_steps, drift, noise, t_start=None, **kw):
     return OD.sample_diffusion(sd, cfg, num_steps=num_steps, energy_drift_opt=drift, noise=noise,
-                               t_start=t_start, **batch)
+                               t_start=t_start, **kw, **batch)
 
 
 def traj_arrays(r, every=1):
@@ -206,7 +208,7 @@ def gen_steps(ref, sd, cfg):
     print(f"[steps] oracle maxabs diff = {worst:g}")
 
 
-def gen_traj(ref, sd, cfg, name, pocket, n_data, num_steps, drift, seed, every=1, std_scale=None):
+def gen_traj(ref, sd, cfg, name, pocket, n_data, num_steps, drift, seed, every=1, std_scale=None, priors=None):
     torch.manual_seed(seed)
     batch = synth.build_sampling_batch(pocket, n_data, per_sample_std_scale=std_scale)
     state = torch.get_rng_state()
@@ -216,7 +218,7 @@ def gen_traj(ref, sd, cfg, name, pocket, n_data, num_steps, drift, seed, every=1
     torch.set_rng_state(state)
     noise = synth.draw_step_noise(num_steps, batch["init_ligand_pos"].size(0), batch["init_ligand_fc_bond_type"].size(0))
     t0 = time.time()
-    ro = run_oracle_sampling(sd, cfg, batch, num_steps, drift, noise)
+    ro = run_oracle_sampling(sd, cfg, batch, num_steps, drift, noise, **(priors or {}))
     t_or = time.time() - t0
     w = max(maxabs(r["pos"], ro["pos"]), maxabs(r["v"], ro["v"]), maxabs(r["bond"], ro["bond"]))
     out = np_inputs(batch)
@@ -226,6 +228,8 @@ def gen_traj(ref, sd, cfg, name, pocket, n_data, num_steps, drift, seed, every=1
     out["noise_checksum"] = np.array([float(noise["u_v"].double().sum()), float(noise["u_b"].double().sum()),
                                       float(noise["eps"].double().sum())])
     out["weight_seed"] = np.array(0)
+    for k, v in (priors or {}).items():
+        out[k] = np.asarray(v)
     out["oracle_vs_reference_maxabs"] = np.array(w)
     out["ref_seconds"], out["oracle_seconds"] = np.array(t_ref), np.array(t_or)
     np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **out)
@@ -274,6 +278,12 @@ def main():
     if want("traj20"):
         gen_traj(ref, sd, cfg, "traj20_plain", synth.make_pocket_small(2), 2, 20, None, 2021)
         gen_traj(ref, sd, cfg, "traj20_drift", synth.make_pocket_small(2), 2, 20, DRIFT, 2022, std_scale=[1.0, 0.85])
+    if want("priortypes"):
+        # non-uniform class priors (FeaturizeLigandAtom(prior_types=True) -> DecompScorePosNet3D(prior_atom_types=...,
+        # prior_bond_types=...), scripts/sample_diffusion_decomp.py:514,541-542): a second reference model
+        priors = dict(prior_atom_types=np.array(GU_PRIOR_ATOM), prior_bond_types=np.array(GU_PRIOR_BOND))
+        ref_p = ref_shims.load_reference_model(cfg.to_dict(), sd, **priors)
+        gen_traj(ref_p, sd, cfg, "traj12_priortypes", synth.make_pocket_small(4), 2, 12, DRIFT, 2024, priors=priors)
     if want("ragged"):
         gen_traj_ragged(ref, sd, cfg, "traj10_ragged", 10, DRIFT, 2023)
     if want("traj1000") and not args.skip_long:

@@ -242,13 +242,14 @@ def install():
         sys.path.insert(0, REFERENCE_ROOT)
 
 
-def load_reference_model(cfg_dict, state=None, protein_dim=29, ligand_dim=10, num_classes=8):
+def load_reference_model(cfg_dict, state=None, protein_dim=29, ligand_dim=10, num_classes=8, prior_atom_types=None,
+                         prior_bond_types=None):
     """Construct the reference's DecompScorePosNet3D and load synthetic weights (strict)."""
     install()
     from models.decompdiff import DecompScorePosNet3D           # noqa: the REFERENCE's module
     model = DecompScorePosNet3D(EasyDict(cfg_dict), protein_atom_feature_dim=protein_dim,
                                 ligand_atom_feature_dim=ligand_dim, num_classes=num_classes,
-                                prior_atom_types=None, prior_bond_types=None)
+                                prior_atom_types=prior_atom_types, prior_bond_types=prior_bond_types)
     if state is not None:
         full = model.state_dict()
         missing = [k for k in state if k not in full]

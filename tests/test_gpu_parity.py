@@ -30,7 +30,14 @@ def dev():
 _MODELS = {}
 
 
-def model(seed=0):
+def model(seed=0, priors=None):
+    if priors is not None:                         # (not cached: one test)
+        cfg = shipped_config()
+        m = DecompScorePosNet3D(cfg, 29, 10, 8, prior_atom_types=priors[0], prior_bond_types=priors[1])
+        sd = m.state_dict()
+        sd.update(synth.synthetic_state_dict(cfg, seed))
+        m.load_state_dict(sd, strict=True)
+        return m.to(dev())
     if seed not in _MODELS:
         cfg = shipped_config()
         m = DecompScorePosNet3D(cfg, 29, 10, 8)
@@ -279,7 +286,7 @@ def _traj_inputs(name, std_scale=None):
     g = GU.load(name)
     b = GU.batch_from_npz(g)
     n_data = int(b["batch_ligand"].max()) + 1
-    seedpocket = {"traj20_plain": 2, "traj20_drift": 2, "traj1000_plain": 3}[name]
+    seedpocket = {"traj20_plain": 2, "traj20_drift": 2, "traj1000_plain": 3, "traj12_priortypes": 4}[name]
     torch.manual_seed(int(g["seed"]))
     synth.build_sampling_batch(synth.make_pocket_small(seedpocket), n_data, per_sample_std_scale=std_scale)
     noise = synth.draw_step_noise(int(g["num_steps"]), b["init_ligand_pos"].size(0), b["init_ligand_fc_bond_type"].size(0))
@@ -301,6 +308,24 @@ def test_trajectory_20_steps_golden(name, std_scale):
     assert maxabs(r["pos"], g["out_pos"]) < POS_TOL
     assert nv == 0 and nb == 0
     assert np.array_equal(r["v"].cpu().numpy(), g["out_v"]) and np.array_equal(r["bond"].cpu().numpy(), g["out_bond"])
+
+
+def test_trajectory_prior_types_golden():
+    """Non-uniform class priors (prior_atom_types / prior_bond_types of the constructor, transitions.py:118-120): the
+    log-priors travel behind the schedule rows of tab_v / tab_b; fixture from a reference model built with them."""
+    g, b, noise = _traj_inputs("traj12_priortypes")
+    drift = json.loads(str(g["drift"]))
+    m = model(0, priors=(g["prior_atom_types"], g["prior_bond_types"]))
+    r = _sample_hip(m, b, 12, drift, noise)
+    nv = int((torch.stack(r["v_traj"]).numpy() != g["traj_v"]).sum())
+    nb = int((torch.stack(r["bond_traj"]).numpy() != g["traj_bond"]).sum())
+    err = maxabs(r["pos"], g["out_pos"])
+    # the priors matter: the uniform-prior model takes a different path from the first steps on
+    r_uniform = _sample_hip(model(0), b, 12, drift, noise)
+    diff = int((r_uniform["bond"].cpu().numpy() != g["out_bond"]).sum())
+    print(f"prior types: pos err {err:.3g}, type mismatches v={nv} bond={nb}; uniform-prior model differs in {diff} bond types")
+    assert err < POS_TOL and nv == 0 and nb == 0
+    assert diff > 0
 
 
 def test_trajectory_1000_steps_golden():

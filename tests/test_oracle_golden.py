@@ -98,14 +98,15 @@ def _replay_traj(name, num_steps, std_scale=None):
                                   b["init_ligand_fc_bond_type"].size(0))
     assert np.array_equal(GU.checksum(noise), g["noise_checksum"])
     noise = {k: v[:num_steps] for k, v in noise.items()}
+    priors = {k: g[k] for k in ("prior_atom_types", "prior_bond_types") if k in g.files}
     r = OD.sample_diffusion(sd, cfg, num_steps=num_steps, energy_drift_opt=drift, noise=noise,
-                            t_start=cfg.num_diffusion_timesteps - 1, **b)
+                            t_start=cfg.num_diffusion_timesteps - 1, **priors, **b)
     return g, r
 
 
 def _pocket_for(name):
     return {"traj20_plain": synth.make_pocket_small(2), "traj20_drift": synth.make_pocket_small(2),
-            "traj1000_plain": synth.make_pocket_small(3)}[name]
+            "traj1000_plain": synth.make_pocket_small(3), "traj12_priortypes": synth.make_pocket_small(4)}[name]
 
 
 def test_trajectory_20_steps_plain():
@@ -121,6 +122,16 @@ def test_trajectory_20_steps_drift():
     assert np.array_equal(g["out_pos"], r["pos"].numpy())
     assert np.array_equal(g["out_v"], r["v"].numpy())
     assert np.array_equal(g["out_bond"], r["bond"].numpy())
+
+
+def test_trajectory_12_steps_prior_types():
+    """Non-uniform class priors of the categorical transitions (DecompScorePosNet3D(prior_atom_types=, prior_bond_types=),
+    transitions.py:118-120): fixture from a reference model built with them."""
+    g, r = _replay_traj("traj12_priortypes", 12)
+    assert np.array_equal(g["out_pos"], r["pos"].numpy())
+    assert np.array_equal(g["out_v"], r["v"].numpy())
+    assert np.array_equal(g["out_bond"], r["bond"].numpy())
+    assert np.array_equal(g["traj_v"], torch.stack(r["v_traj"]).numpy().astype(np.int8))
 
 
 def test_trajectory_1000_first_checkpoint():
