@@ -141,6 +141,7 @@ class DecompScorePosNet3D(nn.Module):
         need(not config.x2h_out_fc and config.norm and config.act_fn == "relu", "x2h_out_fc=False, norm, relu")
         need(getattr(config, "num_bond_classes", 1) == 5, "num_bond_classes=5")
         need(pdim == 29 and ldim == 10, "protein/ligand feature dims 29/10")
+        need(not getattr(config, "sync_twoup", False), "sync_twoup=False")
         need(config.knn <= 32, "knn<=32")
 
     # ------------------------------------------------------------------------------------------
