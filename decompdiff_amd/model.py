@@ -310,6 +310,17 @@ class DecompScorePosNet3D(nn.Module):
         exp_fc = torch.cat([fc + b * NL for b in range(B)], 1)
         if ligand_fc_bond_index.shape != exp_fc.shape or not torch.equal(ligand_fc_bond_index, exp_fc):
             raise NotImplementedError("ligand_fc_bond_index must be the dst-major fully connected graph ('fc' mode)")
+        if protein_v.dim() != 2 or protein_v.shape[1] != 29 or ligand_v_aux.dim() != 2 or ligand_v_aux.shape[1] != 2:
+            raise ValueError("protein_v must be [n,29] and ligand_v_aux [n,2] (27 atom features + 2 arm indicators; "
+                             "arm/scaffold indicator), as the sampling script builds them")
+        if protein_pos.shape != (n_p, 3) or ligand_pos.shape != (n_l, 3) or protein_v.shape[0] != n_p \
+                or ligand_v.shape != (n_l,) or ligand_v_aux.shape[0] != n_l:
+            raise ValueError("per-atom tensors do not match the batch vectors")
+        # class ids out of range: the reference's index_to_log_onehot asserts (transitions.py:66)
+        assert int(ligand_v.min()) >= 0 and int(ligand_v.max()) < self.num_classes, \
+            f"Error: {int(ligand_v.max())} >= {self.num_classes}"
+        assert int(ligand_bond_type.min()) >= 0 and int(ligand_bond_type.max()) < self.num_bond_classes, \
+            f"Error: {int(ligand_bond_type.max())} >= {self.num_bond_classes}"
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
         return dict(B=B, NP=NP, NL=NL, protein_pos=f32(protein_pos).view(B, NP, 3), protein_v=f32(protein_v).view(B, NP, -1),
                     ligand_pos=f32(ligand_pos).view(B, NL, 3), ligand_v=ligand_v.detach().to(torch.int32).contiguous(),

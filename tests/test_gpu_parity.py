@@ -658,3 +658,12 @@ def test_unsupported_inputs_fail_loudly():
           ligand_fc_bond_index=b["ligand_fc_bond_index"], init_ligand_fc_bond_type=b["init_ligand_fc_bond_type"])
     with pytest.raises(ValueError):
         _sample_hip(m, b, 1, [dict(type="nonsense")], None)
+    bad = dict(b)
+    bad["init_ligand_v"] = b["init_ligand_v"].clone()
+    bad["init_ligand_v"][0] = 8                       # class id out of range: AssertionError like index_to_log_onehot
+    with pytest.raises(AssertionError):
+        _sample_hip(m, bad, 1, None, None)
+    bad = dict(b)
+    bad["protein_v"] = b["protein_v"][:, :27]         # features without the arm indicator
+    with pytest.raises(ValueError):
+        _sample_hip(m, bad, 1, None, None)
