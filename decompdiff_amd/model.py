@@ -455,6 +455,12 @@ class DecompScorePosNet3D(nn.Module):
             self._last = (s, bufs)
             return preds
 
+    def get_diffusion_loss(self, *args, **kwargs):
+        """Training objective of the reference (models/decompdiff.py:419-550).  Out of scope here:
+        the fused kernels have no backward; train with the reference and load the checkpoint."""
+        raise NotImplementedError("decompdiff_amd implements the sampling path only; training (get_diffusion_loss) "
+                                  "needs autograd through the fused kernels (SURVEY.md 8f-4)")
+
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
     def sample_diffusion(self, protein_pos, protein_v, batch_protein, protein_group_idx,
