@@ -156,6 +156,47 @@ def main():
                             "restructurings (DESIGN.md 3,5); the kernel is fused, q/k/v never touch HBM",
                     "ms_per_step_by_kernel_class": {k: round(v, 4) for k, v in per_cat.items()},
                     "dominant_attention_class": dom}
+        # ---- HBM roofline of the op-level message-passing kernel: the stand-alone scatter_softmax +
+        #      scatter_sum op of the C ABI on k / v tables larger than the Infinity Cache, algorithmic bytes / event time
+        op_roofline = None
+        try:
+            n_seg, kk = 65536, 32
+            E = n_seg * kk
+            op_traffic = None                                    # HBM bytes per launch from the committed PMC passes
+            try:
+                import json as _json
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as fh:
+                    po = _json.load(fh)["op_level"]
+                if (po["n_seg"], po["edges_per_seg"]) == (n_seg, kk):
+                    op_traffic = int((po["fetch_kib_per_launch"] * po["fetch_correction"] + po["write_kib_per_launch"]) * 1024)
+            except (OSError, KeyError, ValueError):
+                pass
+            tq, tk, tv = (torch.randn(n, 128, device=dev) for n in (n_seg, E, E))
+            tw = torch.rand(E, device=dev)
+            tp = (torch.arange(n_seg + 1, device=dev, dtype=torch.int32) * kk).contiguous()
+            to = torch.empty(n_seg, 128, device=dev)
+            cur = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            call = lambda: hip_lib.check(lib.dd_attn_aggregate_node(hip_lib.ptr(tq), 0, hip_lib.ptr(tk), hip_lib.ptr(tv), hip_lib.ptr(tw),
+                                                                    hip_lib.ptr(tp), n_seg, hip_lib.ptr(to), cur), "dd_attn_aggregate_node")
+            for _ in range(3):
+                call()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(10):
+                call()
+            ev1.record()
+            torch.cuda.synchronize()
+            sec = ev0.elapsed_time(ev1) / 10 * 1e-3
+            nbytes = 1032 * E + 1024 * n_seg
+            op_roofline = {"bound": "hbm", "kernel": "dd_attn_aggregate_node (scatter_softmax + scatter_sum, q/k/v from HBM)",
+                           "achieved": round(nbytes / sec / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                           "frac": round(nbytes / sec / 8e12, 4), "traffic": op_traffic,
+                           "note": f"{n_seg} segments x {kk} edges, {nbytes / 1e6:.0f} MB algorithmic (1032 B/edge + 1024 B/segment, "
+                                   "SURVEY.md 8d), launch time from HIP events; not on the sampling path (the fused kernels keep "
+                                   "q/k/v on chip) -- the op-level boundary of the C ABI"}
+            del tq, tk, tv, tw, tp, to
+        except Exception as exc:                                  # the headline numbers do not depend on this extra
+            op_roofline = {"error": str(exc)}
         cpu = None
         if not args.no_cpu_baseline:
             from oracle import diffusion as OD          # the checker, timed as the CPU baseline only
@@ -186,7 +227,7 @@ def main():
                        "parallelism": f"{world} independent pocket batches (no data-path collective)",
                        "launch": "eager" if args.eager else "hipGraph replay", "noise": "device Philox",
                        "node_launch_split_cus": int(lib.dd_debug_node_split(args.batch, NP, NL, min(cfg.knn, NP + NL - 1)))},
-            "roofline": roofline, "cpu_baseline": cpu, "per_rank": meta,
+            "roofline": roofline, "roofline_op_level": op_roofline, "cpu_baseline": cpu, "per_rank": meta,
         }
         if cpu:
             result["config"]["speedup_vs_cpu_baseline"] = round(steps_per_s / cpu["value"], 1)

@@ -23,6 +23,7 @@ EXPORTED_SYMBOLS = [
     "dd_graph_create", "dd_graph_launch", "dd_graph_destroy",
     "dd_drift_armsca",
     "dd_drift_clash", "dd_workspace_view", "dd_profile_step", "dd_debug_set_clock_buffer", "dd_debug_set_fusion", "dd_debug_set_option", "dd_debug_node_split",
+    "dd_attn_aggregate_node", "dd_attn_aggregate_triplet", "dd_attn_aggregate_pos",
 ]
 
 
@@ -105,6 +106,9 @@ def load():
     lib.dd_debug_set_fusion.argtypes = [c_int]
     lib.dd_debug_set_option.argtypes = [c_int, c_int]
     lib.dd_debug_node_split.argtypes = [c_int, c_int, c_int, c_int]
+    lib.dd_attn_aggregate_node.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
+    lib.dd_attn_aggregate_triplet.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
+    lib.dd_attn_aggregate_pos.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.dd_profile_step.argtypes = [POINTER(DDSampler), c_int, POINTER(c_float), c_void_p]
     for name in EXPORTED_SYMBOLS:
         if name not in ("dd_status_string", "dd_workspace_floats"):

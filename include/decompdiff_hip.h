@@ -145,6 +145,24 @@ int dd_gemm128(const float* X, int x_rows_per_b, long x_stride_b, int ldx, int r
                const float* bias, const float* ln, float* Y, int y_rows_per_b, long y_stride_b, int ldy,
                int ncols, int accumulate, void* stream);
 
+/* Op-level message passing: the torch_scatter pairs of the reference's attention layers as stand-alone ops
+ *     alpha = scatter_softmax((q[dst] * k / sqrt(8)).sum(-1), dst, dim=0);  out = scatter_sum(alpha[..., None] * v, dst, dim=0)
+ * (uni_transformer_edge.py:63-68 NodeUpdateLayer, :158-164 BondUpdateLayer, :205-211 PosUpdateLayer).  16 heads x 8
+ * channels.  Edges grouped by destination: seg_ptr[s] .. seg_ptr[s+1] are the edges of destination s (knn_graph's,
+ * the dst-major bond list's and the SparseTensor triplets' order).  v is multiplied by e_w[edge] when e_w != NULL
+ * (:55-56).  q is [n_seg,128], or per edge [E,128] with q_per_edge != 0 (rows of a segment are then identical and
+ * the first is read).  Destinations without edges get zeros.  The sampling loop does not call these (its fused
+ * kernels never materialise q / k / v); they serve hosts that keep the reference's Python layers. */
+int dd_attn_aggregate_node(const float* q, int q_per_edge, const float* k /*[E,128]*/, const float* v /*[E,128]*/,
+                           const float* e_w /*[E] or NULL*/, const int32_t* seg_ptr /*[n_seg+1]*/, int n_seg,
+                           float* out /*[n_seg,128]*/, void* stream);
+/* BondUpdateLayer form: q per triplet, no e_w. */
+int dd_attn_aggregate_triplet(const float* q /*[E3,128]*/, const float* k, const float* v, const int32_t* seg_ptr, int n_seg,
+                              float* out /*[n_seg,128]*/, void* stream);
+/* PosUpdateLayer form: v16 [E,16] per head, rel_x [E,3]; out[s] = mean_heads(sum_e alpha * v16 * e_w * rel_x) [n_seg,3]. */
+int dd_attn_aggregate_pos(const float* q /*[n_seg,128]*/, const float* k, const float* v16, const float* e_w, const float* rel_x,
+                          const int32_t* seg_ptr, int n_seg, float* out /*[n_seg,3]*/, void* stream);
+
 /* Embeddings (decompdiff.py:219-256, 296-297). protein_h is step-invariant. */
 int dd_embed_protein(const float* protein_v /*[B*NP,29]*/, int rows, const float* W /*[128,29]*/, const float* b,
                      float* protein_h /*[rows,128]*/, void* stream);
