@@ -597,6 +597,47 @@ static int heads_and_step(const dd_sampler* s, hipStream_t st, const StepFold* f
   return DD_OK;
 }
 
+// One reverse step from head outputs the host computed itself (dd_reverse_step): the transitions of heads_and_step
+// without the network -- unfused launches, the step counter advanced behind them.
+static int reverse_step_from_logits(const dd_sampler* s, const float* logits_v, const float* logits_b, const float* x0, hipStream_t st) {
+  const int B = s->B, NL = s->NL;
+  const long Eb = (long)NL * (NL - 1);
+  Workspace w = carve(s->workspace, B, s->NP, NL, s->K);
+  StepRowsArgs r;
+  memset(&r, 0, sizeof(r));
+  r.logits_in = logits_v; r.rows = B * NL; r.NC = DD_NUM_V; r.rows_per_sample = NL;
+  r.tab = s->tab_v; r.T = s->T; r.t_start = s->t_start; r.step_counter = s->step_counter;
+  r.state = s->lig_v; r.uniforms = s->u_v; r.seed = s->seed; r.stream_id = 1;
+  r.logits_out = nullptr; r.traj_recon = s->traj_v0; r.traj_prob = s->traj_vt; r.traj_state = s->traj_v;
+  StepRowsArgs rb = r;
+  rb.logits_in = logits_b; rb.rows = (int)(B * Eb); rb.NC = DD_NUM_B; rb.rows_per_sample = (int)Eb; rb.tab = s->tab_b;
+  rb.state = s->lig_bond; rb.uniforms = s->u_b; rb.stream_id = 2;
+  rb.traj_recon = nullptr; rb.traj_prob = s->traj_bt; rb.traj_state = s->traj_bond;
+  const float* ga = nullptr;
+  const float* gc = nullptr;
+  if (s->drift_armsca) {
+    if (!s->decomp_index) return DD_ERR_BAD_ARG;
+    DD_TRY(launch_drift_armsca(s->lig_pos, s->decomp_index, B, NL, s->armsca_min_d, s->armsca_max_d, w.ga, 0, s->drift_norm_batch, st));
+    ga = w.ga;
+  }
+  if (s->drift_clash) {
+    if (!s->full_protein_pos || s->NF <= 0) return DD_ERR_BAD_ARG;
+    DD_TRY(dd_drift_clash(s->lig_pos, s->offset, s->full_protein_pos, B, NL, s->NF, s->clash_sigma, s->clash_gamma, w.gc, 0, st));
+    gc = w.gc;
+  }
+  StepPosArgs p;
+  memset(&p, 0, sizeof(p));
+  p.B = B; p.NL = NL; p.T = s->T; p.t_start = s->t_start; p.step_counter = s->step_counter; p.NP = s->NP;
+  p.x0 = x0; p.xt = s->lig_pos; p.tab_pos = s->tab_pos; p.tab_score = s->tab_score;
+  p.atom_std = s->atom_std; p.offset = s->offset; p.grad_a = ga; p.scale_a = s->armsca_scale; p.grad_c = gc;
+  p.scale_c = s->clash_scale; p.eps = s->eps; p.seed = s->seed; p.traj_pos = s->traj_pos;
+  DD_TRY(launch_step_rows(r, st));
+  DD_TRY(launch_step_rows(rb, st));
+  DD_TRY(launch_step_pos(p, st));
+  DD_TRY(launch_advance(s->step_counter, st));
+  return DD_OK;
+}
+
 // forward-only head evaluation: logits without sampling (state untouched)
 __global__ __launch_bounds__(256) void k_head_logits(const float* __restrict__ hid, const float* __restrict__ W2,
                                                      const float* __restrict__ b2, int rows, int NC,
@@ -731,6 +772,15 @@ static int one_step(const dd_sampler* s, hipStream_t st) {
   int rc = dd::forward_impl(s, st, &fold);
   if (rc != DD_OK) return rc;
   return dd::heads_and_step(s, st, &fold);
+}
+
+extern "C" int dd_reverse_step(const dd_sampler* s, const float* logits_v, const float* logits_b, const float* x0, void* stream) {
+  if (!s || !logits_v || !logits_b || !x0 || !s->step_counter || !s->tab_pos || !s->tab_v || !s->tab_b || !s->atom_std ||
+      !s->offset || !s->workspace)
+    return DD_ERR_BAD_ARG;
+  int rc = dd::check_shapes(s);
+  if (rc != DD_OK) return rc;
+  return dd::reverse_step_from_logits(s, logits_v, logits_b, x0, (hipStream_t)stream);
 }
 
 extern "C" int dd_sample_steps(const dd_sampler* s, int n_steps, void* stream) {

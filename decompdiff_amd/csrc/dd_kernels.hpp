@@ -90,6 +90,7 @@ int launch_xupdate(const float* x, const float* dxe, const float* dxb, int B, in
 
 struct StepRowsArgs {
   const float* hid;        // [rows,128] first Linear of the head (pre-activation incl. bias)
+  const float* logits_in;  // [rows,NC] head outputs supplied by the host instead of hid / W2 / b2 (k_step_rows only), or NULL
   const float* W2;         // [NC,128]
   const float* b2;         // [NC]
   int rows, NC, rows_per_sample;

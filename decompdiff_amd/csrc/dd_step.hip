@@ -25,14 +25,19 @@ __global__ __launch_bounds__(256) void k_step_rows(const StepRowsArgs a) {
   const int step = *a.step_counter - a.counter_bias;
   const int t = a.t_start - step;
   // ShiftedSoftplus (common.py:66-72): softplus(x) - log 2, torch threshold 20
-  float2 hv = *reinterpret_cast<const float2*>(a.hid + row * 128 + 2 * lane);
-  hv.x = (hv.x > 20.f ? hv.x : log1pf(expf(hv.x))) - 0.6931471805599453f;
-  hv.y = (hv.y > 20.f ? hv.y : log1pf(expf(hv.y))) - 0.6931471805599453f;
   float logit[NC];
+  if (a.logits_in != nullptr) {                          // dd_reverse_step: the host supplies the head outputs
 #pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const float2 w = *reinterpret_cast<const float2*>(a.W2 + c * 128 + 2 * lane);
-    logit[c] = wave_sum(fmaf(hv.y, w.y, hv.x * w.x)) + a.b2[c];
+    for (int c = 0; c < NC; ++c) logit[c] = a.logits_in[row * NC + c];
+  } else {
+    float2 hv = *reinterpret_cast<const float2*>(a.hid + row * 128 + 2 * lane);
+    hv.x = (hv.x > 20.f ? hv.x : log1pf(expf(hv.x))) - 0.6931471805599453f;
+    hv.y = (hv.y > 20.f ? hv.y : log1pf(expf(hv.y))) - 0.6931471805599453f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const float2 w = *reinterpret_cast<const float2*>(a.W2 + c * 128 + 2 * lane);
+      logit[c] = wave_sum(fmaf(hv.y, w.y, hv.x * w.x)) + a.b2[c];
+    }
   }
   if (lane != 0) return;
   // log_softmax

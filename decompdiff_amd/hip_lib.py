@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = [
     "dd_graph_create", "dd_graph_launch", "dd_graph_destroy",
     "dd_drift_armsca",
     "dd_drift_clash", "dd_workspace_view", "dd_profile_step", "dd_debug_set_clock_buffer", "dd_debug_set_fusion", "dd_debug_set_option", "dd_debug_node_split",
-    "dd_attn_aggregate_node", "dd_attn_aggregate_triplet", "dd_attn_aggregate_pos",
+    "dd_attn_aggregate_node", "dd_attn_aggregate_triplet", "dd_attn_aggregate_pos", "dd_reverse_step",
 ]
 
 
@@ -106,6 +106,7 @@ def load():
     lib.dd_debug_set_fusion.argtypes = [c_int]
     lib.dd_debug_set_option.argtypes = [c_int, c_int]
     lib.dd_debug_node_split.argtypes = [c_int, c_int, c_int, c_int]
+    lib.dd_reverse_step.argtypes = [POINTER(DDSampler), c_void_p, c_void_p, c_void_p, c_void_p]
     lib.dd_attn_aggregate_node.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.dd_attn_aggregate_triplet.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.dd_attn_aggregate_pos.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]

@@ -172,6 +172,13 @@ int dd_embed_protein(const float* protein_v /*[B*NP,29]*/, int rows, const float
  * writes s->pred_pos/pred_v/pred_bond. */
 int dd_forward(const dd_sampler* s, void* stream);
 
+/* One reverse transition from network outputs the host computed itself (decompdiff.py:601-689 without the forward):
+ * log_softmax + q_v_posterior + log_sample_categorical for atoms and bonds (logits_v [B*NL,8], logits_b [B*Eb,5]),
+ * C0 posterior mean from x0 [B*NL,3] (centred), drift, noise; updates s->lig_pos / lig_v / lig_bond, writes the
+ * trajectories at the current step index and advances s->step_counter -- exactly what a step of dd_sample_steps does
+ * after its forward (bit-identical when fed dd_forward's pred_*). */
+int dd_reverse_step(const dd_sampler* s, const float* logits_v, const float* logits_b, const float* x0, void* stream);
+
 /* n_steps iterations of the reverse loop (decompdiff.py:575-689): forward, categorical
  * posteriors + Gumbel-argmax, Gaussian posterior mean, optional drift, noise, trajectories. */
 int dd_sample_steps(const dd_sampler* s, int n_steps, void* stream);

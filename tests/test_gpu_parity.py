@@ -472,6 +472,37 @@ def test_step_fold_bit_identical():
             assert torch.equal(torch.stack(ref[k]), torch.stack(o[k])), (key, k)
 
 
+def test_reverse_step_op_equals_the_loop():
+    """dd_reverse_step (transitions only, fed with network outputs the host holds) after dd_forward reproduces
+    dd_sample_steps bit for bit: same state, same trajectories, with drift and injected noise."""
+    lib = hip_lib.load()
+    m = model(0)
+    pocket = synth.make_pocket_small(6)
+    torch.manual_seed(8)
+    b = to_dev(synth.build_sampling_batch(pocket, 2))
+    steps = 3
+    noise = synth.draw_step_noise(steps, b["init_ligand_pos"].size(0), b["init_ligand_fc_bond_type"].size(0))
+
+    def chain():
+        return m._prepare_chain(b["protein_pos"], b["protein_v"], b["batch_protein"], b["init_ligand_pos"], b["init_ligand_v"],
+                                b["ligand_v_aux"], b["batch_ligand"], b["prior_stds"], b["ligand_decomp_batch"],
+                                b["ligand_decomp_index"], None, b["ligand_fc_bond_index"], b["init_ligand_fc_bond_type"], steps,
+                                "protein", GU.DRIFT, b["full_protein_pos"], b["full_batch_protein"], noise, 0, True, 0)
+    st = hip_lib.stream_ptr(dev())
+    a = chain()
+    hip_lib.check(lib.dd_sample_steps(ctypes.byref(a["s"]), steps, st), "dd_sample_steps")
+    c = chain()
+    for _ in range(steps):
+        hip_lib.check(lib.dd_forward(ctypes.byref(c["s"]), st), "dd_forward")
+        cb = c["bufs"]
+        hip_lib.check(lib.dd_reverse_step(ctypes.byref(c["s"]), hip_lib.ptr(cb["pred_v"]), hip_lib.ptr(cb["pred_bond"]),
+                                          hip_lib.ptr(cb["pred_pos"]), st), "dd_reverse_step")
+    torch.cuda.synchronize()
+    for k in ("lig_pos", "lig_v", "lig_bond", "traj_pos", "traj_v", "traj_bond", "traj_v0", "traj_vt", "traj_bt", "step_counter"):
+        assert torch.equal(a["bufs"][k], c["bufs"][k]), k
+    assert int(c["bufs"]["step_counter"]) == steps
+
+
 def test_philox_noise_mode_is_deterministic_and_sane():
     pocket = synth.make_pocket_small(5)
     torch.manual_seed(1)
