@@ -1,0 +1,90 @@
+"""Op-level drop-ins over the C ABI (SURVEY.md §8b "op-level boundary"): the third-party functional calls the
+reference's layers sit on, with the same argument meaning, for hosts that keep the reference's Python modules and
+swap only these ops.  Everything runs on the HIP device; CPU tensors raise (no fallback).
+
+=====================================================  ==========================================================
+reference call                                          here
+=====================================================  ==========================================================
+``torch_geometric.nn.knn_graph(x, k, batch, flow)``     :func:`knn_graph`         (uni_transformer_edge.py:353)
+``scatter_softmax(...); scatter_sum(alpha * v, ...)``   :func:`scatter_attention` (uni_transformer_edge.py:63-68,158-164)
+the same with ``v.unsqueeze(-1) * rel_x`` and ``mean``  :func:`scatter_attention_pos` (uni_transformer_edge.py:199-211)
+=====================================================  ==========================================================
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import hip_lib
+
+
+def knn_graph(x: torch.Tensor, k: int, batch: Optional[torch.Tensor] = None, loop: bool = False,
+              flow: str = "source_to_target") -> torch.Tensor:
+    """``edge_index [2,E]`` (row 0 = neighbour / source, row 1 = centre / target), grouped by centre in ascending
+    order, neighbours by ascending distance, self loops excluded, candidates restricted to the same ``batch`` id — the
+    order torch_cluster returns.  Samples must be contiguous and of equal size (PyG ``Batch`` of one pocket); a sample
+    with fewer than ``k`` other atoms contributes all of them."""
+    if flow != "source_to_target" or loop:
+        raise NotImplementedError("knn_graph: flow='source_to_target', loop=False (the reference's call)")
+    hip_lib.require_gpu(x, "x")
+    n = x.size(0)
+    if batch is None:
+        B, N = 1, n
+    else:
+        B = int(batch.max().item()) + 1
+        N = n // B
+        if n % B or not torch.equal(batch, torch.arange(B, device=x.device).repeat_interleave(N)):
+            raise NotImplementedError("knn_graph: batch must be sorted with equal counts per sample")
+    kk = min(int(k), N - 1)
+    if kk <= 0:
+        return torch.empty(2, 0, dtype=torch.long, device=x.device)
+    nbr = torch.empty(B, N, kk, dtype=torch.int32, device=x.device)
+    xc = x.detach().to(torch.float32).contiguous()
+    hip_lib.check(hip_lib.load().dd_knn(hip_lib.ptr(xc), B, N, kk, hip_lib.ptr(nbr), hip_lib.stream_ptr(x.device)), "dd_knn")
+    base = (torch.arange(B, device=x.device) * N).view(B, 1, 1)
+    src = (nbr.long() + base).reshape(-1)
+    dst = torch.arange(n, device=x.device).repeat_interleave(kk)
+    return torch.stack([src, dst], 0)
+
+
+def _seg_ptr(index: torch.Tensor, dim_size: int) -> torch.Tensor:
+    if index.numel() > 1 and bool((index[1:] < index[:-1]).any().item()):
+        raise NotImplementedError("scatter_attention: edges must be grouped by destination (sorted index), as knn_graph, "
+                                  "the dst-major bond list and the SparseTensor triplets are")
+    ptr = torch.zeros(dim_size + 1, dtype=torch.int32, device=index.device)
+    ptr[1:] = torch.bincount(index, minlength=dim_size).cumsum(0)
+    return ptr
+
+
+def scatter_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, index: torch.Tensor, dim_size: int,
+                      e_w: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``scatter_sum(scatter_softmax((q_e * k / sqrt(8)).sum(-1), index)[..., None] * (v * e_w), index, dim_size)``
+    flattened to ``[dim_size,128]`` (16 heads x 8).  ``q`` is ``[dim_size,128]`` (gathered as ``q[index]`` by the
+    reference's node / coordinate layers) or per edge ``[E,128]`` (bond layer: rows of a segment are identical)."""
+    for name, t in (("q", q), ("k", k), ("v", v)):
+        hip_lib.require_gpu(t, name)
+    E = k.size(0)
+    per_edge = q.size(0) == E and q.size(0) != dim_size
+    f = lambda t: t.detach().to(torch.float32).reshape(t.size(0), -1).contiguous()
+    out = torch.empty(dim_size, 128, device=k.device)
+    ew = None if e_w is None else e_w.detach().to(torch.float32).reshape(-1).contiguous()
+    hip_lib.check(hip_lib.load().dd_attn_aggregate_node(hip_lib.ptr(f(q)), int(per_edge), hip_lib.ptr(f(k)), hip_lib.ptr(f(v)),
+                                                        hip_lib.ptr(ew), hip_lib.ptr(_seg_ptr(index, dim_size)), dim_size,
+                                                        hip_lib.ptr(out), hip_lib.stream_ptr(k.device)), "dd_attn_aggregate_node")
+    return out
+
+
+def scatter_attention_pos(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rel_x: torch.Tensor, index: torch.Tensor,
+                          dim_size: int, e_w: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """PosUpdateLayer's aggregation: ``v`` is ``[E,16]`` (one scalar per head), ``rel_x`` ``[E,3]``; returns
+    ``scatter_sum(alpha[..., None] * (v * e_w)[..., None] * rel_x[:, None], index).mean(1)`` — ``[dim_size,3]``."""
+    for name, t in (("q", q), ("k", k), ("v", v), ("rel_x", rel_x)):
+        hip_lib.require_gpu(t, name)
+    f = lambda t: t.detach().to(torch.float32).reshape(t.size(0), -1).contiguous()
+    out = torch.empty(dim_size, 3, device=k.device)
+    ew = None if e_w is None else e_w.detach().to(torch.float32).reshape(-1).contiguous()
+    hip_lib.check(hip_lib.load().dd_attn_aggregate_pos(hip_lib.ptr(f(q)), hip_lib.ptr(f(k)), hip_lib.ptr(f(v)), hip_lib.ptr(ew),
+                                                       hip_lib.ptr(f(rel_x)), hip_lib.ptr(_seg_ptr(index, dim_size)), dim_size,
+                                                       hip_lib.ptr(out), hip_lib.stream_ptr(k.device)), "dd_attn_aggregate_pos")
+    return out

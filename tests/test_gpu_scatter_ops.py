@@ -81,3 +81,32 @@ def test_attn_aggregate_pos():
 def test_attn_aggregate_rejects_null():
     lib = hip_lib.load()
     assert lib.dd_attn_aggregate_node(None, 0, None, None, None, None, 4, None, None) != 0
+
+
+def test_functional_wrappers_match_the_reference_layer_math():
+    """decompdiff_amd.functional: knn_graph in torch_cluster's order and the two aggregation wrappers fed exactly like
+    NodeUpdateLayer / PosUpdateLayer feed torch_scatter (q gathered by dst, v pre-multiplied or not)."""
+    from decompdiff_amd import functional as F2
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    B, N, K = 3, 70, 32
+    x = torch.randn(B * N, 3, generator=g) * 4
+    batch = torch.arange(B).repeat_interleave(N)
+    want = ops.knn_graph(x, K, batch)
+    got = F2.knn_graph(x.to(dev), K, batch.to(dev)).cpu()
+    assert got.shape == want.shape and torch.equal(got, want)
+    src, dst = got
+    E = src.numel()
+    q, k, v = torch.randn(B * N, 128, generator=g), torch.randn(E, 128, generator=g), torch.randn(E, 128, generator=g)
+    ew = torch.rand(E, 1, generator=g)
+    alpha = _ref_alpha(q[dst], k, dst, B * N)
+    want_n = ops.scatter_sum(alpha.unsqueeze(-1) * (v * ew).view(-1, 16, 8).double(), dst, 0, dim_size=B * N).view(-1, 128)
+    got_n = F2.scatter_attention(q.to(dev), k.to(dev), v.to(dev), dst.to(dev), B * N, e_w=ew.to(dev)).cpu().double()
+    assert float((got_n - want_n).abs().max()) < 2e-5
+    v16 = torch.randn(E, 16, generator=g)
+    rel = x[dst] - x[src]
+    want_p = ops.scatter_sum(alpha.unsqueeze(-1) * ((v16 * ew).unsqueeze(-1) * rel.unsqueeze(1)).double(), dst, 0, dim_size=B * N).mean(1)
+    got_p = F2.scatter_attention_pos(q.to(dev), k.to(dev), v16.to(dev), rel.to(dev), dst.to(dev), B * N, e_w=ew.to(dev)).cpu().double()
+    assert float((got_p - want_p).abs().max()) < 2e-5
+    with pytest.raises(hip_lib.HipLibraryError):
+        F2.knn_graph(x, K, batch)                    # CPU tensors: no fallback
