@@ -35,9 +35,10 @@ __global__ __launch_bounds__(256) void k_attn_aggregate(const float* __restrict_
                                                         const float* __restrict__ rel_x, const int32_t* __restrict__ seg_ptr,
                                                         int n_seg, float* __restrict__ out) {
   const int lane = threadIdx.x & 63;
-  const int seg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // the segment and its edge range are wave-uniform: kept in SGPRs, so e_w / rel_x / seg_ptr become scalar loads
+  const int seg = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
   if (seg >= n_seg) return;
-  const int e0 = seg_ptr[seg], e1 = seg_ptr[seg + 1];
+  const int e0 = __builtin_amdgcn_readfirstlane(seg_ptr[seg]), e1 = __builtin_amdgcn_readfirstlane(seg_ptr[seg + 1]);
   if (e1 <= e0) {                                        // scatter_sum leaves untouched rows at zero
     if (POS) { if (lane < 3) out[(long)seg * 3 + lane] = 0.f; }
     else *reinterpret_cast<float2*>(out + (long)seg * 128 + 2 * lane) = make_float2(0.f, 0.f);
