@@ -26,11 +26,13 @@ from . import synth
 from .pocket_data import PocketData, build_batch
 
 
-def unbatch_traj(traj: List[torch.Tensor], n_data: int, cum: np.ndarray, dtype=None) -> List[np.ndarray]:
-    """reference: unbatch_v_traj (:46-53) — list over steps of [sum_n, ...] -> per sample [T, n_i, ...]"""
+def unbatch_traj(traj: List[torch.Tensor], n_data: int, cum: np.ndarray, dtype=None, stacked=None) -> List[np.ndarray]:
+    """reference: unbatch_v_traj (:46-53) — list over steps of [sum_n, ...] -> per sample [T, n_i, ...].  ``stacked``:
+    the same trajectory as one [T, sum_n, ...] CPU tensor when the model provides it (no re-stacking; the per-sample
+    arrays are then views of it)."""
     if len(traj) == 0:
         return [np.zeros((0,)) for _ in range(n_data)]
-    stacked = torch.stack([t.cpu() for t in traj]).numpy()            # [T, sum_n, ...]
+    stacked = stacked.numpy() if stacked is not None else torch.stack([t.cpu() for t in traj]).numpy()   # [T, sum_n, ...]
     if dtype is not None:
         stacked = stacked.astype(dtype)
     return [stacked[:, cum[k]:cum[k + 1]] for k in range(n_data)]
@@ -86,12 +88,13 @@ def sample_diffusion_ligand_decomp(model, pocket, num_samples: int, batch_size: 
         bond = r["bond"].cpu().numpy()
         bond_index = batch["ligand_fc_bond_index"].numpy()
         decomp = batch["ligand_decomp_index"].numpy()
-        pos_traj = unbatch_traj(r["pos_traj"], n_data, cum_atoms, np.float64)
-        v_traj = unbatch_traj(r["v_traj"], n_data, cum_atoms)
-        v0_traj = unbatch_traj(r["v0_traj"], n_data, cum_atoms)
-        vt_traj = unbatch_traj(r["vt_traj"], n_data, cum_atoms)
-        b_traj = unbatch_traj(r["bond_traj"], n_data, cum_bonds)
-        bt_traj = unbatch_traj(r["bt_traj"], n_data, cum_bonds)
+        stk = r.get("_traj_stacked") or {}
+        pos_traj = unbatch_traj(r["pos_traj"], n_data, cum_atoms, np.float64, stk.get("pos_traj"))
+        v_traj = unbatch_traj(r["v_traj"], n_data, cum_atoms, None, stk.get("v_traj"))
+        v0_traj = unbatch_traj(r["v0_traj"], n_data, cum_atoms, None, stk.get("v0_traj"))
+        vt_traj = unbatch_traj(r["vt_traj"], n_data, cum_atoms, None, stk.get("vt_traj"))
+        b_traj = unbatch_traj(r["bond_traj"], n_data, cum_bonds, None, stk.get("bond_traj"))
+        bt_traj = unbatch_traj(r["bt_traj"], n_data, cum_bonds, None, stk.get("bt_traj"))
         for k in range(n_data):
             a0, a1, b0, b1 = cum_atoms[k], cum_atoms[k + 1], cum_bonds[k], cum_bonds[k + 1]
             out["pred_pos"].append(pos[a0:a1])

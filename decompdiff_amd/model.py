@@ -273,6 +273,8 @@ class DecompScorePosNet3D(nn.Module):
                     traj[k][:, rows] = st
         for k in traj:
             out[k] = list(traj[k].unbind(0)) if traj[k] is not None else []
+        if all(v is not None for v in traj.values()):
+            out["_traj_stacked"] = dict(traj)
         return out
 
     # ------------------------------------------------------------------------------------------
@@ -678,6 +680,10 @@ class DecompScorePosNet3D(nn.Module):
             out["v0_traj"] = list(cpu["traj_v0"].unbind(0))
             out["vt_traj"] = list(cpu["traj_vt"].unbind(0))
             out["bt_traj"] = list(cpu["traj_bt"].unbind(0))
+            # the same data as [T, rows, ...] tensors (the lists above are views of them): lets the harness split per
+            # sample without stacking 6 x T tensors again
+            out["_traj_stacked"] = {"pos_traj": cpu["traj_pos"], "v_traj": cpu["traj_v"].long(), "bond_traj": cpu["traj_bond"].long(),
+                                    "v0_traj": cpu["traj_v0"], "vt_traj": cpu["traj_vt"], "bt_traj": cpu["traj_bt"]}
         else:
             for k in ("pos_traj", "v_traj", "bond_traj", "v0_traj", "vt_traj", "bt_traj"):
                 out[k] = []
