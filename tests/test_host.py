@@ -118,6 +118,19 @@ def test_no_cpu_fallback():
     src = "".join(open(os.path.join(ROOT, "decompdiff_amd", f)).read()
                   for f in os.listdir(os.path.join(ROOT, "decompdiff_amd")) if f.endswith(".py"))
     assert "import oracle" not in src and "from oracle" not in src
+    # the op-level wrappers refuse CPU tensors too
+    from decompdiff_amd import functional as F2
+    x = torch.randn(10, 3)
+    with pytest.raises(hip_lib.HipLibraryError):
+        F2.knn_graph(x, 4)
+    with pytest.raises(hip_lib.HipLibraryError):
+        F2.scatter_attention(torch.randn(2, 128), torch.randn(4, 128), torch.randn(4, 128), torch.tensor([0, 0, 1, 1]), 2)
+    # null / bad arguments are status codes, not crashes (host-side checks: no GPU needed)
+    lib = hip_lib.load()
+    assert lib.dd_graph_launch(None, 1, None) != 0 and lib.dd_graph_destroy(None) != 0
+    assert lib.dd_sample_steps_graph_multi(None, 0, 1, None) != 0
+    assert lib.dd_reverse_step(None, None, None, None, None) != 0
+    assert lib.dd_debug_node_split(8, 300, 30, 32) == -1          # nothing measured in this process
 
 
 def test_harness_batch_builder_layout():
