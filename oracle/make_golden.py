@@ -286,6 +286,8 @@ def main():
         gen_traj(ref_p, sd, cfg, "traj12_priortypes", synth.make_pocket_small(4), 2, 12, DRIFT, 2024, priors=priors)
     if want("ragged"):
         gen_traj_ragged(ref, sd, cfg, "traj10_ragged", 10, DRIFT, 2023)
+    if want("traj1000_drift") and not args.skip_long:
+        gen_traj(ref, sd, cfg, "traj1000_drift", synth.make_pocket_small(5), 1, 1000, DRIFT, 2025, every=50)
     if want("traj1000") and not args.skip_long:
         gen_traj(ref, sd, cfg, "traj1000_plain", synth.make_pocket_small(3), 1, 1000, None, 2021, every=50)
 

@@ -286,7 +286,7 @@ def _traj_inputs(name, std_scale=None):
     g = GU.load(name)
     b = GU.batch_from_npz(g)
     n_data = int(b["batch_ligand"].max()) + 1
-    seedpocket = {"traj20_plain": 2, "traj20_drift": 2, "traj1000_plain": 3, "traj12_priortypes": 4}[name]
+    seedpocket = {"traj20_plain": 2, "traj20_drift": 2, "traj1000_plain": 3, "traj12_priortypes": 4, "traj1000_drift": 5}[name]
     torch.manual_seed(int(g["seed"]))
     synth.build_sampling_batch(synth.make_pocket_small(seedpocket), n_data, per_sample_std_scale=std_scale)
     noise = synth.draw_step_noise(int(g["num_steps"]), b["init_ligand_pos"].size(0), b["init_ligand_fc_bond_type"].size(0))
@@ -328,11 +328,13 @@ def test_trajectory_prior_types_golden():
     assert diff > 0
 
 
-def test_trajectory_1000_steps_golden():
+@pytest.mark.parametrize("name", ["traj1000_plain", "traj1000_drift"])
+def test_trajectory_1000_steps_golden(name):
     """The headline parity claim: a full 1000-step chain on injected reference noise stays within
-    1e-4 on coordinates with identical discrete types at every stored checkpoint."""
-    g, b, noise = _traj_inputs("traj1000_plain")
-    r = _sample_hip(model(0), b, 1000, None, noise)
+    1e-4 on coordinates with identical discrete types at every stored checkpoint — without and with the shipped
+    drift guidance (armsca_prox + clash, configs/sampling_drift.yml)."""
+    g, b, noise = _traj_inputs(name)
+    r = _sample_hip(model(0), b, 1000, json.loads(str(g["drift"])), noise)
     every = int(g["every"])
     tp = torch.stack(r["pos_traj"]).numpy()[every - 1::every]
     tv = torch.stack(r["v_traj"]).numpy()[every - 1::every]
@@ -340,7 +342,7 @@ def test_trajectory_1000_steps_golden():
     err = np.abs(tp.astype(np.float64) - g["traj_pos"]).reshape(len(tp), -1).max(1)
     mv = (tv != g["traj_v"]).reshape(len(tv), -1).sum(1)
     mb = (tb != g["traj_bond"]).reshape(len(tb), -1).sum(1)
-    print("1000-step chain, checkpoints every 50 steps")
+    print(f"1000-step chain ({name}), checkpoints every 50 steps")
     print("  max |pos - golden| :", " ".join(f"{e:.2g}" for e in err))
     print("  atom-type mismatches:", mv.tolist())
     print("  bond-type mismatches:", mb.tolist())

@@ -3,6 +3,7 @@
 import json
 
 import numpy as np
+import pytest
 import torch
 
 import golden_utils as GU
@@ -106,7 +107,8 @@ def _replay_traj(name, num_steps, std_scale=None):
 
 def _pocket_for(name):
     return {"traj20_plain": synth.make_pocket_small(2), "traj20_drift": synth.make_pocket_small(2),
-            "traj1000_plain": synth.make_pocket_small(3), "traj12_priortypes": synth.make_pocket_small(4)}[name]
+            "traj1000_plain": synth.make_pocket_small(3), "traj12_priortypes": synth.make_pocket_small(4),
+            "traj1000_drift": synth.make_pocket_small(5)}[name]
 
 
 def test_trajectory_20_steps_plain():
@@ -134,10 +136,11 @@ def test_trajectory_12_steps_prior_types():
     assert np.array_equal(g["traj_v"], torch.stack(r["v_traj"]).numpy().astype(np.int8))
 
 
-def test_trajectory_1000_first_checkpoint():
-    """The 1000-step golden stores every 50th state; replay the first 50 steps (full chain is
+@pytest.mark.parametrize("name", ["traj1000_plain", "traj1000_drift"])
+def test_trajectory_1000_first_checkpoint(name):
+    """The 1000-step goldens store every 50th state; replay the first 50 steps (the full chains are
     replayed on the GPU by tests/test_gpu_parity.py)."""
-    g, r = _replay_traj("traj1000_plain", 50)
+    g, r = _replay_traj(name, 50)
     assert np.array_equal(g["traj_pos"][0], r["pos_traj"][49].numpy())
     assert np.array_equal(g["traj_v"][0], r["v_traj"][49].numpy().astype(np.int8))
     assert np.array_equal(g["traj_bond"][0], r["bond_traj"][49].numpy().astype(np.int8))
