@@ -221,11 +221,11 @@ def test_forward_intermediates_vs_dense_spec():
 
 @pytest.mark.parametrize("np_,arms,sca,B", [(600, (15, 15), 30, 1), (40, (2, 2), 2, 3), (20, (1, 1), 1, 2), (120, (5, 0), 3, 2),
                                             (60, (6, 5), 6, 2), (60, (6, 6), 6, 2), (100, (11, 11), 11, 2), (100, (11, 11), 12, 1),
-                                            (150, (15, 15), 15, 1), (80, (21, 21), 22, 1)])
+                                            (150, (15, 15), 15, 1), (80, (21, 21), 22, 1), (30, (1,), 1, 2)])
 def test_forward_vs_oracle_other_shapes(np_, arms, sca, B):
     """C-large, tiny graphs with fewer than 32 candidates (K = N-1), NL = 3, an empty arm, and the tile boundaries of the
     segment kernels: NL = 17 / 18 (15 / 16 triplet members: one tile), 33 / 34 (last size of the 2-tile kernels / first
-    of the 4-tile ones), 45 (3 of 4 tiles used), 64 (largest supported ligand)."""
+    of the 4-tile ones), 45 (3 of 4 tiles used), 64 (largest supported ligand), and NL = 2 (bonds without any triplet)."""
     cfg, sd = GU.weights(0)
     arms = tuple(a for a in arms)
     pocket = synth.make_pocket(11, np_, arms, sca, num_full_protein=np_ + 10)
