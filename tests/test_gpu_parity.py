@@ -221,11 +221,11 @@ def test_forward_intermediates_vs_dense_spec():
 
 @pytest.mark.parametrize("np_,arms,sca,B", [(600, (15, 15), 30, 1), (40, (2, 2), 2, 3), (20, (1, 1), 1, 2), (120, (5, 0), 3, 2),
                                             (60, (6, 5), 6, 2), (60, (6, 6), 6, 2), (100, (11, 11), 11, 2), (100, (11, 11), 12, 1),
-                                            (150, (15, 15), 15, 1), (80, (21, 21), 22, 1), (30, (1,), 1, 2)])
+                                            (150, (15, 15), 15, 1), (80, (21, 21), 22, 1), (30, (1,), 1, 2), (1000, (8, 8), 8, 1)])
 def test_forward_vs_oracle_other_shapes(np_, arms, sca, B):
     """C-large, tiny graphs with fewer than 32 candidates (K = N-1), NL = 3, an empty arm, and the tile boundaries of the
     segment kernels: NL = 17 / 18 (15 / 16 triplet members: one tile), 33 / 34 (last size of the 2-tile kernels / first
-    of the 4-tile ones), 45 (3 of 4 tiles used), 64 (largest supported ligand), and NL = 2 (bonds without any triplet)."""
+    of the 4-tile ones), 45 (3 of 4 tiles used), 64 (largest supported ligand), NL = 2 (bonds without any triplet), and the largest supported graph (1000 + 24 = 1024 atoms per sample)."""
     cfg, sd = GU.weights(0)
     arms = tuple(a for a in arms)
     pocket = synth.make_pocket(11, np_, arms, sca, num_full_protein=np_ + 10)
@@ -725,6 +725,9 @@ def test_unsupported_inputs_fail_loudly():
           ligand_fc_bond_index=b["ligand_fc_bond_index"], init_ligand_fc_bond_type=b["init_ligand_fc_bond_type"])
     with pytest.raises(ValueError):
         _sample_hip(m, b, 1, [dict(type="nonsense")], None)
+    big = synth.build_sampling_batch(synth.make_pocket(1, 1001, (8, 8), 8, num_full_protein=1100), 1)     # 1025 atoms
+    with pytest.raises(NotImplementedError):
+        _sample_hip(m, big, 1, None, None)
     bad = dict(b)
     bad["init_ligand_v"] = b["init_ligand_v"].clone()
     bad["init_ligand_v"][0] = 8                       # class id out of range: AssertionError like index_to_log_onehot
