@@ -44,8 +44,15 @@ def sample_diffusion_ligand_decomp(model, pocket, num_samples: int, batch_size: 
                                    energy_drift_opt=None, per_sample_std_scale=None, noise_fn=None, seed: int = 0,
                                    use_graph: bool = True, prior_mode: str = "ref_prior", num_atoms_mode: str = "ref",
                                    arms_natoms_config=None, scaffold_natoms_config=None, natoms_sampler=None,
-                                   atom_prior_probs=None, bond_prior_probs=None) -> Dict[str, list]:
+                                   atom_prior_probs=None, bond_prior_probs=None, pool_batches: int = 1) -> Dict[str, list]:
     """Sample ``num_samples`` ligands for one pocket in batches of ``batch_size``.
+
+    ``pool_batches`` > 1 assembles that many consecutive batches exactly as the reference would (same random draws, same
+    order) and hands them to the model as ONE collated batch: in the modes whose samples differ in size the model runs
+    one dense group per distinct size, and pooling turns many groups of one or two samples into a few groups of several
+    (4 pooled batches of 16 with 12 distinct sizes: 12 groups of ~5 instead of 4 x 12 groups of ~1).  Results come back
+    in the reference's sample order; with device-generated noise the per-sample streams depend on the grouping, as the
+    reference's depend on its batching.
 
     ``pocket`` is a :class:`synth.Pocket` (synthetic, ``ref_prior``-style batches with equal sizes) or a
     :class:`pocket_data.PocketData` (the reference's ``data`` fields; every ``prior_mode`` / ``num_atoms_mode`` of
@@ -58,7 +65,11 @@ def sample_diffusion_ligand_decomp(model, pocket, num_samples: int, batch_size: 
                            "pred_bond_index", "pred_bond_type", "pred_b_traj", "pred_bt_traj", "decomp_mask")}
     time_list = []
     num_batch = int(np.ceil(num_samples / batch_size))
-    for i in range(num_batch):
+    pool_batches = max(1, int(pool_batches))
+    steps = model.num_timesteps if num_steps is None else num_steps
+
+    def build(i):
+        """batch i as the reference assembles it: (kwargs, ligand sizes, injected noise or None)"""
         n_data = batch_size if i < num_batch - 1 else num_samples - batch_size * (num_batch - 1)
         if isinstance(pocket, PocketData):
             batch, n_atoms, _ = build_batch(pocket, n_data, prior_mode=prior_mode, num_atoms_mode=num_atoms_mode,
@@ -73,9 +84,19 @@ def sample_diffusion_ligand_decomp(model, pocket, num_samples: int, batch_size: 
             batch = synth.build_sampling_batch(pocket, n_data, num_bond_classes=model.num_bond_classes,
                                                num_classes=model.num_classes, per_sample_std_scale=scale)
             n_atoms = [pocket.num_ligand_atoms] * n_data
+        noise = noise_fn(i, sum(n_atoms), sum(n * (n - 1) for n in n_atoms), steps) if noise_fn is not None else None
+        return batch, n_atoms, noise
+
+    for i in range(0, num_batch, pool_batches):
+        parts = [build(j) for j in range(i, min(num_batch, i + pool_batches))]
+        if len(parts) == 1:
+            batch, n_atoms, noise = parts[0]
+        else:                                                              # one collated batch (PyG increments re-applied)
+            batch = synth.concat_sampling_batches([p[0] for p in parts])
+            n_atoms = [n for p in parts for n in p[1]]
+            noise = None if parts[0][2] is None else {k: torch.cat([p[2][k] for p in parts], 1) for k in parts[0][2]}
+        n_data = len(n_atoms)
         n_bonds = [n * (n - 1) for n in n_atoms]
-        steps = model.num_timesteps if num_steps is None else num_steps
-        noise = noise_fn(i, sum(n_atoms), sum(n_bonds), steps) if noise_fn is not None else None
         dev_batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
         extra = dict(noise=noise, seed=seed + i, use_graph=use_graph) if _accepts_extras(model) else {}
         t1 = time.time()

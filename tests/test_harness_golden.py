@@ -64,3 +64,25 @@ def test_ragged_modes_really_are_ragged():
              for c in CASES for g in [GU.load("harness_" + c["name"])]}
     assert len(set(sizes["beta_old"])) > 1 and len(set(sizes["subpocket_prior"])) > 1 and len(set(sizes["beta_stat"])) > 1
     assert len(set(sizes["ref_prior"])) == 1
+
+
+@pytest.mark.parametrize("name", ["beta_old", "ref_prior"])
+def test_pooled_batches_give_the_same_samples(name):
+    """pool_batches > 1 collates several reference-order batches into one model call (so that the size groups of the
+    ragged modes get larger); with a model that is a function of its inputs only, every per-sample result is unchanged."""
+    case = [c for c in CASES if c["name"] == name][0]
+    outs = []
+    for pool in (1, 2):
+        torch.manual_seed(case["seed"])
+        np.random.seed(case["seed"])
+        model = GU.RecordingModel()
+        outs.append((harness.sample_diffusion_ligand_decomp(
+            model, _pocket(case), num_samples=case["num_samples"], batch_size=case["batch_size"], device="cpu", num_steps=2,
+            prior_mode=case["prior_mode"], num_atoms_mode=case["num_atoms_mode"], pool_batches=pool), len(model.calls)))
+    (a, calls_a), (b, calls_b) = outs
+    assert calls_a == 2 and calls_b == 1
+    for k in ("pred_pos", "pred_v", "pred_pos_traj", "pred_v_traj", "pred_bond_index", "pred_bond_type", "pred_b_traj",
+              "pred_bt_traj", "decomp_mask"):
+        assert len(a[k]) == len(b[k]) == case["num_samples"]
+        for x, y in zip(a[k], b[k]):
+            assert np.array_equal(np.asarray(x), np.asarray(y)), k
