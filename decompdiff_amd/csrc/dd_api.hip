@@ -711,8 +711,9 @@ bool node_split_applies(int B, int NL, int n_cu);
 }
 
 // One-off measurement per (B, NP, NL, K): how many CUs the persistent bond-layer workgroups of the fused node launch
-// keep (see launch_node_nw).  Times whole forward passes on `st` (eager, min of 3) for a coarse and then a fine set of
-// splits around the work-proportional share; ~40 forward passes, before the first graph of a shape is captured.  The passes only write the workspace and pred_*.
+// keep (see launch_node_nw).  Times whole forward passes on `st` (eager, min of 2 after a warm-up pass) for a coarse and
+// then a fine set of splits around the work-proportional share; ~21 forward passes, before the first graph of a shape
+// is captured.  The passes only write the workspace and pred_*.
 static int autotune_node_split(const dd_sampler* s, hipStream_t st) {
   static int n_cu = 0;
   if (n_cu == 0) {
@@ -729,7 +730,7 @@ static int autotune_node_split(const dd_sampler* s, hipStream_t st) {
   auto time_split = [&](int n_bl, float& best) {
     dd::g_node_split_trial = n_bl;
     best = 1e30f;
-    for (int rep = 0; rep < 4 && rc == DD_OK; ++rep) {
+    for (int rep = 0; rep < 3 && rc == DD_OK; ++rep) {
       if (hipEventRecord(e0, st) != hipSuccess) { rc = DD_ERR_HIP; break; }
       rc = dd::forward_impl(s, st);
       if (rc != DD_OK) break;
@@ -748,7 +749,7 @@ static int autotune_node_split(const dd_sampler* s, hipStream_t st) {
   const double w_bl = ((double)s->B * s->NL * (s->NL - 1) / 8.0) * (0.1 + 0.35 * tiles);
   const double w_node = (double)s->B * ((s->NP + 7) / 8 + (s->NL + 7) / 8) + (double)s->B * s->NL / 8.0;
   const int centre = (int)(n_cu * w_bl / (w_bl + w_node)) / 8 * 8;
-  const int lo = centre - 48 < n_cu / 4 ? n_cu / 4 : centre - 48, hi = centre + 32 > n_cu - 16 ? n_cu - 16 : centre + 32;
+  const int lo = centre - 32 < n_cu / 4 ? n_cu / 4 : centre - 32, hi = centre + 16 > n_cu - 16 ? n_cu - 16 : centre + 16;
   for (int n = lo; n <= hi && rc == DD_OK; n += 16) {
     time_split(n, t);
     if (t < best_t) { best_t = t; best_n = n; }
