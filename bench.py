@@ -7,8 +7,9 @@
 
 Workload (BASELINE.json configs[1]): one synthetic pocket (300 protein + 30 ligand atoms, ref_prior)
 per rank, batch of 8 samples, K steps of the 1000-step reverse chain, no drift, device Philox noise,
-all six trajectories recorded and copied to the host inside the timed region (what the reference's
-`sample_diffusion` returns).  A "step" is one denoising step of the whole batch.  Multi-GPU: every
+all six trajectories recorded and streamed to the host inside the timed region (what the reference's
+`sample_diffusion` returns); the warm-up call also pays the one-off per-shape measurement of the node-launch
+CU split.  A "step" is one denoising step of the whole batch.  Multi-GPU: every
 rank samples its own pocket (independent units, weak scaling); RCCL is used for init, the two
 barriers and one all-reduce(MAX) of the wall time.  `value` = N * K / max-over-ranks seconds.
 
@@ -16,6 +17,8 @@ The JSON line also carries
   roofline     — the dominant kernel (bond-layer triplet attention), its mean launch duration measured
                  live with HIP events on the launch stream, against the fp32 peak (157.3 TFLOP/s vector =
                  matrix on CDNA4) with the algorithmic FLOP count of DESIGN.md §kernels;
+  roofline_op_level — the HBM-bandwidth regime: the op-level scatter_softmax + scatter_sum
+                 kernel of the C ABI on q / k / v tables beyond the Infinity Cache, algorithmic bytes / HIP-event time;
   cpu_baseline — the oracle (CPU restatement of the reference, torch fp32, all host threads) timed on a
                  bounded sample of the same workload.
 """
