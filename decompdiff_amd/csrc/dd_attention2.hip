@@ -952,14 +952,16 @@ static int launch_node_nw(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs
 }
 int launch_attn2_node(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs& bl, hipStream_t st) {
   if (ne.NL > 65) return DD_ERR_UNSUPPORTED_SHAPE;
-  if (ne.NL > 33) return launch_node_nw<8, 4>(ne, nb, bl, st);    // up to 64 members per segment: 4 tiles
+  if (ne.NL > 49) return launch_node_nw<8, 4>(ne, nb, bl, st);    // up to 64 members per segment: 4 tiles
+  if (ne.NL > 33) return launch_node_nw<8, 3>(ne, nb, bl, st);    // up to 48 members: 3 tiles (fewer live registers than 4)
   return launch_node_nw<8, 2>(ne, nb, bl, st);             // (12- and 16-wave workgroups were tried: register spills)
 }
 template <int NW>
 static int launch_pos_nw(const AttnArgs& pe, const AttnArgs& pb, hipStream_t st) {
   using namespace v2;
   const int n = (pe.B * pe.NL + NW - 1) / NW;
-  if (pe.NL > 33) hipLaunchKernelGGL((k_attn2_pos<4, NW>), dim3(2 * n), dim3(NW * 64), 0, st, pe, pb, n);
+  if (pe.NL > 49) hipLaunchKernelGGL((k_attn2_pos<4, NW>), dim3(2 * n), dim3(NW * 64), 0, st, pe, pb, n);
+  else if (pe.NL > 33) hipLaunchKernelGGL((k_attn2_pos<3, NW>), dim3(2 * n), dim3(NW * 64), 0, st, pe, pb, n);
   else hipLaunchKernelGGL((k_attn2_pos<2, NW>), dim3(2 * n), dim3(NW * 64), 0, st, pe, pb, n);
   DD_CHECK_LAUNCH();
   return DD_OK;
