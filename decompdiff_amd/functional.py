@@ -69,8 +69,11 @@ def scatter_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, index: 
     f = lambda t: t.detach().to(torch.float32).reshape(t.size(0), -1).contiguous()
     out = torch.empty(dim_size, 128, device=k.device)
     ew = None if e_w is None else e_w.detach().to(torch.float32).reshape(-1).contiguous()
-    hip_lib.check(hip_lib.load().dd_attn_aggregate_node(hip_lib.ptr(f(q)), int(per_edge), hip_lib.ptr(f(k)), hip_lib.ptr(f(v)),
-                                                        hip_lib.ptr(ew), hip_lib.ptr(_seg_ptr(index, dim_size)), dim_size,
+    # converted copies are bound to locals that outlive the launch: a temporary freed before the kernel is enqueued
+    # would hand its block to the next same-size allocation (k and v would alias)
+    qf, kf, vf, seg = f(q), f(k), f(v), _seg_ptr(index, dim_size)
+    hip_lib.check(hip_lib.load().dd_attn_aggregate_node(hip_lib.ptr(qf), int(per_edge), hip_lib.ptr(kf), hip_lib.ptr(vf),
+                                                        hip_lib.ptr(ew), hip_lib.ptr(seg), dim_size,
                                                         hip_lib.ptr(out), hip_lib.stream_ptr(k.device)), "dd_attn_aggregate_node")
     return out
 
@@ -84,7 +87,8 @@ def scatter_attention_pos(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rel
     f = lambda t: t.detach().to(torch.float32).reshape(t.size(0), -1).contiguous()
     out = torch.empty(dim_size, 3, device=k.device)
     ew = None if e_w is None else e_w.detach().to(torch.float32).reshape(-1).contiguous()
-    hip_lib.check(hip_lib.load().dd_attn_aggregate_pos(hip_lib.ptr(f(q)), hip_lib.ptr(f(k)), hip_lib.ptr(f(v)), hip_lib.ptr(ew),
-                                                       hip_lib.ptr(f(rel_x)), hip_lib.ptr(_seg_ptr(index, dim_size)), dim_size,
+    qf, kf, vf, rf, seg = f(q), f(k), f(v), f(rel_x), _seg_ptr(index, dim_size)      # (alive past the launch, see above)
+    hip_lib.check(hip_lib.load().dd_attn_aggregate_pos(hip_lib.ptr(qf), hip_lib.ptr(kf), hip_lib.ptr(vf), hip_lib.ptr(ew),
+                                                       hip_lib.ptr(rf), hip_lib.ptr(seg), dim_size,
                                                        hip_lib.ptr(out), hip_lib.stream_ptr(k.device)), "dd_attn_aggregate_pos")
     return out

@@ -74,7 +74,7 @@ class DecompScorePosNet3D(nn.Module):
         self.time_emb_dim = config.time_emb_dim
         self.num_classes = num_classes
         self.num_bond_classes = getattr(config, "num_bond_classes", 1)
-        self._check_supported(config, protein_atom_feature_dim, ligand_atom_feature_dim)
+        self._check_supported(config, protein_atom_feature_dim, ligand_atom_feature_dim, num_classes)
 
         # ---- schedule tables (same keys as the reference checkpoint)
         for k, v in schedules.position_tables(config).items():
@@ -121,7 +121,7 @@ class DecompScorePosNet3D(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     @staticmethod
-    def _check_supported(config, pdim, ldim):
+    def _check_supported(config, pdim, ldim, num_classes=8):
         def need(cond, what):
             if not cond:
                 raise NotImplementedError(
@@ -141,6 +141,7 @@ class DecompScorePosNet3D(nn.Module):
         need(not config.x2h_out_fc and config.norm and config.act_fn == "relu", "x2h_out_fc=False, norm, relu")
         need(getattr(config, "num_bond_classes", 1) == 5, "num_bond_classes=5")
         need(pdim == 29 and ldim == 10, "protein/ligand feature dims 29/10")
+        need(num_classes == 8, "num_classes=8 (ligand_atom_mode 'basic'; the step kernels and buffers are 8 classes wide)")
         need(not getattr(config, "sync_twoup", False), "sync_twoup=False")
         need(config.knn <= 32, "knn<=32")
 
@@ -474,12 +475,16 @@ class DecompScorePosNet3D(nn.Module):
                          num_steps=None, center_pos_mode=None,
                          energy_drift_opt=None,
                          full_protein_pos=None, full_batch_protein=None,
-                         noise=None, seed=0, keep_traj=True, use_graph=True, _drift_norm_batch=0):
+                         noise=None, seed=None, keep_traj=True, use_graph=True, _drift_norm_batch=0):
         """Reverse diffusion (reference: models/decompdiff.py:552-703), same arguments and return
         keys.  Extra keyword-only knobs (all optional, reference call sites never pass them):
 
         * ``noise``  dict(u_v [T,B*NL,8], u_b [T,B*Eb,5], eps [T,B*NL,3]) — pre-drawn noise in the
           reference's draw order (parity mode); ``None`` -> device Philox keyed by ``seed``.
+        * ``seed``   key of the device Philox streams.  ``None`` (what the reference's script gets, it passes no
+          seed): a fresh 64-bit key is drawn from torch's global CPU generator on every call, so successive calls
+          see independent noise and ``torch.manual_seed`` / the script's ``seed_all`` govern the chain exactly as
+          they govern the reference's ``torch.randn_like`` draws (decompdiff.py:620,633,680).
         * ``keep_traj`` — record the six trajectories on the device and copy them once at the end.
         * ``use_graph`` — replay one captured hipGraph per step instead of eager launches.
         """
@@ -489,6 +494,8 @@ class DecompScorePosNet3D(nn.Module):
             raise ValueError(self.model_mean_type)
         if num_steps is None:
             num_steps = self.num_timesteps
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
         if self._is_ragged(batch_protein, batch_ligand):
             return self._sample_ragged(
                 dict(protein_pos=protein_pos, protein_v=protein_v, batch_protein=batch_protein,
