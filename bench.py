@@ -1,44 +1,52 @@
 #!/usr/bin/env python
 """bench.py — denoising steps/sec of the reverse-diffusion sampling hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 1000 --warmup 20
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {1,2,3,4}]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): one synthetic pocket (300 protein + 30 ligand atoms, ref_prior)
-per rank, batch of 8 samples, K steps of the 1000-step reverse chain, no drift, device Philox noise,
-all six trajectories recorded and streamed to the host inside the timed region (what the reference's
-`sample_diffusion` returns); the warm-up call also pays the one-off per-shape measurement of the node-launch
-CU split.  A "step" is one denoising step of the whole batch.  Multi-GPU: every
-rank samples its own pocket (independent units, weak scaling); RCCL is used for init, the two
-barriers and one all-reduce(MAX) of the wall time.  `value` = N * K / max-over-ranks seconds.
+`--gpus N` without a torchrun environment re-executes itself under torch.distributed.run with N ranks (one process per
+GPU, RCCL = backend "nccl" for init / two barriers / one all-reduce(MAX) of the wall time / one gather of per-unit
+records; no data-path collective — every (pocket, sample) chain is independent).
+
+`--config` indexes BASELINE.json `configs` (decompdiff_amd/dist.py::plan_job):
+  1 (default)  one synthetic pocket (300 protein + 30 ligand atoms, ref_prior) per rank, batch of 8 samples — the
+               configuration the metric is quoted on; weak scaling (per-GPU work fixed).
+  2            the same with armsca_prox + clash drift guidance (configs/sampling_drift.yml).
+  3            100 pockets (seeds 0..99, NP in [250,350], NL in [20,40]) x batch 16, pocket p -> rank p mod N; strong.
+  4            one C-large pocket (600 + 60 atoms), 64 samples as contiguous shards of batches of 8; strong.
+A "step" is one denoising step of one pocket batch: K steps of the 1000-step reverse chain per unit, device Philox
+noise, all six trajectories recorded and streamed to the host inside the timed region (what the reference's
+`sample_diffusion` returns).  Every unit is warmed up first (W steps: kernels, the one-off per-shape measurement of the
+node-launch CU split, graph capture).  `value` = (units x K) / max-over-ranks seconds.
 
 The JSON line also carries
-  roofline     — the dominant kernel (bond-layer triplet attention), its mean launch duration measured
-                 live with HIP events on the launch stream, against the fp32 peak (157.3 TFLOP/s vector =
-                 matrix on CDNA4) with the algorithmic FLOP count of DESIGN.md §kernels;
-  roofline_op_level — the HBM-bandwidth regime: the op-level scatter_softmax + scatter_sum
-                 kernel of the C ABI on q / k / v tables beyond the Infinity Cache, algorithmic bytes / HIP-event time;
-  cpu_baseline — the oracle (CPU restatement of the reference, torch fp32, all host threads) timed on a
-                 bounded sample of the same workload.
+  roofline          the dominant kernel of a step, the fused node-attention launch dd::v2::k_attn2_node (NE + NB + BL
+                    sub-layers, 6 launches per step): mean launch duration measured live with HIP events on the launch
+                    stream (dd_profile_step, launches serialised), against the fp32 MFMA peak with the FLOPs the matrix
+                    cores really EXECUTE (exact v_mfma_f32_16x16x4_f32 count of this launch x 2048); the algorithmic
+                    count of SURVEY.md 8d is kept under `algorithmic_tflops` and is not a utilisation;
+  roofline_gemm     the projection / query / lin_node GEMM launches of a step (tiles, FLOPs, time, fraction);
+  roofline_op_level the HBM-bandwidth regime: the op-level scatter_softmax + scatter_sum kernel of the
+                    C ABI on q / k / v tables beyond the Infinity Cache, algorithmic bytes / HIP-event time;
+  cpu_baseline      the oracle (CPU restatement of the reference, torch fp32) timed on this host on a bounded sample
+                    of the same workload (N = 1 only).
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from decompdiff_amd import DecompScorePosNet3D, hip_lib, shipped_config, synth  # noqa: E402
-from decompdiff_amd import dist as ddist  # noqa: E402
-
-FP32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 vector == matrix peak
+FP32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 vector == fp32 matrix peak
 HBM_PEAK_GBS = 8000.0
+MFMA_16x16x4_FLOP = 2048
 
 
 def parse():
@@ -46,42 +54,101 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=8, help="samples per pocket batch (BASELINE configs[1]: 8)")
-    ap.add_argument("--workload", default="small", choices=["small", "large"])
-    ap.add_argument("--drift", action="store_true", help="BASELINE configs[2]: armsca_prox + clash guidance")
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4], help="index into BASELINE.json configs")
+    ap.add_argument("--batch", type=int, default=None, help="samples per pocket batch (default: 8, config 3: 16)")
+    ap.add_argument("--pockets", type=int, default=100, help="config 3: number of pockets")
+    ap.add_argument("--num-samples", type=int, default=64, help="config 4: samples of the one pocket")
+    ap.add_argument("--workload", default="small", choices=["small", "large"], help="configs 1/2: pocket size")
+    ap.add_argument("--drift", action="store_true", help="armsca_prox + clash guidance (config 2 implies it)")
     ap.add_argument("--eager", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo lets several "
+                                                    "ranks share one GPU for testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-rooflines", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=20)
+    ap.add_argument("--cpu-warmup", type=int, default=2)
     return ap.parse_args()
 
 
-def executed_flops_bond_layer(B, NL):
-    """FLOPs the fused kernel really performs after the exact restructurings of DESIGN.md §3 (query-side folding of
-    W2k, value projection after aggregation): per member angle contraction (2 x 13x128) + scores (16x128) +
-    aggregation (16x128) MACs, per segment Q~ (128x128) + output projection (128x128) MACs."""
-    eb = NL * (NL - 1)
-    macs = eb * ((NL - 2) * (2 * 13 * 128 + 2 * 16 * 128) + 2 * 128 * 128)
-    return 2.0 * B * macs
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: launch the N ranks ourselves, same arguments."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
-def algorithmic_flops_bond_layer(B, NL):
-    """FLOPs of one bond_layer attention launch, factored count (SURVEY.md §8d / DESIGN.md):
-    per triplet, two MLPs x (13-wide angle contraction + 128x128 second Linear), 2 FLOP per MAC."""
-    e3 = NL * (NL - 1) * (NL - 2)
-    return 2.0 * B * e3 * 2 * (13 * 128 + 128 * 128)
+# ---------------------------------------------------------------------------------------------------------- FLOP counts
+def node_launch_mfma_count(nbr, B, NP, NL, K):
+    """Exact number of v_mfma_f32_16x16x4_f32 wave-instructions of one fused node launch (dd_attention2.hip): per
+    16-member tile the scores and the aggregation take 32 each; the first-Linear table contraction takes 48 per pass and
+    source kind present in the tile (kNN modes; a tile mixing protein and ligand sources runs both tables) or 24 per pass
+    (triplets: 12 merged angle codes); node_layer_with_bond has no table.  `nbr` [B,N,K] is the kNN graph of the step."""
+    N = NP + NL
+    tiles_e = (K + 15) // 16
+    kinds = 0
+    for t in range(tiles_e):
+        m = nbr[:, :, 16 * t:min(K, 16 * t + 16)]
+        has_p = (m < NP).any(-1)
+        has_l = (m >= NP).any(-1)
+        kinds += int(has_p.sum() + has_l.sum())
+    ne = 2 * 48 * kinds + 64 * B * N * tiles_e
+    nb = 64 * B * NL * ((NL - 1 + 15) // 16)
+    bl = (2 * 24 + 64) * B * NL * (NL - 1) * ((NL - 2 + 15) // 16)
+    return ne + nb + bl, {"NE": ne, "NB": nb, "BL": bl}
+
+
+def algorithmic_flops_node_launch(B, NP, NL, K):
+    """SURVEY.md 8d, factored count, of the three sub-layers one fused launch covers (per member two MLPs x (table
+    contraction + 128x128 second Linear)): what the reference's layers would execute after the exact first-Linear
+    factorisation.  The kernel does NOT execute this (DESIGN.md 3, items 2-3 fold the second Linears away)."""
+    N = NP + NL
+    e, eb, e3 = B * N * K, B * NL * (NL - 1), B * NL * (NL - 1) * (NL - 2)
+    return 2.0 * (e * 2 * (21 * 128 + 128 * 128) + eb * 2 * (128 * 128) + e3 * 2 * (13 * 128 + 128 * 128))
+
+
+def gemm_work_per_step(B, NP, NL, num_layers):
+    """(useful FLOPs, 64x64 output tiles) of the dense GEMM launches of one step (dd_api.hip forward_impl)."""
+    N, Eb = NP + NL, NL * (NL - 1)
+    per_layer = [(B * N, 640), (B * NL, 1280), (B * Eb, 640),                 # projections of the old h / h_bond
+                 (B * Eb, 128), (B * N, 128), (B * NL, 128),                  # query MLPs, second Linear
+                 (B * N, 128), (B * Eb, 256),                                 # lin_node, bond projections (coordinates)
+                 (B * N, 256), (B * NL, 1024)]                                # projections of the new h
+    heads = [(B * Eb, 128), (B * NL, 128)]
+    flops = tiles = 0
+    for rows, cols in per_layer * num_layers + heads:
+        flops += 2.0 * rows * 128 * cols
+        tiles += ((rows + 63) // 64) * ((cols + 63) // 64)
+    return flops, tiles
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn_under_torchrun(args))
+
+    import torch
+    from decompdiff_amd import DecompScorePosNet3D, hip_lib, shipped_config, synth
+    from decompdiff_amd import dist as ddist
+
     world, rank, local_rank = ddist.env_world()
     if world > 1:
         # torch CPU ops spin up every host core; with one process per GPU that starves the HIP runtime threads of the
         # other ranks (DESIGN.md 5, Trajectories) -- give each rank its share of the host
         torch.set_num_threads(max(1, min(16, (os.cpu_count() or 16) // (2 * world))))
-    distributed = ddist.init_from_env(backend="nccl")      # RCCL on ROCm; no-op for a single process
-    if not distributed:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if distributed else 0)
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        raise SystemExit("bench.py needs a HIP device (the sampling hot path has no CPU implementation)")
+    dev_index = local_rank % n_dev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    backend = args.backend or "nccl"
+    distributed = ddist.init_from_env(backend=backend, device_index=dev_index)   # RCCL on ROCm; no-op for one process
 
     cfg = shipped_config()
     model = DecompScorePosNet3D(cfg, 29, 10, 8)
@@ -90,148 +157,76 @@ def main():
     model.load_state_dict(sd, strict=True)
     model = model.to(dev)
 
-    pocket = synth.make_pocket_small(seed=rank) if args.workload == "small" else synth.make_pocket_large(seed=rank)
-    torch.manual_seed(2021 + rank)
-    batch_cpu = synth.build_sampling_batch(pocket, args.batch, per_sample_std_scale=[1.0] * args.batch)
-    batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch_cpu.items()}
-    drift = [dict(type="armsca_prox", min_d=1.2, max_d=1.9), dict(type="clash", sigma=2, gamma=4)] if args.drift else None
-    NP, NL = pocket.num_protein_atoms, pocket.num_ligand_atoms
+    units, scaling = ddist.plan_job(args.config, world, batch=args.batch, n_pockets=args.pockets,
+                                    num_samples=args.num_samples, drift=args.drift)
+    if args.workload == "large" and args.config in (1, 2):
+        units = [ddist.Unit(u.uid, u.pocket_seed, 600, (15, 15), 30, u.n_samples, u.init_seed, u.noise_seed, u.drift) for u in units]
+    DRIFT = [dict(type="armsca_prox", min_d=1.2, max_d=1.9), dict(type="clash", sigma=2, gamma=4)]
+    cpu_batches = {}
 
-    def run(n_steps, seed):
-        return model.sample_diffusion(num_steps=n_steps, center_pos_mode="protein", energy_drift_opt=drift,
-                                      seed=seed, keep_traj=True, use_graph=not args.eager, **batch)
+    def prepare(u):
+        """One unit's inputs as the reference's harness assembles them (ref_prior), resident on this rank's device."""
+        n_full = (4000 if u.num_protein >= 600 else 3000) if u.drift else 0
+        pocket = synth.make_pocket(u.pocket_seed, u.num_protein, u.arm_atoms, u.scaffold_atoms, num_full_protein=n_full)
+        torch.manual_seed(u.init_seed)
+        batch_cpu = synth.build_sampling_batch(pocket, u.n_samples, per_sample_std_scale=[1.0] * u.n_samples)
+        cpu_batches[u.uid] = batch_cpu
+        batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch_cpu.items()}
+        return batch, (DRIFT if u.drift else None)
 
-    if args.warmup > 0:
-        run(args.warmup, seed=1)
-    ddist.barrier(dev)                                     # barrier + torch.cuda.synchronize on both sides
-    t0 = time.perf_counter()
-    out = run(args.steps, seed=2)
-    ddist.barrier(dev)
-    elapsed = ddist.max_over_ranks(time.perf_counter() - t0, dev)
-    meta = ddist.gather_metadata({"rank": rank, "pocket_seed": rank, "checksum": ddist.checksum(out)})
-    assert torch.isfinite(out["pos"]).all()
-    assert len(out["pos_traj"]) == args.steps
+    def sample(state, n_steps, seed):
+        batch, drift = state
+        return model.sample_diffusion(num_steps=n_steps, center_pos_mode="protein", energy_drift_opt=drift, seed=seed,
+                                      keep_traj=True, use_graph=not args.eager, **batch)
 
-    result = None
+    job = ddist.run_job(units, args.config, rank, world, prepare, sample, args.steps, args.warmup, dev)
+    out = job["last_out"]
+    if out is not None:
+        assert torch.isfinite(out["pos"]).all()
+        assert len(out["pos_traj"]) == args.steps
+    elapsed = job["elapsed"]
+
     if rank == 0:
-        steps_per_s = world * args.steps / elapsed
-        # ---- per-kernel-class timing with HIP events on the launch stream (live, this process)
-        s, bufs = model._last
-        cats = (ctypes.c_float * len(hip_lib.PROF_CATS))()
-        # profile on a fresh short run so the step counter / trajectory indices stay in range
-        model.sample_diffusion(num_steps=1, center_pos_mode="protein", energy_drift_opt=drift, seed=3, keep_traj=False,
-                               use_graph=False, **batch)
-        s2, bufs2 = model._last
-        bufs2["step_counter"].zero_()
-        n_prof = 10
         lib = hip_lib.load()
-        lib.dd_debug_set_fusion(0)                # one launch per sub-layer so that each kernel class is timed alone
-        try:
-            hip_lib.check(lib.dd_profile_step(ctypes.byref(s2), n_prof, cats, hip_lib.stream_ptr(dev)), "dd_profile_step")
-        finally:
-            lib.dd_debug_set_fusion(1)
-        per_cat = {k: float(cats[i]) for i, k in enumerate(hip_lib.PROF_CATS)}
-        dom = max((k for k in per_cat if k.startswith("attn")), key=lambda k: per_cat[k])
-        n_layers = cfg.num_layers
-        launch_ms = per_cat["attn_BL"] / n_layers
-        flops = algorithmic_flops_bond_layer(args.batch, NL)
-        achieved = flops / (launch_ms * 1e-3) / 1e12
-        executed = executed_flops_bond_layer(args.batch, NL) / (launch_ms * 1e-3) / 1e12
-        # HBM bytes per launch of the same kernel: PMC counters cannot be collected from inside this process, so the
-        # figure comes from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json) when the workload matches
-        traffic, traffic_note = None, "no PMC profile for this workload"
-        try:
-            import json as _json
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as fh:
-                pm = _json.load(fh)
-            if pm["workload"] == {"name": args.workload, "batch": args.batch}:
-                traffic = int((pm["fetch_kib_per_launch"] + pm["write_kib_per_launch"]) * 1024)
-                traffic_note = f"FETCH_SIZE + WRITE_SIZE per launch, {pm['collected']} ({pm['source']}); {pm['note']}"
-        except (OSError, KeyError, ValueError):
-            pass
-        roofline = {"bound": "mfma", "kernel": "dd::v2::k_attn2<M_BL> (bond_layer triplet attention)", "achieved": round(achieved, 3),
-                    "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4),
-                    "traffic": traffic, "traffic_note": traffic_note, "launch_ms": round(launch_ms, 4), "executed_tflops": round(executed, 3),
-                    "executed_frac": round(executed / FP32_PEAK_TFLOPS, 4),
-                    "note": "fp32 FLOP roofline (CDNA4 fp32 vector peak == fp32 MFMA peak); achieved = algorithmic FLOPs "
-                            "(factored count of SURVEY.md 8d) / live HIP-event launch time of the bond-layer launch, measured "
-                            "with one launch per sub-layer; executed_tflops = FLOPs really performed after the exact "
-                            "restructurings (DESIGN.md 3,5); the kernel is fused, q/k/v never touch HBM",
-                    "ms_per_step_by_kernel_class": {k: round(v, 4) for k, v in per_cat.items()},
-                    "dominant_attention_class": dom}
-        # ---- HBM roofline of the op-level message-passing kernel: the stand-alone scatter_softmax +
-        #      scatter_sum op of the C ABI on k / v tables larger than the Infinity Cache, algorithmic bytes / event time
-        op_roofline = None
-        try:
-            n_seg, kk = 65536, 32
-            E = n_seg * kk
-            op_traffic = None                                    # HBM bytes per launch from the committed PMC passes
-            try:
-                import json as _json
-                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as fh:
-                    po = _json.load(fh)["op_level"]
-                if (po["n_seg"], po["edges_per_seg"]) == (n_seg, kk):
-                    op_traffic = int((po["fetch_kib_per_launch"] * po["fetch_correction"] + po["write_kib_per_launch"]) * 1024)
-            except (OSError, KeyError, ValueError):
-                pass
-            tq, tk, tv = (torch.randn(n, 128, device=dev) for n in (n_seg, E, E))
-            tw = torch.rand(E, device=dev)
-            tp = (torch.arange(n_seg + 1, device=dev, dtype=torch.int32) * kk).contiguous()
-            to = torch.empty(n_seg, 128, device=dev)
-            cur = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            call = lambda: hip_lib.check(lib.dd_attn_aggregate_node(hip_lib.ptr(tq), 0, hip_lib.ptr(tk), hip_lib.ptr(tv), hip_lib.ptr(tw),
-                                                                    hip_lib.ptr(tp), n_seg, hip_lib.ptr(to), cur), "dd_attn_aggregate_node")
-            for _ in range(3):
-                call()
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
-            for _ in range(10):
-                call()
-            ev1.record()
-            torch.cuda.synchronize()
-            sec = ev0.elapsed_time(ev1) / 10 * 1e-3
-            nbytes = 1032 * E + 1024 * n_seg
-            op_roofline = {"bound": "hbm", "kernel": "dd_attn_aggregate_node (scatter_softmax + scatter_sum, q/k/v from HBM)",
-                           "achieved": round(nbytes / sec / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                           "frac": round(nbytes / sec / 8e12, 4), "traffic": op_traffic,
-                           "note": f"{n_seg} segments x {kk} edges, {nbytes / 1e6:.0f} MB algorithmic (1032 B/edge + 1024 B/segment, "
-                                   "SURVEY.md 8d), launch time from HIP events; not on the sampling path (the fused kernels keep "
-                                   "q/k/v on chip) -- the op-level boundary of the C ABI"}
-            del tq, tk, tv, tw, tp, to
-        except Exception as exc:                                  # the headline numbers do not depend on this extra
-            op_roofline = {"error": str(exc)}
+        steps_per_s = job["unit_steps"] / elapsed
+        u0 = ddist.units_of_rank(units, args.config, 0, world)[0]
+        B, NP, NL = u0.n_samples, u0.num_protein, sum(u0.arm_atoms) + u0.scaffold_atoms
+        K = min(cfg.knn, NP + NL - 1)
+        roofline = roofline_gemm = op_roofline = None
+        if not args.no_rooflines:
+            roofline, roofline_gemm = measure_step_rooflines(torch, model, hip_lib, lib, prepare(u0), cfg, B, NP, NL, K, dev,
+                                                             args.config, args.workload)
+            op_roofline = measure_op_level_roofline(torch, hip_lib, lib, dev)
         cpu = None
-        if not args.no_cpu_baseline:
-            from oracle import diffusion as OD          # the checker, timed as the CPU baseline only
-            weights = synth.synthetic_state_dict(cfg, seed=0)
-            n_cpu = max(1, args.cpu_steps)
-            best = None
-            for nthreads in sorted({min(16, os.cpu_count()), min(64, os.cpu_count()), torch.get_num_threads()}):
-                torch.set_num_threads(nthreads)           # small-op torch CPU code does not scale to 128 threads
-                torch.manual_seed(7)
-                OD.sample_diffusion(weights, cfg, num_steps=1, energy_drift_opt=drift, keep_traj=False, **batch_cpu)
-                t1 = time.perf_counter()
-                OD.sample_diffusion(weights, cfg, num_steps=n_cpu, energy_drift_opt=drift, keep_traj=True, **batch_cpu)
-                rate = n_cpu / (time.perf_counter() - t1)
-                if best is None or rate > best[0]:
-                    best = (rate, nthreads)
-            cpu = {"value": round(best[0], 4), "unit": "denoising steps/s", "cores": best[1],
-                   "kind": "port", "sample": f"{n_cpu} steps after 1 warm-up step, same pocket batch (B={args.batch}), "
-                   f"oracle = CPU restatement of the reference (torch fp32), best of 16/64/all threads; "
-                   f"host has {os.cpu_count()} logical CPUs"}
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(torch, synth, cfg, cpu_batches[u0.uid], DRIFT if u0.drift else None, B, args.cpu_steps, args.cpu_warmup)
+        wl = {1: "configs[1]: single pocket ref_prior", 2: "configs[2]: single pocket + armsca_prox/clash drift guidance",
+              3: f"configs[3]: {len(units)} pockets (NP in [250,350], NL in [20,40])", 4: "configs[4]: C-large pocket, "
+              f"{args.num_samples} samples in shards"}[args.config]
+        if args.config in (1, 2):
+            wl += f", {NP} protein + {NL} ligand atoms, batch={B} per GPU"
+        elif args.config == 3:
+            wl += f", batch={B} each, pocket p -> rank p mod {world}"
+        else:
+            wl += f" of {B} (600 protein + 60 ligand atoms), contiguous shards over {world} rank(s)"
+        wl += ", trajectories recorded and streamed to the host"
         result = {
             "metric": "denoising steps/sec (1000-step reverse) per pocket", "value": round(steps_per_s, 3),
             "unit": "denoising steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{'configs[1]' if args.workload == 'small' else 'C-large (configs[4] size)'}: single pocket ref_prior, {NP} protein + {NL} ligand atoms, batch={args.batch} "
-                                   f"per GPU, {'drift guidance, ' if args.drift else ''}trajectories recorded and streamed to the host",
-                       "batch_per_gpu": args.batch, "sample_steps_per_s": round(steps_per_s * args.batch, 2),
-                       "parallelism": f"{world} independent pocket batches (no data-path collective)",
+            "ms_per_step": round(1e3 * elapsed / max(1, job["n_local_units"] * args.steps), 4), "higher_is_better": True,
+            "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl, "baseline_config_index": args.config, "batch_per_unit": B, "units": len(units),
+                       "sample_steps_per_s": round(steps_per_s * B, 2),
+                       "parallelism": f"{world} rank(s), independent pocket batches (no data-path collective)",
                        "launch": "eager" if args.eager else "hipGraph replay", "noise": "device Philox",
-                       "node_launch_split_cus": int(lib.dd_debug_node_split(args.batch, NP, NL, min(cfg.knn, NP + NL - 1)))},
-            "roofline": roofline, "roofline_op_level": op_roofline, "cpu_baseline": cpu, "per_rank": meta,
+                       "node_launch_split_cus": int(lib.dd_debug_node_split(B, NP, NL, K))},
+            "roofline": roofline, "roofline_gemm": roofline_gemm, "roofline_op_level": op_roofline, "cpu_baseline": cpu,
+            "per_rank": job["per_rank"], "per_unit": job["per_unit"] if len(units) <= 16 else job["per_unit"][:16],
         }
+        if len(units) > 16:
+            import hashlib
+            result["per_unit_digest"] = hashlib.sha256(json.dumps(job["per_unit"], sort_keys=True, default=str).encode()).hexdigest()[:16]
+            result["per_unit_checksum_pos_sum"] = round(sum(r["checksum"]["pos"] for r in job["per_unit"]), 6)
         if cpu:
             result["config"]["speedup_vs_cpu_baseline"] = round(steps_per_s / cpu["value"], 1)
         print(json.dumps(result), flush=True)
@@ -239,6 +234,137 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measure_step_rooflines(torch, model, hip_lib, lib, state, cfg, B, NP, NL, K, dev, config, workload):
+    """HIP-event timing of every launch class of a step (dd_profile_step: launches serialised on one stream, shipped
+    fused launch structure) and the executed-FLOP accounting of the node-attention and GEMM launches."""
+    batch, drift = state
+    model.sample_diffusion(num_steps=1, center_pos_mode="protein", energy_drift_opt=drift, seed=3, keep_traj=False,
+                           use_graph=False, **batch)
+    s2, bufs2 = model._last
+    torch.cuda.synchronize(dev)
+    view = hip_lib.DDWsView()
+    hip_lib.check(lib.dd_workspace_view(ctypes.byref(s2), ctypes.byref(view)), "dd_workspace_view")
+    ws = bufs2["workspace"]
+    off = (view.nbr - ws.data_ptr()) // 4
+    nbr = ws[off:off + B * (NP + NL) * K].view(torch.int32).view(B, NP + NL, K).cpu()
+    n_mfma, by_mode = node_launch_mfma_count(nbr, B, NP, NL, K)
+    bufs2["step_counter"].zero_()
+    n_prof = 10
+    cats = (ctypes.c_float * len(hip_lib.PROF_CATS))()
+    hip_lib.check(lib.dd_profile_step(ctypes.byref(s2), n_prof, cats, hip_lib.stream_ptr(dev)), "dd_profile_step")
+    per_cat = {k: float(cats[i]) for i, k in enumerate(hip_lib.PROF_CATS)}
+    L = cfg.num_layers
+    launch_ms = per_cat["attn_BL"] / L                    # fused mode: the NE + NB + BL launch is recorded under attn_BL
+    executed = n_mfma * MFMA_16x16x4_FLOP
+    achieved = executed / (launch_ms * 1e-3) / 1e12
+    algorithmic = algorithmic_flops_node_launch(B, NP, NL, K) / (launch_ms * 1e-3) / 1e12
+    traffic, traffic_note = None, "no PMC profile for this workload"
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            pm = json.load(fh)
+        key = f"config{config}_{workload}_B{B}"
+        ent = pm.get("node_launch", {}).get(key)
+        if ent:
+            traffic = int((ent["fetch_kib_per_launch"] + ent["write_kib_per_launch"]) * 1024)
+            traffic_note = ent["note"]
+    except (OSError, KeyError, ValueError):
+        pass
+    roofline = {
+        "bound": "mfma", "kernel": "dd::v2::k_attn2_node (fused node_layer_with_edge + node_layer_with_bond + bond_layer launch, "
+                                   f"{L} per step)",
+        "achieved": round(achieved, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4),
+        "traffic": traffic, "traffic_note": traffic_note, "launch_ms": round(launch_ms, 4),
+        "mfma_instructions_per_launch": n_mfma, "mfma_instructions_by_sublayer": by_mode,
+        "algorithmic_tflops": round(algorithmic, 2),
+        "note": "achieved = FLOPs EXECUTED on the matrix cores (exact count of v_mfma_f32_16x16x4_f32 wave-instructions of this "
+                "launch from the step's kNN graph x 2048; cross-checked against SQ_INSTS_VALU_MFMA_MOPS/SQ_INSTS_MFMA in "
+                "profiles/) / mean duration of the shipped fused launch from HIP events on its stream; VALU work (LayerNorm, "
+                "softmax, query fold, epilogue) is not counted.  algorithmic_tflops = SURVEY.md 8d factored FLOPs of the same "
+                "three sub-layers / the same time: work the exact restructurings of DESIGN.md 3 remove, not a utilisation.  "
+                "The kernel is fused: q / k / v never touch HBM, so it is priced against the fp32 MFMA peak, not HBM.",
+        "ms_per_step_by_launch_class": {k: round(v, 4) for k, v in per_cat.items()},
+    }
+    g_flops, g_tiles = gemm_work_per_step(B, NP, NL, L)
+    g_ms = per_cat["gemm"]
+    roofline_gemm = {"bound": "mfma", "kernel": "dd::k_gemm128_batch (projection / query / lin_node / head GEMMs, serialised)",
+                     "flops_per_step": g_flops, "tiles_64x64_per_step": g_tiles, "ms_per_step": round(g_ms, 4),
+                     "achieved": round(g_flops / (g_ms * 1e-3) / 1e12, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(g_flops / (g_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                     "note": "useful FLOPs (2 x rows x 128 x cols) of every GEMM launch of a step / their summed HIP-event "
+                             "durations with the launches serialised (in the step graph half of them overlap on a second stream)"}
+    return roofline, roofline_gemm
+
+
+def measure_op_level_roofline(torch, hip_lib, lib, dev):
+    """HBM roofline of the op-level message-passing kernel: the stand-alone scatter_softmax +
+    scatter_sum op of the C ABI on k / v tables larger than the Infinity Cache, algorithmic bytes / event time."""
+    try:
+        n_seg, kk = 65536, 32
+        E = n_seg * kk
+        op_traffic = None                                    # HBM bytes per launch from the committed PMC passes
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+                po = json.load(fh)["op_level"]
+            if (po["n_seg"], po["edges_per_seg"]) == (n_seg, kk):
+                op_traffic = int((po["fetch_kib_per_launch"] * po["fetch_correction"] + po["write_kib_per_launch"]) * 1024)
+        except (OSError, KeyError, ValueError):
+            pass
+        tq, tk, tv = (torch.randn(n, 128, device=dev) for n in (n_seg, E, E))
+        tw = torch.rand(E, device=dev)
+        tp = (torch.arange(n_seg + 1, device=dev, dtype=torch.int32) * kk).contiguous()
+        to = torch.empty(n_seg, 128, device=dev)
+        cur = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        call = lambda: hip_lib.check(lib.dd_attn_aggregate_node(hip_lib.ptr(tq), 0, hip_lib.ptr(tk), hip_lib.ptr(tv), hip_lib.ptr(tw),
+                                                                hip_lib.ptr(tp), n_seg, hip_lib.ptr(to), cur), "dd_attn_aggregate_node")
+        for _ in range(3):
+            call()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(10):
+            call()
+        ev1.record()
+        torch.cuda.synchronize()
+        sec = ev0.elapsed_time(ev1) / 10 * 1e-3
+        nbytes = 1032 * E + 1024 * n_seg
+        return {"bound": "hbm", "kernel": "dd_attn_aggregate_node (scatter_softmax + scatter_sum, q/k/v from HBM)",
+                "achieved": round(nbytes / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(nbytes / sec / (HBM_PEAK_GBS * 1e9), 4), "traffic": op_traffic,
+                "note": f"{n_seg} segments x {kk} edges, {nbytes / 1e6:.0f} MB algorithmic (1032 B/edge + 1024 B/segment, "
+                        "SURVEY.md 8d), launch time from HIP events; not on the sampling path (the fused kernels keep "
+                        "q/k/v on chip) -- the op-level boundary of the C ABI"}
+    except Exception as exc:                                  # the headline numbers do not depend on this extra
+        return {"error": str(exc)}
+
+
+def cpu_baseline(torch, synth, cfg, batch_cpu, drift, B, n_cpu, n_warm):
+    """The oracle (the checker; CPU restatement of the reference) timed as the CPU baseline on this host: `n_cpu` steps
+    after `n_warm` warm-up steps of the same pocket batch.  Small-op torch CPU code does not scale to 100+ threads, so
+    the thread count is picked by a one-step probe of 16 / 64 / all threads first."""
+    from oracle import diffusion as OD
+    weights = synth.synthetic_state_dict(cfg, seed=0)
+    n_cpu, n_warm = max(1, n_cpu), max(1, n_warm)
+    ncpu = os.cpu_count() or 1
+    probe = {}
+    for nthreads in sorted({min(16, ncpu), min(64, ncpu), torch.get_num_threads()}):
+        torch.set_num_threads(nthreads)
+        torch.manual_seed(7)
+        OD.sample_diffusion(weights, cfg, num_steps=1, energy_drift_opt=drift, keep_traj=False, **batch_cpu)
+        t1 = time.perf_counter()
+        OD.sample_diffusion(weights, cfg, num_steps=1, energy_drift_opt=drift, keep_traj=False, **batch_cpu)
+        probe[nthreads] = time.perf_counter() - t1
+    best = min(probe, key=probe.get)
+    torch.set_num_threads(best)
+    torch.manual_seed(7)
+    OD.sample_diffusion(weights, cfg, num_steps=n_warm, energy_drift_opt=drift, keep_traj=False, **batch_cpu)
+    t1 = time.perf_counter()
+    OD.sample_diffusion(weights, cfg, num_steps=n_cpu, energy_drift_opt=drift, keep_traj=True, **batch_cpu)
+    rate = n_cpu / (time.perf_counter() - t1)
+    return {"value": round(rate, 4), "unit": "denoising steps/s", "cores": best, "kind": "port",
+            "sample": f"{n_cpu} steps after {n_warm} warm-up steps of the same pocket batch (B={B}); oracle = CPU restatement of "
+                      f"the reference (torch fp32); threads chosen by a 1-step probe of {sorted(probe)} "
+                      f"({', '.join(f'{k}: {v:.2f} s/step' for k, v in sorted(probe.items()))}); host has {ncpu} logical CPUs"}
 
 
 if __name__ == "__main__":

@@ -36,17 +36,21 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, exact: bool = False) -> str:
+    """``exact``: the -DDD_EXACT_MATH=1 variant (correctly rounded 1/sqrt and softmax division instead of v_rsq_f32 and
+    one reciprocal per head) as lib/libdecompdiff_hip_exact.so -- a measurement aid for the parity study of DESIGN.md
+    section 2, selected at run time with DD_HIP_LIB; the default library is unaffected."""
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs, jobs = [], []
+    lib = LIB.replace(".so", "_exact.so") if exact else LIB
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        o = os.path.join(LIBDIR, src.replace(".hip", "_exact.o" if exact else ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([hipcc] + FLAGS + (["-DDD_EXACT_MATH=1"] if exact else []) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -56,10 +60,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError(f"hipcc failed:\n{r.stdout}\n{r.stderr}")
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB])
-    return LIB
+    if force or jobs or _stale(lib, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib])
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, exact="--exact" in sys.argv))

@@ -102,7 +102,7 @@ __device__ __forceinline__ void ln_relu32(float (&P)[32], const float* __restric
   float v = 0.f;
 #pragma unroll
   for (int k = 0; k < 32; ++k) { P[k] -= mean; v = fmaf(P[k], P[k], v); }
-  const float rstd = __builtin_amdgcn_rsqf(quad_sum(v) * (1.0f / 128.0f) + 1e-5f);
+  const float rstd = dd_rsqrt(quad_sum(v) * (1.0f / 128.0f) + 1e-5f);
 #pragma unroll
   for (int nt = 0; nt < 8; ++nt) {
     const float4 g = *reinterpret_cast<const float4*>(ln + 16 * nt + 4 * cg);
@@ -148,7 +148,7 @@ __device__ __forceinline__ void ln_relu_T(float (&Tz)[32], const float* __restri
     float v = 0.f;
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) { Tz[4 * nt + r] -= mean; v = fmaf(Tz[4 * nt + r], Tz[4 * nt + r], v); }
-    const float rstd = __builtin_amdgcn_rsqf(row16_sum(v) * (1.0f / 128.0f) + 1e-5f);
+    const float rstd = dd_rsqrt(row16_sum(v) * (1.0f / 128.0f) + 1e-5f);
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) Tz[4 * nt + r] = fmaxf(fmaf(Tz[4 * nt + r] * rstd, g[nt], be[nt]), 0.f);
   }
@@ -180,7 +180,7 @@ __device__ __forceinline__ void sincos_small(float x, float& sn, float& cs) {
 __device__ __forceinline__ void angle_codes(float n /*|a x b|*/, float dt /*a.b*/, int cg, float (&out)[3]) {
   const float th = atan2f(n, dt);
   const float n2 = fmaf(n, n, dt * dt);
-  const float r = n2 > 0.f ? __builtin_amdgcn_rsqf(n2) : 0.f;
+  const float r = n2 > 0.f ? dd_rsqrt(n2) : 0.f;
   const float s1 = n * r, c1 = n2 > 0.f ? dt * r : 1.0f;
   const float s2 = 2.0f * s1 * c1, c2 = fmaf(c1, c1, -s1 * s1);
   const float s3 = fmaf(s2, c1, c2 * s1), c3 = fmaf(c2, c1, -s2 * s1);
@@ -667,7 +667,11 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
         const int m = 16 * t + 4 * cg + r;
         float w = 1.0f;
         if (KNN) w = ewm[t][r];
+#if defined(DD_EXACT_MATH) && DD_EXACT_MATH
+        const float aw = (m < M) ? (S[t][r] / sum) * w : 0.f;        // scatter_softmax divides per member
+#else
         const float aw = (m < M) ? (S[t][r] * rsum) * w : 0.f;
+#endif
         S[t][r] = aw;
         ssum += aw;
       }

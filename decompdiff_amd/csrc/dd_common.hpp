@@ -21,6 +21,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// 1/sqrt(x) of the LayerNorms and the angle normalisation.  Default: v_rsq_f32 (1 ulp).  -DDD_EXACT_MATH=1 builds the
+// correctly rounded sqrt + division (and a per-member softmax division) instead:
+// `python -m decompdiff_amd.build --exact` -> lib/libdecompdiff_hip_exact.so, selected with DD_HIP_LIB.
+__device__ __forceinline__ float dd_rsqrt(float x) {
+#if defined(DD_EXACT_MATH) && DD_EXACT_MATH
+  return 1.0f / sqrtf(x);
+#else
+  return __builtin_amdgcn_rsqf(x);
+#endif
+}
+
 // ---- cross-lane primitives on the VALU (DPP + v_permlane{16,32}_swap): no LDS round trips ------------
 // DPP controls: quad_perm[1,0,3,2]=0xB1 (lane^1), quad_perm[2,3,0,1]=0x4E (lane^2), row_half_mirror=0x141
 // (i -> 7-i within 8 lanes), row_mirror=0x140 (i -> 15-i within 16), row_ror:8=0x128 (lane^8).
@@ -92,7 +103,7 @@ __device__ __forceinline__ void ln_relu2(float& a, float& b, float g0, float g1,
   float mean = wave_sum(a + b) * (1.0f / 128.0f);
   float da = a - mean, db = b - mean;
   float var = wave_sum(da * da + db * db) * (1.0f / 128.0f);
-  float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);   // v_rsq_f32, 1 ulp
+  float rstd = dd_rsqrt(var + 1e-5f);   // v_rsq_f32, 1 ulp
   a = fmaxf(da * rstd * g0 + be0, 0.f);
   b = fmaxf(db * rstd * g1 + be1, 0.f);
 }

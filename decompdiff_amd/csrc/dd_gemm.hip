@@ -111,7 +111,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int bx, const
         const float mean = half_sum((xv[k].x + xv[k].y) + (xv[k].z + xv[k].w)) * (1.0f / 128.0f);
         const float dx = xv[k].x - mean, dy = xv[k].y - mean, dz = xv[k].z - mean, dw = xv[k].w - mean;
         const float var = half_sum(fmaf(dx, dx, dy * dy) + fmaf(dz, dz, dw * dw)) * (1.0f / 128.0f);
-        const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
+        const float rstd = dd_rsqrt(var + 1e-5f);
         xv[k].x = fmaxf(fmaf(dx * rstd, gm.x, bt.x), 0.f);
         xv[k].y = fmaxf(fmaf(dy * rstd, gm.y, bt.y), 0.f);
         xv[k].z = fmaxf(fmaf(dz * rstd, gm.z, bt.z), 0.f);
@@ -251,7 +251,7 @@ __device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx
         q = fmaf(d0, d0, d1 * d1) + fmaf(d2, d2, d3 * d3); }
       { const float d0 = x1[k].x - mean, d1 = x1[k].y - mean, d2 = x1[k].z - mean, d3 = x1[k].w - mean;
         q += fmaf(d0, d0, d1 * d1) + fmaf(d2, d2, d3 * d3); }
-      const float rstd = __builtin_amdgcn_rsqf(row_sum(q) * (1.0f / 128.0f) + 1e-5f);
+      const float rstd = dd_rsqrt(row_sum(q) * (1.0f / 128.0f) + 1e-5f);
       norm4(xv[k], mean, rstd, g0, b0);
       norm4(x1[k], mean, rstd, g1, b1);
     }
@@ -409,7 +409,7 @@ __device__ __forceinline__ void mlp2_tile(const Mlp2Job& j, const int tile, floa
       const float mean = half_sum((a0.x + a0.y) + (a1.x + a1.y)) * (1.0f / 128.0f);
       const float dx = a0.x - mean, dy = a0.y - mean, dz = a1.x - mean, dw = a1.y - mean;
       const float var = half_sum(fmaf(dx, dx, dy * dy) + fmaf(dz, dz, dw * dw)) * (1.0f / 128.0f);
-      const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
+      const float rstd = dd_rsqrt(var + 1e-5f);
       p[0] = make_float2(fmaxf(fmaf(dx * rstd, gm.x, bt.x), 0.f), fmaxf(fmaf(dy * rstd, gm.y, bt.y), 0.f));
       p[1] = make_float2(fmaxf(fmaf(dz * rstd, gm.z, bt.z), 0.f), fmaxf(fmaf(dw * rstd, gm.w, bt.w), 0.f));
     }
@@ -504,7 +504,7 @@ __device__ __forceinline__ void gemm_tile128(const GemmArgs& a, const int bx, co
       const float var = half_sum(fmaf(dx, dx, dy * dy) + fmaf(dz, dz, dw * dw)) * (1.0f / 128.0f);
       if ((tid & 31) == 0) {
         stats[2 * ((tid >> 5) + 8 * k)] = mean;
-        stats[2 * ((tid >> 5) + 8 * k) + 1] = __builtin_amdgcn_rsqf(var + 1e-5f);
+        stats[2 * ((tid >> 5) + 8 * k) + 1] = dd_rsqrt(var + 1e-5f);
       }
     }
     __syncthreads();

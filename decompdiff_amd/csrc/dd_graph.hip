@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void k_edge_weights2(const float* __restrict__
     for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) { acc[nt][r] -= mean; var = fmaf(acc[nt][r], acc[nt][r], var); }
-    const float rstd = __builtin_amdgcn_rsqf(quad(var) * (1.0f / 128.0f) + 1e-5f);
+    const float rstd = dd_rsqrt(quad(var) * (1.0f / 128.0f) + 1e-5f);
     float dot = 0.f;
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) {

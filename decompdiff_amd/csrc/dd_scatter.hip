@@ -91,6 +91,71 @@ __global__ __launch_bounds__(256) void k_attn_aggregate(const float* __restrict_
   }
 }
 
+
+// ---- stand-alone torch_scatter drop-ins: scatter_sum / scatter_mean / scatter_min / scatter_max and
+// scatter_softmax over dim 0 of a [E, F] fp32 tensor whose rows are grouped by destination (CSR segments).  Call sites in
+// the reference: scatter_softmax / scatter_sum in the three attention layers (uni_transformer_edge.py:64,68,160,164,205,209),
+// scatter_mean in center_pos (decompdiff.py:25), scatter_min in the arm-scaffold drift (guidance_funcs.py:52).
+// One wavefront per (segment, 64-feature chunk).  F <= 32: the wave also splits the segment's rows over 64 / Fp lane
+// groups (Fp = F rounded up to a power of two), combined at the end in a fixed butterfly order -> deterministic.
+enum { OP_SUM = 0, OP_MEAN = 1, OP_MIN = 2, OP_MAX = 3 };
+
+__device__ __forceinline__ int seg_fp(int F) { int p = 1; while (p < F && p < 64) p <<= 1; return p; }
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_segment_reduce(const float* __restrict__ src, const int32_t* __restrict__ seg_ptr, int n_seg,
+                                                        int F, int n_chunk, float* __restrict__ out, int64_t* __restrict__ arg_out,
+                                                        long E) {
+  const int lane = threadIdx.x & 63;
+  const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= (long)n_seg * n_chunk) return;
+  const int seg = (int)(w / n_chunk), chunk = (int)(w % n_chunk);
+  const int e0 = seg_ptr[seg], e1 = seg_ptr[seg + 1];
+  const int Fp = seg_fp(F), G = 64 / Fp;
+  const int f = chunk * 64 + (lane & (Fp - 1)), g = lane / Fp;
+  const bool fv = f < F;
+  float acc = OP == OP_MIN ? INFINITY : (OP == OP_MAX ? -INFINITY : 0.f);
+  long arg = E;
+  for (int e = e0 + g; e < e1; e += G) {
+    const float v = fv ? src[(long)e * F + f] : 0.f;
+    if (OP == OP_MIN) { if (v < acc) { acc = v; arg = e; } }
+    else if (OP == OP_MAX) { if (v > acc) { acc = v; arg = e; } }
+    else acc += v;
+  }
+  for (int off = Fp; off < 64; off <<= 1) {              // combine the lane groups (ties: the smaller row index wins)
+    const float o = __shfl_xor(acc, off);
+    const long oa = __shfl_xor(arg, off);
+    if (OP == OP_MIN) { if (o < acc || (o == acc && oa < arg)) { acc = o; arg = oa; } }
+    else if (OP == OP_MAX) { if (o > acc || (o == acc && oa < arg)) { acc = o; arg = oa; } }
+    else acc += o;
+  }
+  if (!fv || g != 0) return;
+  if (e1 <= e0) { acc = 0.f; arg = E; }                  // torch_scatter: untouched rows are 0, their arg = src.size(dim)
+  if (OP == OP_MEAN && e1 > e0) acc /= (float)(e1 - e0);
+  out[(long)seg * F + f] = acc;
+  if ((OP == OP_MIN || OP == OP_MAX) && arg_out) arg_out[(long)seg * F + f] = arg;
+}
+
+__global__ __launch_bounds__(256) void k_segment_softmax(const float* __restrict__ src, const int32_t* __restrict__ seg_ptr, int n_seg,
+                                                         int F, int n_chunk, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= (long)n_seg * n_chunk) return;
+  const int seg = (int)(w / n_chunk), chunk = (int)(w % n_chunk);
+  const int e0 = seg_ptr[seg], e1 = seg_ptr[seg + 1];
+  const int Fp = seg_fp(F), G = 64 / Fp;
+  const int f = chunk * 64 + (lane & (Fp - 1)), g = lane / Fp;
+  const bool fv = f < F;
+  float mx = -INFINITY;
+  for (int e = e0 + g; e < e1; e += G) mx = fmaxf(mx, fv ? src[(long)e * F + f] : 0.f);
+  for (int off = Fp; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  float sum = 0.f;
+  for (int e = e0 + g; e < e1; e += G) sum += fv ? expf(src[(long)e * F + f] - mx) : 0.f;
+  for (int off = Fp; off < 64; off <<= 1) sum += __shfl_xor(sum, off);
+  if (!fv) return;
+  for (int e = e0 + g; e < e1; e += G) out[(long)e * F + f] = expf(src[(long)e * F + f] - mx) / sum;
+}
+
 }  // namespace
 
 }  // namespace dd
@@ -116,6 +181,34 @@ extern "C" int dd_attn_aggregate_pos(const float* q, const float* k, const float
   if (n_seg == 0) return DD_OK;
   hipLaunchKernelGGL(dd::k_attn_aggregate<true>, dim3((n_seg + 3) / 4), dim3(256), 0, (hipStream_t)stream, q, 0, k, v16, e_w, rel_x,
                      seg_ptr, n_seg, out);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
+extern "C" int dd_segment_reduce(const float* src, const int32_t* seg_ptr, int n_seg, int F, int op, long E, float* out,
+                                 int64_t* arg_out, void* stream) {
+  if (!seg_ptr || !out || n_seg < 0 || F <= 0 || E < 0 || (E > 0 && !src) || op < 0 || op > 3) return DD_ERR_BAD_ARG;
+  if (n_seg == 0) return DD_OK;
+  const int n_chunk = (F + 63) / 64;
+  const dim3 grid((unsigned)(((long)n_seg * n_chunk + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  switch (op) {
+    case dd::OP_SUM: hipLaunchKernelGGL(dd::k_segment_reduce<dd::OP_SUM>, grid, block, 0, st, src, seg_ptr, n_seg, F, n_chunk, out, arg_out, E); break;
+    case dd::OP_MEAN: hipLaunchKernelGGL(dd::k_segment_reduce<dd::OP_MEAN>, grid, block, 0, st, src, seg_ptr, n_seg, F, n_chunk, out, arg_out, E); break;
+    case dd::OP_MIN: hipLaunchKernelGGL(dd::k_segment_reduce<dd::OP_MIN>, grid, block, 0, st, src, seg_ptr, n_seg, F, n_chunk, out, arg_out, E); break;
+    default: hipLaunchKernelGGL(dd::k_segment_reduce<dd::OP_MAX>, grid, block, 0, st, src, seg_ptr, n_seg, F, n_chunk, out, arg_out, E); break;
+  }
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
+extern "C" int dd_segment_softmax(const float* src, const int32_t* seg_ptr, int n_seg, int F, float* out, void* stream) {
+  if (!seg_ptr || n_seg < 0 || F <= 0) return DD_ERR_BAD_ARG;
+  if (n_seg == 0) return DD_OK;
+  if (!src || !out) return DD_ERR_BAD_ARG;
+  const int n_chunk = (F + 63) / 64;
+  hipLaunchKernelGGL(dd::k_segment_softmax, dim3((unsigned)(((long)n_seg * n_chunk + 3) / 4)), dim3(256), 0, (hipStream_t)stream, src,
+                     seg_ptr, n_seg, F, n_chunk, out);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }

@@ -12,6 +12,30 @@
 
 namespace dd {
 
+// Production noise (Philox4x32-10, counter = (row, row >> 32, step, stream id)): one uniform per (row, class) for the
+// Gumbel draws -- classes 0..3 from the block of stream `sid`, 4..7 from the block of `sid | 0x100` -- and one
+// Box-Muller normal per coordinate (stream 7).  Streams: 1 atom types, 2 bond types, 7 coordinates; distinct
+// (row, step, stream) never share a counter.  dd_debug_philox exposes exactly these functions to the statistics test.
+template <int NC>
+__device__ __forceinline__ float philox_uniform(uint64_t seed, long row, int step, uint32_t sid, int c) {
+  Philox ph(seed);
+  uint32_t r[4], r2[4];
+  ph.gen((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)step, sid, r);
+  ph.gen((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)step, sid | 0x100u, r2);
+  uint32_t bits = r[0];
+#pragma unroll
+  for (int k = 1; k < NC; ++k) bits = (c == k) ? (k < 4 ? r[k] : r2[k - 4]) : bits;
+  return u01(bits);
+}
+__device__ __forceinline__ float philox_normal(uint64_t seed, int idx, int step) {
+  Philox ph(seed);
+  uint32_t r[4];
+  ph.gen((uint32_t)idx, 0u, (uint32_t)step, 7u, r);
+  const float u1 = fmaxf(u01(r[0]), 5.9604645e-8f), u2 = u01(r[1]);
+  return sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+
+
 __device__ __forceinline__ float log_add_exp(float a, float b) {
   float m = fmaxf(a, b);
   return m + logf(expf(a - m) + expf(b - m));
@@ -123,11 +147,7 @@ __global__ void k_step_pos(const StepPosArgs a) {
   if (a.eps) {
     e = a.eps[(long)step * n + idx];
   } else {
-    Philox ph(a.seed);
-    uint32_t r[4];
-    ph.gen((uint32_t)idx, 0u, (uint32_t)step, 7u, r);
-    const float u1 = fmaxf(u01(r[0]), 5.9604645e-8f), u2 = u01(r[1]);
-    e = sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+    e = philox_normal(a.seed, idx, step);
   }
   const float nz = t == 0 ? 0.f : 1.f;
   const float nxt = mean + nz * expf(0.5f * a.tab_pos[2 * a.T + t]) * e * a.atom_std[idx];
@@ -286,14 +306,7 @@ __device__ __forceinline__ void step_row(const StepRowsArgs& a, const long row, 
   if (a.uniforms) {
     u = a.uniforms[((long)step * a.rows + row) * NC + c];
   } else {
-    Philox ph(a.seed);
-    uint32_t r[4], r2[4];
-    ph.gen((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)step, a.stream_id, r);
-    ph.gen((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)step, a.stream_id | 0x100u, r2);
-    uint32_t bits = r[0];
-#pragma unroll
-    for (int k = 1; k < NC; ++k) bits = (c == k) ? (k < 4 ? r[k] : r2[k - 4]) : bits;
-    u = u01(bits);
+    u = philox_uniform<NC>(a.seed, row, step, a.stream_id, c);
   }
   const float lp = un - ulse;
   const float sc = -logf(-logf(u + 1e-30f) + 1e-30f) + lp;      // Gumbel-argmax (transitions.py:78-84)
@@ -338,11 +351,7 @@ __device__ __forceinline__ void step_pos_elem(const StepPosArgs& a, const int id
   if (a.eps) {
     e = a.eps[(long)step * n + idx];
   } else {
-    Philox ph(a.seed);
-    uint32_t r[4];
-    ph.gen((uint32_t)idx, 0u, (uint32_t)step, 7u, r);
-    const float u1 = fmaxf(u01(r[0]), 5.9604645e-8f), u2 = u01(r[1]);
-    e = sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+    e = philox_normal(a.seed, idx, step);
   }
   const float nz = t == 0 ? 0.f : 1.f;
   const float nxt = mean + nz * expf(0.5f * a.tab_pos[2 * a.T + t]) * e * a.atom_std[idx];
@@ -396,6 +405,14 @@ int launch_advance(int32_t* ctr, hipStream_t st) {
 }  // namespace dd
 
 namespace dd {
+__global__ __launch_bounds__(256) void k_debug_philox(uint64_t seed, int step, long rows, int kind, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (kind == 7) { if (i < rows) out[i] = philox_normal(seed, (int)i, step); return; }
+  const int NC = kind == 1 ? DD_NUM_V : DD_NUM_B;
+  if (i >= rows * NC) return;
+  const long row = i / NC; const int c = (int)(i % NC);
+  out[i] = kind == 1 ? philox_uniform<DD_NUM_V>(seed, row, step, 1u, c) : philox_uniform<DD_NUM_B>(seed, row, step, 2u, c);
+}
 int launch_drift_armsca(const float* lig_pos, const int32_t* decomp_index, int B, int NL, float min_d, float max_d,
                         float* grad, int accumulate, int norm_B, hipStream_t st) {
   hipLaunchKernelGGL(k_drift_armsca, dim3(B), dim3(64), 0, st, lig_pos, decomp_index, B, NL, min_d, max_d, grad, accumulate,
@@ -417,6 +434,16 @@ extern "C" int dd_drift_clash(const float* lig_pos, const float* offset, const f
   if (!lig_pos || !offset || !full_protein_pos || !grad || B <= 0 || NL <= 0 || NF <= 0) return DD_ERR_BAD_ARG;
   hipLaunchKernelGGL(dd::k_drift_clash, dim3(B * NL), dim3(256), 0, (hipStream_t)stream, lig_pos, offset,
                      full_protein_pos, B, NL, NF, sigma, gamma, grad, accumulate);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
+// Test aid: the production noise of one step, exactly as the step kernels draw it.  kind 1: uniforms [rows,8] of the
+// atom-type stream, 2: uniforms [rows,5] of the bond-type stream, 7: normals [rows] of the coordinate stream.
+extern "C" int dd_debug_philox(uint64_t seed, int step, long rows, int kind, float* out, void* stream) {
+  if (!out || rows <= 0 || (kind != 1 && kind != 2 && kind != 7)) return DD_ERR_BAD_ARG;
+  const long n = kind == 7 ? rows : rows * (kind == 1 ? DD_NUM_V : DD_NUM_B);
+  hipLaunchKernelGGL(dd::k_debug_philox, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, step, rows, kind, out);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }

@@ -92,3 +92,101 @@ def scatter_attention_pos(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rel
                                                        hip_lib.ptr(rf), hip_lib.ptr(seg), dim_size,
                                                        hip_lib.ptr(out), hip_lib.stream_ptr(k.device)), "dd_attn_aggregate_pos")
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Plain torch_scatter drop-ins, same signatures as the wheel the reference imports:
+#     from torch_scatter import scatter_softmax, scatter_sum, scatter_mean, scatter_min
+# over dim 0 with a 1-D index broadcast along it (every call site of the reference: uni_transformer_edge.py:64,68,160,
+# 164,205,209; decompdiff.py:25; guidance_funcs.py:52).  Rows need not be sorted: an unsorted index is stable-sorted
+# first (torch_scatter accumulates in an unspecified order; here the order is fixed -> deterministic results).
+# ------------------------------------------------------------------------------------------------------------------
+_OPS = {"sum": 0, "mean": 1, "min": 2, "max": 3}
+
+
+def _prep_scatter(src: torch.Tensor, index: torch.Tensor, dim: int, dim_size: Optional[int]):
+    hip_lib.require_gpu(src, "src")
+    if dim not in (0, -src.dim()):
+        raise NotImplementedError("decompdiff_amd scatter ops reduce over dim 0 (every call site of the reference does)")
+    if index.dim() != 1:
+        if index.shape != src.shape:
+            raise ValueError("index must be 1-D or have the shape of src")
+        flat = index.reshape(index.size(0), -1)
+        if not bool((flat == flat[:, :1]).all().item()):
+            raise NotImplementedError("index must be constant along the trailing dims (broadcast of a 1-D index)")
+        index = flat[:, 0]
+    if index.numel() != src.size(0):
+        raise ValueError("index and src disagree along dim 0")
+    E = src.size(0)
+    n = int(dim_size) if dim_size is not None else (int(index.max().item()) + 1 if E else 0)
+    if E and (int(index.min().item()) < 0 or int(index.max().item()) >= n):
+        raise IndexError("scatter index out of range")
+    perm = None
+    if E > 1 and bool((index[1:] < index[:-1]).any().item()):
+        index, perm = torch.sort(index, stable=True)
+    x = src.detach().to(torch.float32).reshape(E, -1)
+    x = (x[perm] if perm is not None else x).contiguous()
+    ptr = torch.zeros(n + 1, dtype=torch.int32, device=src.device)
+    if E:
+        ptr[1:] = torch.bincount(index, minlength=n).cumsum(0)
+    return x, ptr, n, perm
+
+
+def _segment_reduce(src, index, dim, dim_size, op, out=None):
+    x, ptr, n, perm = _prep_scatter(src, index, dim, dim_size)
+    E, F = x.shape
+    res = torch.empty(n, F, device=src.device)
+    arg = torch.empty(n, F, dtype=torch.int64, device=src.device) if op in ("min", "max") else None
+    if n and F:
+        hip_lib.check(hip_lib.load().dd_segment_reduce(hip_lib.ptr(x) if E else None, hip_lib.ptr(ptr), n, F, _OPS[op], E,
+                                                       hip_lib.ptr(res), hip_lib.ptr(arg), hip_lib.stream_ptr(src.device)),
+                      "dd_segment_reduce")
+    if arg is not None and perm is not None:                # row ids of the caller's (unsorted) order
+        valid = arg < E
+        arg = torch.where(valid, perm[arg.clamp(max=max(E - 1, 0))], arg)
+    shape = (n,) + tuple(src.shape[1:])
+    res = res.view(shape).to(src.dtype)
+    if out is not None:
+        if op in ("sum", "mean"):
+            raise NotImplementedError("out= (accumulation into a given tensor) is not used by the reference's call sites")
+    return res, (arg.view(shape) if arg is not None else None)
+
+
+def scatter_sum(src: torch.Tensor, index: torch.Tensor, dim: int = -1, out: Optional[torch.Tensor] = None,
+                dim_size: Optional[int] = None) -> torch.Tensor:
+    """``torch_scatter.scatter_sum`` (= ``scatter_add``) over dim 0."""
+    return _segment_reduce(src, index, dim if src.dim() > 1 or dim != -1 else 0, dim_size, "sum", out)[0]
+
+
+def scatter_mean(src: torch.Tensor, index: torch.Tensor, dim: int = -1, out: Optional[torch.Tensor] = None,
+                 dim_size: Optional[int] = None) -> torch.Tensor:
+    """``torch_scatter.scatter_mean`` over dim 0 (sum / max(count, 1))."""
+    return _segment_reduce(src, index, dim if src.dim() > 1 or dim != -1 else 0, dim_size, "mean", out)[0]
+
+
+def scatter_min(src: torch.Tensor, index: torch.Tensor, dim: int = -1, out: Optional[torch.Tensor] = None,
+                dim_size: Optional[int] = None):
+    """``torch_scatter.scatter_min`` over dim 0 -> ``(values, argmin)``; empty destinations hold 0 / ``src.size(0)``."""
+    return _segment_reduce(src, index, dim if src.dim() > 1 or dim != -1 else 0, dim_size, "min", out)
+
+
+def scatter_max(src: torch.Tensor, index: torch.Tensor, dim: int = -1, out: Optional[torch.Tensor] = None,
+                dim_size: Optional[int] = None):
+    """``torch_scatter.scatter_max`` over dim 0 -> ``(values, argmax)``."""
+    return _segment_reduce(src, index, dim if src.dim() > 1 or dim != -1 else 0, dim_size, "max", out)
+
+
+def scatter_softmax(src: torch.Tensor, index: torch.Tensor, dim: int = -1, dim_size: Optional[int] = None) -> torch.Tensor:
+    """``torch_scatter.composite.scatter_softmax`` over dim 0: per destination and trailing element, softmax over the rows
+    scattered to it (max-shifted, no eps: torch_scatter >= 2.1)."""
+    x, ptr, n, perm = _prep_scatter(src, index, dim if src.dim() > 1 or dim != -1 else 0, dim_size)
+    E, F = x.shape
+    res = torch.empty_like(x)
+    if E and F:
+        hip_lib.check(hip_lib.load().dd_segment_softmax(hip_lib.ptr(x), hip_lib.ptr(ptr), n, F, hip_lib.ptr(res),
+                                                        hip_lib.stream_ptr(src.device)), "dd_segment_softmax")
+    if perm is not None:
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(E, device=perm.device)
+        res = res[inv]
+    return res.view(src.shape).to(src.dtype)

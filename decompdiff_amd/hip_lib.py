@@ -23,7 +23,8 @@ EXPORTED_SYMBOLS = [
     "dd_graph_create", "dd_graph_launch", "dd_graph_destroy",
     "dd_drift_armsca",
     "dd_drift_clash", "dd_workspace_view", "dd_profile_step", "dd_debug_set_clock_buffer", "dd_debug_set_fusion", "dd_debug_set_option", "dd_debug_node_split",
-    "dd_attn_aggregate_node", "dd_attn_aggregate_triplet", "dd_attn_aggregate_pos", "dd_reverse_step",
+    "dd_attn_aggregate_node", "dd_attn_aggregate_triplet", "dd_attn_aggregate_pos", "dd_reverse_step", "dd_debug_philox",
+    "dd_segment_reduce", "dd_segment_softmax",
 ]
 
 
@@ -110,6 +111,9 @@ def load():
     lib.dd_attn_aggregate_node.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.dd_attn_aggregate_triplet.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.dd_attn_aggregate_pos.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
+    lib.dd_segment_reduce.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p]
+    lib.dd_segment_softmax.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
+    lib.dd_debug_philox.argtypes = [c_uint64, c_int, c_long, c_int, c_void_p, c_void_p]
     lib.dd_profile_step.argtypes = [POINTER(DDSampler), c_int, POINTER(c_float), c_void_p]
     for name in EXPORTED_SYMBOLS:
         if name not in ("dd_status_string", "dd_workspace_floats"):

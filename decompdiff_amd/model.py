@@ -186,7 +186,7 @@ class DecompScorePosNet3D(nn.Module):
         return bool((cp != cp[0]).any().item() or (cl != cl[0]).any().item())
 
     def _sample_ragged(self, kw, ligand_atom_mask, num_steps, center_pos_mode, energy_drift_opt, noise, seed, keep_traj,
-                       use_graph, concurrent=None):
+                       use_graph, concurrent=None, start_step=0):
         if ligand_atom_mask is not None:
             raise NotImplementedError("ligand_atom_mask (partially fixed ligands) is not part of the shipped sampling path")
         dev = kw["protein_pos"].device
@@ -251,7 +251,7 @@ class DecompScorePosNet3D(nn.Module):
                 sub["ligand_v_aux"], sub["batch_ligand"], sub["prior_stds"], sub["ligand_decomp_batch"],
                 sub["ligand_decomp_index"], None, sub["ligand_fc_bond_index"], sub["init_ligand_fc_bond_type"], num_steps,
                 center_pos_mode, energy_drift_opt, sub.get("full_protein_pos"), sub.get("full_batch_protein"), sub_noise,
-                seed + 7919 * gi, keep_traj, B)                    # (the armsca loss is averaged over the whole batch)
+                seed + 7919 * gi, keep_traj, B, start_step)        # (the armsca loss is averaged over the whole batch)
             prepared.append((chain, d_l, d_b, r_l, r_b))
         if concurrent is None:
             # measured on MI355X (tools/ragged_bench.py): with the runtime's default 4 hardware queues the
@@ -475,7 +475,7 @@ class DecompScorePosNet3D(nn.Module):
                          num_steps=None, center_pos_mode=None,
                          energy_drift_opt=None,
                          full_protein_pos=None, full_batch_protein=None,
-                         noise=None, seed=None, keep_traj=True, use_graph=True, _drift_norm_batch=0):
+                         noise=None, seed=None, keep_traj=True, use_graph=True, start_step=0, _drift_norm_batch=0):
         """Reverse diffusion (reference: models/decompdiff.py:552-703), same arguments and return
         keys.  Extra keyword-only knobs (all optional, reference call sites never pass them):
 
@@ -485,6 +485,9 @@ class DecompScorePosNet3D(nn.Module):
           seed): a fresh 64-bit key is drawn from torch's global CPU generator on every call, so successive calls
           see independent noise and ``torch.manual_seed`` / the script's ``seed_all`` govern the chain exactly as
           they govern the reference's ``torch.randn_like`` draws (decompdiff.py:620,633,680).
+        * ``start_step`` — resume a chain: the state passed in is x_t / v_t / b_t after ``start_step`` reverse steps,
+          i.e. the first step runs at t = num_timesteps - 1 - start_step (``noise`` then holds the draws of the
+          remaining ``num_steps`` steps only).
         * ``keep_traj`` — record the six trajectories on the device and copy them once at the end.
         * ``use_graph`` — replay one captured hipGraph per step instead of eager launches.
         """
@@ -506,12 +509,13 @@ class DecompScorePosNet3D(nn.Module):
                      ligand_decomp_index=ligand_decomp_index, ligand_fc_bond_index=ligand_fc_bond_index,
                      init_ligand_fc_bond_type=init_ligand_fc_bond_type, batch_ligand_bond=batch_ligand_bond,
                      full_protein_pos=full_protein_pos, full_batch_protein=full_batch_protein),
-                ligand_atom_mask, num_steps, center_pos_mode, energy_drift_opt, noise, seed, keep_traj, use_graph)
+                ligand_atom_mask, num_steps, center_pos_mode, energy_drift_opt, noise, seed, keep_traj, use_graph,
+                start_step=start_step)
         chain = self._prepare_chain(protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, ligand_v_aux,
                                     batch_ligand, prior_stds, ligand_decomp_batch, ligand_decomp_index, ligand_atom_mask,
                                     ligand_fc_bond_index, init_ligand_fc_bond_type, num_steps, center_pos_mode,
                                     energy_drift_opt, full_protein_pos, full_batch_protein, noise, seed, keep_traj,
-                                    _drift_norm_batch)
+                                    _drift_norm_batch, start_step)
         self._run_chains([chain], num_steps, use_graph)
         out = self._collect_chain(chain, num_steps, keep_traj)
         self._last = (chain["s"], chain["bufs"])
@@ -520,7 +524,7 @@ class DecompScorePosNet3D(nn.Module):
     def _prepare_chain(self, protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, ligand_v_aux,
                        batch_ligand, prior_stds, ligand_decomp_batch, ligand_decomp_index, ligand_atom_mask,
                        ligand_fc_bond_index, init_ligand_fc_bond_type, num_steps, center_pos_mode, energy_drift_opt,
-                       full_protein_pos, full_batch_protein, noise, seed, keep_traj, drift_norm_batch):
+                       full_protein_pos, full_batch_protein, noise, seed, keep_traj, drift_norm_batch, start_step=0):
         """Validate one dense batch, centre it, allocate its state / workspace and fill the ``dd_sampler`` struct."""
         d = self._dense_inputs(protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, ligand_v_aux,
                                batch_ligand, ligand_fc_bond_index, init_ligand_fc_bond_type, ligand_atom_mask)
@@ -546,9 +550,9 @@ class DecompScorePosNet3D(nn.Module):
             if full_protein_pos.shape[0] % B or not torch.equal(full_batch_protein.to(dev), exp):
                 raise NotImplementedError("full_protein_pos must hold the same number of atoms per sample")
             fpp = full_protein_pos.to(dev).float().contiguous().view(B, nf, 3)
-        t_start = self.num_timesteps - 1              # time_seq = reversed(range(T - num_steps, T)), decompdiff.py:575
-        if num_steps > self.num_timesteps:
-            raise ValueError("num_steps exceeds num_timesteps")
+        t_start = self.num_timesteps - 1 - int(start_step)   # time_seq = reversed(range(T - num_steps, T)), decompdiff.py:575
+        if start_step < 0 or num_steps + start_step > self.num_timesteps:
+            raise ValueError("num_steps (+ start_step) exceeds num_timesteps")
         pw = self._packed_weights()
         s, bufs, _ = self._make_sampler(d, pw, num_steps, t_start, noise, keep_traj, energy_drift_opt, atom_std,
                                         offset.contiguous(), decomp, fpp, seed, drift_norm_batch)

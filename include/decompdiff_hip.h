@@ -163,6 +163,16 @@ int dd_attn_aggregate_triplet(const float* q /*[E3,128]*/, const float* k, const
 int dd_attn_aggregate_pos(const float* q /*[n_seg,128]*/, const float* k, const float* v16, const float* e_w, const float* rel_x,
                           const int32_t* seg_ptr, int n_seg, float* out /*[n_seg,3]*/, void* stream);
 
+/* Stand-alone torch_scatter drop-ins over dim 0 of a [E,F] fp32 tensor whose rows are grouped by destination (CSR
+ * segments seg_ptr [n_seg+1]); reference call sites: scatter_softmax / scatter_sum uni_transformer_edge.py:64,68,160,164,
+ * 205,209, scatter_mean decompdiff.py:25 (center_pos), scatter_min guidance_funcs.py:52.
+ * dd_segment_reduce: op 0 sum, 1 mean, 2 min, 3 max -> out [n_seg,F]; empty segments give 0 (torch_scatter's fill);
+ * min / max also write the row index of the extremum to arg_out [n_seg,F] (may be NULL; E for an empty segment, the
+ * smallest index on ties).  dd_segment_softmax: out[e,f] = exp(src[e,f] - max_seg) / sum_seg exp(...), [E,F]. */
+int dd_segment_reduce(const float* src, const int32_t* seg_ptr, int n_seg, int F, int op, long E, float* out,
+                      int64_t* arg_out, void* stream);
+int dd_segment_softmax(const float* src, const int32_t* seg_ptr, int n_seg, int F, float* out, void* stream);
+
 /* Embeddings (decompdiff.py:219-256, 296-297). protein_h is step-invariant. */
 int dd_embed_protein(const float* protein_v /*[B*NP,29]*/, int rows, const float* W /*[128,29]*/, const float* b,
                      float* protein_h /*[rows,128]*/, void* stream);
@@ -232,6 +242,11 @@ int dd_debug_set_option(int key, int value);
 /* Measured split of the fused node launch for a shape (dd_debug_set_option key 18 = 1): number of CUs kept by the
  * persistent bond-layer workgroups, 0 = node blocks first, -1 = not measured yet. */
 int dd_debug_node_split(int B, int NP, int NL, int K);
+
+/* Test aid: the production (Philox4x32-10) noise of one step exactly as the step kernels draw it -- kind 1: uniforms
+ * [rows,8] of the atom-type stream (transitions.py:79 rand_like), 2: uniforms [rows,5] of the bond-type stream,
+ * 7: normals [rows] of the coordinate stream (decompdiff.py:680 randn_like). */
+int dd_debug_philox(uint64_t seed, int step, long rows, int kind, float* out, void* stream);
 
 /* Debug/test access to intermediate buffers of the last dd_forward (pointers into workspace). */
 typedef struct dd_ws_view {

@@ -208,17 +208,17 @@ def gen_steps(ref, sd, cfg):
     print(f"[steps] oracle maxabs diff = {worst:g}")
 
 
-def gen_traj(ref, sd, cfg, name, pocket, n_data, num_steps, drift, seed, every=1, std_scale=None, priors=None):
+def gen_traj(ref, sd, cfg, name, pocket, n_data, num_steps, drift, seed, every=1, std_scale=None, priors=None, t_start=None):
     torch.manual_seed(seed)
     batch = synth.build_sampling_batch(pocket, n_data, per_sample_std_scale=std_scale)
     state = torch.get_rng_state()
     t0 = time.time()
-    r = run_ref_sampling(ref, batch, num_steps, drift)
+    r = run_ref_sampling(ref, batch, num_steps, drift, t_start)
     t_ref = time.time() - t0
     torch.set_rng_state(state)
     noise = synth.draw_step_noise(num_steps, batch["init_ligand_pos"].size(0), batch["init_ligand_fc_bond_type"].size(0))
     t0 = time.time()
-    ro = run_oracle_sampling(sd, cfg, batch, num_steps, drift, noise, **(priors or {}))
+    ro = run_oracle_sampling(sd, cfg, batch, num_steps, drift, noise, t_start, **(priors or {}))
     t_or = time.time() - t0
     w = max(maxabs(r["pos"], ro["pos"]), maxabs(r["v"], ro["v"]), maxabs(r["bond"], ro["bond"]))
     out = np_inputs(batch)
@@ -228,6 +228,8 @@ def gen_traj(ref, sd, cfg, name, pocket, n_data, num_steps, drift, seed, every=1
     out["noise_checksum"] = np.array([float(noise["u_v"].double().sum()), float(noise["u_b"].double().sum()),
                                       float(noise["eps"].double().sum())])
     out["weight_seed"] = np.array(0)
+    if t_start is not None:
+        out["t_start"] = np.array(t_start)
     for k, v in (priors or {}).items():
         out[k] = np.asarray(v)
     out["oracle_vs_reference_maxabs"] = np.array(w)
@@ -286,6 +288,17 @@ def main():
         gen_traj(ref_p, sd, cfg, "traj12_priortypes", synth.make_pocket_small(4), 2, 12, DRIFT, 2024, priors=priors)
     if want("ragged"):
         gen_traj_ragged(ref, sd, cfg, "traj10_ragged", 10, DRIFT, 2023)
+    if want("scale"):
+        # `scale: True` of the drift terms (decompdiff.py:656-657,667-668), mid-chain where pos_score_coef is not tiny
+        drift_scale = [dict(DRIFT[0], scale=True), dict(DRIFT[1], scale=True)]
+        gen_traj(ref, sd, cfg, "traj3_scale", synth.make_pocket(41, 80, (3, 3), 4, num_full_protein=200), 2, 3, drift_scale, 9,
+                 std_scale=[1.0, 0.8], t_start=600)
+    if want("b16"):
+        # configs[3]-style unit: a pocket of the 100-pocket job's size range (NP = 347, NL = 37), batch of 16
+        gen_traj(ref, sd, cfg, "traj3_b16", synth.make_pocket(7, 347, (9, 9), 19, num_full_protein=0), 16, 3, None, 2031)
+    if want("large"):
+        # configs[4] size (600 + 60 atoms) with drift guidance, batch of 2
+        gen_traj(ref, sd, cfg, "traj3_large_drift", synth.make_pocket_large(6), 2, 3, DRIFT, 2032, std_scale=[1.0, 0.9])
     if want("traj1000_drift") and not args.skip_long:
         gen_traj(ref, sd, cfg, "traj1000_drift", synth.make_pocket_small(5), 1, 1000, DRIFT, 2025, every=50)
     if want("traj1000") and not args.skip_long:

@@ -65,3 +65,86 @@ def test_single_process_paths_are_noops():
     assert list(ddist.shard_samples(5, 0, 1)) == [0, 1, 2, 3, 4]
     assert ddist.max_over_ranks(3.5) == 3.5
     assert ddist.gather_metadata({"a": 1}) == [{"a": 1}]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The sharded job driver of bench.py (dist.plan_job / units_of_rank / run_job) with a stub model: the same code path the
+# multi-GPU bench runs, on gloo.  Units are defined independently of the world size, so the union of the per-unit
+# records of a 2-rank run must equal those of a 1-rank run of the same job.
+# ------------------------------------------------------------------------------------------------------------------
+def _stub_prepare(u):
+    g = torch.Generator().manual_seed(u.init_seed)
+    n_l = sum(u.arm_atoms) + u.scaffold_atoms
+    return {"pos0": torch.randn(u.n_samples * n_l, 3, generator=g), "n_l": n_l, "uid": u.uid}
+
+
+def _stub_sample(state, n_steps, seed):
+    """Deterministic stand-in for model.sample_diffusion: a function of (initial state, steps, seed) only."""
+    g = torch.Generator().manual_seed(seed)
+    pos = state["pos0"].clone()
+    for _ in range(n_steps):
+        pos = 0.9 * pos + 0.1 * torch.randn(pos.shape, generator=g)
+    n = pos.shape[0]
+    return {"pos": pos, "v": torch.arange(n) % 8, "bond": (torch.arange(n * 3) + seed) % 5, "pos_traj": [pos] * n_steps}
+
+
+def _job_worker(rank, world, port, config, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    assert ddist.init_from_env(backend="gloo")
+    units, scaling = ddist.plan_job(config, world, n_pockets=7, num_samples=40)
+    job = ddist.run_job(units, config, rank, world, _stub_prepare, _stub_sample, steps=3, warmup=1)
+    if rank == 0:
+        q.put((scaling, job["per_unit"], job["per_rank"], job["unit_steps"], job["elapsed"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_job_world(world, config):
+    if world == 1:
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            os.environ.pop(k, None)
+        units, scaling = ddist.plan_job(config, 1, n_pockets=7, num_samples=40)
+        job = ddist.run_job(units, config, 0, 1, _stub_prepare, _stub_sample, steps=3, warmup=1)
+        return scaling, job["per_unit"], job["per_rank"], job["unit_steps"], job["elapsed"]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_job_worker, args=(r, world, port, config, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_sharded_job_two_ranks_equals_one_rank():
+    for config in (3, 4):
+        s1, units1, ranks1, steps1, _ = _run_job_world(1, config)
+        s2, units2, ranks2, steps2, t2 = _run_job_world(2, config)
+        assert s1 == s2 == "strong" and steps1 == steps2 and t2 > 0
+        strip = lambda rs: [{k: v for k, v in r.items() if k not in ("rank", "seconds_enqueue")} for r in rs]
+        assert strip(units1) == strip(units2)                      # same units, same checksums, whoever ran them
+        assert [u["unit"] for u in units2] == list(range(len(units2)))
+        assert sorted(u for r in ranks2 for u in r["units"]) == list(range(len(units2)))
+        if config == 3:
+            assert ranks2[0]["units"] == [0, 2, 4, 6] and ranks2[1]["units"] == [1, 3, 5]      # pocket p -> rank p mod N
+        else:
+            assert len(units2) == 5 and units2[-1]["n_samples"] == 8                           # 40 samples = 5 shards of 8
+            assert ranks2[0]["units"] == [0, 1, 2] and ranks2[1]["units"] == [3, 4]            # contiguous sample shards
+
+
+def test_plan_job_weak_configs_scale_with_world():
+    for world in (1, 2, 8):
+        units, scaling = ddist.plan_job(1, world)
+        assert scaling == "weak" and len(units) == world and all(u.n_samples == 8 for u in units)
+        assert [ddist.units_of_rank(units, 1, r, world)[0].uid for r in range(world)] == list(range(world))
+    units, _ = ddist.plan_job(2, 1)
+    assert units[0].drift
+    units, scaling = ddist.plan_job(3, 8)
+    assert len(units) == 100 and scaling == "strong" and all(u.n_samples == 16 for u in units)
+    assert all(250 <= u.num_protein <= 350 and 20 <= sum(u.arm_atoms) + u.scaffold_atoms <= 40 for u in units)
+    units, _ = ddist.plan_job(4, 8)
+    assert len(units) == 8 and all(u.num_protein == 600 and sum(u.arm_atoms) + u.scaffold_atoms == 60 for u in units)

@@ -1,0 +1,196 @@
+"""GPU (-m gpu): the BASELINE.json configurations the round-1 tests did not exercise, the segment-wise bound on the
+1000-step chains, the statistics of the production (Philox) noise, and the multi-rank bench entry.
+Everything goes through the C ABI; fixtures under tests/golden come from the reference itself (oracle/make_golden.py)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import golden_utils as GU
+from decompdiff_amd import hip_lib, synth
+from test_gpu_parity import POS_TOL, _sample_hip, dev, maxabs, model
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _fixture_chain(name, pocket, n_data, std_scale=None):
+    """(golden, batch, noise) of a gen_traj fixture: the batch is stored, the noise is re-drawn (checksum pinned)."""
+    g = GU.load(name)
+    b = GU.batch_from_npz(g)
+    torch.manual_seed(int(g["seed"]))
+    synth.build_sampling_batch(pocket, n_data, per_sample_std_scale=std_scale)
+    noise = synth.draw_step_noise(int(g["num_steps"]), b["init_ligand_pos"].size(0), b["init_ligand_fc_bond_type"].size(0))
+    assert np.array_equal(GU.checksum(noise), g["noise_checksum"])
+    return g, b, noise
+
+
+def _check_chain(name, r, g, steps):
+    tp = torch.stack(r["pos_traj"]).numpy()
+    per_step = np.abs(tp.astype(np.float64) - g["traj_pos"]).reshape(steps, -1).max(1)
+    nv = int((torch.stack(r["v_traj"]).numpy() != g["traj_v"]).sum())
+    nb = int((torch.stack(r["bond_traj"]).numpy() != g["traj_bond"]).sum())
+    err = maxabs(r["pos"], g["out_pos"])
+    print(f"{name}: per-step max pos err {' '.join(f'{e:.2g}' for e in per_step)}; final {err:.3g}; type mismatches v={nv} bond={nb}")
+    assert err < POS_TOL and per_step.max() < POS_TOL
+    assert nv == 0 and nb == 0
+    assert np.array_equal(r["v"].cpu().numpy(), g["out_v"]) and np.array_equal(r["bond"].cpu().numpy(), g["out_bond"])
+
+
+def test_config3_unit_batch16_reference_golden():
+    """BASELINE configs[3]: one unit of the 100-pocket job -- a pocket in its size range (347 protein + 37 ligand atoms:
+    the 3-tile kernel variants), batch of 16 -- 3 reverse steps against the reference's own output."""
+    g, b, noise = _fixture_chain("traj3_b16", synth.make_pocket(7, 347, (9, 9), 19, num_full_protein=0), 16)
+    r = _sample_hip(model(0), b, 3, None, noise)
+    _check_chain("configs[3] unit (NP=347, NL=37, B=16)", r, g, 3)
+    assert hip_lib.load().dd_debug_node_split(16, 347, 37, 32) >= 0         # the per-shape launch measurement ran
+
+
+def test_config4_large_pocket_drift_reference_golden():
+    """BASELINE configs[4] size (600 + 60 atoms: the 4-tile kernel variants) with armsca + clash drift, B=2, 3 reverse
+    steps against the reference's own output."""
+    g, b, noise = _fixture_chain("traj3_large_drift", synth.make_pocket_large(6), 2, [1.0, 0.9])
+    r = _sample_hip(model(0), b, 3, json.loads(str(g["drift"])), noise)
+    _check_chain("configs[4] size (NP=600, NL=60, B=2, drift)", r, g, 3)
+
+
+def test_large_pocket_batch8_matches_batch2_rows():
+    """C-large at the bench's batch size (B=8, where the persistent bond-layer split applies): rows of samples 0-1 equal the
+    B=2 run bit for bit (sharding property at this size), everything finite."""
+    g, b, noise = _fixture_chain("traj3_large_drift", synth.make_pocket_large(6), 2, [1.0, 0.9])
+    drift = json.loads(str(g["drift"]))
+    r2 = _sample_hip(model(0), b, 3, drift, noise)
+    b8 = synth.concat_sampling_batches([b] * 4)
+    n8 = {k: torch.cat([v] * 4, 1) for k, v in noise.items()}
+    r8 = _sample_hip(model(0), b8, 3, drift, n8, _drift_norm_batch=2)      # (the armsca mean is over the reference batch of 2)
+    assert torch.isfinite(r8["pos"]).all()
+    nl2 = r2["pos"].shape[0]
+    for k in range(4):
+        assert torch.equal(r8["pos"][k * nl2:(k + 1) * nl2], r2["pos"]), f"copy {k}"
+        assert torch.equal(r8["v"][k * nl2:(k + 1) * nl2], r2["v"])
+
+
+def test_drift_scale_option_reference_golden():
+    """`scale: True` of the drift terms (decompdiff.py:656-657,667-668) against the reference's own output, mid-chain
+    (t = 600..598) where pos_score_coef is not tiny."""
+    g, b, noise = _fixture_chain("traj3_scale", synth.make_pocket(41, 80, (3, 3), 4, num_full_protein=200), 2, [1.0, 0.8])
+    drift = json.loads(str(g["drift"]))
+    assert all(d["scale"] for d in drift)
+    r = _sample_hip(model(0), b, 3, drift, noise, int(g["t_start"]))
+    _check_chain("drift scale=True (t=600..598)", r, g, 3)
+    unscaled = _sample_hip(model(0), b, 3, [dict(d, scale=False) for d in drift], noise, int(g["t_start"]))
+    assert maxabs(unscaled["pos"], g["out_pos"]) > 1e-3                     # the option matters in this case
+
+
+@pytest.mark.parametrize("name", ["traj1000_plain", "traj1000_drift"])
+def test_chain_segments_from_reference_checkpoints(name):
+    """SURVEY.md H2, the re-synchronised bound: the chain is restarted from EVERY 50-step checkpoint of the reference's
+    1000-step run (positions, atom and bond types at steps 50, 100, ... are in the fixture) and run for the next 50 steps on
+    the reference's noise; each 50-step segment must end within 1e-4 of the reference's next checkpoint with identical
+    types.  This bounds the per-segment error of the HIP path without the chaotic amplification a free-running 1000-step
+    chain adds on top (oracle/sensitivity.py), plain and with armsca + clash drift."""
+    from test_gpu_parity import _traj_inputs
+    g, b, noise = _traj_inputs(name)
+    drift = json.loads(str(g["drift"]))
+    every = int(g["every"])
+    n_ck = g["traj_pos"].shape[0]
+    m = model(0)
+    errs, mv, mb = [], [], []
+    for c in range(n_ck):
+        start = c * every
+        bb = dict(b)
+        if c > 0:                                          # state after `start` steps: the reference's checkpoint c-1
+            bb["init_ligand_pos"] = torch.from_numpy(g["traj_pos"][c - 1].astype(np.float32))
+            bb["init_ligand_v"] = torch.from_numpy(g["traj_v"][c - 1].astype(np.int64))
+            bb["init_ligand_fc_bond_type"] = torch.from_numpy(g["traj_bond"][c - 1].astype(np.int64))
+        seg_noise = {k: v[start:start + every] for k, v in noise.items()}
+        r = _sample_hip(m, bb, every, drift, seg_noise, start_step=start, keep_traj=False)
+        errs.append(maxabs(r["pos"], g["traj_pos"][c]))
+        mv.append(int((r["v"].cpu().numpy() != g["traj_v"][c]).sum()))
+        mb.append(int((r["bond"].cpu().numpy() != g["traj_bond"][c]).sum()))
+    print(f"{name}: 50-step segments restarted from the reference's checkpoints")
+    print("  max |pos - golden| :", " ".join(f"{e:.2g}" for e in errs))
+    print("  type mismatches    : atoms", sum(mv), "bonds", sum(mb))
+    assert sum(mv) == 0 and sum(mb) == 0
+    assert max(errs) < POS_TOL, f"segment error {max(errs):.3g}"
+
+
+def test_philox_noise_statistics():
+    """The production noise (device Philox4x32-10 + Box-Muller), drawn through the same device functions the step kernels
+    use (dd_debug_philox): uniforms in [0,1) with mean 1/2 and variance 1/12, normals with mean 0, variance 1, 4th moment
+    3, a Kolmogorov-Smirnov distance small for 10^6 draws, and no stream shared between rows, steps, classes or the
+    atom / bond / coordinate streams."""
+    from scipy import stats
+    lib = hip_lib.load()
+
+    def draw(seed, step, rows, kind):
+        n = rows * {1: 8, 2: 5, 7: 1}[kind]
+        out = torch.empty(n, device=dev())
+        hip_lib.check(lib.dd_debug_philox(seed, step, rows, kind, hip_lib.ptr(out), hip_lib.stream_ptr()), "dd_debug_philox")
+        torch.cuda.synchronize()
+        return out.cpu().double().numpy()
+
+    u = draw(2021, 3, 125000, 1)                               # 10^6 uniforms, atom-type stream
+    ub = draw(2021, 3, 200000, 2)                              # 10^6 uniforms, bond-type stream
+    z = draw(2021, 3, 1000000, 7)
+    for name, a in (("u_v", u), ("u_b", ub)):
+        ks = stats.kstest(a, "uniform").statistic
+        print(f"{name}: mean {a.mean():.5f} var {a.var():.5f} min {a.min():.3g} max {a.max():.8f} KS {ks:.2g}")
+        assert a.min() >= 0.0 and a.max() < 1.0
+        assert abs(a.mean() - 0.5) < 1e-3 and abs(a.var() - 1.0 / 12.0) < 1e-3 and ks < 2.5e-3
+    ks = stats.kstest(z, "norm").statistic
+    m4 = float((z ** 4).mean())
+    print(f"eps: mean {z.mean():.5f} var {z.var():.5f} 4th moment {m4:.4f} max |z| {np.abs(z).max():.2f} KS {ks:.2g}")
+    assert abs(z.mean()) < 3e-3 and abs(z.var() - 1.0) < 5e-3 and abs(m4 - 3.0) < 0.05 and ks < 2.5e-3
+    assert np.isfinite(z).all() and np.abs(z).max() < 6.0
+    # classes of a row are distinct draws (8 classes = two Philox blocks), neighbouring rows / steps / seeds / streams too
+    uu = u.reshape(-1, 8)
+    assert abs(np.corrcoef(uu[:, 0], uu[:, 4])[0, 1]) < 5e-3 and abs(np.corrcoef(uu[:-1, 7], uu[1:, 0])[0, 1]) < 5e-3
+    assert len(np.unique(u)) > 0.97 * len(u)                 # 24-bit mantissas: ~3 % birthday collisions at most
+    for other in (draw(2021, 4, 125000, 1), draw(2022, 3, 125000, 1)):
+        assert abs(np.corrcoef(u, other)[0, 1]) < 5e-3 and not np.array_equal(u, other)
+    assert abs(np.corrcoef(u[:1000000:8][:100000], ub[:500000:5][:100000])[0, 1]) < 1e-2
+    assert np.array_equal(u, draw(2021, 3, 125000, 1))         # counter-based: reproducible
+
+
+def test_default_seed_is_fresh_per_call_and_follows_torch_manual_seed():
+    """The reference's script passes no seed: successive calls must see independent noise, governed by torch.manual_seed
+    (as the reference's torch.randn_like draws are)."""
+    pocket = synth.make_pocket_small(5)
+    torch.manual_seed(1)
+    b = synth.build_sampling_batch(pocket, 2)
+    m = model(0)
+    torch.manual_seed(77)
+    r1 = _sample_hip(m, b, 4, None, None)
+    r2 = _sample_hip(m, b, 4, None, None)
+    torch.manual_seed(77)
+    r3 = _sample_hip(m, b, 4, None, None)
+    assert not torch.equal(r1["pos"], r2["pos"])
+    assert torch.equal(r1["pos"], r3["pos"]) and torch.equal(r1["bond"], r3["bond"])
+
+
+def test_bench_two_ranks_equal_one_rank():
+    """`python bench.py --gpus 2` (no torchrun environment) spawns two ranks itself; over gloo both may share this box's
+    one GPU.  The per-unit checksums of the 2-rank job must equal those of the 1-rank job (units are defined without
+    reference to the world size) and n_gpus / per_rank must say 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    common = ["--config", "4", "--num-samples", "16", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-rooflines"]
+
+    def run(extra):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra + common, capture_output=True, text=True,
+                           env=env, timeout=900)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+        return json.loads(line)
+
+    one = run(["--gpus", "1"])
+    two = run(["--gpus", "2", "--backend", "gloo"])
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and len(two["per_rank"]) == 2
+    assert [r["units"] for r in two["per_rank"]] == [[0], [1]]
+    strip = lambda rs: [(r["unit"], r["checksum"]) for r in rs]
+    assert strip(one["per_unit"]) == strip(two["per_unit"])
+    assert one["scaling"] == two["scaling"] == "strong"

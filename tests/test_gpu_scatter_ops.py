@@ -110,3 +110,105 @@ def test_functional_wrappers_match_the_reference_layer_math():
     assert float((got_p - want_p).abs().max()) < 2e-5
     with pytest.raises(hip_lib.HipLibraryError):
         F2.knn_graph(x, K, batch)                    # CPU tensors: no fallback
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# plain torch_scatter drop-ins (decompdiff_amd.functional / torch.ops.decompdiff_amd.*) against the oracle's restatement of
+# the published semantics, on the shapes of the reference's call sites
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_seg,sizes,trail", [(330, [32], (16,)), (240, [0, 1, 29], (16, 8)), (7, [300, 301], (3,)),
+                                               (50, [5, 9], (30,)), (9, [4], (130,)), (40, [3, 64, 65], ())])
+def test_scatter_ops_match_torch_scatter_semantics(n_seg, sizes, trail):
+    from decompdiff_amd import functional as Fn
+    import decompdiff_amd.torch_ops  # noqa: F401  (registers torch.ops.decompdiff_amd.*)
+    dev = torch.device("cuda:0")
+    ptr, dst, g = _segments(n_seg, sizes, 3)
+    E = int(ptr[-1])
+    src = torch.randn((E,) + trail, generator=g) * 3
+    srcd, dstd = src.to(dev), dst.to(dev)
+    want_sum = ops.scatter_sum(src.double(), dst, 0, dim_size=n_seg)
+    want_mean = ops.scatter_mean(src.double(), dst, 0, dim_size=n_seg)
+    want_sm = ops.scatter_softmax(src.double(), dst, 0, dim_size=n_seg)
+    got_sum = torch.ops.decompdiff_amd.scatter_sum(srcd, dstd, 0, n_seg)
+    got_mean = Fn.scatter_mean(srcd, dstd, dim=0, dim_size=n_seg)
+    got_sm = torch.ops.decompdiff_amd.scatter_softmax(srcd, dstd, 0, n_seg)
+    e1 = float((got_sum.cpu().double() - want_sum).abs().max())
+    e2 = float((got_mean.cpu().double() - want_mean).abs().max())
+    e3 = float((got_sm.cpu().double() - want_sm).abs().max()) if E else 0.0
+    print(f"scatter n_seg={n_seg} E={E} trail={trail}: sum {e1:.3g} mean {e2:.3g} softmax {e3:.3g}")
+    assert got_sum.shape == want_sum.shape and got_sm.shape == src.shape
+    assert e1 < 1e-4 and e2 < 1e-5 and e3 < 1e-6
+    # min: values exact (no arithmetic), arg = a row holding the minimum; empty destinations 0 / E (torch_scatter's fill)
+    vmin, amin = torch.ops.decompdiff_amd.scatter_min(srcd, dstd, 0, n_seg)
+    vmin, amin = vmin.cpu(), amin.cpu()
+    big = torch.full((n_seg,) + trail, float("inf")).scatter_reduce(0, dst.view([-1] + [1] * len(trail)).expand_as(src), src,
+                                                                     "amin", include_self=True)
+    empty = torch.isinf(big)
+    assert torch.equal(vmin[~empty], big[~empty]) and bool((vmin[empty] == 0).all()) and bool((amin[empty] == E).all())
+    flat_src, flat_arg, flat_v = src.reshape(E, -1), amin.reshape(n_seg, -1), vmin.reshape(n_seg, -1)
+    cols = torch.arange(flat_arg.shape[1]).expand_as(flat_arg)
+    ok = ~empty.reshape(n_seg, -1)
+    assert torch.equal(flat_src[flat_arg[ok], cols[ok]], flat_v[ok])
+    assert torch.equal(dst[flat_arg[ok]], torch.arange(n_seg).view(-1, 1).expand_as(flat_arg)[ok])
+
+
+def test_scatter_ops_unsorted_index_and_reference_call_shapes():
+    """An unsorted index (torch_scatter accepts any order) and the exact calls of the reference: center_pos's
+    scatter_mean (decompdiff.py:25), the drift's scatter_min over arm ids (guidance_funcs.py:52)."""
+    from decompdiff_amd import functional as Fn
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    idx = torch.randint(0, 11, (500,), generator=g)
+    src = torch.randn(500, 16, generator=g)
+    got = Fn.scatter_softmax(src.to(dev), idx.to(dev), dim=0, dim_size=11).cpu()
+    want = ops.scatter_softmax(src.double(), idx, 0, dim_size=11)
+    assert float((got.double() - want).abs().max()) < 1e-6
+    v, a = Fn.scatter_min(src.to(dev), idx.to(dev), dim=0)
+    assert torch.equal(src[a.cpu(), torch.arange(16).expand(11, 16)], v.cpu())
+    # center_pos: offset = scatter_mean(protein_pos, batch_protein, dim=0)
+    pos = torch.randn(900, 3, generator=g) * 20
+    batch = torch.arange(3).repeat_interleave(300)
+    off = Fn.scatter_mean(pos.to(dev), batch.to(dev), dim=0).cpu()
+    assert float((off.double() - ops.scatter_mean(pos.double(), batch, 0)).abs().max()) < 1e-5
+    # armsca: min_dist_all, _ = scatter_min(pairwise_dist [n_arm_atoms, n_sca], arm_index, dim=0)
+    d = torch.rand(16, 14, generator=g) * 5
+    arm = torch.tensor([0] * 8 + [1] * 8)
+    m, _ = Fn.scatter_min(d.to(dev), arm.to(dev), dim=0)
+    assert torch.equal(m.cpu(), torch.stack([d[:8].min(0).values, d[8:].min(0).values]))
+
+
+def test_scatter_attention_accepts_non_contiguous_and_half_inputs():
+    """The wrappers convert to fp32-contiguous copies; those copies must stay alive until the launch is enqueued (a freed
+    temporary would hand its block to the next conversion and k / v would alias)."""
+    from decompdiff_amd import functional as Fn
+    dev = torch.device("cuda:0")
+    n_seg, per = 200, 32
+    g = torch.Generator().manual_seed(2)
+    q, k, v = (torch.randn(n, 256, generator=g) for n in (n_seg, n_seg * per, n_seg * per))
+    dst = torch.arange(n_seg).repeat_interleave(per)
+    qd, kd, vd = (t.to(dev)[:, ::2] for t in (q, k, v))                   # non-contiguous views
+    base = Fn.scatter_attention(qd.contiguous(), kd.contiguous(), vd.contiguous(), dst.to(dev), n_seg)
+    got = Fn.scatter_attention(qd, kd, vd, dst.to(dev), n_seg)
+    assert torch.equal(got, base)
+    got_h = Fn.scatter_attention(qd.half(), kd.half(), vd.half(), dst.to(dev), n_seg)
+    ref_h = Fn.scatter_attention(qd.half().float(), kd.half().float(), vd.half().float(), dst.to(dev), n_seg)
+    assert torch.equal(got_h, ref_h)
+
+
+def test_torch_ops_registered_with_reference_signatures():
+    import decompdiff_amd.torch_ops as T
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    x = (torch.rand(2 * 40, 3, generator=g) * 10).to(dev)
+    batch = torch.arange(2, device=dev).repeat_interleave(40)
+    ei = torch.ops.decompdiff_amd.knn_graph(x, 8, batch)
+    assert ei.shape == (2, 80 * 8) and ei.dtype == torch.long
+    assert torch.equal(ei, __import__("decompdiff_amd").functional.knn_graph(x, 8, batch))
+    T.patch_reference_imports(force=True)
+    import torch_scatter                                           # the module the reference imports
+    s = torch.randn(80 * 8, 16, device=dev)
+    a = torch_scatter.scatter_softmax(s, ei[1], dim=0, dim_size=80)
+    tot = torch_scatter.scatter_sum(a, ei[1], dim=0, dim_size=80)
+    assert float((tot - 1).abs().max()) < 1e-5
+    with pytest.raises(Exception):                                  # CPU tensors: no fallback
+        torch.ops.decompdiff_amd.scatter_sum(torch.randn(4, 2), torch.tensor([0, 0, 1, 1]), 0, 2)

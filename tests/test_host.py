@@ -46,6 +46,8 @@ def test_unsupported_configs_raise():
                  dict(add_prior_node=True), dict(bond_diffusion=False)):
         with pytest.raises(NotImplementedError):
             DecompScorePosNet3D(shipped_config(**over), 29, 10, 8)
+    with pytest.raises(NotImplementedError):                  # the step kernels and buffers are 8 atom classes wide
+        DecompScorePosNet3D(shipped_config(), 29, 10, 13)
 
 
 def test_packing_slots_match_c_enum():
@@ -125,8 +127,20 @@ def test_no_cpu_fallback():
         F2.knn_graph(x, 4)
     with pytest.raises(hip_lib.HipLibraryError):
         F2.scatter_attention(torch.randn(2, 128), torch.randn(4, 128), torch.randn(4, 128), torch.tensor([0, 0, 1, 1]), 2)
+    with pytest.raises(hip_lib.HipLibraryError):
+        F2.scatter_softmax(torch.randn(4, 16), torch.tensor([0, 0, 1, 1]), dim=0)
+    # ... and so do the dispatcher ops (registered for the HIP device type only)
+    import decompdiff_amd.torch_ops  # noqa: F401
+    for name in ("knn_graph", "scatter_attention", "scatter_attention_pos", "scatter_sum", "scatter_mean", "scatter_min",
+                 "scatter_softmax"):
+        assert hasattr(torch.ops.decompdiff_amd, name), name
+    with pytest.raises(NotImplementedError):
+        torch.ops.decompdiff_amd.scatter_sum(torch.randn(4, 2), torch.tensor([0, 0, 1, 1]), 0, 2)
     # null / bad arguments are status codes, not crashes (host-side checks: no GPU needed)
     lib = hip_lib.load()
+    assert lib.dd_segment_reduce(None, None, 4, 16, 0, 0, None, None, None) != 0
+    assert lib.dd_segment_softmax(None, None, 4, 0, None, None) != 0
+    assert lib.dd_debug_philox(1, 0, 0, 1, None, None) != 0
     assert lib.dd_graph_launch(None, 1, None) != 0 and lib.dd_graph_destroy(None) != 0
     assert lib.dd_sample_steps_graph_multi(None, 0, 1, None) != 0
     assert lib.dd_reverse_step(None, None, None, None, None) != 0

@@ -101,15 +101,19 @@ def _replay_traj(name, num_steps, std_scale=None):
     assert np.array_equal(GU.checksum(noise), g["noise_checksum"])
     noise = {k: v[:num_steps] for k, v in noise.items()}
     priors = {k: g[k] for k in ("prior_atom_types", "prior_bond_types") if k in g.files}
+    t_start = int(g["t_start"]) if "t_start" in g.files else cfg.num_diffusion_timesteps - 1
     r = OD.sample_diffusion(sd, cfg, num_steps=num_steps, energy_drift_opt=drift, noise=noise,
-                            t_start=cfg.num_diffusion_timesteps - 1, **priors, **b)
+                            t_start=t_start, **priors, **b)
     return g, r
 
 
 def _pocket_for(name):
     return {"traj20_plain": synth.make_pocket_small(2), "traj20_drift": synth.make_pocket_small(2),
             "traj1000_plain": synth.make_pocket_small(3), "traj12_priortypes": synth.make_pocket_small(4),
-            "traj1000_drift": synth.make_pocket_small(5)}[name]
+            "traj1000_drift": synth.make_pocket_small(5),
+            "traj3_scale": synth.make_pocket(41, 80, (3, 3), 4, num_full_protein=200),
+            "traj3_b16": synth.make_pocket(7, 347, (9, 9), 19, num_full_protein=0),
+            "traj3_large_drift": synth.make_pocket_large(6)}[name]
 
 
 def test_trajectory_20_steps_plain():
@@ -135,6 +139,25 @@ def test_trajectory_12_steps_prior_types():
     assert np.array_equal(g["out_v"], r["v"].numpy())
     assert np.array_equal(g["out_bond"], r["bond"].numpy())
     assert np.array_equal(g["traj_v"], torch.stack(r["v_traj"]).numpy().astype(np.int8))
+
+
+def test_trajectory_drift_scale_option():
+    """`scale: True` drift terms (decompdiff.py:656-657,667-668) at t = 600..598, fixture from the reference."""
+    g, r = _replay_traj("traj3_scale", 3, std_scale=[1.0, 0.8])
+    assert np.array_equal(g["out_pos"], r["pos"].numpy())
+    assert np.array_equal(g["out_v"], r["v"].numpy()) and np.array_equal(g["out_bond"], r["bond"].numpy())
+
+
+@pytest.mark.parametrize("name,std_scale", [("traj3_b16", None), ("traj3_large_drift", [1.0, 0.9])])
+def test_trajectory_bench_config_shapes_first_step(name, std_scale):
+    """BASELINE configs[3] / configs[4] shapes (NP=347, NL=37, B=16; 600 + 60 atoms with drift): the first step of the
+    reference's 3-step fixtures (the full 3 steps are replayed by the HIP path in tests/test_gpu_configs.py; the oracle
+    reproduced all 3 bit for bit when the fixture was generated: `oracle_vs_reference_maxabs` = 0)."""
+    g, r = _replay_traj(name, 1, std_scale=std_scale)
+    assert float(g["oracle_vs_reference_maxabs"]) == 0.0
+    assert np.array_equal(g["traj_pos"][0], r["pos_traj"][0].numpy())
+    assert np.array_equal(g["traj_v"][0], r["v_traj"][0].numpy().astype(np.int8))
+    assert np.array_equal(g["traj_bond"][0], r["bond_traj"][0].numpy().astype(np.int8))
 
 
 @pytest.mark.parametrize("name", ["traj1000_plain", "traj1000_drift"])
