@@ -250,7 +250,7 @@ def measure_step_rooflines(torch, model, hip_lib, lib, state, cfg, B, NP, NL, K,
     off = (view.nbr - ws.data_ptr()) // 4
     nbr = ws[off:off + B * (NP + NL) * K].view(torch.int32).view(B, NP + NL, K).cpu()
     n_mfma, by_mode = node_launch_mfma_count(nbr, B, NP, NL, K)
-    bufs2["step_counter"].zero_()
+    hip_lib.check(lib.dd_sampler_reset(ctypes.byref(s2), hip_lib.stream_ptr(dev)), "dd_sampler_reset")
     n_prof = 10
     cats = (ctypes.c_float * len(hip_lib.PROF_CATS))()
     hip_lib.check(lib.dd_profile_step(ctypes.byref(s2), n_prof, cats, hip_lib.stream_ptr(dev)), "dd_profile_step")

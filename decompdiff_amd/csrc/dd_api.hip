@@ -554,9 +554,9 @@ static int heads_and_step(const dd_sampler* s, hipStream_t st, const StepFold* f
   StepRowsArgs r;
   memset(&r, 0, sizeof(r));
   r.hid = w.qn; r.W2 = GW(DD_G_VH_W2); r.b2 = GW(DD_G_VH_b2); r.rows = B * NL; r.NC = DD_NUM_V; r.rows_per_sample = NL;
-  r.tab = s->tab_v; r.T = s->T; r.t_start = s->t_start; r.step_counter = s->step_counter;
+  r.tab = s->tab_v; r.T = s->T; r.step_counter = s->step_counter;
   r.counter_bias = (fold && fold->advance) ? 1 : 0;
-  r.state = s->lig_v; r.uniforms = s->u_v; r.seed = s->seed; r.stream_id = 1;
+  r.state = s->lig_v; r.uniforms = s->u_v; r.stream_id = 1;
   r.logits_out = s->pred_v; r.traj_recon = s->traj_v0; r.traj_prob = s->traj_vt; r.traj_state = s->traj_v;
   StepRowsArgs rb = r;
   rb.hid = w.qb; rb.W2 = GW(DD_G_BH_W2); rb.b2 = GW(DD_G_BH_b2); rb.rows = (int)(B * Eb); rb.NC = DD_NUM_B;
@@ -578,12 +578,12 @@ static int heads_and_step(const dd_sampler* s, hipStream_t st, const StepFold* f
   }
   StepPosArgs p;
   memset(&p, 0, sizeof(p));
-  p.B = B; p.NL = NL; p.T = s->T; p.t_start = s->t_start; p.step_counter = s->step_counter;
+  p.B = B; p.NL = NL; p.T = s->T; p.step_counter = s->step_counter;
   p.counter_bias = r.counter_bias; p.NP = s->NP;
   if (fold && fold->xprev) { p.x0_prev = fold->xprev; p.x0_dxe = w.dxe; p.x0_dxb = w.dxb; p.x0_out = s->pred_pos; }
   p.x0 = s->pred_pos; p.xt = s->lig_pos; p.tab_pos = s->tab_pos; p.tab_score = s->tab_score;
   p.atom_std = s->atom_std; p.offset = s->offset; p.grad_a = ga; p.scale_a = s->armsca_scale; p.grad_c = gc;
-  p.scale_c = s->clash_scale; p.eps = s->eps; p.seed = s->seed; p.traj_pos = s->traj_pos;
+  p.scale_c = s->clash_scale; p.eps = s->eps; p.traj_pos = s->traj_pos;
   const bool advanced = fold && fold->advance;
   if (g_step_fused) {
     DD_TRYP(DD_PROF_STEP, launch_step_all(rb, r, p, st));
@@ -606,8 +606,8 @@ static int reverse_step_from_logits(const dd_sampler* s, const float* logits_v, 
   StepRowsArgs r;
   memset(&r, 0, sizeof(r));
   r.logits_in = logits_v; r.rows = B * NL; r.NC = DD_NUM_V; r.rows_per_sample = NL;
-  r.tab = s->tab_v; r.T = s->T; r.t_start = s->t_start; r.step_counter = s->step_counter;
-  r.state = s->lig_v; r.uniforms = s->u_v; r.seed = s->seed; r.stream_id = 1;
+  r.tab = s->tab_v; r.T = s->T; r.step_counter = s->step_counter;
+  r.state = s->lig_v; r.uniforms = s->u_v; r.stream_id = 1;
   r.logits_out = nullptr; r.traj_recon = s->traj_v0; r.traj_prob = s->traj_vt; r.traj_state = s->traj_v;
   StepRowsArgs rb = r;
   rb.logits_in = logits_b; rb.rows = (int)(B * Eb); rb.NC = DD_NUM_B; rb.rows_per_sample = (int)Eb; rb.tab = s->tab_b;
@@ -627,10 +627,10 @@ static int reverse_step_from_logits(const dd_sampler* s, const float* logits_v, 
   }
   StepPosArgs p;
   memset(&p, 0, sizeof(p));
-  p.B = B; p.NL = NL; p.T = s->T; p.t_start = s->t_start; p.step_counter = s->step_counter; p.NP = s->NP;
+  p.B = B; p.NL = NL; p.T = s->T; p.step_counter = s->step_counter; p.NP = s->NP;
   p.x0 = x0; p.xt = s->lig_pos; p.tab_pos = s->tab_pos; p.tab_score = s->tab_score;
   p.atom_std = s->atom_std; p.offset = s->offset; p.grad_a = ga; p.scale_a = s->armsca_scale; p.grad_c = gc;
-  p.scale_c = s->clash_scale; p.eps = s->eps; p.seed = s->seed; p.traj_pos = s->traj_pos;
+  p.scale_c = s->clash_scale; p.eps = s->eps; p.traj_pos = s->traj_pos;
   DD_TRY(launch_step_rows(r, st));
   DD_TRY(launch_step_rows(rb, st));
   DD_TRY(launch_step_pos(p, st));
@@ -668,7 +668,15 @@ extern "C" const char* dd_status_string(int status) {
   return "unknown status";
 }
 
-extern "C" int dd_abi_version(void) { return 3; }   // 3: tab_v / tab_b carry the class log-prior after the four schedule rows
+// 3: tab_v / tab_b carry the class log-prior after the four schedule rows
+// 4: step_counter is the [4] int32 run state (steps done, t_start, seed lo, seed hi) written by dd_sampler_reset
+extern "C" int dd_abi_version(void) { return 4; }
+
+extern "C" int dd_sampler_reset(const dd_sampler* s, void* stream) {
+  if (!s || !s->step_counter) return DD_ERR_BAD_ARG;
+  if (s->t_start < 0 || s->t_start >= s->T) return DD_ERR_BAD_ARG;
+  return dd::launch_reset_run_state(s->step_counter, s->t_start, s->seed, (hipStream_t)stream);
+}
 
 extern "C" size_t dd_workspace_floats(int B, int NP, int NL, int K) {
   if (B <= 0 || NP < 0 || NL <= 0 || K <= 0) return 0;
@@ -976,7 +984,9 @@ extern "C" int dd_profile_step(const dd_sampler* s, int n_iters, float* ms_per_c
 
 // Profiling aid: when set, the tiled attention kernel of class `mode` (0 NE,1 NB,2 BL,3 PE,4 PB) writes 16
 // s_memtime stamps per workgroup (wave 0) into `buf` ([n_workgroups][16] int64, device memory).
+static int g_options_epoch = 0;
 extern "C" int dd_debug_set_clock_buffer(long long* buf, int mode) {
+  ++g_options_epoch;
   if (mode == 100) { dd::g_gemm_dbg = buf; return DD_OK; }      // dd_gemm128 phase stamps
   dd::g_gemm_dbg = nullptr;
   dd::g_dbg_clock = buf;
@@ -985,7 +995,12 @@ extern "C" int dd_debug_set_clock_buffer(long long* buf, int mode) {
 }
 
 // Profiling aid: 0 = one launch per sub-layer (so dd_profile_step can time each kernel class), 1 = fused launches.
+// Bumped by every dd_debug_set_* call: hosts that keep captured step graphs (model.py's chain cache) compare it to know
+// when the launch structure may have changed under them.
+extern "C" int dd_debug_options_epoch(void) { return g_options_epoch; }
+
 extern "C" int dd_debug_set_fusion(int mode) {
+  ++g_options_epoch;
   dd::g_fuse = (mode == 1 || mode == 3) ? 1 : 0;
   dd::g_overlap = mode == 1 ? 1 : 0;
   dd::g_use_v1 = mode == 2 ? 1 : 0;
@@ -998,6 +1013,7 @@ namespace dd { extern int g_gemm_ksplit; extern int g_attn_waves; extern int g_a
 extern "C" int dd_debug_node_split(int B, int NP, int NL, int K) { return dd::node_split_lookup(B, NP, NL, K); }
 
 extern "C" int dd_debug_set_option(int key, int value) {
+  ++g_options_epoch;
   if (key == 0) return dd_debug_set_fusion(value);
   if (key == 1) { dd::g_gemm_ksplit = value ? 1 : 0; return DD_OK; }
   if (key == 3) { dd::g_attn_persist = value ? 1 : 0; return DD_OK; }

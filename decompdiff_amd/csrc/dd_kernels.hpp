@@ -95,20 +95,20 @@ struct StepRowsArgs {
   const float* b2;         // [NC]
   int rows, NC, rows_per_sample;
   const float* tab;        // [4][T] log_alphas, log_1m_alphas, log_cumprod, log_1m_cumprod, then [NC] log prior
-  int T, t_start;
-  const int32_t* step_counter;
-  int counter_bias;        // step index = *step_counter - counter_bias (1 when the forward's first launch advanced it)
+  int T;
+  const int32_t* step_counter;   // run state [4]: steps done, t_start, seed lo, seed hi (dd_sampler_reset)
+  int counter_bias;        // step index = step_counter[0] - counter_bias (1 when the forward's first launch advanced it)
   int32_t* state;          // [rows] current class, updated in place
   const float* uniforms;   // [n_steps, rows, NC] or NULL
-  uint64_t seed; uint32_t stream_id;
+  uint32_t stream_id;
   float* logits_out;       // [rows,NC] raw logits (pred_*), may be NULL
   float* traj_recon;       // [n_steps, rows, NC] log_softmax(logits), may be NULL
   float* traj_prob;        // [n_steps, rows, NC] posterior log-probs, may be NULL
   int32_t* traj_state;     // [n_steps, rows] sampled classes, may be NULL
 };
 struct StepPosArgs {
-  int B, NL, T, t_start;
-  const int32_t* step_counter;
+  int B, NL, T;
+  const int32_t* step_counter;   // run state [4], see StepRowsArgs
   int counter_bias;
   const float* x0;          // [B*NL,3] predicted x0 (centred)
   // deferred tail of the forward: x0 = x0_prev[ligand rows] + x0_dxe + x0_dxb (the last layer's coordinate update,
@@ -122,12 +122,12 @@ struct StepPosArgs {
   const float* grad_a; int scale_a;   // armsca gradient (may be NULL)
   const float* grad_c; int scale_c;   // clash gradient (may be NULL)
   const float* eps;         // [n_steps,B*NL,3] or NULL
-  uint64_t seed;
   float* traj_pos;          // [n_steps,B*NL,3] or NULL
 };
 int launch_step_rows(const StepRowsArgs& a, hipStream_t st);
 int launch_step_pos(const StepPosArgs& a, hipStream_t st);
 int launch_advance(int32_t* ctr, hipStream_t st);
+int launch_reset_run_state(int32_t* rs, int t_start, uint64_t seed, hipStream_t st);
 int launch_step_all(const StepRowsArgs& rb, const StepRowsArgs& rv, const StepPosArgs& p, hipStream_t st);
 
 }  // namespace dd

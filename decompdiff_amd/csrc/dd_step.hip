@@ -36,6 +36,18 @@ __device__ __forceinline__ float philox_normal(uint64_t seed, int idx, int step)
 }
 
 
+// Run state in device memory (dd_sampler.step_counter, [4] int32: steps done, t_start, seed lo, seed hi; written by
+// dd_sampler_reset): a captured step graph is replayed for every step AND re-used for the next chain of the same shape
+// with another seed / start time -- nothing chain-specific is baked into its kernel arguments.
+struct RunState { int step, t_start; uint64_t seed; };
+__device__ __forceinline__ RunState load_run_state(const int32_t* __restrict__ rs, int counter_bias) {
+  RunState r;
+  r.step = rs[0] - counter_bias;
+  r.t_start = rs[1];
+  r.seed = (uint64_t)(uint32_t)rs[2] | ((uint64_t)(uint32_t)rs[3] << 32);
+  return r;
+}
+
 __device__ __forceinline__ float log_add_exp(float a, float b) {
   float m = fmaxf(a, b);
   return m + logf(expf(a - m) + expf(b - m));
@@ -46,8 +58,8 @@ __global__ __launch_bounds__(256) void k_step_rows(const StepRowsArgs a) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.rows) return;
-  const int step = *a.step_counter - a.counter_bias;
-  const int t = a.t_start - step;
+  const RunState rs = load_run_state(a.step_counter, a.counter_bias);
+  const int step = rs.step, t = rs.t_start - step;
   // ShiftedSoftplus (common.py:66-72): softplus(x) - log 2, torch threshold 20
   float logit[NC];
   if (a.logits_in != nullptr) {                          // dd_reverse_step: the host supplies the head outputs
@@ -101,7 +113,7 @@ __global__ __launch_bounds__(256) void k_step_rows(const StepRowsArgs a) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) u[c] = a.uniforms[((long)step * a.rows + row) * NC + c];
   } else {
-    Philox ph(a.seed);
+    Philox ph(rs.seed);
     uint32_t r[4], r2[4];
     ph.gen((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)step, a.stream_id, r);
     ph.gen((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)step, a.stream_id | 0x100u, r2);
@@ -126,8 +138,8 @@ __global__ void k_step_pos(const StepPosArgs a) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = a.B * a.NL * 3;
   if (idx >= n) return;
-  const int step = *a.step_counter - a.counter_bias;
-  const int t = a.t_start - step;
+  const RunState rs = load_run_state(a.step_counter, a.counter_bias);
+  const int step = rs.step, t = rs.t_start - step;
   const int atom = idx / 3, c = idx % 3, b = atom / a.NL;
   const float xt = a.xt[idx];
   float x0;
@@ -147,7 +159,7 @@ __global__ void k_step_pos(const StepPosArgs a) {
   if (a.eps) {
     e = a.eps[(long)step * n + idx];
   } else {
-    e = philox_normal(a.seed, idx, step);
+    e = philox_normal(rs.seed, idx, step);
   }
   const float nz = t == 0 ? 0.f : 1.f;
   const float nxt = mean + nz * expf(0.5f * a.tab_pos[2 * a.T + t]) * e * a.atom_std[idx];
@@ -156,6 +168,9 @@ __global__ void k_step_pos(const StepPosArgs a) {
 }
 
 __global__ void k_advance(int32_t* step_counter) { *step_counter += 1; }
+__global__ void k_reset_run_state(int32_t* rs, int t_start, uint32_t seed_lo, uint32_t seed_hi) {
+  rs[0] = 0; rs[1] = t_start; rs[2] = (int32_t)seed_lo; rs[3] = (int32_t)seed_hi;
+}
 
 // ------------------------------------------------------------------------------ drift: armsca
 // Per sample: d_arm = min over (arm atom a in arm, scaffold atom s) |x_a - x_s|;
@@ -264,8 +279,8 @@ __global__ __launch_bounds__(256) void k_drift_clash(const float* __restrict__ p
 // second head Linear uses the whole wave, the per-class posterior / Gumbel arithmetic runs one class per lane with
 // the cross-class sums taken in class order through v_readlane (bit-identical to the serial k_step_rows).
 template <int NC>
-__device__ __forceinline__ void step_row(const StepRowsArgs& a, const long row, const int lane, const int step) {
-  const int t = a.t_start - step;
+__device__ __forceinline__ void step_row(const StepRowsArgs& a, const long row, const int lane, const RunState rs) {
+  const int step = rs.step, t = rs.t_start - step;
   float2 hv = *reinterpret_cast<const float2*>(a.hid + row * 128 + 2 * lane);
   hv.x = (hv.x > 20.f ? hv.x : log1pf(expf(hv.x))) - 0.6931471805599453f;
   hv.y = (hv.y > 20.f ? hv.y : log1pf(expf(hv.y))) - 0.6931471805599453f;
@@ -306,7 +321,7 @@ __device__ __forceinline__ void step_row(const StepRowsArgs& a, const long row, 
   if (a.uniforms) {
     u = a.uniforms[((long)step * a.rows + row) * NC + c];
   } else {
-    u = philox_uniform<NC>(a.seed, row, step, a.stream_id, c);
+    u = philox_uniform<NC>(rs.seed, row, step, a.stream_id, c);
   }
   const float lp = un - ulse;
   const float sc = -logf(-logf(u + 1e-30f) + 1e-30f) + lp;      // Gumbel-argmax (transitions.py:78-84)
@@ -328,10 +343,10 @@ __device__ __forceinline__ void step_row(const StepRowsArgs& a, const long row, 
   }
 }
 
-__device__ __forceinline__ void step_pos_elem(const StepPosArgs& a, const int idx, const int step) {
+__device__ __forceinline__ void step_pos_elem(const StepPosArgs& a, const int idx, const RunState rs) {
   const int n = a.B * a.NL * 3;
   if (idx >= n) return;
-  const int t = a.t_start - step;
+  const int step = rs.step, t = rs.t_start - step;
   const int atom = idx / 3, c = idx % 3, b = atom / a.NL;
   const float xt = a.xt[idx];
   float x0;
@@ -351,7 +366,7 @@ __device__ __forceinline__ void step_pos_elem(const StepPosArgs& a, const int id
   if (a.eps) {
     e = a.eps[(long)step * n + idx];
   } else {
-    e = philox_normal(a.seed, idx, step);
+    e = philox_normal(rs.seed, idx, step);
   }
   const float nz = t == 0 ? 0.f : 1.f;
   const float nxt = mean + nz * expf(0.5f * a.tab_pos[2 * a.T + t]) * e * a.atom_std[idx];
@@ -361,15 +376,15 @@ __device__ __forceinline__ void step_pos_elem(const StepPosArgs& a, const int id
 
 __global__ __launch_bounds__(256) void k_step_all(const StepRowsArgs rb, const StepRowsArgs rv, const StepPosArgs p, int nb_b, int nb_v) {
   const int blk = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int step = *rb.step_counter - rb.counter_bias;
+  const RunState rs = load_run_state(rb.step_counter, rb.counter_bias);
   if (blk < nb_b) {
     const long row = (long)blk * 4 + wave;
-    if (row < rb.rows) step_row<DD_NUM_B>(rb, row, lane, step);
+    if (row < rb.rows) step_row<DD_NUM_B>(rb, row, lane, rs);
   } else if (blk < nb_b + nb_v) {
     const long row = (long)(blk - nb_b) * 4 + wave;
-    if (row < rv.rows) step_row<DD_NUM_V>(rv, row, lane, step);
+    if (row < rv.rows) step_row<DD_NUM_V>(rv, row, lane, rs);
   } else {
-    step_pos_elem(p, (blk - nb_b - nb_v) * 256 + threadIdx.x, step);
+    step_pos_elem(p, (blk - nb_b - nb_v) * 256 + threadIdx.x, rs);
   }
 }
 
@@ -393,6 +408,11 @@ int launch_step_rows(const StepRowsArgs& a, hipStream_t st) {
 int launch_step_pos(const StepPosArgs& a, hipStream_t st) {
   int n = a.B * a.NL * 3;
   hipLaunchKernelGGL(k_step_pos, dim3((n + 255) / 256), dim3(256), 0, st, a);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+int launch_reset_run_state(int32_t* rs, int t_start, uint64_t seed, hipStream_t st) {
+  hipLaunchKernelGGL(k_reset_run_state, dim3(1), dim3(1), 0, st, rs, t_start, (uint32_t)seed, (uint32_t)(seed >> 32));
   DD_CHECK_LAUNCH();
   return DD_OK;
 }

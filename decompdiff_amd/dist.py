@@ -157,7 +157,7 @@ def run_job(units: List[Unit], config: int, rank: int, world: int, prepare: Call
     states = [prepare(u) for u in mine]
     if warmup > 0:
         for u, st in zip(mine, states):
-            sample(st, warmup, u.noise_seed + 1)
+            checksum(sample(st, warmup, u.noise_seed + 1))      # (also loads the reduction kernels the timed region uses)
     barrier(device)
     t0 = time.perf_counter()
     records = []

@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "dd_drift_armsca",
     "dd_drift_clash", "dd_workspace_view", "dd_profile_step", "dd_debug_set_clock_buffer", "dd_debug_set_fusion", "dd_debug_set_option", "dd_debug_node_split",
     "dd_attn_aggregate_node", "dd_attn_aggregate_triplet", "dd_attn_aggregate_pos", "dd_reverse_step", "dd_debug_philox",
-    "dd_segment_reduce", "dd_segment_softmax",
+    "dd_segment_reduce", "dd_segment_softmax", "dd_sampler_reset", "dd_debug_options_epoch",
 ]
 
 
@@ -57,7 +57,7 @@ class DDWsView(ctypes.Structure):
 PROF_CATS = ["misc", "gemm", "assemble", "attn_NE", "attn_NB", "attn_BL", "attn_PE", "attn_PB", "step"]
 
 
-ABI_VERSION = 3          # include/decompdiff_hip.h: layout of struct dd_sampler and of the tables it points to
+ABI_VERSION = 4          # include/decompdiff_hip.h: layout of struct dd_sampler and of the tables it points to
 
 
 class HipLibraryError(RuntimeError):
@@ -93,6 +93,8 @@ def load():
                                c_long, c_int, c_int, c_int, c_void_p]
     lib.dd_embed_protein.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.dd_forward.argtypes = [POINTER(DDSampler), c_void_p]
+    lib.dd_sampler_reset.argtypes = [POINTER(DDSampler), c_void_p]
+    lib.dd_debug_options_epoch.argtypes = []
     lib.dd_sample_steps.argtypes = [POINTER(DDSampler), c_int, c_void_p]
     lib.dd_sample_steps_graph.argtypes = [POINTER(DDSampler), c_int, c_void_p]
     lib.dd_graph_create.argtypes = [POINTER(DDSampler), c_int, c_void_p, POINTER(c_void_p)]

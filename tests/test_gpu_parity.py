@@ -536,7 +536,7 @@ def test_reverse_step_op_equals_the_loop():
     torch.cuda.synchronize()
     for k in ("lig_pos", "lig_v", "lig_bond", "traj_pos", "traj_v", "traj_bond", "traj_v0", "traj_vt", "traj_bt", "step_counter"):
         assert torch.equal(a["bufs"][k], c["bufs"][k]), k
-    assert int(c["bufs"]["step_counter"]) == steps
+    assert int(c["bufs"]["step_counter"][0]) == steps          # run state: [steps done, t_start, seed lo, seed hi]
 
 
 def test_philox_noise_mode_is_deterministic_and_sane():
@@ -702,7 +702,7 @@ def test_ragged_groups_together_equals_one_by_one(monkeypatch):
     outs = []
     for conc in ("0", "1"):
         monkeypatch.setenv("DD_RAGGED_CONCURRENT", conc)
-        outs.append(_sample_hip(m, b, 25, drift, None))
+        outs.append(_sample_hip(m, b, 25, drift, None, seed=11))
     for k in ("pos", "v", "bond"):
         assert torch.equal(outs[0][k], outs[1][k]), k
     for k in ("pos_traj", "v_traj", "bond_traj", "v0_traj", "vt_traj", "bt_traj"):

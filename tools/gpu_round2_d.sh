@@ -1,0 +1,11 @@
+#!/bin/bash
+set -x
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+O=gpurun_out/r2d; mkdir -p $O
+python -m pytest tests -m gpu -q -s -x > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee $O/pytest.rc
+grep -E "passed|failed|FAILED|Error" $O/pytest.log | tail -15
+python tools/short_calls.py 20 6 > $O/short_calls.log 2>&1
+for i in 1 2; do python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-rooflines 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench 20 steps:', d['value'], d['ms_per_step'])"; done > $O/bench20.log 2>&1
+python bench.py --steps 1000 --warmup 20 --no-cpu-baseline --no-rooflines 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench 1000 steps:', d['value'], d['ms_per_step'])" >> $O/bench20.log 2>&1
+cat $O/short_calls.log $O/bench20.log
