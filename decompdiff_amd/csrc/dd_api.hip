@@ -64,6 +64,7 @@ static int check_shapes(const dd_sampler* s) {
   const int N = s->NP + s->NL;
   if (s->NL > DD_NL_MAX || N > DD_N_MAX || s->K > DD_KNN_MAX || s->K > N - 1) return DD_ERR_UNSUPPORTED_SHAPE;
   if (s->workspace_floats < dd_workspace_floats(s->B, s->NP, s->NL, s->K)) return DD_ERR_WORKSPACE_TOO_SMALL;
+  if ((s->nl_real != nullptr) != (s->bl_prefix != nullptr) || (s->np_real != nullptr && s->nl_real == nullptr)) return DD_ERR_BAD_ARG;
   return DD_OK;
 }
 
@@ -184,6 +185,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
   float* xnext = w.xb;
   const long hN = (long)N * 128;
   const bool fused = g_fuse && !g_use_v1 && NL <= g_fused_max_nl && g_dbg_clock == nullptr;
+  if (s->nl_real != nullptr && g_use_v1) return DD_ERR_UNSUPPORTED_SHAPE;     // the v1 cross-check kernels are dense-only
   const bool overlap = fused && g_overlap && g_prof == nullptr && s->num_layers <= 8;
   if (overlap) DD_TRY(ensure_side_stream());
 
@@ -200,9 +202,9 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
       if (hipEventRecord(g_ev_fork[8], st) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_fork[8], 0) != hipSuccess) return DD_ERR_HIP;
       gs = g_side;
     }
-    DD_TRYP(DD_PROF_MISC, launch_knn(w.xa, B, N, K, w.nbr, gs));
+    DD_TRYP(DD_PROF_MISC, launch_knn(w.xa, B, N, K, w.nbr, gs, NP, s->np_real, s->nl_real));
     DD_TRYP(DD_PROF_MISC, launch_edge_weights(w.xa, w.nbr, B, N, K, GW(DD_G_EW_W1T), GW(DD_G_EW_b1), GW(DD_G_EW_ln), GW(DD_G_EW_w2),
-                               GW(DD_G_EW_b2), w.ew, gs));
+                               GW(DD_G_EW_b2), w.ew, gs, NP, s->np_real, s->nl_real));
     if (overlap) {
       if (hipEventRecord(g_ev_join[8], g_side) != hipSuccess) return DD_ERR_HIP;
       head_join = true;
@@ -330,6 +332,8 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     {
       AttnArgs ne, nb, bl;
       memset(&ne, 0, sizeof(ne)); memset(&nb, 0, sizeof(nb)); memset(&bl, 0, sizeof(bl));
+      ne.np_real = nb.np_real = bl.np_real = s->np_real; ne.nl_real = nb.nl_real = bl.nl_real = s->nl_real;
+      bl.bl_prefix = s->bl_prefix;
       ne.B = B; ne.NP = NP; ne.NL = NL; ne.K = K; ne.x = xcur; ne.nbr = w.nbr; ne.ew = w.ew;
       ne.kd = w.P; ne.ks = w.P + 128; ne.vd = w.P + 256; ne.vs = w.P + 384; ne.ld_kd = ne.ld_ks = ne.ld_vd = ne.ld_vs = 640;
       ne.q = w.qn; ne.Ak = LW(l, DD_NE_Ak); ne.Av = LW(l, DD_NE_Av); ne.Akp = LW(l, DD_NE_Akp); ne.Avp = LW(l, DD_NE_Avp); ne.lnk = LW(l, DD_NE_lnk); ne.lnv = LW(l, DD_NE_lnv);
@@ -404,6 +408,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     {
       AttnArgs pe, pb;
       memset(&pe, 0, sizeof(pe)); memset(&pb, 0, sizeof(pb));
+      pe.np_real = pb.np_real = s->np_real; pe.nl_real = pb.nl_real = s->nl_real;
       pe.B = B; pe.NP = NP; pe.NL = NL; pe.K = K; pe.x = xcur; pe.nbr = w.nbr; pe.ew = w.ew;
       pe.kd = w.PL2; pe.vd = w.PL2 + 128; pe.ld_kd = pe.ld_vd = 1024; pe.ks = w.P2; pe.vs = w.P2 + 128; pe.ld_ks = pe.ld_vs = 256;
       pe.q = w.ql; pe.Ak = LW(l, DD_PE_Ak); pe.Av = LW(l, DD_PE_Av); pe.Akp = LW(l, DD_PE_Akp); pe.Avp = LW(l, DD_PE_Avp); pe.lnk = LW(l, DD_PE_lnk); pe.lnv = LW(l, DD_PE_lnv);
@@ -467,6 +472,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     // ---- node_layer_with_edge
     AttnArgs a;
     memset(&a, 0, sizeof(a));
+    a.np_real = s->np_real; a.nl_real = s->nl_real;
     a.B = B; a.NP = NP; a.NL = NL; a.K = K; a.x = xcur; a.nbr = w.nbr; a.ew = w.ew;
     a.kd = w.P; a.ks = w.P + 128; a.vd = w.P + 256; a.vs = w.P + 384; a.ld_kd = a.ld_ks = a.ld_vd = a.ld_vs = 640;
     a.q = w.qn; a.Ak = LW(l, DD_NE_Ak); a.Av = LW(l, DD_NE_Av); a.Akp = LW(l, DD_NE_Akp); a.Avp = LW(l, DD_NE_Avp); a.lnk = LW(l, DD_NE_lnk); a.lnv = LW(l, DD_NE_lnv);
@@ -474,6 +480,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     DD_TRYP(DD_PROF_ATTN_NE, attn_dispatch(M_NE, a, st));
     // ---- node_layer_with_bond (adds into the ligand rows of A)
     memset(&a, 0, sizeof(a));
+    a.np_real = s->np_real; a.nl_real = s->nl_real;
     a.B = B; a.NP = NP; a.NL = NL; a.K = K; a.x = xcur;
     a.kd = w.PL; a.ks = w.PL + 128; a.vd = w.PL + 256; a.vs = w.PL + 384; a.ld_kd = a.ld_ks = a.ld_vd = a.ld_vs = 1280;
     a.ke = w.PB; a.ve = w.PB + 128; a.ld_ke = a.ld_ve = 640;
@@ -482,6 +489,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     DD_TRYP(DD_PROF_ATTN_NB, attn_dispatch(M_NB, a, st));
     // ---- bond_layer (residual add into h_bond)
     memset(&a, 0, sizeof(a));
+    a.np_real = s->np_real; a.nl_real = s->nl_real;
     a.B = B; a.NP = NP; a.NL = NL; a.K = K; a.x = xcur;
     a.ke = w.Ek; a.ve = w.Ev; a.ld_ke = a.ld_ve = 128;
     a.q = w.qb; a.Wg2k = LW(l, DD_BL_Wg2k); a.Wg2v = LW(l, DD_BL_Wg2v); a.Wak = LW(l, DD_BL_Wak); a.Wav = LW(l, DD_BL_Wav); a.Wakp = LW(l, DD_BL_Wakp); a.Wavp = LW(l, DD_BL_Wavp);
@@ -501,6 +509,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.PL + 256, B * NL, 0, 1024, B * NL, LW(l, DD_PE_W2q), LW(l, DD_PE_b2q), LW(l, DD_PE_lnq), w.ql,
                            B * NL, 0, 128, 128, 0}, st));
     memset(&a, 0, sizeof(a));
+    a.np_real = s->np_real; a.nl_real = s->nl_real;
     a.B = B; a.NP = NP; a.NL = NL; a.K = K; a.x = xcur; a.nbr = w.nbr; a.ew = w.ew;
     a.kd = w.PL; a.vd = w.PL + 128; a.ld_kd = a.ld_vd = 1024; a.ks = w.P; a.vs = w.P + 128; a.ld_ks = a.ld_vs = 256;
     a.q = w.ql; a.Ak = LW(l, DD_PE_Ak); a.Av = LW(l, DD_PE_Av); a.Akp = LW(l, DD_PE_Akp); a.Avp = LW(l, DD_PE_Avp); a.lnk = LW(l, DD_PE_lnk); a.lnv = LW(l, DD_PE_lnv);
@@ -510,6 +519,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.PL + 896, B * NL, 0, 1024, B * NL, LW(l, DD_PB_W2q), LW(l, DD_PB_b2q), LW(l, DD_PB_lnq), w.ql,
                            B * NL, 0, 128, 128, 0}, st));
     memset(&a, 0, sizeof(a));
+    a.np_real = s->np_real; a.nl_real = s->nl_real;
     a.B = B; a.NP = NP; a.NL = NL; a.K = K; a.x = xcur;
     a.kd = w.PL + 384; a.ks = w.PL + 512; a.vd = w.PL + 640; a.vs = w.PL + 768; a.ld_kd = a.ld_ks = a.ld_vd = a.ld_vs = 1024;
     a.ke = w.PB; a.ve = w.PB + 128; a.ld_ke = a.ld_ve = 256;
@@ -573,7 +583,8 @@ static int heads_and_step(const dd_sampler* s, hipStream_t st, const StepFold* f
   }
   if (s->drift_clash) {
     if (!s->full_protein_pos || s->NF <= 0) return DD_ERR_BAD_ARG;
-    DD_TRYP(DD_PROF_STEP, dd_drift_clash(s->lig_pos, s->offset, s->full_protein_pos, B, NL, s->NF, s->clash_sigma, s->clash_gamma, w.gc, 0, st));
+    DD_TRYP(DD_PROF_STEP, launch_drift_clash(s->lig_pos, s->offset, s->full_protein_pos, B, NL, s->NF, s->clash_sigma, s->clash_gamma,
+                                             w.gc, 0, s->nl_real, st));
     gc = w.gc;
   }
   StepPosArgs p;
@@ -622,7 +633,8 @@ static int reverse_step_from_logits(const dd_sampler* s, const float* logits_v, 
   }
   if (s->drift_clash) {
     if (!s->full_protein_pos || s->NF <= 0) return DD_ERR_BAD_ARG;
-    DD_TRY(dd_drift_clash(s->lig_pos, s->offset, s->full_protein_pos, B, NL, s->NF, s->clash_sigma, s->clash_gamma, w.gc, 0, st));
+    DD_TRY(launch_drift_clash(s->lig_pos, s->offset, s->full_protein_pos, B, NL, s->NF, s->clash_sigma, s->clash_gamma, w.gc, 0,
+                              s->nl_real, st));
     gc = w.gc;
   }
   StepPosArgs p;
@@ -670,7 +682,8 @@ extern "C" const char* dd_status_string(int status) {
 
 // 3: tab_v / tab_b carry the class log-prior after the four schedule rows
 // 4: step_counter is the [4] int32 run state (steps done, t_start, seed lo, seed hi) written by dd_sampler_reset
-extern "C" int dd_abi_version(void) { return 4; }
+// 5: np_real / nl_real / bl_prefix (padded heterogeneous batches) appended to dd_sampler
+extern "C" int dd_abi_version(void) { return 5; }
 
 extern "C" int dd_sampler_reset(const dd_sampler* s, void* stream) {
   if (!s || !s->step_counter) return DD_ERR_BAD_ARG;
@@ -844,7 +857,7 @@ extern "C" int dd_sample_steps_graph(const dd_sampler* s, int n_steps, void* str
   return rc;
 }
 
-namespace { struct StepGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; }; }
+namespace { struct StepGraph { unsigned magic = 0x44444753u; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; }; }
 
 extern "C" int dd_graph_create(const dd_sampler* s, int steps_per_graph, void* stream, void** graph_out) {
   if (!s || !graph_out || steps_per_graph < 1 || steps_per_graph > 64 || !s->step_counter || !s->tab_pos || !s->tab_v ||
@@ -878,7 +891,7 @@ extern "C" int dd_graph_create(const dd_sampler* s, int steps_per_graph, void* s
 
 extern "C" int dd_graph_launch(void* graph, int n_graphs, void* stream) {
   StepGraph* g = (StepGraph*)graph;
-  if (!g || !g->exec || n_graphs < 0 || !stream) return DD_ERR_BAD_ARG;
+  if (!g || g->magic != 0x44444753u || !g->exec || n_graphs < 0 || !stream) return DD_ERR_BAD_ARG;
   for (int i = 0; i < n_graphs; ++i)
     if (hipGraphLaunch(g->exec, (hipStream_t)stream) != hipSuccess) { (void)hipGetLastError(); return DD_ERR_HIP; }
   return DD_OK;
@@ -886,7 +899,8 @@ extern "C" int dd_graph_launch(void* graph, int n_graphs, void* stream) {
 
 extern "C" int dd_graph_destroy(void* graph) {
   StepGraph* g = (StepGraph*)graph;
-  if (!g) return DD_ERR_BAD_ARG;
+  if (!g || g->magic != 0x44444753u) return DD_ERR_BAD_ARG;
+  g->magic = 0;
   if (g->exec) (void)hipGraphExecDestroy(g->exec);
   if (g->graph) (void)hipGraphDestroy(g->graph);
   delete g;
@@ -946,7 +960,7 @@ extern "C" int dd_sample_steps_graph_multi(const dd_sampler* const* ss, int n, i
   }
   for (int i = 0; i < n; ++i)
     if (hipStreamSynchronize((hipStream_t)streams[i]) != hipSuccess) rc = rc == DD_OK ? DD_ERR_HIP : rc;
-  for (int i = 0; i < n; ++i) {
+  for (int i = n - 1; i >= 0; --i) {                      // newest first (see model.py::_evict_chain_cache)
     if (exec[i]) (void)hipGraphExecDestroy(exec[i]);
     if (graph[i]) (void)hipGraphDestroy(graph[i]);
   }

@@ -231,7 +231,7 @@ __host__ __device__ inline int ne_blocks_per_sample(int NP, int NL, int NW) { re
 // state lives in registers; LDS only holds the (read-only) weight images shared by the workgroup.
 // PERSIST (modes without Gaussian tables): the workgroup stages its images once and every wave then pulls segments
 // from the global counter a.work_counter until none are left -- no barriers after the first one.
-template <int MODE, int MAXT, int NW, bool PERSIST = false>
+template <int MODE, int MAXT, int NW, bool PERSIST = false, bool RAG = false>
 __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, float* smem) {
   constexpr bool KNN = (MODE == M_NE || MODE == M_PE);
   constexpr bool POS = (MODE == M_PE || MODE == M_PB);
@@ -247,13 +247,33 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
   const int wave = threadIdx.x >> 6, lane0 = threadIdx.x & 63;
 
   const int N = a.NP + a.NL, NLm1 = a.NL - 1, Eb = a.NL * NLm1;
-  const int nseg = (MODE == M_NE) ? a.B * N : (TRIP ? a.B * Eb : a.B * a.NL);
-  const int M = KNN ? a.K : (TRIP ? a.NL - 2 : NLm1);
-  const int T = (M + 15) >> 4;
+  // Padded heterogeneous batch (a.nl_real != NULL): sample b's real atoms are the first np_real[b] / nl_real[b] rows of
+  // its blocks.  Padding atoms own no segment and are no members: kNN lists hold real atoms only, and because padding
+  // sits at the END of a ligand block the real members of a bond / triplet segment are a PREFIX of the dense member
+  // order -- the member count M (and tile count T) simply becomes a per-segment value.  The persistent bond-layer
+  // workgroups enumerate the real segments compactly through the prefix sums a.bl_prefix.
+  // (RAG is a template parameter: the dense instantiations keep their register allocation -- the masked code costs
+  // 1.5 % of the step when it shares a kernel with the dense path)
+  constexpr bool COMPACT = RAG && TRIP && PERSIST;
+  const int nseg = COMPACT ? a.bl_prefix[a.B] : ((MODE == M_NE) ? a.B * N : (TRIP ? a.B * Eb : a.B * a.NL));
+  int M = KNN ? a.K : (TRIP ? a.NL - 2 : NLm1);
+  int T = (M + 15) >> 4;
+  // compact index r of a real bond-layer segment -> its id in the dense (padded) enumeration b*Eb + i*(NL-1) + j'
+  auto bl_dense_seg = [&](int r) -> int {
+    if (!COMPACT) return r;
+    int bb = 0;
+    while (a.bl_prefix[bb + 1] <= r) ++bb;               // B <= 64 samples, wave-uniform scalar loop
+    const int nm1 = a.nl_real[bb] - 1, e = r - a.bl_prefix[bb];
+    return bb * Eb + (e / nm1) * NLm1 + (e % nm1);
+  };
   // node_layer_with_edge: block -> (sample, protein or ligand centres, first node)
   const int ne_bps = ne_blocks_per_sample(a.NP, a.NL, NW), ne_nbp = (a.NP + NW - 1) / NW;
   const int ne_b = block / ne_bps, ne_rb = block % ne_bps;
   const bool wg_protein = (MODE == M_NE) && ne_rb < ne_nbp;
+  if (MODE == M_NE && RAG && ne_b < a.B) {               // a block of padding centres only: nothing to do (block-uniform)
+    const int first = wg_protein ? ne_rb * NW : (ne_rb - ne_nbp) * NW;
+    if (first >= (wg_protein ? (a.np_real ? a.np_real[ne_b] : a.NP) : a.nl_real[ne_b])) return;
+  }
   long long* dbg = a.dbg_clock ? a.dbg_clock + (long)block * 16 : nullptr;
 #define DD_STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
   DD_STAMP(0);
@@ -316,20 +336,27 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
       sb[(it + 1) & 1] = atomicAdd(a.work_counter, NW);
       __hip_atomic_store(&sb[2], it + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    seg = base + wave;
+    seg = base + wave < nseg ? bl_dense_seg(base + wave) : a.B * Eb;
   } else if (MODE == M_NE) {
     const int nd = wg_protein ? ne_rb * NW + wave : a.NP + (ne_rb - ne_nbp) * NW + wave;
     seg = (nd < (wg_protein ? a.NP : N) && ne_b < a.B) ? ne_b * N + nd : nseg;
   } else {
     seg = block * NW + wave;
   }
-  const bool active = seg < nseg;
+  bool active = seg < ((MODE == M_NE) ? a.B * N : (TRIP ? a.B * Eb : a.B * a.NL));
 
   int b = 0, si = 0, sj = 0, node = 0;
   if (active) {
     if (MODE == M_NE) { b = seg / N; node = seg % N; }
     else if (TRIP) { b = seg / Eb; const int e = seg % Eb; si = e / NLm1; const int jp = e % NLm1; sj = jp + (jp >= si ? 1 : 0); }
     else { b = seg / a.NL; si = seg % a.NL; node = a.NP + si; }
+    if (RAG) {
+      const int nlb = a.nl_real[b], npb = a.np_real ? a.np_real[b] : a.NP;
+      if (MODE == M_NE) active = node < a.NP ? node < npb : node - a.NP < nlb;
+      else if (TRIP) active = si < nlb && sj < nlb;
+      else active = si < nlb;
+      if (!KNN) { M = TRIP ? nlb - 2 : nlb - 1; T = (M + 15) >> 4; }
+    }
   }
   const float* xb = a.x + (long)b * N * 3;
   const float* xl = xb + (long)a.NP * 3;
@@ -759,8 +786,9 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
   DD_STAMP(9);
   if (PERSIST) {                                       // next trip's query
     while (__hip_atomic_load(&sb[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < it + 1) {}
-    const int nseg2 = sb[(it + 1) & 1] + wave;
-    if (nseg2 < nseg) {
+    const int r2 = sb[(it + 1) & 1] + wave;
+    if (r2 < nseg) {
+      const int nseg2 = bl_dense_seg(r2);
       qn0 = *reinterpret_cast<const float4*>(a.q + (long)nseg2 * 128 + mm * 8);
       qn1 = *reinterpret_cast<const float4*>(a.q + (long)nseg2 * 128 + mm * 8 + 4);
     }
@@ -807,10 +835,10 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
 #undef DD_STAMP
 }
 
-template <int MODE, int MAXT, int NW>
+template <int MODE, int MAXT, int NW, bool RAG = false>
 __global__ __launch_bounds__(NW * 64) void k_attn2(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[Lds<MODE>::TOTAL + ((MODE == M_PE || MODE == M_PB) ? NW * 256 : 0)];
-  attn2_body<MODE, MAXT, NW>(a, blockIdx.x, smem);
+  attn2_body<MODE, MAXT, NW, false, RAG>(a, blockIdx.x, smem);
 }
 
 constexpr int imax(int a, int b) { return a > b ? a : b; }
@@ -819,7 +847,7 @@ constexpr int imax(int a, int b) { return a > b ? a : b; }
 // (long, one batch of NW segments each) come first, then the few NB ones; the BL workgroups are persistent and pull
 // single segments from a global counter, so they fill whatever the coarse NE schedule leaves idle and all finish
 // within one segment of each other.
-template <int MAXT, int NW>
+template <int MAXT, int NW, bool RAG = false>
 __global__ __launch_bounds__(NW * 64) void k_attn2_node(const AttnArgs ne, const AttnArgs nb, const AttnArgs bl, int n_ne, int n_nb,
                                                         int persist, int n_bl_first) {
   constexpr int SZ = imax(imax(Lds<M_NE>::TOTAL, Lds<M_NB>::TOTAL), Lds<M_BL>::TOTAL) + 4;
@@ -828,25 +856,25 @@ __global__ __launch_bounds__(NW * 64) void k_attn2_node(const AttnArgs ne, const
   // n_bl_first > 0: the persistent bond-layer workgroups come first in dispatch order and keep their CUs for the whole
   // launch, the node blocks cycle through the remaining CUs -- both parts then end together (see launch_node_nw)
   if (n_bl_first > 0) {
-    if (blk < n_bl_first) { attn2_body<M_BL, MAXT, NW, true>(bl, blk, smem); return; }
+    if (blk < n_bl_first) { attn2_body<M_BL, MAXT, NW, true, RAG>(bl, blk, smem); return; }
     blk -= n_bl_first;
-    if (blk < n_ne) attn2_body<M_NE, 2, NW>(ne, blk, smem);
-    else attn2_body<M_NB, MAXT, NW>(nb, blk - n_ne, smem);
+    if (blk < n_ne) attn2_body<M_NE, 2, NW, false, RAG>(ne, blk, smem);
+    else attn2_body<M_NB, MAXT, NW, false, RAG>(nb, blk - n_ne, smem);
     return;
   }
-  if (blk < n_ne) attn2_body<M_NE, 2, NW>(ne, blk, smem);
-  else if (blk < n_ne + n_nb) attn2_body<M_NB, MAXT, NW>(nb, blk - n_ne, smem);
-  else if (persist) attn2_body<M_BL, MAXT, NW, true>(bl, blk - n_ne - n_nb, smem);
-  else attn2_body<M_BL, MAXT, NW>(bl, blk - n_ne - n_nb, smem);
+  if (blk < n_ne) attn2_body<M_NE, 2, NW, false, RAG>(ne, blk, smem);
+  else if (blk < n_ne + n_nb) attn2_body<M_NB, MAXT, NW, false, RAG>(nb, blk - n_ne, smem);
+  else if (persist) attn2_body<M_BL, MAXT, NW, true, RAG>(bl, blk - n_ne - n_nb, smem);
+  else attn2_body<M_BL, MAXT, NW, false, RAG>(bl, blk - n_ne - n_nb, smem);
 }
 // Same for the two coordinate sub-layers (both write their own delta buffer; x is updated afterwards).
-template <int MAXT, int NW>
+template <int MAXT, int NW, bool RAG = false>
 __global__ __launch_bounds__(NW * 64) void k_attn2_pos(const AttnArgs pe, const AttnArgs pb, int n_pe) {
   constexpr int SZ = imax(Lds<M_PE>::TOTAL, Lds<M_PB>::TOTAL) + NW * 256;   // + per-wave scratch of the in-kernel query MLP
   __shared__ __attribute__((aligned(16))) float smem[SZ];
   const int blk = blockIdx.x;
-  if (blk < n_pe) attn2_body<M_PE, 2, NW>(pe, blk, smem);
-  else attn2_body<M_PB, MAXT, NW>(pb, blk - n_pe, smem);
+  if (blk < n_pe) attn2_body<M_PE, 2, NW, false, RAG>(pe, blk, smem);
+  else attn2_body<M_PB, MAXT, NW, false, RAG>(pb, blk - n_pe, smem);
   // x update (x += (dx_edge + dx_bond) on the ligand rows, uni_transformer_edge.py:285) by the workgroup that finishes
   // last: ~120 workgroups, so the ticket costs nothing and a launch on the critical chain is saved
   if (pe.work_counter == nullptr) return;
@@ -874,7 +902,8 @@ __global__ __launch_bounds__(NW * 64) void k_attn2_pos(const AttnArgs pe, const 
 template <int MODE, int MAXT, int NW>
 static int launch_mode(const AttnArgs& a, int nseg, hipStream_t st) {
   if (nseg <= 0) return DD_OK;
-  hipLaunchKernelGGL((k_attn2<MODE, MAXT, NW>), dim3((nseg + NW - 1) / NW), dim3(NW * 64), 0, st, a);
+  if (a.nl_real != nullptr) hipLaunchKernelGGL((k_attn2<MODE, MAXT, NW, true>), dim3((nseg + NW - 1) / NW), dim3(NW * 64), 0, st, a);
+  else hipLaunchKernelGGL((k_attn2<MODE, MAXT, NW>), dim3((nseg + NW - 1) / NW), dim3(NW * 64), 0, st, a);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
@@ -943,14 +972,21 @@ static int launch_node_nw(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs
       int want = g_bl_first > 1 ? g_bl_first : (g_node_split_trial >= 0 ? g_node_split_trial : node_split_lookup(ne.B, ne.NP, ne.NL, ne.K));
       if (want > 0) {
         n_bl = want < 16 ? 16 : (want > n_cu - 16 ? n_cu - 16 : want);
-        hipLaunchKernelGGL((k_attn2_node<MAXT, NW>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, bl, n_ne, n_nb, persist,
-                           n_bl);
+        if (ne.nl_real != nullptr)
+          hipLaunchKernelGGL((k_attn2_node<MAXT, NW, true>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, bl, n_ne, n_nb,
+                             persist, n_bl);
+        else
+          hipLaunchKernelGGL((k_attn2_node<MAXT, NW>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, bl, n_ne, n_nb, persist,
+                             n_bl);
         DD_CHECK_LAUNCH();
         return DD_OK;
       }
     }
   }
-  hipLaunchKernelGGL((k_attn2_node<MAXT, NW>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, bl, n_ne, n_nb, persist, 0);
+  if (ne.nl_real != nullptr)
+    hipLaunchKernelGGL((k_attn2_node<MAXT, NW, true>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, bl, n_ne, n_nb, persist, 0);
+  else
+    hipLaunchKernelGGL((k_attn2_node<MAXT, NW>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, bl, n_ne, n_nb, persist, 0);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
@@ -964,7 +1000,11 @@ template <int NW>
 static int launch_pos_nw(const AttnArgs& pe, const AttnArgs& pb, hipStream_t st) {
   using namespace v2;
   const int n = (pe.B * pe.NL + NW - 1) / NW;
-  if (pe.NL > 49) hipLaunchKernelGGL((k_attn2_pos<4, NW>), dim3(2 * n), dim3(NW * 64), 0, st, pe, pb, n);
+  if (pe.nl_real != nullptr) {
+    if (pe.NL > 49) hipLaunchKernelGGL((k_attn2_pos<4, NW, true>), dim3(2 * n), dim3(NW * 64), 0, st, pe, pb, n);
+    else if (pe.NL > 33) hipLaunchKernelGGL((k_attn2_pos<3, NW, true>), dim3(2 * n), dim3(NW * 64), 0, st, pe, pb, n);
+    else hipLaunchKernelGGL((k_attn2_pos<2, NW, true>), dim3(2 * n), dim3(NW * 64), 0, st, pe, pb, n);
+  } else if (pe.NL > 49) hipLaunchKernelGGL((k_attn2_pos<4, NW>), dim3(2 * n), dim3(NW * 64), 0, st, pe, pb, n);
   else if (pe.NL > 33) hipLaunchKernelGGL((k_attn2_pos<3, NW>), dim3(2 * n), dim3(NW * 64), 0, st, pe, pb, n);
   else hipLaunchKernelGGL((k_attn2_pos<2, NW>), dim3(2 * n), dim3(NW * 64), 0, st, pe, pb, n);
   DD_CHECK_LAUNCH();

@@ -39,12 +39,22 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
   return v;
 }
 
+// atom n of sample b is real (not padding): protein rows n < NP count up to np_real[b], ligand rows up to nl_real[b]
+__device__ __forceinline__ bool atom_is_real(int n, int NP, int npb, int nlb) { return n < NP ? n < npb : (n - NP) < nlb; }
+
 template <int CAND>
-__global__ __launch_bounds__(256) void k_knn(const float* __restrict__ x, int B, int N, int K, int32_t* __restrict__ nbr) {
+__global__ __launch_bounds__(256) void k_knn(const float* __restrict__ x, int B, int N, int K, int32_t* __restrict__ nbr, int NP,
+                                             const int32_t* __restrict__ np_real, const int32_t* __restrict__ nl_real) {
   const int lane = threadIdx.x & 63;
   const int centre = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (centre >= B * N) return;
   const int b = centre / N, i = centre % N;
+  const bool masked = nl_real != nullptr;
+  const int npb = masked && np_real ? np_real[b] : NP, nlb = masked ? nl_real[b] : N - NP;
+  if (masked && !atom_is_real(i, NP, npb, nlb)) {          // a padding atom is no centre: its list is never read
+    if (lane < K) nbr[(long)centre * K + lane] = 0;
+    return;
+  }
   const float* xb = x + (long)b * N * 3;
   const float cx = xb[3 * i], cy = xb[3 * i + 1], cz = xb[3 * i + 2];
   unsigned khi[CAND], klo[CAND];                         // key = (bits(d2), index): d2 >= 0, so unsigned order = float order
@@ -52,7 +62,7 @@ __global__ __launch_bounds__(256) void k_knn(const float* __restrict__ x, int B,
   for (int t = 0; t < CAND; ++t) {
     const int c = lane + 64 * t;
     khi[t] = ~0u; klo[t] = ~0u;
-    if (c < N && c != i) {
+    if (c < N && c != i && (!masked || atom_is_real(c, NP, npb, nlb))) {
       float dx = __fsub_rn(cx, xb[3 * c]), dy = __fsub_rn(cy, xb[3 * c + 1]), dz = __fsub_rn(cz, xb[3 * c + 2]);
       float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
       khi[t] = __float_as_uint(d2); klo[t] = (unsigned)c;
@@ -127,11 +137,13 @@ __global__ __launch_bounds__(256) void k_edge_weights2(const float* __restrict__
                                                        int N, int K, const float* __restrict__ W1T,
                                                        const float* __restrict__ b1, const float* __restrict__ ln,
                                                        const float* __restrict__ w2, const float* __restrict__ b2,
-                                                       float* __restrict__ ew) {
+                                                       float* __restrict__ ew, int NP, const int32_t* __restrict__ np_real,
+                                                       const int32_t* __restrict__ nl_real) {
   const int lane = threadIdx.x & 63, mm = lane & 15, cg = lane >> 4;
   const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (node >= B * N) return;
   const int b = node / N, i = node % N;
+  if (nl_real != nullptr && !atom_is_real(i, NP, np_real ? np_real[b] : NP, nl_real[b])) return;   // padding atom
   const float* xb = x + (long)b * N * 3;
   const float cx = xb[3 * i], cy = xb[3 * i + 1], cz = xb[3 * i + 2];
   float Wa[5][8];                                        // A operands: W1T[4s + cg][16nt + mm]
@@ -558,22 +570,27 @@ int launch_xupdate(const float* x, const float* dxe, const float* dxb, int B, in
   return DD_OK;
 }
 
-int launch_knn(const float* x, int B, int N, int K, int32_t* nbr, hipStream_t st) {
+int launch_knn(const float* x, int B, int N, int K, int32_t* nbr, hipStream_t st, int NP, const int32_t* np_real,
+               const int32_t* nl_real) {
   const dim3 grid((B * N + 3) / 4), block(256);
   const int cand = (N + 63) / 64;
-  if (cand <= 2) hipLaunchKernelGGL(k_knn<2>, grid, block, 0, st, x, B, N, K, nbr);
-  else if (cand <= 4) hipLaunchKernelGGL(k_knn<4>, grid, block, 0, st, x, B, N, K, nbr);
-  else if (cand <= 6) hipLaunchKernelGGL(k_knn<6>, grid, block, 0, st, x, B, N, K, nbr);
-  else if (cand <= 11) hipLaunchKernelGGL(k_knn<11>, grid, block, 0, st, x, B, N, K, nbr);
-  else hipLaunchKernelGGL(k_knn<DD_N_MAX / 64>, grid, block, 0, st, x, B, N, K, nbr);
+  if (NP < 0) { NP = N; np_real = nl_real = nullptr; }
+  if (cand <= 2) hipLaunchKernelGGL(k_knn<2>, grid, block, 0, st, x, B, N, K, nbr, NP, np_real, nl_real);
+  else if (cand <= 4) hipLaunchKernelGGL(k_knn<4>, grid, block, 0, st, x, B, N, K, nbr, NP, np_real, nl_real);
+  else if (cand <= 6) hipLaunchKernelGGL(k_knn<6>, grid, block, 0, st, x, B, N, K, nbr, NP, np_real, nl_real);
+  else if (cand <= 11) hipLaunchKernelGGL(k_knn<11>, grid, block, 0, st, x, B, N, K, nbr, NP, np_real, nl_real);
+  else hipLaunchKernelGGL(k_knn<DD_N_MAX / 64>, grid, block, 0, st, x, B, N, K, nbr, NP, np_real, nl_real);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
 int g_ew_mfma = 1;           // dd_debug_set_option(15, v): matrix-core edge-weight kernel
 
 int launch_edge_weights(const float* x, const int32_t* nbr, int B, int N, int K, const float* W1T, const float* b1,
-                        const float* ln, const float* w2, const float* b2, float* ew, hipStream_t st) {
-  if (g_ew_mfma) hipLaunchKernelGGL(k_edge_weights2, dim3((B * N + 3) / 4), dim3(256), 0, st, x, nbr, B, N, K, W1T, b1, ln, w2, b2, ew);
+                        const float* ln, const float* w2, const float* b2, float* ew, hipStream_t st, int NP, const int32_t* np_real,
+                        const int32_t* nl_real) {
+  if (NP < 0) { NP = N; np_real = nl_real = nullptr; }
+  if (g_ew_mfma || nl_real) hipLaunchKernelGGL(k_edge_weights2, dim3((B * N + 3) / 4), dim3(256), 0, st, x, nbr, B, N, K, W1T, b1, ln, w2, b2, ew,
+                                               NP, np_real, nl_real);
   else hipLaunchKernelGGL(k_edge_weights, dim3((B * N + 3) / 4), dim3(256), 0, st, x, nbr, B, N, K, W1T, b1, ln, w2, b2, ew);
   DD_CHECK_LAUNCH();
   return DD_OK;

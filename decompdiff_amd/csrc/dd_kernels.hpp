@@ -40,9 +40,14 @@ int launch_embed_all(const float* protein_h, const float* protein_pos, const flo
                      hipStream_t st, int32_t* advance = nullptr);
 int launch_drift_armsca(const float* lig_pos, const int32_t* decomp_index, int B, int NL, float min_d, float max_d,
                         float* grad, int accumulate, int norm_B, hipStream_t st);
-int launch_knn(const float* x, int B, int N, int K, int32_t* nbr, hipStream_t st);
+// (NP, np_real, nl_real: padded heterogeneous batches -- padding atoms are neither centres nor candidates)
+int launch_drift_clash(const float* lig_pos, const float* offset, const float* full_protein_pos, int B, int NL, int NF,
+                       float sigma, float gamma, float* grad, int accumulate, const int32_t* nl_real, hipStream_t st);
+int launch_knn(const float* x, int B, int N, int K, int32_t* nbr, hipStream_t st, int NP = -1, const int32_t* np_real = nullptr,
+               const int32_t* nl_real = nullptr);
 int launch_edge_weights(const float* x, const int32_t* nbr, int B, int N, int K, const float* W1T, const float* b1,
-                        const float* ln, const float* w2, const float* b2, float* ew, hipStream_t st);
+                        const float* ln, const float* w2, const float* b2, float* ew, hipStream_t st, int NP = -1,
+                        const int32_t* np_real = nullptr, const int32_t* nl_real = nullptr);
 int launch_embed_nodes(const float* protein_h, const float* protein_pos, const float* lig_pos, const int32_t* lig_v,
                        const float* lig_aux, const float* Wl, const float* bl, int B, int NP, int NL, float* h,
                        float* xa, float* xb, hipStream_t st);
@@ -81,6 +86,8 @@ struct AttnArgs {
   const float *Rk, *Rv;    // BL (tiled kernel): per-edge G(d_ji) partial sums [B*Eb,128]
   long long* dbg_clock;    // optional [n_blocks][16] s_memtime stamps of wave 0 (profiling aid), may be NULL
   int out_assign;          // NB: 1 = write (=) rows [B*NL,128] of `out` instead of accumulating into the node table
+  // padded heterogeneous batches (dd_sampler.np_real / nl_real / bl_prefix), all NULL for dense batches
+  const int32_t *np_real, *nl_real, *bl_prefix;
 };
 int launch_attn(int mode, const AttnArgs& a, hipStream_t st);    // v1: one member at a time, VALU only
 int launch_attn2(int mode, const AttnArgs& a, hipStream_t st);   // v2: 16-member tiles, scores/aggregation on MFMA

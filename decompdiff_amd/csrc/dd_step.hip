@@ -243,9 +243,15 @@ __global__ __launch_bounds__(64) void k_drift_armsca(const float* __restrict__ p
 // One workgroup (256 threads) per ligand atom.
 __global__ __launch_bounds__(256) void k_drift_clash(const float* __restrict__ pos, const float* __restrict__ offset,
                                                      const float* __restrict__ prot, int B, int NL, int NF, float sigma,
-                                                     float gamma, float* __restrict__ grad, int accumulate) {
+                                                     float gamma, float* __restrict__ grad, int accumulate,
+                                                     const int32_t* __restrict__ nl_real) {
   __shared__ float red[4][4];
   const int atom = blockIdx.x, b = atom / NL;
+  const int nlb = nl_real ? nl_real[b] : NL;             // the loss is the mean over the sample's REAL ligand atoms
+  if (atom % NL >= nlb) {                                // padding atom of a heterogeneous batch
+    if (threadIdx.x < 3 && !accumulate) grad[(long)atom * 3 + threadIdx.x] = 0.f;
+    return;
+  }
   const float yx = pos[(long)atom * 3] + offset[b * 3], yy = pos[(long)atom * 3 + 1] + offset[b * 3 + 1],
               yz = pos[(long)atom * 3 + 2] + offset[b * 3 + 2];
   const float* pb = prot + (long)b * NF * 3;
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(256) void k_drift_clash(const float* __restrict__ p
     float v = red[0][1 + threadIdx.x] + red[1][1 + threadIdx.x] + red[2][1 + threadIdx.x] + red[3][1 + threadIdx.x];
     float G = -sigma * logf(1e-3f + St);
     float g = 0.f;
-    if (gamma - G > 0.f) g = -(1.0f / (float)NL) * 2.0f / (1e-3f + St) * v;
+    if (gamma - G > 0.f) g = -(1.0f / (float)nlb) * 2.0f / (1e-3f + St) * v;
     float* dst = grad + (long)atom * 3 + threadIdx.x;
     *dst = accumulate ? *dst + g : g;
   }
@@ -449,13 +455,21 @@ extern "C" int dd_drift_armsca(const float* lig_pos, const int32_t* decomp_index
   return dd::launch_drift_armsca(lig_pos, decomp_index, B, NL, min_d, max_d, grad, accumulate, B, (hipStream_t)stream);
 }
 
+namespace dd {
+int launch_drift_clash(const float* lig_pos, const float* offset, const float* full_protein_pos, int B, int NL, int NF,
+                       float sigma, float gamma, float* grad, int accumulate, const int32_t* nl_real, hipStream_t st) {
+  hipLaunchKernelGGL(k_drift_clash, dim3(B * NL), dim3(256), 0, st, lig_pos, offset, full_protein_pos, B, NL, NF, sigma, gamma,
+                     grad, accumulate, nl_real);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+}  // namespace dd
+
 extern "C" int dd_drift_clash(const float* lig_pos, const float* offset, const float* full_protein_pos, int B, int NL,
                               int NF, float sigma, float gamma, float* grad, int accumulate, void* stream) {
   if (!lig_pos || !offset || !full_protein_pos || !grad || B <= 0 || NL <= 0 || NF <= 0) return DD_ERR_BAD_ARG;
-  hipLaunchKernelGGL(dd::k_drift_clash, dim3(B * NL), dim3(256), 0, (hipStream_t)stream, lig_pos, offset,
-                     full_protein_pos, B, NL, NF, sigma, gamma, grad, accumulate);
-  DD_CHECK_LAUNCH();
-  return DD_OK;
+  return dd::launch_drift_clash(lig_pos, offset, full_protein_pos, B, NL, NF, sigma, gamma, grad, accumulate, nullptr,
+                                (hipStream_t)stream);
 }
 
 // Test aid: the production noise of one step, exactly as the step kernels draw it.  kind 1: uniforms [rows,8] of the

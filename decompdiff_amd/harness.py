@@ -143,22 +143,65 @@ def _accepts_extras(model) -> bool:
         return False
 
 
+# index -> atomic number of the 8 atom classes, ligand_atom_mode 'basic' (utils/transforms.py:41-50,73-75)
+ATOMIC_NUMBER_OF_CLASS = (1, 6, 7, 8, 9, 15, 16, 17)
+
+
+def atomic_numbers_from_index(pred_v) -> List[int]:
+    """trans.get_atomic_number_from_index(pred_v, mode='basic') (utils/transforms.py:73-75)."""
+    return [ATOMIC_NUMBER_OF_CLASS[int(i)] for i in np.asarray(pred_v).tolist()]
+
+
+def bond_graph(pred_bond_index, pred_bond_type):
+    """The undirected molecular graph the reference's reconstruction builds from the predicted fully connected bond list
+    (utils/reconstruct.py:593-606: a directed entry (i, j) with i < j and type > 0 becomes one bond, type 1-4 = single,
+    double, triple, aromatic): ``(bonds [(i, j, order)], n_fragments)`` without RDKit.  ``n_fragments == 1`` is the
+    reference's "complete" criterion (``'.' not in smiles``, scripts/sample_diffusion_decomp.py:445)."""
+    bi = np.asarray(pred_bond_index)
+    bt = np.asarray(pred_bond_type)
+    n = int(bi.max()) + 1 if bi.size else 0
+    bonds = [(int(i), int(j), int(t)) for i, j, t in zip(bi[0], bi[1], bt) if i < j and t > 0]
+    parent = list(range(n))
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+    for i, j, _ in bonds:
+        parent[find(i)] = find(j)
+    return bonds, len({find(a) for a in range(n)})
+
+
 def to_result_records(out: Dict[str, list], ligand_filename: Optional[str] = None, reconstruct=None) -> List[dict]:
     """Per-sample records in the layout of the reference's ``result.pt`` (scripts/sample_diffusion_decomp.py:416-457,
     609-619): ``mol, smiles, pred_pos, pred_v, pred_pos_traj, pred_v_traj, decomp_mask, pred_bond_index (list),
     pred_bond_type`` (+ ``ligand_filename``), so that ``evaluate_mol_from_meta_full.py`` can consume them unchanged.
 
     Molecule reconstruction is RDKit/OpenBabel CPU chemistry outside the sampling hot path: pass the
-    reference's ``reconstruct_from_generated_with_bond``-style callable as ``reconstruct(pred_pos, pred_v,
-    pred_bond_index, pred_bond_type) -> (mol, smiles)`` where those packages exist; without it ``mol`` is ``None`` and
-    ``smiles`` empty, exactly what the reference stores when reconstruction fails (:440-443).
-    """
+    reference's ``recon.reconstruct_from_generated_with_bond`` (utils/reconstruct.py:579) -- or anything with its
+    signature ``reconstruct(pred_pos, atomic_numbers, pred_bond_index, pred_bond_type) -> mol`` -- where those packages
+    exist; a ``(mol, smiles)`` return is accepted too, otherwise ``smiles`` comes from ``Chem.MolToSmiles`` when RDKit is
+    importable.  An exception from the callable is a failed reconstruction: ``mol`` None and ``smiles`` '' -- exactly
+    what the reference stores (:440-443).  Without a callable the same placeholders are stored."""
     records = []
     for i in range(len(out["pred_pos"])):
         bond_index = np.asarray(out["pred_bond_index"][i]).tolist()
         mol, smiles = None, ""
         if reconstruct is not None:
-            mol, smiles = reconstruct(out["pred_pos"][i], out["pred_v"][i], bond_index, out["pred_bond_type"][i])
+            try:
+                r = reconstruct(out["pred_pos"][i], atomic_numbers_from_index(out["pred_v"][i]), bond_index, out["pred_bond_type"][i])
+                if isinstance(r, tuple):
+                    mol, smiles = r
+                else:
+                    mol = r
+                    try:
+                        from rdkit import Chem                     # noqa: only where the chemistry stack exists
+                        smiles = Chem.MolToSmiles(mol)
+                    except ImportError:
+                        smiles = ""
+            except Exception:                                      # recon.MolReconsError in the reference
+                mol, smiles = None, ""
         rec = {"mol": mol, "smiles": smiles, "pred_pos": out["pred_pos"][i], "pred_v": out["pred_v"][i],
                "pred_pos_traj": out["pred_pos_traj"][i], "pred_v_traj": out["pred_v_traj"][i],
                "decomp_mask": out["decomp_mask"][i], "pred_bond_index": bond_index,
@@ -167,3 +210,13 @@ def to_result_records(out: Dict[str, list], ligand_filename: Optional[str] = Non
             rec["ligand_filename"] = ligand_filename
         records.append(rec)
     return records
+
+
+def save_result_pt(records: List[dict], path: str) -> None:
+    """``torch.save(results, .../result.pt)`` (scripts/sample_diffusion_decomp.py:616-619): the list of per-sample dicts."""
+    torch.save(records, path)
+
+
+def load_result_pt(path: str) -> List[dict]:
+    """What ``evaluate_mol_from_meta_full.py`` does first: ``torch.load(result.pt)`` (numpy arrays inside: full unpickling)."""
+    return torch.load(path, weights_only=False)

@@ -222,6 +222,131 @@ class DecompScorePosNet3D(nn.Module):
         cl = torch.bincount(batch_ligand, minlength=B)
         return bool((cp != cp[0]).any().item() or (cl != cl[0]).any().item())
 
+    def _sample_heterogeneous(self, kw, ligand_atom_mask, num_steps, center_pos_mode, energy_drift_opt, noise, seed, keep_traj,
+                              use_graph, start_step=0):
+        """Samples with different atom counts in one batch (PyG collate, utils/data.py:389-446).  Default: ONE launch
+        sequence over the batch padded to its largest pocket / ligand with per-sample real counts (`_sample_padded`).
+        Fallbacks to equal-size groups (`_sample_ragged`): DD_RAGGED_MODE=groups, or a sample with fewer than knn + 1
+        atoms (its kNN lists would be shorter than the others')."""
+        mode = os.environ.get("DD_RAGGED_MODE", "padded")
+        if mode != "groups":
+            bp, bl = kw["batch_protein"], kw["batch_ligand"]
+            B = int(bp.max().item()) + 1
+            n_p = torch.bincount(bp, minlength=B).cpu()
+            n_l = torch.bincount(bl, minlength=B).cpu()
+            fits = int((n_p + n_l).min()) - 1 >= int(self.config.knn) and int(n_l.min()) >= 2 and int(n_l.max()) <= 64 \
+                and int(n_p.max()) + int(n_l.max()) <= 1024
+            if fits:
+                return self._sample_padded(kw, ligand_atom_mask, num_steps, center_pos_mode, energy_drift_opt, noise, seed,
+                                           keep_traj, use_graph, start_step, n_p.tolist(), n_l.tolist())
+        return self._sample_ragged(kw, ligand_atom_mask, num_steps, center_pos_mode, energy_drift_opt, noise, seed, keep_traj,
+                                   use_graph, start_step=start_step)
+
+    def _sample_padded(self, kw, ligand_atom_mask, num_steps, center_pos_mode, energy_drift_opt, noise, seed, keep_traj,
+                       use_graph, start_step, n_p, n_l):
+        """Heterogeneous batch as one padded dense batch: every sample's atoms are the first rows of its [NPmax] / [NLmax]
+        blocks, the kernels read the real counts from dd_sampler.np_real / nl_real (padding atoms are no kNN candidates,
+        own no softmax segment and are no members of one) and the results are gathered back into the caller's flat order.
+        Exact: a sample's chain does not depend on its batch, with the one batch-wide quantity of the reference -- the
+        armsca loss is averaged over the whole batch (guidance_funcs.py:78) -- unchanged because the batch is whole."""
+        _check_ligand_atom_mask(ligand_atom_mask, kw["batch_ligand"].numel())
+        dev = kw["protein_pos"].device
+        hip_lib.require_gpu(kw["protein_pos"], "protein_pos")
+        hip_lib.require_gpu(kw["init_ligand_pos"], "init_ligand_pos")
+        bp, bl, bpr = kw["batch_protein"], kw["batch_ligand"], kw["batch_prior"]
+        for name, t in (("batch_protein", bp), ("batch_ligand", bl), ("batch_prior", bpr)):
+            if t.numel() > 1 and bool((t[1:] < t[:-1]).any().item()):
+                raise NotImplementedError(f"{name} must be sorted (PyG Batch order)")
+        B = len(n_p)
+        NP, NL = max(n_p), max(n_l)
+        Eb = NL * (NL - 1)
+        n_b = [n * (n - 1) for n in n_l]
+        if kw["ligand_fc_bond_index"] is None or kw["init_ligand_fc_bond_type"] is None:
+            raise NotImplementedError("the uni_o2_bond path needs the fully connected ligand bond graph")
+        cnt = lambda t: torch.bincount(t.cpu(), minlength=B).tolist()
+        if kw["init_ligand_fc_bond_type"].numel() != sum(n_b) or \
+                (kw["batch_ligand_bond"] is not None and cnt(kw["batch_ligand_bond"]) != n_b):
+            raise NotImplementedError("ligand_fc_bond_index must be the dst-major fully connected graph ('fc' mode)")
+        has_full = kw["full_protein_pos"] is not None and kw["full_batch_protein"] is not None
+        n_f = cnt(kw["full_batch_protein"]) if has_full else [0] * B
+        NF = max(n_f) if has_full else 0
+        ar = torch.arange
+        # flat (caller) row -> padded row
+        rows_p = torch.cat([b * NP + ar(n_p[b]) for b in range(B)])
+        rows_l = torch.cat([b * NL + ar(n_l[b]) for b in range(B)])
+        o_l = [0] + list(np.cumsum(n_l))
+        exp_fc, rows_b = [], []
+        for b in range(B):
+            n = n_l[b]
+            dst = ar(n).repeat_interleave(n - 1)
+            sp = ar(n - 1).repeat(n)
+            src = sp + (sp >= dst).long()
+            exp_fc.append(torch.stack([src, dst], 0) + o_l[b])
+            rows_b.append(b * Eb + dst * (NL - 1) + sp)
+        exp_fc, rows_b = torch.cat(exp_fc, 1), torch.cat(rows_b)
+        if kw["ligand_fc_bond_index"].shape != exp_fc.shape or not torch.equal(kw["ligand_fc_bond_index"].cpu(), exp_fc):
+            raise NotImplementedError("ligand_fc_bond_index must be the dst-major fully connected graph ('fc' mode)")
+        d_p, d_l, d_b = rows_p.to(dev), rows_l.to(dev), rows_b.to(dev)
+        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32)
+        protein_v, ligand_v, aux = kw["protein_v"], kw["init_ligand_v"], kw["ligand_v_aux"]
+        if protein_v.dim() != 2 or protein_v.shape[1] != 29 or aux.dim() != 2 or aux.shape[1] != 2:
+            raise ValueError("protein_v must be [n,29] and ligand_v_aux [n,2]")
+        assert int(ligand_v.min()) >= 0 and int(ligand_v.max()) < self.num_classes, f"Error: {int(ligand_v.max())} >= {self.num_classes}"
+        bt = kw["init_ligand_fc_bond_type"]
+        assert int(bt.min()) >= 0 and int(bt.max()) < self.num_bond_classes, f"Error: {int(bt.max())} >= {self.num_bond_classes}"
+        # center_pos (decompdiff.py:20-32): per-sample mean of the REAL protein atoms, fp32 in row order (as the dense path)
+        if center_pos_mode == "protein":
+            tot = torch.zeros(B, 3).index_add_(0, bp.cpu(), kw["protein_pos"].detach().float().cpu())
+            offset = (tot / torch.tensor(n_p, dtype=torch.float32).clamp(min=1).view(B, 1)).to(dev)
+        elif center_pos_mode == "none":
+            offset = torch.zeros(B, 3, device=dev)
+        else:
+            raise NotImplementedError(center_pos_mode)
+        zeros = lambda *shape, dtype=torch.float32: torch.zeros(*shape, dtype=dtype, device=dev)
+        ppos = zeros(B * NP, 3).index_copy_(0, d_p, f32(kw["protein_pos"]) - offset[bp.to(dev)])
+        lpos = zeros(B * NL, 3).index_copy_(0, d_l, f32(kw["init_ligand_pos"]) - offset[bl.to(dev)])
+        d = dict(B=B, NP=NP, NL=NL, protein_pos=ppos.view(B, NP, 3), ligand_pos=lpos.view(B, NL, 3),
+                 protein_pos_centered=ppos.view(B, NP, 3), ligand_pos_centered=lpos.view(B, NL, 3),
+                 protein_v=zeros(B * NP, 29).index_copy_(0, d_p, f32(protein_v)).view(B, NP, 29),
+                 ligand_v=zeros(B * NL, dtype=torch.int32).index_copy_(0, d_l, ligand_v.to(device=dev, dtype=torch.int32)),
+                 ligand_aux=zeros(B * NL, 2).index_copy_(0, d_l, f32(aux)).view(B, NL, 2),
+                 bond=zeros(B * Eb, dtype=torch.int32).index_copy_(0, d_b, bt.to(device=dev, dtype=torch.int32)))
+        atom_std = zeros(B * NL, 3).index_copy_(0, d_l, f32(kw["prior_stds"])[kw["ligand_decomp_batch"].to(dev)])
+        decomp = None
+        if kw["ligand_decomp_index"] is not None:                          # -2: neither arm nor scaffold (padding)
+            decomp = torch.full((B * NL,), -2, dtype=torch.int32, device=dev).index_copy_(
+                0, d_l, kw["ligand_decomp_index"].to(device=dev, dtype=torch.int32))
+        fpp = None
+        if energy_drift_opt is not None and any(dr["type"] == "clash" for dr in energy_drift_opt):
+            if not has_full:
+                raise ValueError("clash drift needs full_protein_pos / full_batch_protein")
+            rows_f = torch.cat([b * NF + ar(n_f[b]) for b in range(B)]).to(dev)
+            # padding far away: exp(-|p - y|^2 / sigma) underflows to exactly 0, so it adds nothing to any sum
+            fpp = torch.full((B * NF, 3), 1.0e6, device=dev).index_copy_(0, rows_f, f32(kw["full_protein_pos"])).view(B, NF, 3)
+        pad_noise = None
+        if noise is not None:
+            n_lig, n_bond = sum(n_l), sum(n_b)
+            for k, shp in (("u_v", (num_steps, n_lig, 8)), ("u_b", (num_steps, n_bond, 5)), ("eps", (num_steps, n_lig, 3))):
+                if tuple(noise[k].shape) != shp:
+                    raise ValueError(f"noise['{k}'] must have shape {shp}, got {tuple(noise[k].shape)}")
+            pad_noise = {
+                "u_v": torch.full((num_steps, B * NL, 8), 0.5, device=dev).index_copy_(1, d_l, f32(noise["u_v"])),
+                "u_b": torch.full((num_steps, B * Eb, 5), 0.5, device=dev).index_copy_(1, d_b, f32(noise["u_b"])),
+                "eps": zeros(num_steps, B * NL, 3).index_copy_(1, d_l, f32(noise["eps"]))}
+        prefix = np.concatenate([[0], np.cumsum(n_b)]).astype(np.int32)
+        masks = {"np_real": torch.tensor(n_p, dtype=torch.int32), "nl_real": torch.tensor(n_l, dtype=torch.int32),
+                 "bl_prefix": torch.from_numpy(prefix)}
+        if num_steps + start_step > self.num_timesteps or start_step < 0:
+            raise ValueError("num_steps (+ start_step) exceeds num_timesteps")
+        pw = self._packed_weights()
+        s, bufs, ent = self._make_sampler(d, pw, num_steps, self.num_timesteps - 1 - int(start_step), pad_noise, keep_traj,
+                                          energy_drift_opt, atom_std, offset.contiguous(), decomp, fpp, seed, 0, masks=masks)
+        chain = dict(s=s, bufs=bufs, offset=offset, B=B, NL=NL, dev=dev, ent=ent)
+        self._run_chains([chain], num_steps, use_graph)
+        out = self._collect_chain(chain, num_steps, keep_traj, rows_atoms=rows_l, rows_bonds=rows_b)
+        self._last = (s, bufs)
+        return out
+
     def _sample_ragged(self, kw, ligand_atom_mask, num_steps, center_pos_mode, energy_drift_opt, noise, seed, keep_traj,
                        use_graph, concurrent=None, start_step=0):
         _check_ligand_atom_mask(ligand_atom_mask, kw["batch_ligand"].numel())
@@ -367,25 +492,37 @@ class DecompScorePosNet3D(nn.Module):
     # allocation, 70 MB of memsets, stream capture and graph instantiation again (2.8 ms per call; the driver's
     # 20-step bench is 27 ms of GPU work).  Chains with injected noise (parity mode) are not cached.
     _CACHE_MAX = int(os.environ.get("DD_CHAIN_CACHE_SIZE", "4"))
+    _graph_counter = 0
+    _chain_cache: Dict[tuple, dict] = {}      # process-wide (keys carry device and weight arena): ONE destruction order for all graphs
 
     def _evict_chain_cache(self, keep=0):
+        """Drop the least recently used entries beyond `keep`.  Captured graphs are only ever destroyed newest-first and
+        all together: destroying an OLDER executable graph while newer ones stay alive, then capturing another one, crashed
+        inside hipGraphLaunch on ROCm 7.2 (reproducible in the GPU test suite); the surviving entries keep their buffers
+        and re-capture their step graph on next use (0.4 ms)."""
         cache = getattr(self, "_chain_cache", None)
-        if not cache:
+        if not cache or len(cache) <= keep:
             return
         lib = hip_lib.load()
+        live = sorted((e for e in cache.values() if e.get("graph") is not None), key=lambda e: -e.get("graph_id", 0))
+        if live:
+            torch.cuda.synchronize(live[0]["dev"])
+        for e in live:
+            lib.dd_graph_destroy(e["graph"])
+            e["graph"] = None
         while len(cache) > keep:
-            key = next(iter(cache))                       # oldest first (dicts keep insertion order)
-            ent = cache.pop(key)
-            if ent.get("graph") is not None:
-                torch.cuda.synchronize(ent["dev"])
-                lib.dd_graph_destroy(ent["graph"])
-                ent["graph"] = None
+            cache.pop(next(iter(cache)))                  # oldest first (dicts keep insertion order)
 
-    def __del__(self):
-        try:
-            self._evict_chain_cache(0)
-        except Exception:
-            pass
+    def _drop_cached_graphs(self):
+        """Destroy every cached step graph, newest first (see _evict_chain_cache); buffers stay cached."""
+        cache = getattr(self, "_chain_cache", None) or {}
+        live = sorted((e for e in cache.values() if e.get("graph") is not None), key=lambda e: -e.get("graph_id", 0))
+        if live:
+            torch.cuda.synchronize(live[0]["dev"])
+        lib = hip_lib.load()
+        for e in live:
+            lib.dd_graph_destroy(e["graph"])
+            e["graph"] = None
 
     def _expected_layout(self, B, NP, NL, dev):
         """PyG Batch vectors and the dst-major fully connected bond index of a dense batch (validated against the
@@ -404,7 +541,7 @@ class DecompScorePosNet3D(nn.Module):
         return memo[key]
 
     def _make_sampler(self, d, pw, n_steps, t_start, noise, keep_traj, drift, atom_std, offset, decomp_index,
-                      full_protein_pos, seed, drift_norm_batch=0):
+                      full_protein_pos, seed, drift_norm_batch=0, masks=None):
         lib = hip_lib.load()
         dev = d["protein_pos"].device
         B, NP, NL = d["B"], d["NP"], d["NL"]
@@ -417,8 +554,9 @@ class DecompScorePosNet3D(nn.Module):
         cap = n_steps
         if cacheable and keep_traj:
             cap = max(32, 1 << (int(n_steps) - 1).bit_length())        # trajectory capacity: 5 and 20 steps share buffers
-        key = (str(dev), B, NP, NL, K, NF, cap if keep_traj else 0, bool(keep_traj), decomp_index is not None, arena.data_ptr())
-        cache = self.__dict__.setdefault("_chain_cache", {})
+        key = (str(dev), B, NP, NL, K, NF, cap if keep_traj else 0, bool(keep_traj), decomp_index is not None, arena.data_ptr(),
+               masks is not None)
+        cache = DecompScorePosNet3D._chain_cache
         ent = cache.pop(key, None) if cacheable else None
         if ent is None:
             z = lambda *shape, dtype=torch.float32: torch.zeros(*shape, dtype=dtype, device=dev)
@@ -431,6 +569,9 @@ class DecompScorePosNet3D(nn.Module):
             # state
             bufs["lig_pos"], bufs["lig_v"], bufs["lig_bond"] = z(B, NL, 3), z(B * NL, dtype=torch.int32), z(B * Eb, dtype=torch.int32)
             bufs["step_counter"] = z(4, dtype=torch.int32)             # run state: steps done, t_start, seed lo / hi
+            if masks is not None:                                      # padded heterogeneous batch (dd_sampler.np_real ...)
+                bufs["np_real"], bufs["nl_real"] = z(B, dtype=torch.int32), z(B, dtype=torch.int32)
+                bufs["bl_prefix"] = z(B + 1, dtype=torch.int32)
             bufs["pred_pos"], bufs["pred_v"], bufs["pred_bond"] = z(B * NL, 3), z(B * NL, 8), z(B * Eb, 5)
             ws_floats = int(lib.dd_workspace_floats(B, NP, NL, K))
             bufs["workspace"] = z(ws_floats)
@@ -468,6 +609,9 @@ class DecompScorePosNet3D(nn.Module):
         bufs["lig_pos"].copy_(d["ligand_pos_centered"])
         bufs["lig_v"].copy_(d["ligand_v"])
         bufs["lig_bond"].copy_(d["bond"])
+        if masks is not None:
+            for k in ("np_real", "nl_real", "bl_prefix"):
+                bufs[k].copy_(masks[k])
         for k in ("u_v", "u_b", "eps"):
             bufs[k] = None
         if noise is not None:
@@ -480,7 +624,8 @@ class DecompScorePosNet3D(nn.Module):
         sm.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         for k in ("protein_pos", "protein_h", "lig_aux", "atom_std", "offset", "decomp_index", "full_protein_pos",
                   "lig_pos", "lig_v", "lig_bond", "step_counter", "u_v", "u_b", "eps", "traj_pos", "traj_v",
-                  "traj_bond", "traj_v0", "traj_vt", "traj_bt", "pred_pos", "pred_v", "pred_bond", "workspace"):
+                  "traj_bond", "traj_v0", "traj_vt", "traj_bt", "pred_pos", "pred_v", "pred_bond", "workspace",
+                  "np_real", "nl_real", "bl_prefix"):
             t = bufs.get(k)
             if t is not None:
                 assert t.is_contiguous() and t.device == dev, k
@@ -559,11 +704,41 @@ class DecompScorePosNet3D(nn.Module):
             self._last = (s, bufs)
             return preds
 
-    def get_diffusion_loss(self, *args, **kwargs):
-        """Training objective of the reference (models/decompdiff.py:419-550).  Out of scope here:
-        the fused kernels have no backward; train with the reference and load the checkpoint."""
-        raise NotImplementedError("decompdiff_amd implements the sampling path only; training (get_diffusion_loss) "
-                                  "needs autograd through the fused kernels (SURVEY.md 8f-4)")
+    def train(self, mode: bool = True):
+        self.__dict__["_packed"] = None                     # parameters are about to change (or just did)
+        return super().train(mode)
+
+    def get_diffusion_loss(self, protein_pos, protein_v, batch_protein, protein_group_idx,
+                           ligand_pos, ligand_v, ligand_v_aux, batch_ligand, ligand_group_idx,
+                           prior_centers, prior_stds, prior_num_atoms, batch_prior, prior_group_idx,
+                           ligand_decomp_batch, ligand_decomp_index,
+                           ligand_fc_bond_index=None, ligand_fc_bond_type=None, batch_ligand_bond=None, ligand_atom_mask=None,
+                           time_step=None):
+        """Training / validation objective of the reference (models/decompdiff.py:419-550), same arguments and result keys.
+
+        With autograd enabled the network runs through :mod:`decompdiff_amd.training` (torch dense layers + the HIP graph
+        ops with analytic backward passes), so ``results['losses']`` can be back-propagated into all parameters.  Under
+        ``torch.no_grad()`` (the reference's validation loop) the network output comes from the fused ``dd_forward``
+        kernels instead.  Dense batches only (equal atom counts per sample)."""
+        from . import training
+        _check_ligand_atom_mask(ligand_atom_mask, batch_ligand.numel())
+        if ligand_fc_bond_index is None or ligand_fc_bond_type is None or batch_ligand_bond is None:
+            raise NotImplementedError("the uni_o2_bond path needs the fully connected ligand bond graph")
+        if self._is_ragged(batch_protein, batch_ligand):
+            raise NotImplementedError("get_diffusion_loss: batch samples of equal size (the padded heterogeneous layout is a "
+                                      "sampling-path feature)")
+        hip_lib.require_gpu(protein_pos, "protein_pos")
+        grad = torch.is_grad_enabled()
+        if grad:
+            self.__dict__["_packed"] = None                 # an optimizer step will follow: never reuse a packed copy
+            net = training.network
+        else:
+            def net(model, p_pos, p_v, b_p, x_t, v_t, aux, b_l, fc, b_t):
+                return model.forward(p_pos, p_v, b_p, None, x_t, v_t, aux, b_l, None, None, None, None, None, fc, b_t)
+        return training.diffusion_loss(self, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, ligand_v_aux,
+                                       batch_ligand, prior_centers, prior_stds, prior_num_atoms, batch_prior,
+                                       ligand_decomp_batch, ligand_fc_bond_index, ligand_fc_bond_type, batch_ligand_bond,
+                                       time_step=time_step, network_fn=net)
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -601,7 +776,7 @@ class DecompScorePosNet3D(nn.Module):
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
         if self._is_ragged(batch_protein, batch_ligand):
-            return self._sample_ragged(
+            return self._sample_heterogeneous(
                 dict(protein_pos=protein_pos, protein_v=protein_v, batch_protein=batch_protein,
                      protein_group_idx=protein_group_idx, init_ligand_pos=init_ligand_pos, init_ligand_v=init_ligand_v,
                      ligand_v_aux=ligand_v_aux, batch_ligand=batch_ligand, ligand_group_idx=ligand_group_idx,
@@ -734,15 +909,15 @@ class DecompScorePosNet3D(nn.Module):
             spg = 1
         gsig = (ent["sig"], spg, side.cuda_stream)
         if ent.get("graph") is not None and ent["graph_sig"] != gsig:      # launch structure changed: capture again
-            side.synchronize()
-            lib.dd_graph_destroy(ent["graph"])
-            ent["graph"] = None
+            self._drop_cached_graphs()
         if ent.get("graph") is None:
             graph = ctypes.c_void_p()
             hip_lib.check(lib.dd_graph_create(ctypes.byref(s), spg, side.cuda_stream, ctypes.byref(graph)), "dd_graph_create")
             ent["graph"], ent["graph_sig"] = graph, gsig
+            DecompScorePosNet3D._graph_counter += 1
+            ent["graph_id"] = DecompScorePosNet3D._graph_counter
         graph = ent["graph"]
-        cached = any(e is ent for e in self.__dict__.get("_chain_cache", {}).values())
+        cached = any(e is ent for e in DecompScorePosNet3D._chain_cache.values())
 
         dbg = int(os.environ.get("DD_TRAJ_DEBUG", "0"))
         final_np = {k: v.numpy() for k, v in final.items()}
@@ -793,26 +968,30 @@ class DecompScorePosNet3D(nn.Module):
         cur.wait_stream(side)
         chain["traj_cpu"] = final
 
-    def _collect_chain(self, chain, num_steps, keep_traj):
+    def _collect_chain(self, chain, num_steps, keep_traj, rows_atoms=None, rows_bonds=None):
+        """Result dict of a finished chain.  rows_atoms / rows_bonds (padded batches): the rows of the dense [B*NL] /
+        [B*Eb] layouts that are real, in the caller's flat order."""
         bufs, B, NL, offset = chain["bufs"], chain["B"], chain["NL"], chain["offset"]
         ligand_pos = bufs["lig_pos"].view(B, NL, 3) + offset[:, None, :]
+        dev = chain["dev"]
+        pick_a = (lambda t: t) if rows_atoms is None else (lambda t, r=rows_atoms.to(dev): t.index_select(0, r))
+        pick_b = (lambda t: t) if rows_bonds is None else (lambda t, r=rows_bonds.to(dev): t.index_select(0, r))
         out = {
-            "pos": ligand_pos.reshape(B * NL, 3),
-            "v": bufs["lig_v"].long(),
-            "bond": bufs["lig_bond"].long(),
+            "pos": pick_a(ligand_pos.reshape(B * NL, 3)),
+            "v": pick_a(bufs["lig_v"]).long(),
+            "bond": pick_b(bufs["lig_bond"]).long(),
         }
         if keep_traj and num_steps > 0:
             cpu = chain.get("traj_cpu") or {k: bufs[k][:num_steps].cpu() for k in self._TRAJ_KEYS}
-            out["pos_traj"] = list(cpu["traj_pos"].unbind(0))
-            out["v_traj"] = list(cpu["traj_v"].long().unbind(0))
-            out["bond_traj"] = list(cpu["traj_bond"].long().unbind(0))
-            out["v0_traj"] = list(cpu["traj_v0"].unbind(0))
-            out["vt_traj"] = list(cpu["traj_vt"].unbind(0))
-            out["bt_traj"] = list(cpu["traj_bt"].unbind(0))
+            sel_a = (lambda t: t) if rows_atoms is None else (lambda t: t.index_select(1, rows_atoms))
+            sel_b = (lambda t: t) if rows_bonds is None else (lambda t: t.index_select(1, rows_bonds))
+            st = {"pos_traj": sel_a(cpu["traj_pos"]), "v_traj": sel_a(cpu["traj_v"].long()), "bond_traj": sel_b(cpu["traj_bond"].long()),
+                  "v0_traj": sel_a(cpu["traj_v0"]), "vt_traj": sel_a(cpu["traj_vt"]), "bt_traj": sel_b(cpu["traj_bt"])}
+            for k, t in st.items():
+                out[k] = list(t.unbind(0))
             # the same data as [T, rows, ...] tensors (the lists above are views of them): lets the harness split per
             # sample without stacking 6 x T tensors again
-            out["_traj_stacked"] = {"pos_traj": cpu["traj_pos"], "v_traj": cpu["traj_v"].long(), "bond_traj": cpu["traj_bond"].long(),
-                                    "v0_traj": cpu["traj_v0"], "vt_traj": cpu["traj_vt"], "bt_traj": cpu["traj_bt"]}
+            out["_traj_stacked"] = st
         else:
             for k in ("pos_traj", "v_traj", "bond_traj", "v0_traj", "vt_traj", "bt_traj"):
                 out[k] = []

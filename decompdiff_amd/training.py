@@ -1,0 +1,363 @@
+"""Differentiable path of the score network and the training objective.
+
+The sampling loop runs hand-fused HIP kernels that have no backward.  Training needs gradients for all 616 tensors,
+so this module states the same network with autograd: dense layers are torch (rocBLAS) ops, the graph ops are the HIP
+kernels of the op-level C ABI wrapped in ``torch.autograd.Function`` s with analytic backward passes that again run on
+the HIP kernels (``scatter_sum`` <-> gather, ``scatter_softmax`` <-> y * (g - scatter_sum(y * g)[index])), and the
+kNN graph comes from ``dd_knn``.  Like the fused kernels it uses the exact first-Linear factorisation
+(W.[a;b;c] = W_a a + W_b b + W_c c: per-node / per-bond projection tables that the edges gather) instead of materialising
+the 340- / 384- / 437-wide concatenations of the reference (uni_transformer_edge.py:48,148-149,194), which cuts the
+activation memory autograd keeps by ~3x; everything else follows the reference layer for layer:
+
+    forward            models/decompdiff.py:213-351 -> UniTransformerO2TwoUpdateGeneralBond (uni_transformer_edge.py:394-443)
+    get_diffusion_loss models/decompdiff.py:419-550 (C0 parameterisation, 'mse' position loss, categorical KL for atom
+                       and bond types, bond diffusion)
+
+Everything runs on the HIP device; CPU tensors raise (no fallback).  ``DecompScorePosNet3D.get_diffusion_loss`` calls
+into here; with autograd disabled (validation, scripts/train_diffusion_decomp.py validate()) the network output comes
+from the fused ``dd_forward`` instead.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import functional as FN
+from . import hip_lib
+
+GAUSS_OFFSETS = [0, 1, 1.25, 1.5, 1.75, 2, 2.25, 2.5, 2.75, 3, 3.5, 4, 4.5, 5, 5.5, 6, 7, 8, 9, 10]
+H, NH = 128, 16
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# graph ops with autograd (forward and backward on the HIP kernels)
+# --------------------------------------------------------------------------------------------------------------------
+class _ScatterSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, index, dim_size):
+        ctx.save_for_backward(index)
+        return FN.scatter_sum(src, index, dim=0, dim_size=dim_size)
+
+    @staticmethod
+    def backward(ctx, g):
+        (index,) = ctx.saved_tensors
+        return g.index_select(0, index), None, None
+
+
+class _ScatterSoftmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, index, dim_size):
+        y = FN.scatter_softmax(src, index, dim=0, dim_size=dim_size)
+        ctx.save_for_backward(y, index)
+        ctx.dim_size = dim_size
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, index = ctx.saved_tensors
+        yg = y * g
+        return yg - y * FN.scatter_sum(yg, index, dim=0, dim_size=ctx.dim_size).index_select(0, index), None, None
+
+
+def scatter_sum(src, index, dim_size):
+    return _ScatterSum.apply(src, index, dim_size)
+
+
+def scatter_softmax(src, index, dim_size):
+    return _ScatterSoftmax.apply(src, index, dim_size)
+
+
+def _gauss(d):
+    off = torch.tensor(GAUSS_OFFSETS, dtype=d.dtype, device=d.device)
+    return torch.exp(-0.5 * (d.reshape(-1, 1) - off) ** 2)                # GaussianSmearing, coeff -0.5 (common.py:23)
+
+
+def _angle_code(theta):
+    f = torch.tensor([1.0, 2.0, 3.0, 1.0, 0.5, 1.0 / 3.0], dtype=theta.dtype, device=theta.device)
+    a = theta.unsqueeze(-1)
+    return torch.cat([a, torch.sin(a * f), torch.cos(a * f)], -1)           # AngularEncoding (common.py:46-54), 13 wide
+
+
+class _P:
+    """Parameter access by reference key (``refine_net.base_block.0.lin_node.weight`` ...)."""
+
+    def __init__(self, model):
+        self.p = dict(model.named_parameters())
+
+    def lin(self, name, x):
+        return F.linear(x, self.p[name + ".weight"], self.p[name + ".bias"])
+
+    def w(self, name):
+        return self.p[name + ".weight"]
+
+    def b(self, name):
+        return self.p[name + ".bias"]
+
+    def mlp_tail(self, name, pre):
+        """LayerNorm -> ReLU -> second Linear of MLP(num_layer=2, norm=True) (common.py:85-105) on a pre-activation."""
+        y = F.layer_norm(pre, (H,), self.p[name + ".net.1.weight"], self.p[name + ".net.1.bias"], 1e-5)
+        return self.lin(name + ".net.3", F.relu(y))
+
+    def mlp(self, name, x):
+        return self.mlp_tail(name, self.lin(name + ".net.0", x))
+
+
+def _attention(q_e, k, v, seg, n_seg):
+    """alpha = scatter_softmax((q k / sqrt(d)).sum(-1)); out = scatter_sum(alpha v)  (uni_transformer_edge.py:63-68)."""
+    hd = k.shape[1] // NH
+    score = (q_e.view(-1, NH, hd) * k.view(-1, NH, hd)).sum(-1) / math.sqrt(hd)
+    alpha = scatter_softmax(score, seg, n_seg)
+    return alpha
+
+
+def _edge_mlp_pre(P, name, W_off, dst_tab, src_tab, dst, src, extra):
+    """first Linear of an edge MLP, factorised: W[:, a:b] applied per node once, gathered per edge."""
+    return dst_tab.index_select(0, dst) + src_tab.index_select(0, src) + extra + P.b(name + ".net.0")
+
+
+def network(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, ligand_v_aux, batch_ligand,
+            ligand_fc_bond_index, ligand_bond_type) -> Dict[str, torch.Tensor]:
+    """DecompScorePosNet3D.forward for the shipped configuration, differentiable w.r.t. the model's parameters.
+    Dense batches (equal sizes per sample, sorted batch vectors, dst-major fc bond index) as in the sampling path."""
+    cfg = model.config
+    P = _P(model)
+    dev = protein_pos.device
+    hip_lib.require_gpu(protein_pos, "protein_pos")
+    B = int(batch_protein.max().item()) + 1
+    NP, NL = batch_protein.numel() // B, batch_ligand.numel() // B
+    N = NP + NL
+    K = min(int(cfg.knn), N - 1)
+    # ---- embeddings + context order [protein..., ligand...] per sample (compose_context, common.py:153-194)
+    lig_feat = torch.cat([F.one_hot(ligand_v, model.num_classes).float(), ligand_v_aux.float()], -1)
+    h_p = torch.cat([P.lin("protein_atom_emb", protein_v.float()), torch.zeros(B * NP, 1, device=dev)], -1)
+    h_l = torch.cat([P.lin("ligand_atom_emb", lig_feat), torch.ones(B * NL, 1, device=dev)], -1)
+    h = torch.cat([h_p.view(B, NP, H), h_l.view(B, NL, H)], 1).reshape(B * N, H)
+    x = torch.cat([protein_pos.view(B, NP, 3), ligand_pos.view(B, NL, 3)], 1).reshape(B * N, 3)
+    is_lig = torch.cat([torch.zeros(NP, dtype=torch.bool), torch.ones(NL, dtype=torch.bool)]).repeat(B).to(dev)
+    batch_all = torch.arange(B, device=dev).repeat_interleave(N)
+    lig_rows = is_lig.nonzero().squeeze(1)
+    bond_src, bond_dst = lig_rows[ligand_fc_bond_index[0]], lig_rows[ligand_fc_bond_index[1]]
+    h_bond = P.lin("ligand_bond_emb", F.one_hot(ligand_bond_type, model.num_bond_classes).float())
+    Eb_tot = h_bond.shape[0]
+    # ---- graph of the step (uni_transformer_edge.py:404-427): kNN among all atoms of a sample, fixed for all layers
+    edge_index = FN.knn_graph(x.detach(), K, batch_all)
+    src, dst = edge_index[0], edge_index[1]
+    etype = 2 * (~is_lig[src]).long() + (~is_lig[dst]).long()             # 0 ll, 1 l->p(dst p), 2 p->l, 3 pp
+    etype_1h = F.one_hot(etype, 4).float()
+    d0 = (x[dst] - x[src]).norm(dim=-1)
+    e_w = torch.sigmoid(P.mlp("refine_net.edge_pred_layer", _gauss(d0)))
+    # ---- triplets k -> j -> i over the fully connected ligand bond graph (BondUpdateLayer.triplets, :103-123)
+    NLm1, Ebs = NL - 1, NL * (NL - 1)
+    trip = None
+    if NL > 2:
+        e_ji = torch.arange(Ebs, device=dev).repeat_interleave(NL - 2)                  # segment = bond (j -> i), dst-major
+        i_loc, jp = e_ji // NLm1, e_ji % NLm1
+        j_loc = jp + (jp >= i_loc).long()
+        mc = torch.arange(NL - 2, device=dev).repeat(Ebs)
+        lo, hi = torch.minimum(i_loc, j_loc), torch.maximum(i_loc, j_loc)
+        k_loc = mc + (mc >= lo).long()
+        k_loc = k_loc + (k_loc >= hi).long()
+        e_kj = j_loc * NLm1 + (k_loc - (k_loc > j_loc).long())                          # bond (k -> j)
+        boff = (torch.arange(B, device=dev) * Ebs).repeat_interleave(Ebs * (NL - 2))
+        aoff = (torch.arange(B, device=dev) * N + NP).repeat_interleave(Ebs * (NL - 2))
+        rep = lambda t: t.repeat(B)
+        trip = dict(ji=rep(e_ji) + boff, kj=rep(e_kj) + boff, i=rep(i_loc) + aoff, j=rep(j_loc) + aoff, k=rep(k_loc) + aoff)
+    mask_l = is_lig.float().unsqueeze(-1)
+    for l in range(int(cfg.num_layers)):
+        p = f"refine_net.base_block.{l}"
+        rel = x[dst] - x[src]
+        dist = rel.norm(dim=-1)
+        g = _gauss(dist)
+        ef_type = torch.cat([(etype_1h.unsqueeze(-1) * g.unsqueeze(1)).reshape(-1, 80), etype_1h], -1)      # [E, 84]
+
+        def node_layer_edge(name, hh, v_width):
+            """kNN sub-layers: first Linear columns [0:84] edge feature, [84:212] h[dst], [212:340] h[src]."""
+            outs = []
+            for f_ in ("k", "v"):
+                nm = f"{p}.{name}.{'h' if name.startswith('node') else 'x'}{f_}_func"
+                W = P.w(nm + ".net.0")
+                pre = _edge_mlp_pre(P, nm, None, F.linear(hh, W[:, 84:212]), F.linear(hh, W[:, 212:340]), dst, src,
+                                    F.linear(ef_type, W[:, 0:84]))
+                outs.append(P.mlp_tail(nm, pre))
+            return outs
+
+        def node_layer_bond(name, hh, hb):
+            """bond sub-layers: columns [0:128] h_bond[e], [128:256] h[dst], [256:384] h[src]."""
+            outs = []
+            for f_ in ("k", "v"):
+                nm = f"{p}.{name}.{'h' if name.startswith('node') else 'x'}{f_}_func"
+                W = P.w(nm + ".net.0")
+                pre = _edge_mlp_pre(P, nm, None, F.linear(hh, W[:, 128:256]), F.linear(hh, W[:, 256:384]), bond_dst, bond_src,
+                                    F.linear(hb, W[:, 0:128]))
+                outs.append(P.mlp_tail(nm, pre))
+            return outs
+
+        # node_layer_with_edge (NodeUpdateLayer, :42-74)
+        k_e, v_e = node_layer_edge("node_layer_with_edge", h, H)
+        q_e = P.mlp(f"{p}.node_layer_with_edge.hq_func", h)
+        alpha = _attention(q_e.index_select(0, dst), k_e, v_e, dst, B * N)
+        a_edge = scatter_sum((alpha.unsqueeze(-1) * (v_e * e_w).view(-1, NH, H // NH)).reshape(-1, H), dst, B * N)
+        # node_layer_with_bond
+        k_b, v_b = node_layer_bond("node_layer_with_bond", h, h_bond)
+        q_b = P.mlp(f"{p}.node_layer_with_bond.hq_func", h)
+        alpha = _attention(q_b.index_select(0, bond_dst), k_b, v_b, bond_dst, B * N)
+        a_bond = scatter_sum((alpha.unsqueeze(-1) * v_b.view(-1, NH, H // NH)).reshape(-1, H), bond_dst, B * N)
+        # bond_layer (BondUpdateLayer, :125-167): kv = [h_bond[kj](128), G(d_kj)(20), G(d_ji)(20), angle(13), h[k], h[j]]
+        if trip is not None:
+            nm_b = f"{p}.bond_layer"
+            d_bond = (x[bond_dst] - x[bond_src]).norm(dim=-1)
+            gb = _gauss(d_bond)
+            v_ji, v_ki = x[trip["j"]] - x[trip["i"]], x[trip["k"]] - x[trip["i"]]
+            theta = torch.atan2(torch.cross(v_ji, v_ki, dim=-1).norm(dim=-1), (v_ji * v_ki).sum(-1))
+            code = _angle_code(theta)
+            kv = []
+            for f_ in ("hk_func", "hv_func"):
+                W = P.w(f"{nm_b}.{f_}.net.0")
+                per_kj = F.linear(torch.cat([h_bond, gb], -1), W[:, 0:148])                     # h_bond[kj], G(d_kj)
+                per_ji = F.linear(gb, W[:, 148:168])                                             # G(d_ji)
+                pre = per_kj.index_select(0, trip["kj"]) + per_ji.index_select(0, trip["ji"]) + F.linear(code, W[:, 168:181]) \
+                    + F.linear(h, W[:, 181:309]).index_select(0, trip["k"]) + F.linear(h, W[:, 309:437]).index_select(0, trip["j"]) \
+                    + P.b(f"{nm_b}.{f_}.net.0")
+                kv.append(P.mlp_tail(f"{nm_b}.{f_}", pre))
+            # hq depends on the (j -> i) bond only: evaluated per bond, gathered per triplet (exact)
+            q_bond = P.mlp(f"{nm_b}.hq_func", torch.cat([h_bond, h.index_select(0, bond_dst)], -1))
+            alpha = _attention(q_bond.index_select(0, trip["ji"]), kv[0], kv[1], trip["ji"], Eb_tot)
+            d_hb = scatter_sum((alpha.unsqueeze(-1) * kv[1].view(-1, NH, H // NH)).reshape(-1, H), trip["ji"], Eb_tot)
+        else:
+            d_hb = torch.zeros_like(h_bond)
+        new_h_bond = h_bond + d_hb
+        new_h = h + P.lin(f"{p}.lin_node", a_edge + a_bond)
+        # pos_layer_with_edge / pos_layer_with_bond (PosUpdateLayer, :188-210), with the NEW h / h_bond
+        k_pe, v_pe = node_layer_edge("pos_layer_with_edge", new_h, NH)
+        q_pe = P.mlp(f"{p}.pos_layer_with_edge.xq_func", new_h)
+        alpha = _attention(q_pe.index_select(0, dst), k_pe, None, dst, B * N)
+        dx_e = scatter_sum((alpha * (v_pe * e_w)).unsqueeze(-1) * rel.unsqueeze(1), dst, B * N).mean(1)
+        k_pb, v_pb = node_layer_bond("pos_layer_with_bond", new_h, new_h_bond)
+        q_pb = P.mlp(f"{p}.pos_layer_with_bond.xq_func", new_h)
+        alpha = _attention(q_pb.index_select(0, bond_dst), k_pb, None, bond_dst, B * N)
+        rel_b = x[bond_dst] - x[bond_src]
+        dx_b = scatter_sum((alpha * v_pb).unsqueeze(-1) * rel_b.unsqueeze(1), bond_dst, B * N).mean(1)
+        x = x + (dx_e + dx_b) * mask_l
+        h, h_bond = new_h, new_h_bond
+    softplus = lambda t: F.softplus(t) - math.log(2.0)                              # ShiftedSoftplus (common.py:66-72)
+    final_h = h.index_select(0, lig_rows)
+    out = {"pred_ligand_pos": x.index_select(0, lig_rows),
+           "pred_ligand_v": P.lin("v_inference.2", softplus(P.lin("v_inference.0", final_h))),
+           "pred_bond": P.lin("bond_inference.2", softplus(P.lin("bond_inference.0", h_bond)))}
+    return out
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# the objective
+# --------------------------------------------------------------------------------------------------------------------
+def _log_onehot(idx, k):
+    return torch.log(F.one_hot(idx, k).float().clamp(min=1e-30))
+
+
+def _log_add_exp(a, b):
+    m = torch.max(a, b)
+    return m + torch.log(torch.exp(a - m) + torch.exp(b - m))
+
+
+class _Trans:
+    """DiscreteTransition (models/transitions.py:97-161) over the model's schedule tables."""
+
+    def __init__(self, mod):
+        self.t = mod
+
+    def pred(self, log_v0, t, batch):                      # q(v_t | v_0)
+        return _log_add_exp(log_v0 + self.t.log_alphas_cumprod_v[t][batch].unsqueeze(-1),
+                            self.t.log_one_minus_alphas_cumprod_v[t][batch].unsqueeze(-1) + self.t.prior_probs)
+
+    def pred_one(self, log_vt_1, t, batch):                 # q(v_t | v_{t-1})
+        return _log_add_exp(log_vt_1 + self.t.log_alphas_v[t][batch].unsqueeze(-1),
+                            self.t.log_one_minus_alphas_v[t][batch].unsqueeze(-1) + self.t.prior_probs)
+
+    def posterior(self, log_v0, log_vt, t, batch):          # q(v_{t-1} | v_t, v_0)
+        tm1 = torch.where(t - 1 < 0, torch.zeros_like(t), t - 1)
+        un = self.pred(log_v0, tm1, batch) + self.pred_one(log_vt, t, batch)
+        return un - torch.logsumexp(un, dim=-1, keepdim=True)
+
+
+def _v_loss(log_model, log_v0, log_true, t, batch, n):
+    kl = (log_true.exp() * (log_true - log_model)).sum(1)                  # categorical_kl (decompdiff.py:35-37)
+    nll = -(log_v0.exp() * log_model).sum(1)                                # -log_categorical (decompdiff.py:40-41)
+    mask = (t == 0).float()[batch]
+    per = mask * nll + (1.0 - mask) * kl
+    return FN_mean(per, batch, n)
+
+
+def FN_mean(per_row, batch, n):
+    """scatter_mean over samples, differentiable (sum through the HIP scatter, count is constant)."""
+    cnt = torch.bincount(batch, minlength=n).clamp(min=1).to(per_row.dtype)
+    return scatter_sum(per_row.unsqueeze(-1), batch, n).squeeze(-1) / cnt
+
+
+def sample_time(model, num_graphs, device):
+    """sample_time, 'symmetric' (decompdiff.py:391-397); the draw is made on the CPU generator (torch.manual_seed)."""
+    if model.sample_time_method != "symmetric":
+        raise NotImplementedError("sample_time_method='importance' (Lt_history bookkeeping) is not implemented")
+    ts = torch.randint(0, model.num_timesteps, size=(num_graphs // 2 + 1,))
+    ts = torch.cat([ts, model.num_timesteps - ts - 1], 0)[:num_graphs]
+    return ts.to(device), torch.ones(num_graphs, device=device) / model.num_timesteps
+
+
+def diffusion_loss(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, ligand_v_aux, batch_ligand,
+                   prior_centers, prior_stds, prior_num_atoms, batch_prior, ligand_decomp_batch, ligand_fc_bond_index,
+                   ligand_fc_bond_type, batch_ligand_bond, time_step=None, network_fn=None) -> Dict:
+    """get_diffusion_loss (decompdiff.py:419-550).  Noise is drawn on the CPU generator in the reference's order
+    (time steps, position noise, atom-type Gumbel uniforms, bond-type Gumbel uniforms) and moved to the device, so a
+    seeded call reproduces the reference's CPU run."""
+    dev = protein_pos.device
+    B = int(batch_protein.max().item()) + 1
+    if time_step is None:
+        time_step, _ = sample_time(model, B, dev)
+    time_step = time_step.to(dev)
+    a = model.alphas_cumprod.index_select(0, time_step)
+    assert len(ligand_decomp_batch) == int(prior_num_atoms.sum().item())
+    centers = prior_centers[ligand_decomp_batch]
+    stds = prior_stds[ligand_decomp_batch]
+    a_pos = a[batch_ligand].unsqueeze(-1)
+    pos_noise = torch.zeros(ligand_pos.shape).normal_().to(dev)
+    pos_pert = a_pos.sqrt() * (ligand_pos - centers) + (1.0 - a_pos).sqrt() * pos_noise * stds + centers
+    tv, tb = _Trans(model.atom_type_trans), _Trans(model.bond_type_trans)
+    log_v0 = _log_onehot(ligand_v, model.num_classes)
+    log_qv = tv.pred(log_v0, time_step, batch_ligand)
+    u = torch.rand(log_qv.shape).to(dev)
+    v_pert = (-torch.log(-torch.log(u + 1e-30) + 1e-30) + log_qv).argmax(-1)
+    log_vt = _log_onehot(v_pert, model.num_classes)
+    log_b0 = _log_onehot(ligand_fc_bond_type, model.num_bond_classes)
+    log_qb = tb.pred(log_b0, time_step, batch_ligand_bond)
+    u = torch.rand(log_qb.shape).to(dev)
+    b_pert = (-torch.log(-torch.log(u + 1e-30) + 1e-30) + log_qb).argmax(-1)
+    log_bt = _log_onehot(b_pert, model.num_bond_classes)
+    # center_pos (decompdiff.py:20-32)
+    if model.center_pos_mode == "protein":
+        NP = batch_protein.numel() // B
+        offset = protein_pos.view(B, NP, 3).mean(1)
+    elif model.center_pos_mode == "none":
+        offset = torch.zeros(B, 3, device=dev)
+    else:
+        raise NotImplementedError(model.center_pos_mode)
+    p_pos = protein_pos - offset[batch_protein]
+    x_t = pos_pert - offset[batch_ligand]
+    x_0 = ligand_pos - offset[batch_ligand]
+    net = network_fn or network
+    preds = net(model, p_pos, protein_v, batch_protein, x_t, v_pert, ligand_v_aux, batch_ligand, ligand_fc_bond_index, b_pert)
+    pred_pos, pred_v = preds["pred_ligand_pos"], preds["pred_ligand_v"]
+    log_v_recon = F.log_softmax(pred_v, dim=-1)
+    kl_v = _v_loss(tv.posterior(log_v_recon, log_vt, time_step, batch_ligand), log_v0,
+                   tv.posterior(log_v0, log_vt, time_step, batch_ligand), time_step, batch_ligand, B)
+    log_b_recon = F.log_softmax(preds["pred_bond"], dim=-1)
+    kl_b = _v_loss(tb.posterior(log_b_recon, log_bt, time_step, batch_ligand_bond), log_b0,
+                   tb.posterior(log_b0, log_bt, time_step, batch_ligand_bond), time_step, batch_ligand_bond, B)
+    if model.loss_pos_type != "mse":
+        raise ValueError(model.loss_pos_type)
+    loss_pos = FN_mean((((pred_pos - x_0) ** 2) / (stds ** 2)).sum(-1), batch_ligand, B).mean()
+    return {"losses": {"pos": loss_pos, "v": kl_v.mean(), "bond": kl_b.mean()},
+            "x0": x_0, "pred_ligand_pos": pred_pos, "pred_ligand_v": pred_v, "pred_pos_noise": pred_pos - x_t,
+            "ligand_v_recon": F.softmax(pred_v, dim=-1), "ligand_b_recon": F.softmax(preds["pred_bond"], dim=-1),
+            "time_step": time_step}

@@ -122,6 +122,15 @@ typedef struct dd_sampler {
   float* pred_bond;                /* [B,Eb,5]  logits                            */
   /* scratch */
   float* workspace; size_t workspace_floats;
+  /* heterogeneous batches ("padded/masked fixed-size pocket+ligand graphs"): samples with fewer atoms than NP / NL are
+   * padded to the dense shape -- sample b's real protein atoms are rows 0 .. np_real[b]-1 of its protein block, its real
+   * ligand atoms rows 0 .. nl_real[b]-1 of its ligand block (PyG collate of samples with different sizes:
+   * utils/data.py:389-446, scripts/sample_diffusion_decomp.py:300-326).  Padding rows never enter a kNN list, a bond
+   * or triplet segment, a softmax or a drift term; their own rows hold finite don't-care values.  NULL = dense. */
+  const int32_t* np_real;          /* [B] or NULL */
+  const int32_t* nl_real;          /* [B] or NULL */
+  const int32_t* bl_prefix;        /* [B+1] prefix sums of nl_real*(nl_real-1) (compact enumeration of the real
+                                      bond-layer segments); required when nl_real is given */
 } dd_sampler;
 
 const char* dd_status_string(int status);

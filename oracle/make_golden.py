@@ -258,6 +258,53 @@ def gen_traj_ragged(ref, sd, cfg, name, num_steps, drift, seed):
     print(f"[{name}] {num_steps} steps, ragged batch: oracle maxabs diff = {w:g}")
 
 
+GRAD_KEYS = ["protein_atom_emb.weight", "ligand_atom_emb.weight", "ligand_bond_emb.bias", "refine_net.edge_pred_layer.net.3.weight",
+             "refine_net.base_block.0.lin_node.weight", "refine_net.base_block.0.node_layer_with_edge.hk_func.net.0.weight",
+             "refine_net.base_block.2.bond_layer.hv_func.net.0.weight", "refine_net.base_block.3.bond_layer.hq_func.net.3.weight",
+             "refine_net.base_block.5.pos_layer_with_edge.xv_func.net.3.weight",
+             "refine_net.base_block.5.pos_layer_with_bond.xq_func.net.1.weight", "refine_net.base_block.4.node_layer_with_bond.hv_func.net.1.bias",
+             "v_inference.2.bias", "bond_inference.0.weight"]
+
+
+def gen_loss(ref, cfg):
+    """Training objective: the reference's get_diffusion_loss + backward on a small dense batch, fixed
+    time steps, noise from torch.manual_seed on the CPU generator.  Stored: the three losses, the network outputs, the
+    gradient of a spread of parameters (full tensors) and the gradient norm of EVERY parameter."""
+    pocket = synth.make_pocket(31, 90, (4, 3), 5, num_full_protein=0)
+    torch.manual_seed(77)
+    batch = synth.build_sampling_batch(pocket, 3, per_sample_std_scale=[1.0, 0.9, 1.1])
+    time_step = torch.tensor([700, 12, 0])
+    kw = dict(protein_pos=batch["protein_pos"], protein_v=batch["protein_v"], batch_protein=batch["batch_protein"],
+              protein_group_idx=batch["protein_group_idx"], ligand_pos=batch["init_ligand_pos"], ligand_v=batch["init_ligand_v"],
+              ligand_v_aux=batch["ligand_v_aux"], batch_ligand=batch["batch_ligand"], ligand_group_idx=batch["ligand_group_idx"],
+              prior_centers=batch["prior_centers"], prior_stds=batch["prior_stds"], prior_num_atoms=batch["prior_num_atoms"],
+              batch_prior=batch["batch_prior"], prior_group_idx=batch["prior_group_idx"],
+              ligand_decomp_batch=batch["ligand_decomp_batch"], ligand_decomp_index=batch["ligand_decomp_index"],
+              ligand_fc_bond_index=batch["ligand_fc_bond_index"], ligand_fc_bond_type=batch["init_ligand_fc_bond_type"],
+              batch_ligand_bond=batch["batch_ligand_bond"], time_step=time_step)
+    ref.zero_grad()
+    torch.manual_seed(1234)
+    res = ref.get_diffusion_loss(**kw)
+    loss = res["losses"]["pos"] + 100.0 * res["losses"]["v"] + 100.0 * res["losses"]["bond"]    # train_diffusion_decomp.py weights
+    loss.backward()
+    out = np_inputs(batch)
+    out["time_step"] = time_step.numpy()
+    out["noise_seed"] = np.array(1234)
+    for k in ("pos", "v", "bond"):
+        out["loss_" + k] = res["losses"][k].detach().numpy()
+    for k in ("pred_ligand_pos", "pred_ligand_v", "x0"):
+        out["out_" + k] = res[k].detach().numpy()
+    params = dict(ref.named_parameters())
+    for k in GRAD_KEYS:
+        out["grad__" + k.replace(".", "__")] = params[k].grad.numpy()
+    names = sorted(k for k, p_ in params.items() if p_.requires_grad and p_.grad is not None)
+    out["grad_norm_names"] = np.array(names)
+    out["grad_norms"] = np.array([float(params[k].grad.double().norm()) for k in names])
+    np.savez_compressed(os.path.join(GOLDEN, "loss_grad.npz"), **out)
+    print(f"[loss_grad] losses pos {float(res['losses']['pos']):.6g} v {float(res['losses']['v']):.6g} bond "
+          f"{float(res['losses']['bond']):.6g}; {len(names)} parameter gradients, total norm {float(np.linalg.norm(out['grad_norms'])):.6g}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-long", action="store_true", help="skip the 1000-step trajectory (~10 min)")
@@ -288,6 +335,8 @@ def main():
         gen_traj(ref_p, sd, cfg, "traj12_priortypes", synth.make_pocket_small(4), 2, 12, DRIFT, 2024, priors=priors)
     if want("ragged"):
         gen_traj_ragged(ref, sd, cfg, "traj10_ragged", 10, DRIFT, 2023)
+    if want("loss"):
+        gen_loss(ref, cfg)
     if want("scale"):
         # `scale: True` of the drift terms (decompdiff.py:656-657,667-668), mid-chain where pos_score_coef is not tiny
         drift_scale = [dict(DRIFT[0], scale=True), dict(DRIFT[1], scale=True)]

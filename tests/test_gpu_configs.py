@@ -236,7 +236,6 @@ def test_chain_cache_reuses_buffers_and_graph_without_changing_results(monkeypat
         return outs
 
     cached, fresh = go(True), go(False)
-    assert len(m.__dict__.get("_chain_cache", {})) == 0 or True
     for i, (c, f) in enumerate(zip(cached, fresh)):
         for k in ("pos", "v", "bond"):
             assert torch.equal(c[k], f[k]), (i, k)
@@ -248,3 +247,45 @@ def test_chain_cache_reuses_buffers_and_graph_without_changing_results(monkeypat
     _sample_hip(m, b1, 5, None, None, seed=1)
     _sample_hip(m, b1, 20, None, None, seed=2)                       # 5 and 20 steps share one entry (capacity 32)
     assert len(m._chain_cache) == 1
+
+
+def _hetero_batch(sizes, n_protein, seed=0):
+    torch.manual_seed(seed)
+    parts = []
+    for i, (nl, np_) in enumerate(zip(sizes, n_protein)):
+        arm = max(2, nl // 4)
+        p = synth.make_pocket(seed=300 + i, num_protein=np_, arm_atoms=(arm, arm), scaffold_atoms=nl - 2 * arm, num_full_protein=np_ + 150)
+        parts.append(synth.build_sampling_batch(p, 1))
+    return synth.concat_sampling_batches(parts)
+
+
+def test_padded_heterogeneous_batch_equals_size_groups(monkeypatch):
+    """North star "padded/masked fixed-size pocket+ligand graphs": a batch whose samples differ in pocket AND ligand size
+    (ligands 9..37 atoms: one, two and three member tiles; pockets 120..260 atoms) run as ONE padded launch sequence must
+    reproduce the per-size-group path (every group a dense batch, validated against the reference's ragged golden) on the
+    same injected noise, with armsca + clash drift: coordinates to fp32 rounding, types exactly."""
+    sizes = [9, 37, 20, 33, 17, 25]
+    n_prot = [150, 260, 120, 200, 180, 131]
+    b = _hetero_batch(sizes, n_prot, seed=4)
+    steps = 4
+    noise = synth.draw_step_noise(steps, b["init_ligand_pos"].size(0), b["init_ligand_fc_bond_type"].size(0))
+    m = model(0)
+    outs = {}
+    for mode in ("padded", "groups"):
+        monkeypatch.setenv("DD_RAGGED_MODE", mode)
+        outs[mode] = _sample_hip(m, b, steps, GU.DRIFT, noise)
+    p, g = outs["padded"], outs["groups"]
+    err = maxabs(p["pos"], g["pos"])
+    e_bt = maxabs(torch.stack(p["bt_traj"]), torch.stack(g["bt_traj"]))
+    print(f"padded vs groups ({len(sizes)} distinct sizes): pos diff {err:.3g}, bond log-prob diff {e_bt:.3g}")
+    assert p["pos"].shape == g["pos"].shape == (sum(sizes), 3)
+    assert err < 5e-6 and e_bt < 5e-5
+    assert torch.equal(p["v"], g["v"]) and torch.equal(p["bond"], g["bond"])
+    assert torch.equal(torch.stack(p["v_traj"]), torch.stack(g["v_traj"]))
+    # production noise: deterministic, finite, cached resources re-used for the next heterogeneous batch of these maxima
+    monkeypatch.setenv("DD_RAGGED_MODE", "padded")
+    r1 = _sample_hip(m, b, 6, GU.DRIFT, None, seed=5)
+    b2 = _hetero_batch([37, 9, 25, 33, 20, 17], [260, 150, 131, 200, 120, 180], seed=4)     # same maxima, other per-sample counts
+    _sample_hip(m, b2, 6, GU.DRIFT, None, seed=5)
+    r3 = _sample_hip(m, b, 6, GU.DRIFT, None, seed=5)
+    assert torch.isfinite(r1["pos"]).all() and torch.equal(r1["pos"], r3["pos"]) and torch.equal(r1["bond"], r3["bond"])

@@ -638,9 +638,12 @@ def test_drift_scale_option_vs_oracle():
     assert torch.equal(got["v"].cpu(), want["v"]) and torch.equal(got["bond"].cpu(), want["bond"])
 
 
-def test_ragged_batch_golden():
-    """samples with different atom counts in one batch (fixture from the reference).  The HIP path
-    runs one dense group per distinct size and scatters the results back into batch order."""
+@pytest.mark.parametrize("mode", ["padded", "groups"])
+def test_ragged_batch_golden(mode, monkeypatch):
+    """samples with different atom counts in one batch (fixture from the reference).  The HIP path runs
+    ONE launch sequence over the batch padded to its largest pocket / ligand with per-sample real counts ("padded", the
+    default), or one dense group per distinct size scattered back into batch order ("groups")."""
+    monkeypatch.setenv("DD_RAGGED_MODE", mode)
     g = GU.load("traj10_ragged")
     b = GU.batch_from_npz(g)
     T = int(g["num_steps"])
@@ -653,7 +656,7 @@ def test_ragged_batch_golden():
     per_step = np.abs(tp.astype(np.float64) - g["traj_pos"]).reshape(T, -1).max(1)
     nv = int((torch.stack(r["v_traj"]).numpy() != g["traj_v"]).sum())
     nb = int((torch.stack(r["bond_traj"]).numpy() != g["traj_bond"]).sum())
-    print(f"ragged: per-step max pos err first/last {per_step[0]:.3g}/{per_step[-1]:.3g}; type mismatches v={nv} bond={nb}")
+    print(f"ragged ({mode}): per-step max pos err first/last {per_step[0]:.3g}/{per_step[-1]:.3g}; type mismatches v={nv} bond={nb}")
     assert maxabs(r["pos"], g["out_pos"]) < POS_TOL
     assert nv == 0 and nb == 0
     assert np.array_equal(r["v"].cpu().numpy(), g["out_v"]) and np.array_equal(r["bond"].cpu().numpy(), g["out_bond"])
@@ -695,6 +698,7 @@ def test_ragged_groups_together_equals_one_by_one(monkeypatch):
     """DD_RAGGED_CONCURRENT=1 advances the groups of a ragged batch together (dd_sample_steps_graph_multi: one graph,
     one stream and one launching thread per group); every group keeps its own state and workspace, so the result must
     be bit-identical to running the groups one after the other (device Philox noise)."""
+    monkeypatch.setenv("DD_RAGGED_MODE", "groups")
     g = GU.load("traj10_ragged")
     b = GU.batch_from_npz(g)
     m = model(0)

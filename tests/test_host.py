@@ -102,7 +102,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(hip_lib.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.dd_abi_version() == hip_lib.ABI_VERSION == 4
+    assert lib.dd_abi_version() == hip_lib.ABI_VERSION == 5
     assert lib.dd_status_string(0) == b"ok" and b"workspace" in lib.dd_status_string(-3)
     # pure host helper: workspace size grows with the batch and is non-zero
     w1, w8 = lib.dd_workspace_floats(1, 300, 30, 32), lib.dd_workspace_floats(8, 300, 30, 32)
@@ -179,3 +179,43 @@ def test_result_records_layout():
                             "pred_bond_index", "pred_bond_type", "ligand_filename"}
     assert recs[0]["mol"] == "MOL" and recs[0]["smiles"] == "C" and isinstance(recs[0]["pred_bond_index"], list)
     assert to_result_records(out)[1]["mol"] is None and to_result_records(out)[1]["smiles"] == ""
+
+
+def test_result_pt_round_trip_and_reconstruction_hand_off(tmp_path):
+    """result.pt as the reference writes it (torch.save of the record list, sample_diffusion_decomp.py:
+    616-619) read back as evaluate_mol_from_meta_full.py does; the reconstruction callable gets the reference's arguments
+    (positions, ATOMIC NUMBERS, bond index list, bond types: sample_diffusion_decomp.py:421-430); a raising callable is a
+    failed reconstruction (mol None, smiles ''); the bond graph / completeness criterion works without RDKit."""
+    from decompdiff_amd import harness
+    rng = np.random.default_rng(0)
+    NL, T = 5, 2
+    fc = synth.fc_bond_index(NL).numpy()
+    btype = np.zeros(fc.shape[1], dtype=np.int64)
+    for (i, j, t) in ((0, 1, 1), (1, 2, 2), (3, 4, 4)):                      # two fragments: {0,1,2} and {3,4}
+        btype[(fc[0] == i) & (fc[1] == j)] = t
+        btype[(fc[0] == j) & (fc[1] == i)] = t
+    out = {"pred_pos": [rng.normal(size=(NL, 3))], "pred_v": [np.array([1, 2, 3, 1, 7])],
+           "pred_pos_traj": [rng.normal(size=(T, NL, 3))], "pred_v_traj": [rng.integers(0, 8, (T, NL))],
+           "pred_bond_index": [fc], "pred_bond_type": [btype], "decomp_mask": [np.array([0, 0, 1, -1, -1])]}
+    seen = {}
+
+    def recon(pos, atomic_nums, bond_index, bond_type):
+        seen.update(pos=pos, nums=atomic_nums, bi=bond_index, bt=bond_type)
+        return "MOL"
+    recs = harness.to_result_records(out, ligand_filename="a/b.sdf", reconstruct=recon)
+    assert seen["nums"] == [6, 7, 8, 6, 17] and isinstance(seen["bi"], list) and recs[0]["mol"] == "MOL"
+    bonds, n_frag = harness.bond_graph(out["pred_bond_index"][0], out["pred_bond_type"][0])
+    assert sorted(bonds) == [(0, 1, 1), (1, 2, 2), (3, 4, 4)] and n_frag == 2
+
+    def failing(*a):
+        raise RuntimeError("MolReconsError")
+    assert harness.to_result_records(out, reconstruct=failing)[0]["mol"] is None
+    path = str(tmp_path / "result.pt")
+    harness.save_result_pt(recs, path)
+    back = harness.load_result_pt(path)
+    assert len(back) == 1 and set(back[0]) == set(recs[0])
+    for k, v in recs[0].items():
+        if isinstance(v, np.ndarray):
+            assert np.array_equal(back[0][k], v), k
+        else:
+            assert back[0][k] == v, k

@@ -23,8 +23,9 @@ rag = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synth.concat_samp
 dense = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synth.build_sampling_batch(synth.make_pocket_small(0), B).items()}
 
 
-def run(batch, seq):
+def run(batch, seq, mode="groups"):
     os.environ["DD_RAGGED_CONCURRENT"] = "0" if seq else "1"
+    os.environ["DD_RAGGED_MODE"] = mode
     best = 1e9
     for _ in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -35,12 +36,18 @@ def run(batch, seq):
 
 t_seq, r_seq = run(rag, True)
 t_con, r_con = run(rag, False)
+t_pad, r_pad = run(rag, True, "padded")
 t_den, _ = run(dense, False)
+dense40 = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synth.build_sampling_batch(synth.make_pocket(0, 300, (10, 10), 20), B).items()}
+t_den40, _ = run(dense40, False)
 same = all(torch.equal(r_seq[k], r_con[k]) for k in ("pos", "v", "bond"))
 print(f"ligand sizes {sizes} x {B // n_sizes if B % n_sizes == 0 else '~' + str(B / n_sizes)}; {steps} steps (incl. graph capture / setup)")
 print(f"ragged, group after group : {t_seq / steps * 1e3:8.3f} ms/step")
 print(f"ragged, groups together   : {t_con / steps * 1e3:8.3f} ms/step   (x{t_seq / t_con:.2f}; results identical: {same})")
+print(f"ragged, ONE padded sequence: {t_pad / steps * 1e3:8.3f} ms/step   ({t_den / t_pad:.2f}x the dense B=16 NL=30 rate, "
+      f"{t_den40 / t_pad:.2f}x the dense B=16 NL=40 rate)")
 print(f"dense B=16, NL=30         : {t_den / steps * 1e3:8.3f} ms/step")
+print(f"dense B=16, NL=40         : {t_den40 / steps * 1e3:8.3f} ms/step")
 for bb in (1, 2, 4):
     dd = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synth.build_sampling_batch(synth.make_pocket_small(0), bb).items()}
     print(f"dense B={bb}, NL=30          : {run(dd, False)[0] / steps * 1e3:8.3f} ms/step")
