@@ -108,7 +108,6 @@ static bool g_gemm_ksplit_on() { return g_gemm_ksplit != 0; }   // (the addend f
 static hipStream_t g_side = nullptr, g_side2 = nullptr;   // g_side2: query MLPs of the node / bond sub-layers
 static hipEvent_t g_ev_qa_fork[8], g_ev_qa_join[8], g_ev_qb_fork[8];
 static int g_step_fused = 1;                   // dd_debug_set_option(7, v): rows + coordinates + counter in one launch
-extern int g_assemble_persist;                 // (dd_graph.hip) 2 = matrix-core assemble kernel
 static int g_step_fold = 1;                    // dd_debug_set_option(20, v): step boundary folded (counter advanced by the forward's
                                                // first launch; last x update + x0 extraction inside the step kernel)
 static int g_xup_in_asm = 1;                   // dd_debug_set_option(19, v): x += dx applied by the next layer's assemble launch
@@ -126,7 +125,6 @@ static int g_lin_with_pb2 = 1;                 // dd_debug_set_option(16, v): bo
 static int g_pb_early = 1;                     // dd_debug_set_option(17, v): next layer's bond projections in the lin_node launch
 static int g_q1_in_gemm = 1;                   // dd_debug_set_option(12, v): bond-layer query hidden row summed inside the query GEMM
 static int g_q_in_pos = 1;                     // dd_debug_set_option(9, v): coordinate query MLPs' second layer inside attn_pos
-static int g_mlp_fused = 0;                    // dd_debug_set_option(6, v): fused 2-layer query MLPs beside the projections
 static hipEvent_t g_ev_fork[9], g_ev_join[9];   // [0..7] per layer, [8] graph construction at the head of a forward
 // DD_SIDE_PRIO: 1 (default) lowest priority for the side stream, 0 default priority, 2 highest
 static int g_side_low_priority = [] { const char* e = getenv("DD_SIDE_PRIO"); return (e && e[0] == '0') ? 0 : ((e && e[0] == '2') ? 2 : 1); }();
@@ -156,12 +154,11 @@ extern long long* g_gemm_dbg;              // dd_gemm.hip
 static long long* g_dbg_clock = nullptr;   // set by dd_debug_set_clock_buffer (profiling aid)
 static int g_dbg_mode = -1;
 
-static int g_use_v1 = [] { const char* e = getenv("DD_ATTN_V1"); return (e && e[0] == '1') ? 1 : 0; }();
 
 static int attn_dispatch(int mode, const AttnArgs& a0, hipStream_t st) {
   AttnArgs a = a0;
   a.dbg_clock = (mode == g_dbg_mode) ? g_dbg_clock : nullptr;
-  return g_use_v1 ? launch_attn(mode, a, st) : launch_attn2(mode, a, st);
+  return launch_attn2(mode, a, st);
 }
 
 // What one_step hands from the forward to the step kernels when the step boundary is folded (option 20).
@@ -184,8 +181,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
   float* xcur = w.xa;
   float* xnext = w.xb;
   const long hN = (long)N * 128;
-  const bool fused = g_fuse && !g_use_v1 && NL <= g_fused_max_nl && g_dbg_clock == nullptr;
-  if (s->nl_real != nullptr && g_use_v1) return DD_ERR_UNSUPPORTED_SHAPE;     // the v1 cross-check kernels are dense-only
+  const bool fused = g_fuse && NL <= g_fused_max_nl && g_dbg_clock == nullptr;
   const bool overlap = fused && g_overlap && g_prof == nullptr && s->num_layers <= 8;
   if (overlap) DD_TRY(ensure_side_stream());
 
@@ -230,62 +226,38 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
   const float* xup_prev = nullptr;                       // != nullptr: x of the previous layer, its update still pending
   for (int l = 0; l < s->num_layers && fused; ++l) {
     const int nE = (int)(B * Eb);
-    const bool mlpf = g_mlp_fused != 0;
-    // ---- query MLPs of the three node / bond sub-layers: fused 2-layer kernels on their own stream, beside the
-    //      projections (they only read the old h / h_bond).  First-Linear blocks: see packing.py (q1 / q_hb / q_hi).
-    if (mlpf) {
-      Mlp2Job q[3];
-      memset(q, 0, sizeof(q));
-      q[0].X1 = w.hb; q[0].x_rows_per_b = nE; q[0].x_stride_b = 0; q[0].ldx = 128; q[0].rows = nE;
-      q[0].X2 = w.h; q[0].x2_Eb = (int)Eb; q[0].x2_N = N; q[0].x2_NP = NP; q[0].x2_NLm1 = NL - 1;
-      q[0].W1a = LW(l, DD_W_b1) + 512 * 128; q[0].W1b = LW(l, DD_W_l1) + 1152 * 128; q[0].b1 = LW(l, DD_b_b1) + 512;
-      q[0].ln = LW(l, DD_BL_lnq); q[0].W2 = LW(l, DD_BL_W2q); q[0].b2 = LW(l, DD_BL_b2q); q[0].Y = w.qb;
-      q[1].X1 = w.h; q[1].x_rows_per_b = B * N; q[1].x_stride_b = 0; q[1].ldx = 128; q[1].rows = B * N;
-      q[1].W1a = LW(l, DD_W_n1) + 512 * 128; q[1].b1 = LW(l, DD_b_n1) + 512;
-      q[1].ln = LW(l, DD_NE_lnq); q[1].W2 = LW(l, DD_NE_W2q); q[1].b2 = LW(l, DD_NE_b2q); q[1].Y = w.qn;
-      q[2].X1 = w.h + (long)NP * 128; q[2].x_rows_per_b = NL; q[2].x_stride_b = hN; q[2].ldx = 128; q[2].rows = B * NL;
-      q[2].W1a = LW(l, DD_W_l1) + 512 * 128; q[2].b1 = LW(l, DD_b_l1) + 512;
-      q[2].ln = LW(l, DD_NB_lnq); q[2].W2 = LW(l, DD_NB_W2q); q[2].b2 = LW(l, DD_NB_b2q); q[2].Y = w.qlnb;
-      if (overlap) {
-        if (hipEventRecord(g_ev_qa_fork[l], st) != hipSuccess || hipStreamWaitEvent(g_side2, g_ev_qa_fork[l], 0) != hipSuccess) return DD_ERR_HIP;
-        DD_TRY(launch_mlp2_batch(q, 3, g_side2));
-        if (hipEventRecord(g_ev_qa_join[l], g_side2) != hipSuccess) return DD_ERR_HIP;
-      } else {
-        DD_TRYP(DD_PROF_GEMM, launch_mlp2_batch(q, 3, st));
-      }
-    }
     // ---- projections of the old h / h_bond: one launch (the q blocks are the last columns: skipped when fused above).
     //      With the projection-ahead schedule this launch was already issued on the side stream right after the
     //      previous layer's lin_node (it needs h and h_bond only) and is joined before its first consumer.
     auto launch_batch1 = [&](int ll, hipStream_t sx) -> int {
       GemmArgs j[3] = {
-          gemm_args(w.h, B * N, 0, 128, B * N, LW(ll, DD_W_n1), LW(ll, DD_b_n1), nullptr, w.P, B * N, 0, 640, mlpf ? 512 : 640, 0),
-          gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(ll, DD_W_l1), LW(ll, DD_b_l1), nullptr, w.PL, B * NL, 0, 1280, mlpf ? 1152 : 1280, 0),
-          gemm_args(w.hb, nE, 0, 128, nE, LW(ll, DD_W_b1), LW(ll, DD_b_b1), nullptr, w.PB, nE, 0, 640, mlpf ? 512 : 640, 0)};
+          gemm_args(w.h, B * N, 0, 128, B * N, LW(ll, DD_W_n1), LW(ll, DD_b_n1), nullptr, w.P, B * N, 0, 640, 640, 0),
+          gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(ll, DD_W_l1), LW(ll, DD_b_l1), nullptr, w.PL, B * NL, 0, 1280, 1280, 0),
+          gemm_args(w.hb, nE, 0, 128, nE, LW(ll, DD_W_b1), LW(ll, DD_b_b1), nullptr, w.PB, nE, 0, 640, 640, 0)};
       return launch_gemm128_batch(j, 3, sx);
     };
     // (schedule 2) the same projections in two launches: the bond part only needs h_bond, final once the node
     // attention is done; the node parts need h (lin_node)
     auto launch_batch1_part = [&](int ll, int part, hipStream_t sx) -> int {
       if (part == 0) {
-        GemmArgs j[1] = {gemm_args(w.hb, nE, 0, 128, nE, LW(ll, DD_W_b1), LW(ll, DD_b_b1), nullptr, w.PB, nE, 0, 640, mlpf ? 512 : 640, 0)};
+        GemmArgs j[1] = {gemm_args(w.hb, nE, 0, 128, nE, LW(ll, DD_W_b1), LW(ll, DD_b_b1), nullptr, w.PB, nE, 0, 640, 640, 0)};
         return launch_gemm128_batch(j, 1, sx);
       }
       GemmArgs j[2] = {
-          gemm_args(w.h, B * N, 0, 128, B * N, LW(ll, DD_W_n1), LW(ll, DD_b_n1), nullptr, w.P, B * N, 0, 640, mlpf ? 512 : 640, 0),
-          gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(ll, DD_W_l1), LW(ll, DD_b_l1), nullptr, w.PL, B * NL, 0, 1280, mlpf ? 1152 : 1280, 0)};
+          gemm_args(w.h, B * N, 0, 128, B * N, LW(ll, DD_W_n1), LW(ll, DD_b_n1), nullptr, w.P, B * N, 0, 640, 640, 0),
+          gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(ll, DD_W_l1), LW(ll, DD_b_l1), nullptr, w.PL, B * NL, 0, 1280, 1280, 0)};
       return launch_gemm128_batch(j, 2, sx);
     };
     const bool ahead = overlap && g_sched >= 1;
     const bool ahead_split = overlap && g_sched >= 2;
-    const bool ahead_b2 = overlap && g_sched == 3 && !mlpf && g_q1_in_gemm && g_gemm_ksplit_on();
+    const bool ahead_b2 = overlap && g_sched == 3 && g_q1_in_gemm && g_gemm_ksplit_on();
     const bool pb_early = g_pb_early && g_lin_with_pb2 && !ahead;   // next layer's bond projections ride with lin_node
     if (pb_early && l > 0) DD_TRYP(DD_PROF_GEMM, launch_batch1_part(l, 1, st));
     else if (!(ahead && l > 0)) DD_TRYP(DD_PROF_GEMM, launch_batch1(l, st));
     // ---- queries (second Linear of the q MLPs, LayerNorm+ReLU prologue): one launch.  The bond-layer hidden row is
     //      q_hb[bond] + q_hi[dst atom], summed while the GEMM stages its rows, so this launch depends on the projections
     //      only and runs before the coordinates of the previous layer are joined.
-    const bool q1_in_gemm = g_q1_in_gemm && !mlpf && g_gemm_ksplit_on();
+    const bool q1_in_gemm = g_q1_in_gemm && g_gemm_ksplit_on();
     auto launch_b2 = [&](int ll, hipStream_t sx) -> int {
       GemmArgs j[3] = {
           gemm_args(w.q1bl, nE, 0, 128, nE, LW(ll, DD_BL_W2q), LW(ll, DD_BL_b2q), LW(ll, DD_BL_lnq), w.qb, nE, 0, 128, 128, 0),
@@ -314,16 +286,11 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     }
     if (ahead && l > 0 && !b1_joined && hipStreamWaitEvent(st, g_ev_join[l], 0) != hipSuccess) return DD_ERR_HIP;   // projections of this layer
     // (a deferred coordinate update of the previous layer is applied here: xcur's ligand rows are written by this launch)
-    DD_TRYP(DD_PROF_ASSEMBLE, launch_bl_assemble(xcur, w.PB, w.PL, LW(l, DD_BL_Wg1k), LW(l, DD_BL_Wg1v), LW(l, DD_BL_Wg2k),
-                                                  LW(l, DD_BL_Wg2v), LW(l, DD_BL_Wgp), B, NP, NL, w.Ek, w.Ev,
-                                                  (mlpf || q1_in_gemm) ? nullptr : w.q1bl, w.Rk, w.Rv, st, xup_prev, w.dxe, w.dxb,
+    DD_TRYP(DD_PROF_ASSEMBLE, launch_bl_assemble(xcur, w.PB, w.PL, LW(l, DD_BL_Wgp), B, NP, NL, w.Ek, w.Ev,
+                                                  q1_in_gemm ? nullptr : w.q1bl, w.Rk, w.Rv, st, xup_prev, w.dxe, w.dxb,
                                                   xup_prev ? xcur : nullptr));
     xup_prev = nullptr;
-    if (!mlpf && !q1_in_gemm) {
-      DD_TRYP(DD_PROF_GEMM, launch_b2(l, st));
-    } else if (mlpf && overlap) {
-      if (hipStreamWaitEvent(st, g_ev_qa_join[l], 0) != hipSuccess) return DD_ERR_HIP;
-    }
+    if (!q1_in_gemm) DD_TRYP(DD_PROF_GEMM, launch_b2(l, st));
     if (head_join) {                                     // kNN graph + edge weights: first needed by the node attention
       if (hipStreamWaitEvent(st, g_ev_join[8], 0) != hipSuccess) return DD_ERR_HIP;
       head_join = false;
@@ -336,18 +303,18 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
       bl.bl_prefix = s->bl_prefix;
       ne.B = B; ne.NP = NP; ne.NL = NL; ne.K = K; ne.x = xcur; ne.nbr = w.nbr; ne.ew = w.ew;
       ne.kd = w.P; ne.ks = w.P + 128; ne.vd = w.P + 256; ne.vs = w.P + 384; ne.ld_kd = ne.ld_ks = ne.ld_vd = ne.ld_vs = 640;
-      ne.q = w.qn; ne.Ak = LW(l, DD_NE_Ak); ne.Av = LW(l, DD_NE_Av); ne.Akp = LW(l, DD_NE_Akp); ne.Avp = LW(l, DD_NE_Avp); ne.lnk = LW(l, DD_NE_lnk); ne.lnv = LW(l, DD_NE_lnv);
-      ne.W2k = LW(l, DD_NE_W2k); ne.W2vT = LW(l, DD_NE_W2vT); ne.W2v = LW(l, DD_NE_W2v); ne.b2v = LW(l, DD_NE_b2v); ne.out = w.A;
+      ne.q = w.qn; ne.Akp = LW(l, DD_NE_Akp); ne.Avp = LW(l, DD_NE_Avp); ne.lnk = LW(l, DD_NE_lnk); ne.lnv = LW(l, DD_NE_lnv);
+      ne.W2k = LW(l, DD_NE_W2k); ne.W2v = LW(l, DD_NE_W2v); ne.b2v = LW(l, DD_NE_b2v); ne.out = w.A;
       nb.B = B; nb.NP = NP; nb.NL = NL; nb.K = K; nb.x = xcur;
       nb.kd = w.PL; nb.ks = w.PL + 128; nb.vd = w.PL + 256; nb.vs = w.PL + 384; nb.ld_kd = nb.ld_ks = nb.ld_vd = nb.ld_vs = 1280;
       nb.ke = w.PB; nb.ve = w.PB + 128; nb.ld_ke = nb.ld_ve = 640;
       nb.q = w.qlnb; nb.lnk = LW(l, DD_NB_lnk); nb.lnv = LW(l, DD_NB_lnv);
-      nb.W2k = LW(l, DD_NB_W2k); nb.W2vT = LW(l, DD_NB_W2vT); nb.W2v = LW(l, DD_NB_W2v); nb.b2v = LW(l, DD_NB_b2v); nb.out = w.Anb; nb.out_assign = 1;
+      nb.W2k = LW(l, DD_NB_W2k); nb.W2v = LW(l, DD_NB_W2v); nb.b2v = LW(l, DD_NB_b2v); nb.out = w.Anb; nb.out_assign = 1;
       bl.B = B; bl.NP = NP; bl.NL = NL; bl.K = K; bl.x = xcur;
       bl.ke = w.Ek; bl.ve = w.Ev; bl.ld_ke = bl.ld_ve = 128;
-      bl.q = w.qb; bl.Wg2k = LW(l, DD_BL_Wg2k); bl.Wg2v = LW(l, DD_BL_Wg2v); bl.Wak = LW(l, DD_BL_Wak); bl.Wav = LW(l, DD_BL_Wav); bl.Wakp = LW(l, DD_BL_Wakp); bl.Wavp = LW(l, DD_BL_Wavp);
+      bl.q = w.qb; bl.Wakp = LW(l, DD_BL_Wakp); bl.Wavp = LW(l, DD_BL_Wavp);
       bl.lnk = LW(l, DD_BL_lnk); bl.lnv = LW(l, DD_BL_lnv);
-      bl.W2k = LW(l, DD_BL_W2k); bl.W2vT = LW(l, DD_BL_W2vT); bl.W2v = LW(l, DD_BL_W2v); bl.b2v = LW(l, DD_BL_b2v); bl.out = w.hb;
+      bl.W2k = LW(l, DD_BL_W2k); bl.W2v = LW(l, DD_BL_W2v); bl.b2v = LW(l, DD_BL_b2v); bl.out = w.hb;
       bl.Rk = w.Rk; bl.Rv = w.Rv;
       bl.work_counter = (l < 64) ? w.counters + l : nullptr;
       DD_TRYP(DD_PROF_ATTN_BL, launch_attn2_node(ne, nb, bl, st));
@@ -364,41 +331,23 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
                          gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b2), LW(l, DD_b_b2), nullptr, w.PB2, nE, 0, 256, 256, 0)};
         const bool more = pb_early && l + 1 < s->num_layers;
         if (more)                                          // ... and so do the next layer's bond projections (h_bond is final)
-          j[2] = gemm_args(w.hb, nE, 0, 128, nE, LW(l + 1, DD_W_b1), LW(l + 1, DD_b_b1), nullptr, w.PB, nE, 0, 640, mlpf ? 512 : 640, 0);
+          j[2] = gemm_args(w.hb, nE, 0, 128, nE, LW(l + 1, DD_W_b1), LW(l + 1, DD_b_b1), nullptr, w.PB, nE, 0, 640, 640, 0);
         DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, more ? 3 : 2, st));
       } else {
         DD_TRYP(DD_PROF_GEMM, launch_gemm128(g, st));
       }
     }
     if (ahead && l + 1 < s->num_layers && hipEventRecord(g_ev_fork[l + 1], st) != hipSuccess) return DD_ERR_HIP;   // h, h_bond final
-    // ---- query MLPs of the two coordinate sub-layers: fused, on the stream the sub-layers themselves run on
-    if (mlpf) {
-      Mlp2Job q[2];
-      memset(q, 0, sizeof(q));
-      for (int i = 0; i < 2; ++i) {
-        q[i].X1 = w.h + (long)NP * 128; q[i].x_rows_per_b = NL; q[i].x_stride_b = hN; q[i].ldx = 128; q[i].rows = B * NL;
-      }
-      q[0].W1a = LW(l, DD_W_l2) + 256 * 128; q[0].b1 = LW(l, DD_b_l2) + 256;
-      q[0].ln = LW(l, DD_PE_lnq); q[0].W2 = LW(l, DD_PE_W2q); q[0].b2 = LW(l, DD_PE_b2q); q[0].Y = w.ql;
-      q[1].W1a = LW(l, DD_W_l2) + 896 * 128; q[1].b1 = LW(l, DD_b_l2) + 896;
-      q[1].ln = LW(l, DD_PB_lnq); q[1].W2 = LW(l, DD_PB_W2q); q[1].b2 = LW(l, DD_PB_b2q); q[1].Y = w.ql2;
-      if (overlap && !ahead) {
-        if (hipEventRecord(g_ev_qb_fork[l], st) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_qb_fork[l], 0) != hipSuccess) return DD_ERR_HIP;
-        DD_TRY(launch_mlp2_batch(q, 2, g_side));        // (the pos launch follows on the same stream)
-      } else {
-        DD_TRYP(DD_PROF_GEMM, launch_mlp2_batch(q, 2, st));
-      }
-    }
     // ---- projections of the new h / h_bond: one launch
     {
       GemmArgs j[3] = {
           gemm_args(w.h, B * N, 0, 128, B * N, LW(l, DD_W_n2), LW(l, DD_b_n2), nullptr, w.P2, B * N, 0, 256, 256, 0),
-          gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(l, DD_W_l2), LW(l, DD_b_l2), nullptr, w.PL2, B * NL, 0, 1024, mlpf ? 896 : 1024, 0),
+          gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(l, DD_W_l2), LW(l, DD_b_l2), nullptr, w.PL2, B * NL, 0, 1024, 1024, 0),
           gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b2), LW(l, DD_b_b2), nullptr, w.PB2, nE, 0, 256, 256, 0)};
       DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, g_lin_with_pb2 ? 2 : 3, st));
     }
-    const bool q_in_pos = g_q_in_pos && !mlpf;           // second layer of the coordinate query MLPs inside attn_pos
-    if (!mlpf && !q_in_pos) {
+    const bool q_in_pos = g_q_in_pos;           // second layer of the coordinate query MLPs inside attn_pos
+    if (!q_in_pos) {
       GemmArgs j[2] = {
           gemm_args(w.PL2 + 256, B * NL, 0, 1024, B * NL, LW(l, DD_PE_W2q), LW(l, DD_PE_b2q), LW(l, DD_PE_lnq), w.ql, B * NL, 0, 128, 128, 0),
           gemm_args(w.PL2 + 896, B * NL, 0, 1024, B * NL, LW(l, DD_PB_W2q), LW(l, DD_PB_b2q), LW(l, DD_PB_lnq), w.ql2, B * NL, 0, 128, 128, 0)};
@@ -411,7 +360,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
       pe.np_real = pb.np_real = s->np_real; pe.nl_real = pb.nl_real = s->nl_real;
       pe.B = B; pe.NP = NP; pe.NL = NL; pe.K = K; pe.x = xcur; pe.nbr = w.nbr; pe.ew = w.ew;
       pe.kd = w.PL2; pe.vd = w.PL2 + 128; pe.ld_kd = pe.ld_vd = 1024; pe.ks = w.P2; pe.vs = w.P2 + 128; pe.ld_ks = pe.ld_vs = 256;
-      pe.q = w.ql; pe.Ak = LW(l, DD_PE_Ak); pe.Av = LW(l, DD_PE_Av); pe.Akp = LW(l, DD_PE_Akp); pe.Avp = LW(l, DD_PE_Avp); pe.lnk = LW(l, DD_PE_lnk); pe.lnv = LW(l, DD_PE_lnv);
+      pe.q = w.ql; pe.Akp = LW(l, DD_PE_Akp); pe.Avp = LW(l, DD_PE_Avp); pe.lnk = LW(l, DD_PE_lnk); pe.lnv = LW(l, DD_PE_lnv);
       pe.W2k = LW(l, DD_PE_W2k); pe.W2v16 = LW(l, DD_PE_W2v); pe.b2v16 = LW(l, DD_PE_b2v); pe.out = w.dxe;
       pb.B = B; pb.NP = NP; pb.NL = NL; pb.K = K; pb.x = xcur;
       pb.kd = w.PL2 + 384; pb.ks = w.PL2 + 512; pb.vd = w.PL2 + 640; pb.vs = w.PL2 + 768; pb.ld_kd = pb.ld_ks = pb.ld_vd = pb.ld_vs = 1024;
@@ -420,7 +369,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
       pb.W2k = LW(l, DD_PB_W2k); pb.W2v16 = LW(l, DD_PB_W2v); pb.b2v16 = LW(l, DD_PB_b2v); pb.out = w.dxb; pb.x_next = nullptr;
       const bool xup_in_pos = g_xup_in_pos != 0;           // x update by the last workgroup of the coordinate launch
       // ... or by the next layer's assemble launch, the first consumer of the new x (one launch less on the chain)
-      const bool xup_in_asm = !xup_in_pos && ((g_xup_in_asm && g_assemble_persist == 2 && l + 1 < s->num_layers) ||
+      const bool xup_in_asm = !xup_in_pos && ((g_xup_in_asm && l + 1 < s->num_layers) ||
                                               (fold && fold->fold_tail && l + 1 == s->num_layers));   // (... or by the step kernel)
       if (xup_in_pos) { pe.work_counter = w.counters + 32 + (l & 15); pe.x_next = xnext; }
       if (q_in_pos) {
@@ -460,8 +409,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
                            B * NL, 0, 1280, 1280, 0}, st));
     DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.hb, (int)(B * Eb), 0, 128, (int)(B * Eb), LW(l, DD_W_b1), LW(l, DD_b_b1), nullptr, w.PB,
                            (int)(B * Eb), 0, 640, 640, 0}, st));
-    DD_TRYP(DD_PROF_ASSEMBLE, launch_bl_assemble(xcur, w.PB, w.PL, LW(l, DD_BL_Wg1k), LW(l, DD_BL_Wg1v), LW(l, DD_BL_Wg2k),
-                                                  LW(l, DD_BL_Wg2v), LW(l, DD_BL_Wgp), B, NP, NL, w.Ek, w.Ev, w.q1bl, w.Rk, w.Rv, st));
+    DD_TRYP(DD_PROF_ASSEMBLE, launch_bl_assemble(xcur, w.PB, w.PL, LW(l, DD_BL_Wgp), B, NP, NL, w.Ek, w.Ev, w.q1bl, w.Rk, w.Rv, st));
     // ---- queries: second Linear of the q MLPs (LayerNorm+ReLU prologue)
     DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.P + 512, B * N, 0, 640, B * N, LW(l, DD_NE_W2q), LW(l, DD_NE_b2q), LW(l, DD_NE_lnq), w.qn,
                            B * N, 0, 128, 128, 0}, st));
@@ -475,8 +423,8 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     a.np_real = s->np_real; a.nl_real = s->nl_real;
     a.B = B; a.NP = NP; a.NL = NL; a.K = K; a.x = xcur; a.nbr = w.nbr; a.ew = w.ew;
     a.kd = w.P; a.ks = w.P + 128; a.vd = w.P + 256; a.vs = w.P + 384; a.ld_kd = a.ld_ks = a.ld_vd = a.ld_vs = 640;
-    a.q = w.qn; a.Ak = LW(l, DD_NE_Ak); a.Av = LW(l, DD_NE_Av); a.Akp = LW(l, DD_NE_Akp); a.Avp = LW(l, DD_NE_Avp); a.lnk = LW(l, DD_NE_lnk); a.lnv = LW(l, DD_NE_lnv);
-    a.W2k = LW(l, DD_NE_W2k); a.W2vT = LW(l, DD_NE_W2vT); a.W2v = LW(l, DD_NE_W2v); a.b2v = LW(l, DD_NE_b2v); a.out = w.A;
+    a.q = w.qn; a.Akp = LW(l, DD_NE_Akp); a.Avp = LW(l, DD_NE_Avp); a.lnk = LW(l, DD_NE_lnk); a.lnv = LW(l, DD_NE_lnv);
+    a.W2k = LW(l, DD_NE_W2k); a.W2v = LW(l, DD_NE_W2v); a.b2v = LW(l, DD_NE_b2v); a.out = w.A;
     DD_TRYP(DD_PROF_ATTN_NE, attn_dispatch(M_NE, a, st));
     // ---- node_layer_with_bond (adds into the ligand rows of A)
     memset(&a, 0, sizeof(a));
@@ -485,16 +433,16 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     a.kd = w.PL; a.ks = w.PL + 128; a.vd = w.PL + 256; a.vs = w.PL + 384; a.ld_kd = a.ld_ks = a.ld_vd = a.ld_vs = 1280;
     a.ke = w.PB; a.ve = w.PB + 128; a.ld_ke = a.ld_ve = 640;
     a.q = w.ql; a.lnk = LW(l, DD_NB_lnk); a.lnv = LW(l, DD_NB_lnv);
-    a.W2k = LW(l, DD_NB_W2k); a.W2vT = LW(l, DD_NB_W2vT); a.W2v = LW(l, DD_NB_W2v); a.b2v = LW(l, DD_NB_b2v); a.out = w.A;
+    a.W2k = LW(l, DD_NB_W2k); a.W2v = LW(l, DD_NB_W2v); a.b2v = LW(l, DD_NB_b2v); a.out = w.A;
     DD_TRYP(DD_PROF_ATTN_NB, attn_dispatch(M_NB, a, st));
     // ---- bond_layer (residual add into h_bond)
     memset(&a, 0, sizeof(a));
     a.np_real = s->np_real; a.nl_real = s->nl_real;
     a.B = B; a.NP = NP; a.NL = NL; a.K = K; a.x = xcur;
     a.ke = w.Ek; a.ve = w.Ev; a.ld_ke = a.ld_ve = 128;
-    a.q = w.qb; a.Wg2k = LW(l, DD_BL_Wg2k); a.Wg2v = LW(l, DD_BL_Wg2v); a.Wak = LW(l, DD_BL_Wak); a.Wav = LW(l, DD_BL_Wav); a.Wakp = LW(l, DD_BL_Wakp); a.Wavp = LW(l, DD_BL_Wavp);
+    a.q = w.qb; a.Wakp = LW(l, DD_BL_Wakp); a.Wavp = LW(l, DD_BL_Wavp);
     a.lnk = LW(l, DD_BL_lnk); a.lnv = LW(l, DD_BL_lnv);
-    a.W2k = LW(l, DD_BL_W2k); a.W2vT = LW(l, DD_BL_W2vT); a.W2v = LW(l, DD_BL_W2v); a.b2v = LW(l, DD_BL_b2v); a.out = w.hb;
+    a.W2k = LW(l, DD_BL_W2k); a.W2v = LW(l, DD_BL_W2v); a.b2v = LW(l, DD_BL_b2v); a.out = w.hb;
     a.Rk = w.Rk; a.Rv = w.Rv;
     DD_TRYP(DD_PROF_ATTN_BL, attn_dispatch(M_BL, a, st));
     // ---- h += lin_node(A)
@@ -512,7 +460,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     a.np_real = s->np_real; a.nl_real = s->nl_real;
     a.B = B; a.NP = NP; a.NL = NL; a.K = K; a.x = xcur; a.nbr = w.nbr; a.ew = w.ew;
     a.kd = w.PL; a.vd = w.PL + 128; a.ld_kd = a.ld_vd = 1024; a.ks = w.P; a.vs = w.P + 128; a.ld_ks = a.ld_vs = 256;
-    a.q = w.ql; a.Ak = LW(l, DD_PE_Ak); a.Av = LW(l, DD_PE_Av); a.Akp = LW(l, DD_PE_Akp); a.Avp = LW(l, DD_PE_Avp); a.lnk = LW(l, DD_PE_lnk); a.lnv = LW(l, DD_PE_lnv);
+    a.q = w.ql; a.Akp = LW(l, DD_PE_Akp); a.Avp = LW(l, DD_PE_Avp); a.lnk = LW(l, DD_PE_lnk); a.lnv = LW(l, DD_PE_lnv);
     a.W2k = LW(l, DD_PE_W2k); a.W2v16 = LW(l, DD_PE_W2v); a.b2v16 = LW(l, DD_PE_b2v); a.out = w.dxe;
     DD_TRYP(DD_PROF_ATTN_PE, attn_dispatch(M_PE, a, st));
     // ---- pos_layer_with_bond + coordinate update (ligand rows only: mask_ligand_atom)
@@ -701,7 +649,7 @@ extern "C" int dd_workspace_view(const dd_sampler* s, dd_ws_view* out) {
   dd::Workspace w = dd::carve(s->workspace, s->B, s->NP, s->NL, s->K);
   out->x = (s->num_layers & 1) ? w.xb : w.xa;
   out->h = w.h; out->hb = w.hb; out->ew = w.ew; out->A = w.A; out->nbr = w.nbr;
-  out->Anb = (dd::g_fuse && !dd::g_use_v1 && s->NL <= dd::g_fused_max_nl) ? w.Anb : nullptr;
+  out->Anb = (dd::g_fuse && s->NL <= dd::g_fused_max_nl) ? w.Anb : nullptr;
   return DD_OK;
 }
 
@@ -743,7 +691,7 @@ static int autotune_node_split(const dd_sampler* s, hipStream_t st) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return DD_ERR_HIP;
     n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  const bool fused = dd::g_fuse && !dd::g_use_v1 && s->NL <= dd::g_fused_max_nl && dd::g_dbg_clock == nullptr;
+  const bool fused = dd::g_fuse && s->NL <= dd::g_fused_max_nl && dd::g_dbg_clock == nullptr;
   if (!fused || !dd::node_split_applies(s->B, s->NL, n_cu) || dd::node_split_lookup(s->B, s->NP, s->NL, s->K) >= 0) return DD_OK;
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return DD_ERR_HIP;
@@ -1015,13 +963,13 @@ extern "C" int dd_debug_options_epoch(void) { return g_options_epoch; }
 
 extern "C" int dd_debug_set_fusion(int mode) {
   ++g_options_epoch;
+  if (mode != 0 && mode != 1 && mode != 3) return DD_ERR_BAD_ARG;
   dd::g_fuse = (mode == 1 || mode == 3) ? 1 : 0;
   dd::g_overlap = mode == 1 ? 1 : 0;
-  dd::g_use_v1 = mode == 2 ? 1 : 0;
   return DD_OK;
 }
 
-namespace dd { extern int g_gemm_ksplit; extern int g_attn_waves; extern int g_attn_persist; extern int g_assemble_persist; extern int g_pos_waves; extern int g_gemm_big; extern int g_ew_mfma; extern int g_bl_first; extern int g_gemm_xcd; }
+namespace dd { extern int g_gemm_ksplit; extern int g_attn_waves; extern int g_attn_persist; extern int g_pos_waves; extern int g_bl_first; extern int g_gemm_xcd; }
 // Measurement aid: runtime switches for A/B timing inside one process.  key 0: attention launch structure (same
 // values as dd_debug_set_fusion), key 1: K-split projection GEMM tiles (1 = on).
 extern "C" int dd_debug_node_split(int B, int NP, int NL, int K) { return dd::node_split_lookup(B, NP, NL, K); }
@@ -1037,18 +985,14 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 18) { if (value < 0 || value > 1024) return DD_ERR_BAD_ARG; dd::g_bl_first = value; return DD_OK; }
   if (key == 17) { dd::g_pb_early = value ? 1 : 0; return DD_OK; }
   if (key == 16) { dd::g_lin_with_pb2 = value ? 1 : 0; return DD_OK; }
-  if (key == 15) { dd::g_ew_mfma = value ? 1 : 0; return DD_OK; }
   if (key == 14) { dd::g_defer_pos = value ? 1 : 0; return DD_OK; }
   if (key == 13) { dd::g_fused_max_nl = value; return DD_OK; }
   if (key == 12) { dd::g_q1_in_gemm = value ? 1 : 0; return DD_OK; }
   if (key == 11) { dd::g_xup_in_pos = value ? 1 : 0; return DD_OK; }
-  if (key == 10) { dd::g_gemm_big = value ? 1 : 0; return DD_OK; }
   if (key == 9) { dd::g_q_in_pos = value ? 1 : 0; return DD_OK; }
   if (key == 8) { if (value < 0 || value > 3) return DD_ERR_BAD_ARG; dd::g_sched = value; return DD_OK; }
   if (key == 7) { dd::g_step_fused = value ? 1 : 0; return DD_OK; }
-  if (key == 6) { dd::g_mlp_fused = value ? 1 : 0; return DD_OK; }
   if (key == 5) { if (value != 2 && value != 4 && value != 8) return DD_ERR_BAD_ARG; dd::g_pos_waves = value; return DD_OK; }
-  if (key == 4) { if (value < 0 || value > 2) return DD_ERR_BAD_ARG; dd::g_assemble_persist = value; return DD_OK; }
   if (key == 2) { if (value != 8) return DD_ERR_BAD_ARG; dd::g_attn_waves = value; return DD_OK; }
   return DD_ERR_BAD_ARG;
 }

@@ -297,327 +297,6 @@ __device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx
 }
 
 
-// ---------------------------------------------------------------------------------------------- fused 2-layer MLP
-// Y[r, 0:128] = W2 . relu(LayerNorm(W1a . X1[r] (+ W1b . X2[x2row(r)]) + b1)) + b2       (models/common.py:85-105)
-// One workgroup = 64 rows: the hidden activation never leaves the CU (LDS), so the query MLPs of the five attention
-// sub-layers cost one launch beside the projection GEMMs instead of a GEMM -> GEMM chain on the critical path.
-// LDS: X / hidden tile 64 x 130 (33 KB) + one whole 128 x 130 weight image (66.5 KB) = 99.8 KB.
-constexpr int MP = 130;
-constexpr int MT = 512;                                  // threads per workgroup (8 waves: 2 row halves x 4 column groups)
-struct WImg { float4 v[8]; };
-__device__ __forceinline__ void mlp2_load_w(WImg& t, const float* __restrict__ W /*[128,128]*/) {
-#pragma unroll
-  for (int k = 0; k < 8; ++k) t.v[k] = reinterpret_cast<const float4*>(W)[threadIdx.x + k * MT];
-}
-__device__ __forceinline__ void mlp2_store_w(float* Ws, const WImg& t) {
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int i = threadIdx.x + k * MT, r = i >> 5, c4 = (i & 31) * 4;
-    float2* d = reinterpret_cast<float2*>(&Ws[r * MP + c4]);
-    d[0] = make_float2(t.v[k].x, t.v[k].y);
-    d[1] = make_float2(t.v[k].z, t.v[k].w);
-  }
-}
-// 32 rows x 32 columns per wave, K = 128
-__device__ __forceinline__ void mlp2_mfma(const float* Xs, const float* Ws, f32x16& acc) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 2, wc = wave & 3, li = lane & 31, hh = lane >> 5;
-  const float* xa = &Xs[(wr * 32 + li) * MP + 2 * hh];
-  const float* wb = &Ws[(wc * 32 + li) * MP + 2 * hh];
-#pragma unroll 8
-  for (int kk = 0; kk < 32; ++kk) {
-    const float2 av = *reinterpret_cast<const float2*>(xa + 4 * kk);
-    const float2 bv = *reinterpret_cast<const float2*>(wb + 4 * kk);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
-  }
-}
-__device__ __forceinline__ void mlp2_tile(const Mlp2Job& j, const int tile, float* Xs, float* Ws) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 2, wc = wave & 3, li = lane & 31, hh = lane >> 5;
-  const int row0 = tile * GT;
-  const bool xplain = j.x_rows_per_b >= j.rows;
-  f32x16 acc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  auto load_x = [&](int part, float4 (&xv)[4]) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = tid + k * MT, r = i >> 5, c4 = (i & 31) * 4, gr = row0 + r;
-      xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gr < j.rows) {
-        const float* src;
-        if (part == 0) src = j.X1 + row_offset(gr, j.x_rows_per_b, j.x_stride_b, j.ldx, xplain) + c4;
-        else src = j.X2 + ((long)(gr / j.x2_Eb) * j.x2_N + j.x2_NP + (gr % j.x2_Eb) / j.x2_NLm1) * 128 + c4;   // bond -> its dst atom
-        xv[k] = *reinterpret_cast<const float4*>(src);
-      }
-    }
-  };
-  auto store_x = [&](const float4 (&xv)[4]) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = tid + k * MT, r = i >> 5, c4 = (i & 31) * 4;
-      float2* d = reinterpret_cast<float2*>(&Xs[r * MP + c4]);
-      d[0] = make_float2(xv[k].x, xv[k].y);
-      d[1] = make_float2(xv[k].z, xv[k].w);
-    }
-  };
-  // every stage's operands are requested while the previous stage multiplies
-  float4 xv[4];
-  WImg wimg;
-  load_x(0, xv);
-  mlp2_load_w(wimg, j.W1a);
-  store_x(xv);
-  mlp2_store_w(Ws, wimg);
-  __syncthreads();
-  if (j.X2) { load_x(1, xv); mlp2_load_w(wimg, j.W1b); } else { mlp2_load_w(wimg, j.W2); }
-  mlp2_mfma(Xs, Ws, acc);
-  if (j.X2) {
-    __syncthreads();                                     // first half consumed
-    store_x(xv);
-    mlp2_store_w(Ws, wimg);
-    __syncthreads();
-    mlp2_load_w(wimg, j.W2);
-    mlp2_mfma(Xs, Ws, acc);
-  }
-  __syncthreads();                                       // both operand images dead
-  // hidden pre-activation (+ b1) -> Xs; second weight image -> Ws
-  {
-    const int c0 = wc * 32 + li;
-    const float bA = j.b1[c0];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      Xs[row * MP + c0] = acc[r] + bA;
-    }
-  }
-  mlp2_store_w(Ws, wimg);
-  __syncthreads();
-  // LayerNorm + ReLU in place: thread -> rows (tid >> 5) + 16k, channels 4 * (tid & 31) .. +3 (a row = one half wave)
-  {
-    const int c4 = (tid & 31) * 4;
-    const float4 gm = *reinterpret_cast<const float4*>(j.ln + c4);
-    const float4 bt = *reinterpret_cast<const float4*>(j.ln + 128 + c4);
-    auto half_sum = [](float v) {
-      v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); v += dpp_mov<0x140>(v);
-      return swap16_sum(v, v);
-    };
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float2* p = reinterpret_cast<float2*>(&Xs[((tid >> 5) + 16 * k) * MP + c4]);
-      const float2 a0 = p[0], a1 = p[1];
-      const float mean = half_sum((a0.x + a0.y) + (a1.x + a1.y)) * (1.0f / 128.0f);
-      const float dx = a0.x - mean, dy = a0.y - mean, dz = a1.x - mean, dw = a1.y - mean;
-      const float var = half_sum(fmaf(dx, dx, dy * dy) + fmaf(dz, dz, dw * dw)) * (1.0f / 128.0f);
-      const float rstd = dd_rsqrt(var + 1e-5f);
-      p[0] = make_float2(fmaxf(fmaf(dx * rstd, gm.x, bt.x), 0.f), fmaxf(fmaf(dy * rstd, gm.y, bt.y), 0.f));
-      p[1] = make_float2(fmaxf(fmaf(dz * rstd, gm.z, bt.z), 0.f), fmaxf(fmaf(dw * rstd, gm.w, bt.w), 0.f));
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  mlp2_mfma(Xs, Ws, acc);
-  __syncthreads();
-  // output tile 64 x 128 through LDS (pitch 132, in the weight buffer) -> 16-byte row pieces
-  {
-    float* Os = Ws;
-    const int c0 = wc * 32 + li;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      Os[row * 132 + c0] = acc[r];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = tid + k * MT, r = i >> 5, c4 = (i & 31) * 4, gr = row0 + r;
-      if (gr >= j.rows) continue;
-      const float4 v = *reinterpret_cast<const float4*>(&Os[r * 132 + c4]);
-      const float4 bb = *reinterpret_cast<const float4*>(j.b2 + c4);
-      *reinterpret_cast<float4*>(j.Y + (long)gr * 128 + c4) = make_float4(v.x + bb.x, v.y + bb.y, v.z + bb.z, v.w + bb.w);
-    }
-  }
-}
-
-struct Mlp2Batch { Mlp2Job job[3]; int end[3]; int njobs; };
-__global__ __launch_bounds__(512) void k_mlp2_batch(Mlp2Batch mb) {
-  __shared__ __attribute__((aligned(16))) float Xs[GT * MP];
-  __shared__ __attribute__((aligned(16))) float Ws[128 * MP];
-  const int blk = blockIdx.x;
-  if (blk < mb.end[0]) mlp2_tile(mb.job[0], blk, Xs, Ws);
-  else if (blk < mb.end[1]) mlp2_tile(mb.job[1], blk - mb.end[0], Xs, Ws);
-  else mlp2_tile(mb.job[2], blk - mb.end[1], Xs, Ws);
-}
-
-int launch_mlp2_batch(const Mlp2Job* jobs, int njobs, hipStream_t st) {
-  if (njobs <= 0 || njobs > 3) return DD_ERR_BAD_ARG;
-  Mlp2Batch mb;
-  mb.njobs = njobs;
-  int total = 0;
-  for (int i = 0; i < 3; ++i) {
-    mb.job[i] = jobs[i < njobs ? i : 0];
-    if (i < njobs) total += (jobs[i].rows + GT - 1) / GT;
-    mb.end[i] = total;
-  }
-  if (total <= 0) return DD_OK;
-  hipLaunchKernelGGL(k_mlp2_batch, dim3(total), dim3(512), 0, st, mb);
-  DD_CHECK_LAUNCH();
-  return DD_OK;
-}
-
-
-// ------------------------------------------------------------------------------------------ 128 x 128 tile
-// Large jobs (>= 1024 rows, >= 128 columns): one workgroup = 128 rows x 128 columns, every wave a 64 x 64 quadrant
-// (four 32x32 accumulators: 8 MFMAs per 4 LDS operand reads).  K = 128 goes through one 34.8 KB LDS buffer in four
-// chunks of 32; the next chunk's global loads fly while the current one multiplies.  Four times the MFMA work of the
-// 64 x 64 tile per workgroup for about the same fixed cost (fetch latency, barriers, epilogue), same LDS class
-// (4 workgroups/CU).  LayerNorm prologue: a first pass over the rows leaves (mean, rstd) per row in LDS, the chunk
-// commits apply it.  Same k-ascending MFMA order per output element as the 64 x 64 tiles.
-constexpr int BT = 128, BK = 32, BP = 34;            // tile, K chunk, LDS pitch of a chunk row
-constexpr int BIG_LDS = 2 * BT * BP + 2 * BT;          // floats
-__device__ __forceinline__ void gemm_tile128(const GemmArgs& a, const int bx, const int by, float* smb /*>= BIG_LDS floats*/) {
-  float* Xc = smb;
-  float* Wc = smb + BT * BP;
-  float* stats = smb + 2 * BT * BP;                      // [128][2] mean, rstd (LayerNorm jobs)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row0 = bx * BT, col0 = by * BT;
-  const bool xplain = a.x_rows_per_b >= a.rows;
-  if (a.ln != nullptr) {
-    // rows (tid >> 5) + 8k, channels 4 * (tid & 31) .. +3: a row = one half wave
-    const int c4 = (tid & 31) * 4;
-    auto half_sum = [](float v) {
-      v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); v += dpp_mov<0x140>(v);
-      return swap16_sum(v, v);
-    };
-    float4 xv[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int gr = row0 + (tid >> 5) + 8 * k;
-      xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gr < a.rows) xv[k] = *reinterpret_cast<const float4*>(a.X + row_offset(gr, a.x_rows_per_b, a.x_stride_b, a.ldx, xplain) + c4);
-    }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const float mean = half_sum((xv[k].x + xv[k].y) + (xv[k].z + xv[k].w)) * (1.0f / 128.0f);
-      const float dx = xv[k].x - mean, dy = xv[k].y - mean, dz = xv[k].z - mean, dw = xv[k].w - mean;
-      const float var = half_sum(fmaf(dx, dx, dy * dy) + fmaf(dz, dz, dw * dw)) * (1.0f / 128.0f);
-      if ((tid & 31) == 0) {
-        stats[2 * ((tid >> 5) + 8 * k)] = mean;
-        stats[2 * ((tid >> 5) + 8 * k) + 1] = dd_rsqrt(var + 1e-5f);
-      }
-    }
-    __syncthreads();
-  }
-  float4 xr[4], wr4[4];
-  auto fetch = [&](int ch) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = tid + k * 256;
-      const int r = i >> 3, c4 = ch * BK + (i & 7) * 4;
-      const int gr = row0 + r, gc = col0 + r;
-      xr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      wr4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gr < a.rows) xr[k] = *reinterpret_cast<const float4*>(a.X + row_offset(gr, a.x_rows_per_b, a.x_stride_b, a.ldx, xplain) + c4);
-      if (gc < a.ncols) wr4[k] = *reinterpret_cast<const float4*>(a.W + (long)gc * 128 + c4);
-    }
-  };
-  auto commit = [&](int ch) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = tid + k * 256;
-      const int r = i >> 3, cl = (i & 7) * 4;
-      float4 v = xr[k];
-      if (a.ln != nullptr) {
-        const float2 st = *reinterpret_cast<const float2*>(stats + 2 * r);
-        const float4 g = *reinterpret_cast<const float4*>(a.ln + ch * BK + cl);
-        const float4 b = *reinterpret_cast<const float4*>(a.ln + 128 + ch * BK + cl);
-        v.x = fmaxf(fmaf((v.x - st.x) * st.y, g.x, b.x), 0.f);
-        v.y = fmaxf(fmaf((v.y - st.x) * st.y, g.y, b.y), 0.f);
-        v.z = fmaxf(fmaf((v.z - st.x) * st.y, g.z, b.z), 0.f);
-        v.w = fmaxf(fmaf((v.w - st.x) * st.y, g.w, b.w), 0.f);
-      }
-      float2* d = reinterpret_cast<float2*>(&Xc[r * BP + cl]);
-      d[0] = make_float2(v.x, v.y);
-      d[1] = make_float2(v.z, v.w);
-      float2* e = reinterpret_cast<float2*>(&Wc[r * BP + cl]);
-      e[0] = make_float2(wr4[k].x, wr4[k].y);
-      e[1] = make_float2(wr4[k].z, wr4[k].w);
-    }
-  };
-  const int wrow = wave >> 1, wcol = wave & 1, li = lane & 31, hh = lane >> 5;
-  const float* xa = &Xc[(wrow * 64 + li) * BP + 2 * hh];
-  const float* wb = &Wc[(wcol * 64 + li) * BP + 2 * hh];
-  f32x16 acc[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
-  fetch(0);
-#pragma unroll 1
-  for (int ch = 0; ch < 128 / BK; ++ch) {
-    if (ch > 0) __syncthreads();                         // previous chunk consumed
-    commit(ch);
-    __syncthreads();
-    if (ch + 1 < 128 / BK) fetch(ch + 1);
-#pragma unroll
-    for (int kk = 0; kk < BK / 4; ++kk) {
-      const float2 a0 = *reinterpret_cast<const float2*>(xa + 4 * kk);
-      const float2 a1 = *reinterpret_cast<const float2*>(xa + 32 * BP + 4 * kk);
-      const float2 b0 = *reinterpret_cast<const float2*>(wb + 4 * kk);
-      const float2 b1 = *reinterpret_cast<const float2*>(wb + 32 * BP + 4 * kk);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, acc[1], 0, 0, 0);
-      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc[2], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc[3], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b1.y, acc[1], 0, 0, 0);
-      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, acc[2], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc[3], 0, 0, 0);
-    }
-  }
-  // ---- epilogue: two passes of 64 rows x 128 columns through the chunk buffers (pitch 132), 16-byte row pieces out
-  const bool yplain = a.y_rows_per_b >= a.rows;
-  const bool vec_ok = ((a.ldy & 3) == 0) && ((a.y_stride_b & 3) == 0) && ((reinterpret_cast<size_t>(a.Y) & 15) == 0);
-  float* Os = smb;                                       // 64 x 132 = 8448 floats <= 2 * 128 * 34
-#pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-    __syncthreads();
-    if (wrow == pass) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int rb = (q >> 1) * 32, cb = wcol * 64 + (q & 1) * 32;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Os[(rb + (r & 3) + 8 * (r >> 2) + 4 * hh) * 132 + cb + li] = acc[q][r];
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int i = tid + k * 256;
-      const int r = i >> 5, c4 = (i & 31) * 4;
-      const int gr = row0 + pass * 64 + r, gc = col0 + c4;
-      if (gr >= a.rows || gc >= a.ncols) continue;
-      const float4 v = *reinterpret_cast<const float4*>(&Os[r * 132 + c4]);
-      float o[4] = {v.x, v.y, v.z, v.w};
-      float* dst = a.Y + row_offset(gr, a.y_rows_per_b, a.y_stride_b, a.ldy, yplain) + gc;
-      if (vec_ok && gc + 3 < a.ncols) {
-        if (a.bias) { const float4 bb = *reinterpret_cast<const float4*>(a.bias + gc); o[0] += bb.x; o[1] += bb.y; o[2] += bb.z; o[3] += bb.w; }
-        if (a.accumulate) { const float4 old = *reinterpret_cast<const float4*>(dst); o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w; }
-        *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (gc + e < a.ncols) {
-            float x = o[e] + (a.bias ? a.bias[gc + e] : 0.f);
-            if (a.accumulate) x += dst[e];
-            dst[e] = x;
-          }
-      }
-    }
-  }
-}
-
 __global__ __launch_bounds__(256) void k_gemm128(GemmArgs a) { gemm_tile(a, blockIdx.x, blockIdx.y); }
 __global__ __launch_bounds__(256) void k_gemm128_ks(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float sm[2 * GT * GPH];
@@ -656,19 +335,9 @@ __global__ __launch_bounds__(256) void k_gemm128_batch(GemmBatch gb) {
   const GemmArgs a = gb.job[j];
   gemm_job<KS>(a, lb, gb.nbx[j], gb.big[j], sm);
 }
-__global__ __launch_bounds__(256) void k_gemm128_big(GemmArgs a) {
-  __shared__ __attribute__((aligned(16))) float sm[BIG_LDS];
-  gemm_tile128(a, blockIdx.x, blockIdx.y, sm);
-}
 
 long long* g_gemm_dbg = nullptr;
 int g_gemm_ksplit = 1;   // dd_debug_set_option(1, v): K-split tiles for jobs without a LayerNorm prologue
-
-int g_gemm_big = 0;      // dd_debug_set_option(10, v): 128 x 128 tiles for the large jobs (measured slower at these sizes:
-                         // too few workgroups, 4 serial K chunks per workgroup; 6960x640: 27.8 vs 22.0 us)
-static bool use_big_tile(const GemmArgs& a) {
-  return g_gemm_big && g_gemm_ksplit && a.rows >= 1024 && a.ncols >= 128 && a.X2 == nullptr && a.dbg == nullptr;
-}
 
 int g_gemm_xcd = 1;      // dd_debug_set_option(21, v): XCD-aware tile order in the batched projection launches
 
@@ -705,11 +374,6 @@ int launch_gemm128_batch(const GemmArgs* jobs, int njobs, hipStream_t st) {
 
 int launch_gemm128(const GemmArgs& a, hipStream_t st) {
   if (a.rows <= 0 || a.ncols <= 0) return DD_OK;
-  if (use_big_tile(a)) {
-    hipLaunchKernelGGL(k_gemm128_big, dim3((a.rows + BT - 1) / BT, (a.ncols + BT - 1) / BT), dim3(256), 0, st, a);
-    DD_CHECK_LAUNCH();
-    return DD_OK;
-  }
   dim3 grid((a.rows + GT - 1) / GT, (a.ncols + GT - 1) / GT);
   if (!g_gemm_ksplit) hipLaunchKernelGGL(k_gemm128, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(k_gemm128_ks, grid, dim3(256), 0, st, a);

@@ -2,7 +2,7 @@
 //   k_knn            torch_cluster.knn via torch_geometric.nn.knn_graph (uni_transformer_edge.py:353)
 //   k_edge_weights   e_w = sigmoid(MLP_{20->128->1}(G(dist)))           (uni_transformer_edge.py:422-427)
 //   k_embed_*        atom / bond embeddings + context composition        (decompdiff.py:219-256,279,296-297)
-//   k_bl_assemble    per-bond-edge partial sums of the bond_layer first Linear (packing.py docstring)
+//   k_bl_assemble3   per-bond-edge partial sums of the bond_layer first Linear (packing.py docstring)
 // One wavefront (64 lanes) per centre / edge row; feature rows are 128 floats = 2 per lane,
 // so every gather is a single coalesced 512-byte row read.
 #include "dd_kernels.hpp"
@@ -87,48 +87,7 @@ __global__ __launch_bounds__(256) void k_knn(const float* __restrict__ x, int B,
 }
 
 // ------------------------------------------------------------------------------ edge weights
-__global__ __launch_bounds__(256) void k_edge_weights(const float* __restrict__ x, const int32_t* __restrict__ nbr, int B,
-                                                      int N, int K, const float* __restrict__ W1T,
-                                                      const float* __restrict__ b1, const float* __restrict__ ln,
-                                                      const float* __restrict__ w2, const float* __restrict__ b2,
-                                                      float* __restrict__ ew) {
-  const int lane = threadIdx.x & 63;
-  const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (node >= B * N) return;
-  const int b = node / N, i = node % N;
-  const float* xb = x + (long)b * N * 3;
-  const float cx = xb[3 * i], cy = xb[3 * i + 1], cz = xb[3 * i + 2];
-  float w1a[DD_NGAUSS], w1b[DD_NGAUSS];
-#pragma unroll
-  for (int g = 0; g < DD_NGAUSS; ++g) {
-    float2 t = *reinterpret_cast<const float2*>(W1T + g * 128 + 2 * lane);
-    w1a[g] = t.x; w1b[g] = t.y;
-  }
-  const float2 bb = *reinterpret_cast<const float2*>(b1 + 2 * lane);
-  const float2 gm = *reinterpret_cast<const float2*>(ln + 2 * lane);
-  const float2 bt = *reinterpret_cast<const float2*>(ln + 128 + 2 * lane);
-  const float2 ww = *reinterpret_cast<const float2*>(w2 + 2 * lane);
-  const float bias2 = b2[0];
-  for (int s = 0; s < K; ++s) {
-    int j = nbr[(long)node * K + s];
-    float dx = cx - xb[3 * j], dy = cy - xb[3 * j + 1], dz = cz - xb[3 * j + 2];
-    float d = sqrtf(dx * dx + dy * dy + dz * dz);
-    float gl = gauss_feat(d, lane < DD_NGAUSS ? lane : 0);
-    float p0 = bb.x, p1 = bb.y;
-#pragma unroll
-    for (int g = 0; g < DD_NGAUSS; ++g) {
-      float gg = lane_bcast(gl, g);
-      p0 = fmaf(w1a[g], gg, p0);
-      p1 = fmaf(w1b[g], gg, p1);
-    }
-    ln_relu2(p0, p1, gm.x, gm.y, bt.x, bt.y);
-    float logit = wave_sum(p0 * ww.x + p1 * ww.y) + bias2;
-    if (lane == 0) ew[(long)node * K + s] = 1.0f / (1.0f + expf(-logit));
-  }
-}
-
-
-// Matrix-core variant (default): one wave per node, 16 neighbours per tile in the attention kernels' k-pass layout
+// One wave per node, 16 neighbours per tile in the attention kernels' k-pass layout
 // (lane = (member mm, channel group cg), 32 hidden channels per lane).  hidden = b1 + W1 . G(d) is 5 k-steps of
 // v_mfma_f32_16x16x4_f32 with the weights as A operands held in 40 registers; LayerNorm + ReLU and the 128 -> 1
 // output layer reduce over the 4 lanes of a member with permlane swaps.
@@ -213,45 +172,6 @@ __global__ void k_embed_protein(const float* __restrict__ feat, int rows, const 
   out[idx] = acc + b[c];
 }
 
-// Per step: h = [protein_h ; ligand_emb(onehot(v) ++ aux)], x = [protein_pos ; lig_pos]
-__global__ void k_embed_nodes(const float* __restrict__ protein_h, const float* __restrict__ protein_pos,
-                              const float* __restrict__ lig_pos, const int32_t* __restrict__ lig_v,
-                              const float* __restrict__ lig_aux, const float* __restrict__ Wl /*[128,10]*/,
-                              const float* __restrict__ bl, int B, int NP, int NL, float* __restrict__ h,
-                              float* __restrict__ xa, float* __restrict__ xb) {
-  const int N = NP + NL;
-  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)B * N * 128) return;
-  int c = idx & 127;
-  long node = idx >> 7;
-  int b = node / N, n = node % N;
-  float val;
-  if (n < NP) {
-    val = protein_h[((long)b * NP + n) * 128 + c];
-  } else {
-    int l = n - NP;
-    long a = (long)b * NL + l;
-    const float* w = Wl + c * 10;
-    val = w[lig_v[a]] + w[8] * lig_aux[2 * a] + w[9] * lig_aux[2 * a + 1] + bl[c];
-  }
-  h[idx] = val;
-  if (c < 3) {
-    float p = n < NP ? protein_pos[((long)b * NP + n) * 3 + c] : lig_pos[((long)b * NL + (n - NP)) * 3 + c];
-    xa[node * 3 + c] = p;
-    xb[node * 3 + c] = p;
-  }
-}
-
-__global__ void k_embed_bonds(const int32_t* __restrict__ bond, long rows, const float* __restrict__ Wb /*[128,5]*/,
-                              const float* __restrict__ bb, float* __restrict__ hb) {
-  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= rows * 128) return;
-  int c = idx & 127;
-  long e = idx >> 7;
-  hb[idx] = Wb[c * 5 + bond[e]] + bb[c];
-}
-
-
 // One launch at the head of a step: node embedding / context, bond embedding, and the per-forward work counters
 // of the persistent kernels (64 ints) set to zero.
 __global__ __launch_bounds__(256) void k_embed_all(const float* __restrict__ protein_h, const float* __restrict__ protein_pos,
@@ -304,138 +224,7 @@ __global__ __launch_bounds__(256) void k_embed_all(const float* __restrict__ pro
 //   q1[e] = PB.q_hb[e] + PL[t].q_hi
 // PB row layout [640]: NB ke | NB ve | BL k_hb | BL v_hb | BL q_hb;  PL row layout [1280]: see packing.py.
 //   Rk[e] = Wg2k . G(d_e),  Rv[e] = Wg2v . G(d_e)   (the G(d_ji) columns, constant over a triplet segment)
-__global__ __launch_bounds__(256) void k_bl_assemble(const float* __restrict__ x, const float* __restrict__ PB,
-                                                     const float* __restrict__ PL, const float* __restrict__ Wg1k,
-                                                     const float* __restrict__ Wg1v, const float* __restrict__ Wg2k,
-                                                     const float* __restrict__ Wg2v, int B, int NP, int NL,
-                                                     float* __restrict__ Ek, float* __restrict__ Ev,
-                                                     float* __restrict__ q1, float* __restrict__ Rk,
-                                                     float* __restrict__ Rv) {
-  const int lane = threadIdx.x & 63;
-  const long e_glob = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int Eb = NL * (NL - 1), N = NP + NL;
-  if (e_glob >= (long)B * Eb) return;
-  const int b = e_glob / Eb, e = e_glob % Eb;
-  const int t = e / (NL - 1), sp = e % (NL - 1);
-  const int s = sp + (sp >= t ? 1 : 0);
-  const float* xl = x + ((long)b * N + NP) * 3;
-  float dx = xl[3 * t] - xl[3 * s], dy = xl[3 * t + 1] - xl[3 * s + 1], dz = xl[3 * t + 2] - xl[3 * s + 2];
-  float d = sqrtf(dx * dx + dy * dy + dz * dz);
-  float gl = gauss_feat(d, lane < DD_NGAUSS ? lane : 0);
-  const float* pb = PB + e_glob * 640 + 2 * lane;
-  const float* ps = PL + ((long)b * NL + s) * 1280 + 2 * lane;
-  const float* pt = PL + ((long)b * NL + t) * 1280 + 2 * lane;
-  float2 k = *reinterpret_cast<const float2*>(pb + 256);
-  float2 v = *reinterpret_cast<const float2*>(pb + 384);
-  float2 q = *reinterpret_cast<const float2*>(pb + 512);
-  float2 rk = make_float2(0.f, 0.f), rv = make_float2(0.f, 0.f);
-#pragma unroll
-  for (int g = 0; g < DD_NGAUSS; ++g) {
-    float gg = lane_bcast(gl, g);
-    float2 wk = *reinterpret_cast<const float2*>(Wg1k + g * 128 + 2 * lane);
-    float2 wv = *reinterpret_cast<const float2*>(Wg1v + g * 128 + 2 * lane);
-    k.x = fmaf(wk.x, gg, k.x); k.y = fmaf(wk.y, gg, k.y);
-    v.x = fmaf(wv.x, gg, v.x); v.y = fmaf(wv.y, gg, v.y);
-    float2 uk = *reinterpret_cast<const float2*>(Wg2k + g * 128 + 2 * lane);
-    float2 uv = *reinterpret_cast<const float2*>(Wg2v + g * 128 + 2 * lane);
-    rk.x = fmaf(uk.x, gg, rk.x); rk.y = fmaf(uk.y, gg, rk.y);
-    rv.x = fmaf(uv.x, gg, rv.x); rv.y = fmaf(uv.y, gg, rv.y);
-  }
-  float2 a;
-  a = *reinterpret_cast<const float2*>(ps + 640);  k.x += a.x; k.y += a.y;
-  a = *reinterpret_cast<const float2*>(pt + 768);  k.x += a.x; k.y += a.y;
-  a = *reinterpret_cast<const float2*>(ps + 896);  v.x += a.x; v.y += a.y;
-  a = *reinterpret_cast<const float2*>(pt + 1024); v.x += a.x; v.y += a.y;
-  a = *reinterpret_cast<const float2*>(pt + 1152); q.x += a.x; q.y += a.y;
-  *reinterpret_cast<float2*>(Ek + e_glob * 128 + 2 * lane) = k;
-  *reinterpret_cast<float2*>(Ev + e_glob * 128 + 2 * lane) = v;
-  if (q1) *reinterpret_cast<float2*>(q1 + e_glob * 128 + 2 * lane) = q;
-  *reinterpret_cast<float2*>(Rk + e_glob * 128 + 2 * lane) = rk;
-  *reinterpret_cast<float2*>(Rv + e_glob * 128 + 2 * lane) = rv;
-}
-
-
-// Persistent variant used by the sampler: the four 20x128 Gaussian weight tables live in LDS (40 KB), every wave
-// walks over bonds with two bonds in flight (all row gathers of a pair are requested before either is consumed).
-struct BondRows { float2 k, v, q, sk, tk, sv, tv, tq; float d; };
-__global__ __launch_bounds__(256) void k_bl_assemble2(const float* __restrict__ x, const float* __restrict__ PB,
-                                                      const float* __restrict__ PL, const float* __restrict__ Wg1k,
-                                                      const float* __restrict__ Wg1v, const float* __restrict__ Wg2k,
-                                                      const float* __restrict__ Wg2v, int B, int NP, int NL,
-                                                      float* __restrict__ Ek, float* __restrict__ Ev,
-                                                      float* __restrict__ q1, float* __restrict__ Rk,
-                                                      float* __restrict__ Rv) {
-  __shared__ __attribute__((aligned(16))) float tab[4 * DD_NGAUSS * 128];
-  {
-    const float* src[4] = {Wg1k, Wg1v, Wg2k, Wg2v};
-    float4 tmp[10];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-      const int idx = threadIdx.x + i * 256;               // 4 tables x 640 float4
-      tmp[i] = reinterpret_cast<const float4*>(src[idx / 640])[idx % 640];
-    }
-#pragma unroll
-    for (int i = 0; i < 10; ++i) reinterpret_cast<float4*>(tab)[threadIdx.x + i * 256] = tmp[i];
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const int Eb = NL * (NL - 1), N = NP + NL;
-  const long nrows = (long)B * Eb;
-  const long nwaves = (long)gridDim.x * 4;
-  auto fetch = [&](long e_glob, BondRows& r) {
-    const int b = e_glob / Eb, e = e_glob % Eb;
-    const int t = e / (NL - 1), sp = e % (NL - 1);
-    const int s = sp + (sp >= t ? 1 : 0);
-    const float* xl = x + ((long)b * N + NP) * 3;
-    const float dx = xl[3 * t] - xl[3 * s], dy = xl[3 * t + 1] - xl[3 * s + 1], dz = xl[3 * t + 2] - xl[3 * s + 2];
-    r.d = sqrtf(dx * dx + dy * dy + dz * dz);
-    const float* pb = PB + e_glob * 640 + 2 * lane;
-    const float* ps = PL + ((long)b * NL + s) * 1280 + 2 * lane;
-    const float* pt = PL + ((long)b * NL + t) * 1280 + 2 * lane;
-    r.k = *reinterpret_cast<const float2*>(pb + 256);
-    r.v = *reinterpret_cast<const float2*>(pb + 384);
-    r.q = q1 ? *reinterpret_cast<const float2*>(pb + 512) : make_float2(0.f, 0.f);
-    r.sk = *reinterpret_cast<const float2*>(ps + 640);
-    r.tk = *reinterpret_cast<const float2*>(pt + 768);
-    r.sv = *reinterpret_cast<const float2*>(ps + 896);
-    r.tv = *reinterpret_cast<const float2*>(pt + 1024);
-    r.tq = q1 ? *reinterpret_cast<const float2*>(pt + 1152) : make_float2(0.f, 0.f);
-  };
-  auto finish = [&](long e_glob, const BondRows& r) {
-    const float gl = gauss_feat(r.d, lane < DD_NGAUSS ? lane : 0);
-    float2 k = r.k, v = r.v, rk = make_float2(0.f, 0.f), rv = make_float2(0.f, 0.f);
-#pragma unroll
-    for (int g = 0; g < DD_NGAUSS; ++g) {
-      const float gg = lane_bcast(gl, g);
-      const float2 wk = *reinterpret_cast<const float2*>(tab + (0 * DD_NGAUSS + g) * 128 + 2 * lane);
-      const float2 wv = *reinterpret_cast<const float2*>(tab + (1 * DD_NGAUSS + g) * 128 + 2 * lane);
-      const float2 uk = *reinterpret_cast<const float2*>(tab + (2 * DD_NGAUSS + g) * 128 + 2 * lane);
-      const float2 uv = *reinterpret_cast<const float2*>(tab + (3 * DD_NGAUSS + g) * 128 + 2 * lane);
-      k.x = fmaf(wk.x, gg, k.x); k.y = fmaf(wk.y, gg, k.y);
-      v.x = fmaf(wv.x, gg, v.x); v.y = fmaf(wv.y, gg, v.y);
-      rk.x = fmaf(uk.x, gg, rk.x); rk.y = fmaf(uk.y, gg, rk.y);
-      rv.x = fmaf(uv.x, gg, rv.x); rv.y = fmaf(uv.y, gg, rv.y);
-    }
-    k.x += r.sk.x; k.y += r.sk.y; k.x += r.tk.x; k.y += r.tk.y;      // same order as k_bl_assemble
-    v.x += r.sv.x; v.y += r.sv.y; v.x += r.tv.x; v.y += r.tv.y;
-    const float2 q = make_float2(r.q.x + r.tq.x, r.q.y + r.tq.y);
-    *reinterpret_cast<float2*>(Ek + e_glob * 128 + 2 * lane) = k;
-    *reinterpret_cast<float2*>(Ev + e_glob * 128 + 2 * lane) = v;
-    if (q1) *reinterpret_cast<float2*>(q1 + e_glob * 128 + 2 * lane) = q;
-    *reinterpret_cast<float2*>(Rk + e_glob * 128 + 2 * lane) = rk;
-    *reinterpret_cast<float2*>(Rv + e_glob * 128 + 2 * lane) = rv;
-  };
-  for (long e0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6); e0 < nrows; e0 += 2 * nwaves) {
-    const long e1 = e0 + nwaves;
-    BondRows r0, r1;
-    fetch(e0, r0);
-    if (e1 < nrows) fetch(e1, r1);
-    finish(e0, r0);
-    if (e1 < nrows) finish(e1, r1);
-  }
-}
-
-// Matrix-core variant (default): 16 bonds per wave tile, lane = (bond mm, channel group cg), 32 channels per lane as in
+// 16 bonds per wave tile, lane = (bond mm, channel group cg), 32 channels per lane as in
 // the attention kernel's k-pass layout.  The four Gaussian contractions  out^T[c][bond] += sum_g W[g][c] G[bond][g]
 // (20 Gaussians = 5 k-steps of v_mfma_f32_16x16x4_f32) take the tables as A operands from a channel-permuted LDS image
 // (packing.py BL_Wgp, 40 KB) and the per-lane Gaussians as B; the gathered projection rows enter as the accumulator.
@@ -583,24 +372,11 @@ int launch_knn(const float* x, int B, int N, int K, int32_t* nbr, hipStream_t st
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
-int g_ew_mfma = 1;           // dd_debug_set_option(15, v): matrix-core edge-weight kernel
-
 int launch_edge_weights(const float* x, const int32_t* nbr, int B, int N, int K, const float* W1T, const float* b1,
                         const float* ln, const float* w2, const float* b2, float* ew, hipStream_t st, int NP, const int32_t* np_real,
                         const int32_t* nl_real) {
   if (NP < 0) { NP = N; np_real = nl_real = nullptr; }
-  if (g_ew_mfma || nl_real) hipLaunchKernelGGL(k_edge_weights2, dim3((B * N + 3) / 4), dim3(256), 0, st, x, nbr, B, N, K, W1T, b1, ln, w2, b2, ew,
-                                               NP, np_real, nl_real);
-  else hipLaunchKernelGGL(k_edge_weights, dim3((B * N + 3) / 4), dim3(256), 0, st, x, nbr, B, N, K, W1T, b1, ln, w2, b2, ew);
-  DD_CHECK_LAUNCH();
-  return DD_OK;
-}
-int launch_embed_nodes(const float* protein_h, const float* protein_pos, const float* lig_pos, const int32_t* lig_v,
-                       const float* lig_aux, const float* Wl, const float* bl, int B, int NP, int NL, float* h,
-                       float* xa, float* xb, hipStream_t st) {
-  long n = (long)B * (NP + NL) * 128;
-  hipLaunchKernelGGL(k_embed_nodes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, protein_h, protein_pos, lig_pos,
-                     lig_v, lig_aux, Wl, bl, B, NP, NL, h, xa, xb);
+  hipLaunchKernelGGL(k_edge_weights2, dim3((B * N + 3) / 4), dim3(256), 0, st, x, nbr, B, N, K, W1T, b1, ln, w2, b2, ew, NP, np_real, nl_real);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
@@ -615,33 +391,15 @@ int launch_embed_all(const float* protein_h, const float* protein_pos, const flo
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
-int launch_embed_bonds(const int32_t* bond, long rows, const float* Wb, const float* bb, float* hb, hipStream_t st) {
-  long n = rows * 128;
-  hipLaunchKernelGGL(k_embed_bonds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bond, rows, Wb, bb, hb);
-  DD_CHECK_LAUNCH();
-  return DD_OK;
-}
-int g_assemble_persist = 2;   // dd_debug_set_option(4, v): 2 = matrix-core kernel, 1 = persistent VALU kernel, 0 = wave per bond
-
-int launch_bl_assemble(const float* x, const float* PB, const float* PL, const float* Wg1k, const float* Wg1v,
-                       const float* Wg2k, const float* Wg2v, const float* Wgp, int B, int NP, int NL, float* Ek, float* Ev,
+int launch_bl_assemble(const float* x, const float* PB, const float* PL, const float* Wgp, int B, int NP, int NL, float* Ek, float* Ev,
                        float* q1, float* Rk, float* Rv, hipStream_t st, const float* xprev, const float* dxe, const float* dxb,
                        float* xout) {
-  long rows = (long)B * NL * (NL - 1);
-  if (xprev != nullptr && !(g_assemble_persist == 2 && Wgp != nullptr)) return DD_ERR_BAD_ARG;   // only the MFMA kernel defers
-  if (g_assemble_persist == 2 && Wgp != nullptr) {
-    const long tiles = (rows + 15) / 16;
-    const int bpo = (int)((tiles + 3) / 4);                            // blocks per output (4 tiles each)
-    hipLaunchKernelGGL(k_bl_assemble3, dim3((unsigned)(bpo * (q1 ? 5 : 4))), dim3(256), 0, st, x, PB, PL, Wgp, B, NP, NL, Ek, Ev, q1,
-                       Rk, Rv, bpo, xprev, dxe, dxb, xout);
-  } else if (g_assemble_persist) {
-    const long want = (rows + 7) / 8;                      // >= 2 bonds per wave
-    hipLaunchKernelGGL(k_bl_assemble2, dim3((unsigned)(want < 512 ? (want > 0 ? want : 1) : 512)), dim3(256), 0, st, x, PB, PL, Wg1k,
-                       Wg1v, Wg2k, Wg2v, B, NP, NL, Ek, Ev, q1, Rk, Rv);
-  } else {
-    hipLaunchKernelGGL(k_bl_assemble, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, PB, PL, Wg1k, Wg1v, Wg2k, Wg2v,
-                       B, NP, NL, Ek, Ev, q1, Rk, Rv);
-  }
+  if (Wgp == nullptr) return DD_ERR_BAD_ARG;
+  const long rows = (long)B * NL * (NL - 1);
+  const long tiles = (rows + 15) / 16;
+  const int bpo = (int)((tiles + 3) / 4);                            // blocks per output (4 tiles each)
+  hipLaunchKernelGGL(k_bl_assemble3, dim3((unsigned)(bpo * (q1 ? 5 : 4))), dim3(256), 0, st, x, PB, PL, Wgp, B, NP, NL, Ek, Ev, q1,
+                     Rk, Rv, bpo, xprev, dxe, dxb, xout);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }

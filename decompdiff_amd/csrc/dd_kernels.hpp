@@ -22,14 +22,6 @@ inline GemmArgs gemm_args(const float* X, int x_rows_per_b, long x_stride_b, int
              nullptr, 0, 0, 0, 0, 0, nullptr};
   return g;
 }
-// fused query MLP (dd_gemm.hip): Y = W2 . relu(LN(W1a . X1[r] (+ W1b . X2[dst atom of bond r]) + b1)) + b2
-struct Mlp2Job {
-  const float* X1; int x_rows_per_b; long x_stride_b; int ldx; int rows;
-  const float* X2; int x2_Eb, x2_N, x2_NP, x2_NLm1;    // optional second input: h row of the destination atom of bond r
-  const float *W1a, *W1b, *b1, *ln, *W2, *b2;
-  float* Y;                                            // [rows, 128]
-};
-int launch_mlp2_batch(const Mlp2Job* jobs, int njobs, hipStream_t st);
 int launch_gemm128(const GemmArgs& a, hipStream_t st);
 // up to 4 independent projections in one launch (small ones ride along with the big ones)
 int launch_gemm128_batch(const GemmArgs* jobs, int njobs, hipStream_t st);
@@ -48,12 +40,7 @@ int launch_knn(const float* x, int B, int N, int K, int32_t* nbr, hipStream_t st
 int launch_edge_weights(const float* x, const int32_t* nbr, int B, int N, int K, const float* W1T, const float* b1,
                         const float* ln, const float* w2, const float* b2, float* ew, hipStream_t st, int NP = -1,
                         const int32_t* np_real = nullptr, const int32_t* nl_real = nullptr);
-int launch_embed_nodes(const float* protein_h, const float* protein_pos, const float* lig_pos, const int32_t* lig_v,
-                       const float* lig_aux, const float* Wl, const float* bl, int B, int NP, int NL, float* h,
-                       float* xa, float* xb, hipStream_t st);
-int launch_embed_bonds(const int32_t* bond, long rows, const float* Wb, const float* bb, float* hb, hipStream_t st);
-int launch_bl_assemble(const float* x, const float* PB, const float* PL, const float* Wg1k, const float* Wg1v,
-                       const float* Wg2k, const float* Wg2v, const float* Wgp, int B, int NP, int NL, float* Ek, float* Ev,
+int launch_bl_assemble(const float* x, const float* PB, const float* PL, const float* Wgp, int B, int NP, int NL, float* Ek, float* Ev,
                        float* q1, float* Rk, float* Rv, hipStream_t st, const float* xprev = nullptr, const float* dxe = nullptr,
                        const float* dxb = nullptr, float* xout = nullptr);
 int launch_extract_ligand(const float* x, int B, int NP, int NL, float* out, hipStream_t st);
@@ -68,13 +55,11 @@ struct AttnArgs {
   const float *kd, *ks, *vd, *vs, *ke, *ve;   // projection tables
   int ld_kd, ld_ks, ld_vd, ld_vs, ld_ke, ld_ve;
   const float* q;          // [segments,128]
-  const float *Ak, *Av;    // [4,21,128]
   const float *Akp, *Avp;  // [4,24,128] MFMA A-operand layout (tiled kernel)
   const float *Wakp, *Wavp; // [12,128] merged angle-code columns (BL, tiled kernel)
-  const float *Wg2k, *Wg2v, *Wak, *Wav;
   const float *lnk, *lnv;  // [2,128]
   const float* W2k;        // [128,128]
-  const float *W2vT, *b2v; // node modes
+  const float* b2v;        // node modes
   const float* W2v;        // node modes, tiled kernel: [128 o][128 c]
   // coordinate modes, optional: second layer of the query MLP evaluated in the kernel (q is then ignored)
   const float *qhid, *lnq, *W2q, *b2q; int ld_qhid;   // hidden pre-activation rows [B*NL, ld_qhid], LN [2,128], W2q^T [128 k,128 o], [128]
@@ -89,8 +74,7 @@ struct AttnArgs {
   // padded heterogeneous batches (dd_sampler.np_real / nl_real / bl_prefix), all NULL for dense batches
   const int32_t *np_real, *nl_real, *bl_prefix;
 };
-int launch_attn(int mode, const AttnArgs& a, hipStream_t st);    // v1: one member at a time, VALU only
-int launch_attn2(int mode, const AttnArgs& a, hipStream_t st);   // v2: 16-member tiles, scores/aggregation on MFMA
+int launch_attn2(int mode, const AttnArgs& a, hipStream_t st);   // one sub-layer: 16-member tiles, scores/aggregation on MFMA
 int launch_attn2_node(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs& bl, hipStream_t st);   // NE+NB+BL, one launch
 int launch_attn2_pos(const AttnArgs& pe, const AttnArgs& pb, hipStream_t st);                        // PE+PB, one launch
 int launch_xupdate(const float* x, const float* dxe, const float* dxb, int B, int NP, int NL, float* x_next, hipStream_t st);

@@ -247,9 +247,8 @@ int dd_profile_step(const dd_sampler* s, int n_iters, float* ms_per_category /*H
 /* Profiling aid: per-workgroup s_memtime phase stamps of one attention kernel class (see dd_api.hip). */
 int dd_debug_set_clock_buffer(long long* buf, int mode);
 /* Launch structure of the attention sub-layers: 1 (default) = fused multi-mode launches of the tiled kernels,
- * 0 = one launch per sub-layer (per-kernel timing), 2 = one launch per sub-layer with the v1 (one member at a
- * time, VALU-only) kernels, 3 = fused launches without the second-stream overlap of the coordinate sub-layers with the
- * next layer's projections (the default 1 has the overlap on).
+ * 0 = one launch per sub-layer (per-kernel timing; the cross-check variant), 3 = fused launches without the
+ * second-stream overlap of the coordinate sub-layers with the next layer's projections (the default 1 has the overlap on).
  * All variants produce the same results up to fp32 summation order. */
 int dd_debug_set_fusion(int mode);
 /* Measurement aid: runtime switches for A/B timing in one process (key 0: as dd_debug_set_fusion; key 1: K-split

@@ -421,20 +421,21 @@ def test_center_pos_mode_none_consistent():
 
 
 def test_launch_variants_agree():
-    """fused tiled kernels (default) == one launch per sub-layer == the v1 member-at-a-time kernels."""
+    """fused launches (default) == one launch per sub-layer (the cross-check variant) == fused without stream overlap."""
     g = GU.load("forward_small")
     b = GU.batch_from_npz(g)
     lib = hip_lib.load()
     outs = {}
     try:
-        for mode in (1, 0, 2, 3):
+        assert lib.dd_debug_set_fusion(2) != 0            # (the v1 member-at-a-time kernels are gone)
+        for mode in (1, 0, 3):
             lib.dd_debug_set_fusion(mode)
             o = _forward_hip(model(0), b)
             torch.cuda.synchronize()
             outs[mode] = {k: v.clone() for k, v in o.items()}
     finally:
         lib.dd_debug_set_fusion(1)
-    for mode in (0, 2, 3):
+    for mode in (0, 3):
         errs = {k: maxabs(outs[mode][k], outs[1][k]) for k in outs[1]}
         print(f"launch variant {mode} vs fused:", {k: f"{v:.3g}" for k, v in errs.items()})
         assert max(errs.values()) < 2e-5
@@ -446,10 +447,12 @@ def test_runtime_options_agree():
     g = GU.load("forward_small")
     b = GU.batch_from_npz(g)
     lib = hip_lib.load()
-    defaults = {1: 1, 3: 1, 4: 2, 5: 4, 6: 0, 7: 1, 8: 3, 9: 1, 10: 0, 11: 0, 12: 1, 14: 0, 15: 1, 16: 1, 17: 1, 18: 1, 19: 1, 20: 1, 21: 1}
+    defaults = {1: 1, 3: 1, 5: 4, 7: 1, 8: 3, 9: 1, 11: 0, 12: 1, 14: 0, 16: 1, 17: 1, 18: 1, 19: 1, 20: 1, 21: 1}
     ref = {k: v.clone() for k, v in _forward_hip(model(0), b).items()}
     try:
-        for key, val in ((1, 0), (3, 0), (4, 0), (4, 1), (5, 8), (5, 2), (6, 1), (8, 1), (8, 2), (8, 3), (9, 0), (10, 1), (11, 1), (12, 0), (14, 1), (15, 0), (16, 0), (17, 0), (18, 0), (18, 96), (19, 0), (8, 0), (21, 0)):
+        for key in (4, 6, 10, 15):                               # removed kernel variants: their keys are rejected
+            assert lib.dd_debug_set_option(key, 1) != 0
+        for key, val in ((1, 0), (3, 0), (5, 8), (5, 2), (8, 1), (8, 2), (8, 3), (9, 0), (11, 1), (12, 0), (14, 1), (16, 0), (17, 0), (18, 0), (18, 96), (19, 0), (8, 0), (21, 0)):
             assert lib.dd_debug_set_option(key, val) == 0
             o = _forward_hip(model(0), b)
             torch.cuda.synchronize()
