@@ -9,15 +9,16 @@ dev = torch.device("cuda:0")
 cfg = shipped_config()
 m = DecompScorePosNet3D(cfg, 29, 10, 8); sd = m.state_dict(); sd.update(synth.synthetic_state_dict(cfg, 0)); m.load_state_dict(sd); m = m.to(dev)
 pocket = synth.make_pocket_small(0); torch.manual_seed(0)
-b = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synth.build_sampling_batch(pocket, 8).items()}
+import os
+b = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synth.build_sampling_batch(pocket, int(os.environ.get("DD_B", "8"))).items()}
 lib = hip_lib.load()
 variants = [("baseline", [])] + [(a, [tuple(int(x) for x in kv.split("=")) for kv in a.split(",")]) for a in sys.argv[1:]]
-DEFAULTS = {0: 1, 1: 1, 2: 8, 3: 1, 4: 2, 5: 4, 6: 0, 7: 1, 8: 3, 9: 1, 10: 0, 11: 0, 12: 1, 14: 0, 15: 1, 16: 1, 17: 1, 18: 1, 19: 1, 20: 1, 21: 1}
+DEFAULTS = {0: 1, 1: 1, 2: 8, 3: 1, 5: 4, 7: 1, 8: 3, 9: 1, 11: 0, 12: 1, 14: 0, 16: 1, 17: 1, 18: 1, 19: 1, 20: 1, 21: 1}
 def run(settings, steps=200):
     for k, v in DEFAULTS.items(): lib.dd_debug_set_option(k, v)
     for k, v in settings: lib.dd_debug_set_option(k, v)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    m.sample_diffusion(num_steps=steps, center_pos_mode="protein", keep_traj=True, use_graph=True, **b)
+    m.sample_diffusion(num_steps=steps, center_pos_mode="protein", keep_traj=True, use_graph=True, seed=1, **b)
     torch.cuda.synchronize(); return 1e3 * (time.perf_counter() - t0) / steps
 for name, st in variants: run(st, 20)
 res = {name: [] for name, _ in variants}
