@@ -932,6 +932,7 @@ extern "C" int dd_profile_step(const dd_sampler* s, int n_iters, float* ms_per_c
     prof.n = 0;
     dd::g_prof = &prof;
     rc = one_step(s, st);
+    { dd::ProfScope empty_pair(DD_PROF_EVENT_PAIR, st); }
     dd::g_prof = nullptr;
     if (hipStreamSynchronize(st) != hipSuccess) return DD_ERR_HIP;
     for (int i = 0; i < prof.n; ++i) {

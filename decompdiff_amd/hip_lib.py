@@ -55,7 +55,7 @@ class DDWsView(ctypes.Structure):
                 ("nbr", c_void_p), ("Anb", c_void_p)]
 
 
-PROF_CATS = ["misc", "gemm", "assemble", "attn_NE", "attn_NB", "attn_BL", "attn_PE", "attn_PB", "step"]
+PROF_CATS = ["misc", "gemm", "assemble", "attn_NE", "attn_NB", "attn_BL", "attn_PE", "attn_PB", "step", "event_pair"]
 
 
 ABI_VERSION = 5          # include/decompdiff_hip.h: layout of struct dd_sampler and of the tables it points to

@@ -58,12 +58,18 @@ class Pocket:
         return int(sum(self.arm_num_atoms) + self.scaffold_num_atoms)
 
 
-def _sample_shell(rng, n, r_in, r_out, min_dist, max_tries=200000):
-    """Rejection-sample n points in a spherical shell with a minimum spacing."""
+def _sample_shell(rng, n, r_in, r_out, min_dist, max_tries=200000, restart_after=None):
+    """Rejection-sample n points in a spherical shell with a minimum spacing.  ``restart_after``: start over when that
+    many batches of candidates in a row placed nothing (a few widely spaced points -- the prior centres -- can paint
+    themselves into a corner; seeds that never got stuck draw exactly the same points as before)."""
     pts = np.zeros((0, 3), dtype=np.float64)
-    tries = 0
+    tries = stuck = 0
     while pts.shape[0] < n:
         tries += 1
+        stuck += 1
+        if restart_after is not None and stuck > restart_after:
+            pts = np.zeros((0, 3), dtype=np.float64)
+            stuck = 0
         if tries > max_tries:
             raise RuntimeError("pocket generator: could not place atoms; enlarge the ball")
         cand = rng.uniform(-r_out, r_out, size=(64, 3))
@@ -72,6 +78,7 @@ def _sample_shell(rng, n, r_in, r_out, min_dist, max_tries=200000):
         for c in cand:
             if pts.shape[0] == 0 or np.min(np.linalg.norm(pts - c, axis=1)) >= min_dist:
                 pts = np.vstack([pts, c[None]])
+                stuck = 0
                 if pts.shape[0] == n:
                     break
     return pts
@@ -98,7 +105,7 @@ def make_pocket(seed: int = 0, num_protein: int = 300, arm_atoms=(8, 8), scaffol
     feat[np.arange(num_protein), 27 + arm_ind.astype(np.int64)] = 1.0
 
     n_prior = len(arm_atoms) + 1
-    centers = _sample_shell(rng, n_prior, 0.0, 0.75 * r_in, 0.85 * r_in) + shift
+    centers = _sample_shell(rng, n_prior, 0.0, 0.75 * r_in, 0.85 * r_in, restart_after=200) + shift
     stds = np.full((n_prior, 3), prior_std, dtype=np.float32)
 
     n_extra = max(num_full_protein - num_protein, 0)

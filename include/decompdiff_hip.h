@@ -240,7 +240,9 @@ int dd_drift_clash(const float* lig_pos, const float* offset, const float* full_
  * (Synchronises `stream`; not for use inside a capture.) */
 typedef enum dd_prof_cat {
   DD_PROF_MISC, DD_PROF_GEMM, DD_PROF_ASSEMBLE, DD_PROF_ATTN_NE, DD_PROF_ATTN_NB, DD_PROF_ATTN_BL, DD_PROF_ATTN_PE,
-  DD_PROF_ATTN_PB, DD_PROF_STEP, DD_NUM_PROF_CATS
+  DD_PROF_ATTN_PB, DD_PROF_STEP,
+  DD_PROF_EVENT_PAIR,   /* one empty start/stop event pair per step: what the event bracket itself adds to every launch */
+  DD_NUM_PROF_CATS
 } dd_prof_cat;
 int dd_profile_step(const dd_sampler* s, int n_iters, float* ms_per_category /*HOST [DD_NUM_PROF_CATS]*/, void* stream);
 

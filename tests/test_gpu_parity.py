@@ -355,12 +355,15 @@ def test_trajectory_1000_steps_golden(name):
         assert err.max() < POS_TOL, f"coordinate drift {err.max():.3g}"
         assert maxabs(r["pos"], g["out_pos"]) < POS_TOL
     else:
-        # The unscaled drift gradients make the chain ~20-40x more sensitive to per-step rounding than the plain chain
-        # (oracle/sensitivity.py: a 2e-6 per-step perturbation of the ORACLE ends 2.5e-3 from the plain fixture and
-        # 9.6e-2 from this one): the HIP chain stays within 1e-4 for the first 450 steps and within 2e-3 to the end --
-        # ~130x closer than that perturbed reference -- with every discrete type identical throughout.
-        assert err[:9].max() < POS_TOL, f"coordinate drift {err[:9].max():.3g} in the first 450 steps"
-        assert err.max() < 2e-3, f"coordinate drift {err.max():.3g}"
+        # The unscaled drift gradients make the FREE-RUNNING chain 20-40x more sensitive to per-step rounding than the plain
+        # one (oracle/sensitivity.py: a 2e-6 per-step perturbation of the ORACLE ends 2.5e-3 from the plain fixture and
+        # 9.6e-2 from this one).  The bound that holds step for step is the re-synchronised one -- every 50-step segment
+        # restarted from the reference's own checkpoint ends within 1e-4 with identical types
+        # (tests/test_gpu_configs.py::test_chain_segments_from_reference_checkpoints: <= 1.3e-5 measured); the free-running
+        # chain stays within 1e-4 for 600 steps (9.7e-5 at 700) and ends at 4e-4 (correctly rounded rsqrt / softmax division --
+        # `python -m decompdiff_amd.build --exact` -- end at 4.7e-4: it is summation order, not the last bit of rsqrt).
+        assert err[:12].max() < POS_TOL, f"coordinate drift {err[:12].max():.3g} in the first 600 steps"
+        assert err.max() < 1e-3, f"coordinate drift {err.max():.3g}"
 
 
 def test_graph_replay_equals_eager_launches():

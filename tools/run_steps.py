@@ -2,7 +2,7 @@
 """Run N sampling steps of the shipped workload with optional dd_debug_set_option settings (profiling aid).
 usage: python tools/run_steps.py [steps] [key=value ...]"""
 import sys, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from decompdiff_amd import DecompScorePosNet3D, hip_lib, shipped_config, synth
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 dev = torch.device("cuda:0"); cfg = shipped_config()
