@@ -1,6 +1,7 @@
 // C ABI orchestration: workspace carving, the score-network forward (launch sequence of
 // models/decompdiff.py:213-351 + uni_transformer_edge.py:259-287,394-443) and the reverse loop
 // (decompdiff.py:575-689), eager or as a replayed hipGraph.
+#include <mutex>
 #include <thread>
 #include <vector>
 #include <stdlib.h>
@@ -60,7 +61,7 @@ static Workspace carve(float* base, int B, int NP, int NL, int K) {
 
 static int check_shapes(const dd_sampler* s) {
   if (!s || !s->weights || !s->slot_off || !s->workspace) return DD_ERR_BAD_ARG;
-  if (s->B <= 0 || s->NP < 0 || s->NL < 2 || s->K <= 0) return DD_ERR_BAD_ARG;
+  if (s->B <= 0 || s->NP < 0 || s->NL < 2 || s->K <= 0 || s->num_layers < 1 || s->num_layers > 64) return DD_ERR_BAD_ARG;
   const int N = s->NP + s->NL;
   if (s->NL > DD_NL_MAX || N > DD_N_MAX || s->K > DD_KNN_MAX || s->K > N - 1) return DD_ERR_UNSUPPORTED_SHAPE;
   if (s->workspace_floats < dd_workspace_floats(s->B, s->NP, s->NL, s->K)) return DD_ERR_WORKSPACE_TOO_SMALL;
@@ -105,8 +106,25 @@ struct ProfScope {
 // projection GEMMs); fork/join through events, which stream capture turns into graph edges
 extern int g_gemm_ksplit;                      // dd_gemm.hip
 static bool g_gemm_ksplit_on() { return g_gemm_ksplit != 0; }   // (the addend form above lives in the K-split tile)
-static hipStream_t g_side = nullptr, g_side2 = nullptr;   // g_side2: query MLPs of the node / bond sub-layers
-static hipEvent_t g_ev_qa_fork[8], g_ev_qa_join[8], g_ev_qb_fork[8];
+// Side stream and fork / join events, one set per device (a process may drive several devices; multi-GPU runs use one
+// process per GPU, where this is a single entry).  They only shape a graph while it is being captured, and captures are
+// serialised by g_capture_mutex, so one set per device is enough for any number of samplers.
+struct DevCtx {
+  hipStream_t side = nullptr;
+  hipEvent_t ev_qa_fork[8], ev_qb_fork[8], ev_fork[9], ev_join[9];
+};
+static DevCtx g_dev_ctx[16];
+static std::mutex g_capture_mutex;
+static DevCtx& dev_ctx() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+  return g_dev_ctx[dev];
+}
+#define g_side (dev_ctx().side)
+#define g_ev_qa_fork (dev_ctx().ev_qa_fork)
+#define g_ev_qb_fork (dev_ctx().ev_qb_fork)
+#define g_ev_fork (dev_ctx().ev_fork)
+#define g_ev_join (dev_ctx().ev_join)
 static int g_step_fused = 1;                   // dd_debug_set_option(7, v): rows + coordinates + counter in one launch
 static int g_step_fold = 1;                    // dd_debug_set_option(20, v): step boundary folded (counter advanced by the forward's
                                                // first launch; last x update + x0 extraction inside the step kernel)
@@ -125,7 +143,7 @@ static int g_lin_with_pb2 = 1;                 // dd_debug_set_option(16, v): bo
 static int g_pb_early = 1;                     // dd_debug_set_option(17, v): next layer's bond projections in the lin_node launch
 static int g_q1_in_gemm = 1;                   // dd_debug_set_option(12, v): bond-layer query hidden row summed inside the query GEMM
 static int g_q_in_pos = 1;                     // dd_debug_set_option(9, v): coordinate query MLPs' second layer inside attn_pos
-static hipEvent_t g_ev_fork[9], g_ev_join[9];   // [0..7] per layer, [8] graph construction at the head of a forward
+// (ev_fork / ev_join: [0..7] per layer, [8] graph construction at the head of a forward)
 // DD_SIDE_PRIO: 1 (default) lowest priority for the side stream, 0 default priority, 2 highest
 static int g_side_low_priority = [] { const char* e = getenv("DD_SIDE_PRIO"); return (e && e[0] == '0') ? 0 : ((e && e[0] == '2') ? 2 : 1); }();
 static int g_overlap = 1;                     // measured in-process A/B: -3.5 % step time
@@ -136,10 +154,8 @@ static int ensure_side_stream() {
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; (void)hipGetLastError(); }
     if (hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, g_side_low_priority == 1 ? lo : (g_side_low_priority == 2 ? hi : 0)) != hipSuccess) return DD_ERR_HIP;
   }
-  if (hipStreamCreateWithFlags(&g_side2, hipStreamNonBlocking) != hipSuccess) return DD_ERR_HIP;
   for (int i = 0; i < 8; ++i)
     if (hipEventCreateWithFlags(&g_ev_qa_fork[i], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&g_ev_qa_join[i], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&g_ev_qb_fork[i], hipEventDisableTiming) != hipSuccess)
       return DD_ERR_HIP;
   for (int i = 0; i < 9; ++i)
@@ -692,6 +708,9 @@ static int autotune_node_split(const dd_sampler* s, hipStream_t st) {
     n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   const bool fused = dd::g_fuse && s->NL <= dd::g_fused_max_nl && dd::g_dbg_clock == nullptr;
+  // DD_NODE_SPLIT_AUTOTUNE=0: no measurement passes (the node blocks then simply come first in the launch)
+  static const bool enabled = [] { const char* e = getenv("DD_NODE_SPLIT_AUTOTUNE"); return !(e && e[0] == '0'); }();
+  if (!enabled) return DD_OK;
   if (!fused || !dd::node_split_applies(s->B, s->NL, n_cu) || dd::node_split_lookup(s->B, s->NP, s->NL, s->K) >= 0) return DD_OK;
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return DD_ERR_HIP;
@@ -778,12 +797,14 @@ extern "C" int dd_sample_steps_graph(const dd_sampler* s, int n_steps, void* str
   if (st == nullptr) return DD_ERR_BAD_ARG;      // the legacy default stream cannot be captured
   rc = autotune_node_split(s, st);
   if (rc != DD_OK) return rc;
+  std::unique_lock<std::mutex> capture_lock(dd::g_capture_mutex);   // (the side stream / events of the device are shared)
   if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
     (void)hipGetLastError();                     // do not leave a sticky error behind for the caller
     return DD_ERR_HIP;
   }
   rc = one_step(s, st);
   hipError_t e = hipStreamEndCapture(st, &graph);
+  capture_lock.unlock();
   if (rc != DD_OK || e != hipSuccess || !graph) {
     if (graph) (void)hipGraphDestroy(graph);
     (void)hipGetLastError();
@@ -818,6 +839,7 @@ extern "C" int dd_graph_create(const dd_sampler* s, int steps_per_graph, void* s
   rc = autotune_node_split(s, st);
   if (rc != DD_OK) return rc;
   StepGraph* g = new StepGraph();
+  std::unique_lock<std::mutex> capture_lock(dd::g_capture_mutex);   // (the side stream / events of the device are shared)
   if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
     (void)hipGetLastError();
     delete g;
@@ -825,6 +847,7 @@ extern "C" int dd_graph_create(const dd_sampler* s, int steps_per_graph, void* s
   }
   for (int i = 0; i < steps_per_graph && rc == DD_OK; ++i) rc = one_step(s, st);
   hipError_t e = hipStreamEndCapture(st, &g->graph);
+  capture_lock.unlock();
   if (rc == DD_OK && (e != hipSuccess || !g->graph)) rc = DD_ERR_HIP;
   if (rc == DD_OK && hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0) != hipSuccess) rc = DD_ERR_HIP;
   if (rc != DD_OK) {
@@ -877,6 +900,7 @@ extern "C" int dd_sample_steps_graph_multi(const dd_sampler* const* ss, int n, i
     hipStream_t st = (hipStream_t)streams[i];
     rc = autotune_node_split(ss[i], st);
     if (rc != DD_OK) break;
+    std::lock_guard<std::mutex> capture_lock(dd::g_capture_mutex);
     if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { rc = DD_ERR_HIP; break; }
     int rs = one_step(ss[i], st);
     hipError_t e = hipStreamEndCapture(st, &graph[i]);
