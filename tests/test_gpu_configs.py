@@ -289,3 +289,31 @@ def test_padded_heterogeneous_batch_equals_size_groups(monkeypatch):
     _sample_hip(m, b2, 6, GU.DRIFT, None, seed=5)
     r3 = _sample_hip(m, b, 6, GU.DRIFT, None, seed=5)
     assert torch.isfinite(r1["pos"]).all() and torch.equal(r1["pos"], r3["pos"]) and torch.equal(r1["bond"], r3["bond"])
+
+
+def test_bench_json_line_contract():
+    """The driver's contract for bench.py: ONE JSON line from rank 0 with the metric of BASELINE.json, the whole-job value,
+    and the roofline / cpu_baseline objects."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--cpu-steps", "1",
+                        "--cpu-warmup", "1"], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["metric"] in base["metric"] and d["unit"] == "denoising steps/s"
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
+    assert "configs[1]" in d["config"]["workload"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.05 < r["frac"] < 1.0
+    assert r["traffic"] is None or r["traffic"] > 0
+    g = d["roofline_gemm"]
+    assert 0.0 < g["frac"] < 1.0
+    o = d["roofline_op_level"]
+    assert o["bound"] == "hbm" and o["unit"] == "GB/s" and 0.3 < o["frac"] < 1.0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "steps" in c["sample"]
