@@ -129,10 +129,13 @@ static int g_step_fused = 1;                   // dd_debug_set_option(7, v): row
 static int g_step_fold = 1;                    // dd_debug_set_option(20, v): step boundary folded (counter advanced by the forward's
                                                // first launch; last x update + x0 extraction inside the step kernel)
 static int g_xup_in_asm = 1;                   // dd_debug_set_option(19, v): x += dx applied by the next layer's assemble launch
-static int g_sched = 3;                        // dd_debug_set_option(8, v): 0 = coordinate sub-layers on the side stream,
+static int g_sched = 4;                        // dd_debug_set_option(8, v): 0 = coordinate sub-layers on the side stream,
                                                // 1 = next layer's projections ahead on the side stream, 2 = the same in two
-                                               // launches (bond part forked at the node attention), 3 (default, -3 % in the
-                                               // in-process A/B) = 2 + the next layer's query GEMMs on the side stream too
+                                               // launches (bond part forked at the node attention), 3 (-3 % in the
+                                               // in-process A/B) = 2 + the next layer's query GEMMs on the side stream too,
+                                               // 4 (default, another -2 %) = 3 with two joins: assemble waits for the
+                                               // projections only and runs beside the query GEMMs, which are joined at the
+                                               // node attention
 static int g_xup_in_pos = 0;                   // dd_debug_set_option(11, v): x update inside the coordinate launch (last workgroup);
                                                // measured 1 % slower than the separate 3-block launch, off
 static int g_fused_max_nl = 64;                // dd_debug_set_option(13, v): largest ligand handled by the fused launches
@@ -266,7 +269,8 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     };
     const bool ahead = overlap && g_sched >= 1;
     const bool ahead_split = overlap && g_sched >= 2;
-    const bool ahead_b2 = overlap && g_sched == 3 && g_q1_in_gemm && g_gemm_ksplit_on();
+    const bool ahead_b2 = overlap && g_sched >= 3 && g_q1_in_gemm && g_gemm_ksplit_on();
+    const bool two_joins = ahead_b2 && g_sched >= 4;     // g_ev_qb_fork[l]: layer l's projections done (side stream)
     const bool pb_early = g_pb_early && g_lin_with_pb2 && !ahead;   // next layer's bond projections ride with lin_node
     if (pb_early && l > 0) DD_TRYP(DD_PROF_GEMM, launch_batch1_part(l, 1, st));
     else if (!(ahead && l > 0)) DD_TRYP(DD_PROF_GEMM, launch_batch1(l, st));
@@ -300,7 +304,9 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
       if (hipStreamWaitEvent(st, g_ev_join[pending_join], 0) != hipSuccess) return DD_ERR_HIP;
       pending_join = -1;
     }
-    if (ahead && l > 0 && !b1_joined && hipStreamWaitEvent(st, g_ev_join[l], 0) != hipSuccess) return DD_ERR_HIP;   // projections of this layer
+    const bool late_join = two_joins && b2_ahead && !b1_joined;
+    if (ahead && l > 0 && !b1_joined && hipStreamWaitEvent(st, late_join ? g_ev_qb_fork[l] : g_ev_join[l], 0) != hipSuccess)
+      return DD_ERR_HIP;                                 // projections of this layer
     // (a deferred coordinate update of the previous layer is applied here: xcur's ligand rows are written by this launch)
     DD_TRYP(DD_PROF_ASSEMBLE, launch_bl_assemble(xcur, w.PB, w.PL, LW(l, DD_BL_Wgp), B, NP, NL, w.Ek, w.Ev,
                                                   q1_in_gemm ? nullptr : w.q1bl, w.Rk, w.Rv, st, xup_prev, w.dxe, w.dxb,
@@ -311,6 +317,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
       if (hipStreamWaitEvent(st, g_ev_join[8], 0) != hipSuccess) return DD_ERR_HIP;
       head_join = false;
     }
+    if (late_join && hipStreamWaitEvent(st, g_ev_join[l], 0) != hipSuccess) return DD_ERR_HIP;   // this layer's query GEMMs
     // ---- node_layer_with_edge + node_layer_with_bond + bond_layer: one launch
     {
       AttnArgs ne, nb, bl;
@@ -409,6 +416,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
         DD_TRY(launch_batch1_part(l + 1, 0, g_side));
         if (hipStreamWaitEvent(g_side, g_ev_fork[l + 1], 0) != hipSuccess) return DD_ERR_HIP;
         DD_TRY(launch_batch1_part(l + 1, 1, g_side));
+        if (two_joins && hipEventRecord(g_ev_qb_fork[l + 1], g_side) != hipSuccess) return DD_ERR_HIP;
         if (ahead_b2) DD_TRY(launch_b2(l + 1, g_side));
       } else {
         if (hipStreamWaitEvent(g_side, g_ev_fork[l + 1], 0) != hipSuccess) return DD_ERR_HIP;
@@ -1015,7 +1023,7 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 12) { dd::g_q1_in_gemm = value ? 1 : 0; return DD_OK; }
   if (key == 11) { dd::g_xup_in_pos = value ? 1 : 0; return DD_OK; }
   if (key == 9) { dd::g_q_in_pos = value ? 1 : 0; return DD_OK; }
-  if (key == 8) { if (value < 0 || value > 3) return DD_ERR_BAD_ARG; dd::g_sched = value; return DD_OK; }
+  if (key == 8) { if (value < 0 || value > 4) return DD_ERR_BAD_ARG; dd::g_sched = value; return DD_OK; }
   if (key == 7) { dd::g_step_fused = value ? 1 : 0; return DD_OK; }
   if (key == 5) { if (value != 2 && value != 4 && value != 8) return DD_ERR_BAD_ARG; dd::g_pos_waves = value; return DD_OK; }
   if (key == 2) { if (value != 8) return DD_ERR_BAD_ARG; dd::g_attn_waves = value; return DD_OK; }

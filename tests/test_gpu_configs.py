@@ -232,7 +232,7 @@ def test_chain_cache_reuses_buffers_and_graph_without_changing_results(monkeypat
             if i == 5:
                 assert lib.dd_debug_set_option(8, 0) == 0            # another launch schedule: the cached graph is stale
             outs.append(_sample_hip(m, b, 6 if i % 2 else 9, drift, None, seed=seed, start_step=start))
-        assert lib.dd_debug_set_option(8, 3) == 0
+        assert lib.dd_debug_set_option(8, 4) == 0
         return outs
 
     cached, fresh = go(True), go(False)

@@ -450,7 +450,7 @@ def test_runtime_options_agree():
     g = GU.load("forward_small")
     b = GU.batch_from_npz(g)
     lib = hip_lib.load()
-    defaults = {1: 1, 3: 1, 5: 4, 7: 1, 8: 3, 9: 1, 11: 0, 12: 1, 14: 0, 16: 1, 17: 1, 18: 1, 19: 1, 20: 1, 21: 1}
+    defaults = {1: 1, 3: 1, 5: 4, 7: 1, 8: 4, 9: 1, 11: 0, 12: 1, 14: 0, 16: 1, 17: 1, 18: 1, 19: 1, 20: 1, 21: 1}
     ref = {k: v.clone() for k, v in _forward_hip(model(0), b).items()}
     try:
         for key in (4, 6, 10, 15):                               # removed kernel variants: their keys are rejected
