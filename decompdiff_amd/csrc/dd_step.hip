@@ -12,10 +12,12 @@
 
 namespace dd {
 
-// Production noise (Philox4x32-10, counter = (row, row >> 32, step, stream id)): one uniform per (row, class) for the
+// Production noise (Philox4x32-10, counter = (row, row >> 32, t, stream id)): one uniform per (row, class) for the
 // Gumbel draws -- classes 0..3 from the block of stream `sid`, 4..7 from the block of `sid | 0x100` -- and one
 // Box-Muller normal per coordinate (stream 7).  Streams: 1 atom types, 2 bond types, 7 coordinates; distinct
-// (row, step, stream) never share a counter.  dd_debug_philox exposes exactly these functions to the statistics test.
+// (row, t, stream) never share a counter.  `t` is the diffusion time index of the step (t_start - steps done), not the
+// step number of the call: a chain resumed with start_step and the same seed continues the noise of the unsplit chain
+// (tests/test_gpu_properties.py) instead of replaying the draws of its first steps.  dd_debug_philox exposes exactly these functions to the statistics test.
 template <int NC>
 __device__ __forceinline__ float philox_uniform(uint64_t seed, long row, int step, uint32_t sid, int c) {
   Philox ph(seed);
@@ -159,7 +161,7 @@ __global__ void k_step_pos(const StepPosArgs a) {
   if (a.eps) {
     e = a.eps[(long)step * n + idx];
   } else {
-    e = philox_normal(rs.seed, idx, step);
+    e = philox_normal(rs.seed, idx, t);
   }
   const float nz = t == 0 ? 0.f : 1.f;
   const float nxt = mean + nz * expf(0.5f * a.tab_pos[2 * a.T + t]) * e * a.atom_std[idx];
@@ -327,7 +329,7 @@ __device__ __forceinline__ void step_row(const StepRowsArgs& a, const long row, 
   if (a.uniforms) {
     u = a.uniforms[((long)step * a.rows + row) * NC + c];
   } else {
-    u = philox_uniform<NC>(rs.seed, row, step, a.stream_id, c);
+    u = philox_uniform<NC>(rs.seed, row, t, a.stream_id, c);
   }
   const float lp = un - ulse;
   const float sc = -logf(-logf(u + 1e-30f) + 1e-30f) + lp;      // Gumbel-argmax (transitions.py:78-84)
@@ -372,7 +374,7 @@ __device__ __forceinline__ void step_pos_elem(const StepPosArgs& a, const int id
   if (a.eps) {
     e = a.eps[(long)step * n + idx];
   } else {
-    e = philox_normal(rs.seed, idx, step);
+    e = philox_normal(rs.seed, idx, t);
   }
   const float nz = t == 0 ? 0.f : 1.f;
   const float nxt = mean + nz * expf(0.5f * a.tab_pos[2 * a.T + t]) * e * a.atom_std[idx];

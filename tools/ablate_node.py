@@ -21,4 +21,4 @@ for rnd in range(4):
     if rnd: rounds.append([float(c) for c in cats])
 per = {k: min(r[i] for r in rounds) for i, k in enumerate(hip_lib.PROF_CATS)}
 print(f"{os.path.basename(os.environ.get('DD_HIP_LIB', 'default')):40s} node launch {1e3 * (per['attn_BL'] / cfg.num_layers - per.get('event_pair', 0)):7.1f} us   "
-      f"pos launch {1e3 * per.get('attn_PB', 0) / cfg.num_layers:6.1f} us")
+      f"pos launch {1e3 * (per.get('attn_PE', 0) / cfg.num_layers - per.get('event_pair', 0)):6.1f} us")

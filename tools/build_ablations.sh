@@ -1,7 +1,7 @@
 #!/bin/bash
 # Timing-only builds of the attention kernels with parts removed: tools/ablate_node.patch (applied to a scratch copy of
 # csrc/) adds -DDD_ABLATE=<mask> switches -- 1 table MFMAs (+ the features feeding them), 2 score MFMAs, 4 aggregation
-# MFMAs, 8 row gathers, 16 LayerNorms, 32 query fold, 64 epilogue mat-vec.  Results are wrong for mask != 0.
+# MFMAs, 8 row gathers, 16 LayerNorms, 32 query fold, 64 epilogue mat-vec, 128 in-kernel query MLP of the coordinate launch, 256 its v-pass gathers, 512 weight-image staging.  Results are wrong for mask != 0.
 #   tools/build_ablations.sh 0 1 2 4 8 16 32 64 127   ->  decompdiff_amd/lib/libdd_abl_<mask>.so
 #   DD_HIP_LIB=$PWD/decompdiff_amd/lib/libdd_abl_1.so python tools/ablate_node.py      (on an MI355X)
 cd "$(dirname "$0")/.." || exit 1
