@@ -441,14 +441,18 @@ class DecompScorePosNet3D(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def _dense_inputs(self, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, ligand_v_aux, batch_ligand,
-                      ligand_fc_bond_index, ligand_bond_type, ligand_atom_mask):
-        """Flat PyG-style batch -> dense [B, ...] tensors (validated, no arithmetic)."""
+                      ligand_fc_bond_index, ligand_bond_type, ligand_atom_mask, layout=None):
+        """Flat PyG-style batch -> dense [B, ...] tensors (validated, no arithmetic).  ``layout`` = (B, NP, NL) already
+        established for these very batch-vector / bond-list tensors by an earlier call: their checks are skipped."""
         for name, t in (("protein_pos", protein_pos), ("ligand_pos", ligand_pos)):
             hip_lib.require_gpu(t, name)
         _check_ligand_atom_mask(ligand_atom_mask, batch_ligand.numel())
         if ligand_fc_bond_index is None or ligand_bond_type is None:
             raise NotImplementedError("the uni_o2_bond path needs the fully connected ligand bond graph")
-        B = int(batch_protein.max().item()) + 1 if batch_protein.numel() else 0
+        if layout is not None:
+            B = layout[0]
+        else:
+            B = int(batch_protein.max().item()) + 1 if batch_protein.numel() else 0
         if B <= 0:
             raise ValueError("empty batch")
         n_p, n_l = batch_protein.numel(), batch_ligand.numel()
@@ -457,15 +461,16 @@ class DecompScorePosNet3D(nn.Module):
                                       "batch samples of one pocket with equal ligand sizes")
         NP, NL = n_p // B, n_l // B
         dev = protein_pos.device
-        exp_p, exp_l, exp_fc = self._expected_layout(B, NP, NL, dev)
-        if not (torch.equal(batch_protein, exp_p) and torch.equal(batch_ligand, exp_l)):
-            raise NotImplementedError("batch vectors must be sorted with equal counts per sample (PyG Batch order)")
+        if layout is None:
+            exp_p, exp_l, exp_fc = self._expected_layout(B, NP, NL, dev)
+            if not (torch.equal(batch_protein, exp_p) and torch.equal(batch_ligand, exp_l)):
+                raise NotImplementedError("batch vectors must be sorted with equal counts per sample (PyG Batch order)")
         if NL < 2 or NL > 64:
             raise NotImplementedError(f"ligand size {NL} outside the supported range [2, 64]")
         if NP + NL > 1024:
             raise NotImplementedError("more than 1024 atoms per sample")
         # the fused kernels use the closed-form fc layout of FeaturizeLigandBond('fc') (utils/transforms.py:331-337)
-        if ligand_fc_bond_index.shape != exp_fc.shape or not torch.equal(ligand_fc_bond_index, exp_fc):
+        if layout is None and (ligand_fc_bond_index.shape != exp_fc.shape or not torch.equal(ligand_fc_bond_index, exp_fc)):
             raise NotImplementedError("ligand_fc_bond_index must be the dst-major fully connected graph ('fc' mode)")
         if protein_v.dim() != 2 or protein_v.shape[1] != 29 or ligand_v_aux.dim() != 2 or ligand_v_aux.shape[1] != 2:
             raise ValueError("protein_v must be [n,29] and ligand_v_aux [n,2] (27 atom features + 2 arm indicators; "
@@ -474,10 +479,10 @@ class DecompScorePosNet3D(nn.Module):
                 or ligand_v.shape != (n_l,) or ligand_v_aux.shape[0] != n_l:
             raise ValueError("per-atom tensors do not match the batch vectors")
         # class ids out of range: the reference's index_to_log_onehot asserts (transitions.py:66)
-        assert int(ligand_v.min()) >= 0 and int(ligand_v.max()) < self.num_classes, \
-            f"Error: {int(ligand_v.max())} >= {self.num_classes}"
-        assert int(ligand_bond_type.min()) >= 0 and int(ligand_bond_type.max()) < self.num_bond_classes, \
-            f"Error: {int(ligand_bond_type.max())} >= {self.num_bond_classes}"
+        lo_v, hi_v, lo_b, hi_b = torch.stack([ligand_v.min(), ligand_v.max(), ligand_bond_type.min().to(ligand_v.dtype),
+                                              ligand_bond_type.max().to(ligand_v.dtype)]).tolist()      # (one sync)
+        assert lo_v >= 0 and hi_v < self.num_classes, f"Error: {hi_v} >= {self.num_classes}"
+        assert lo_b >= 0 and hi_b < self.num_bond_classes, f"Error: {hi_b} >= {self.num_bond_classes}"
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
         return dict(B=B, NP=NP, NL=NL, protein_pos=f32(protein_pos).view(B, NP, 3), protein_v=f32(protein_v).view(B, NP, -1),
                     ligand_pos=f32(ligand_pos).view(B, NL, 3), ligand_v=ligand_v.detach().to(torch.int32).contiguous(),
@@ -523,6 +528,24 @@ class DecompScorePosNet3D(nn.Module):
         for e in live:
             lib.dd_graph_destroy(e["graph"])
             e["graph"] = None
+
+    # Validation / centring of the inputs that do not change between the calls of one sampling job (the pocket, the
+    # batch vectors, the bond list).  A call that passes the SAME tensor objects with unchanged version counters reuses
+    # the result of the previous call: layout checks (six device -> host syncs), the protein centroid (a device -> host
+    # copy) and the centred protein block cost ~1 ms per call, 5 % of a 20-step call.  The entry holds references to
+    # the tensors, so their memory cannot be recycled for other data while it is cached.
+    def _static_memo_get(self, tensors, extra):
+        m = self.__dict__.get("_static_memo")
+        if m is None or m["extra"] != extra or len(m["tensors"]) != len(tensors):
+            return None
+        for t, (u, ver) in zip(tensors, m["tensors"]):
+            if t is not u or (t is not None and t._version != ver):
+                return None
+        return m["value"]
+
+    def _static_memo_put(self, tensors, extra, value):
+        self.__dict__["_static_memo"] = dict(tensors=[(t, None if t is None else t._version) for t in tensors], extra=extra,
+                                             value=value)
 
     def _expected_layout(self, B, NP, NL, dev):
         """PyG Batch vectors and the dst-major fully connected bond index of a dense batch (validated against the
@@ -775,7 +798,9 @@ class DecompScorePosNet3D(nn.Module):
             num_steps = self.num_timesteps
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
-        if self._is_ragged(batch_protein, batch_ligand):
+        key_t = (protein_pos, batch_protein, batch_ligand, ligand_fc_bond_index)
+        static = self._static_memo_get(key_t, center_pos_mode)        # (only dense batches are remembered)
+        if static is None and self._is_ragged(batch_protein, batch_ligand):
             return self._sample_heterogeneous(
                 dict(protein_pos=protein_pos, protein_v=protein_v, batch_protein=batch_protein,
                      protein_group_idx=protein_group_idx, init_ligand_pos=init_ligand_pos, init_ligand_v=init_ligand_v,
@@ -791,7 +816,9 @@ class DecompScorePosNet3D(nn.Module):
                                     batch_ligand, prior_stds, ligand_decomp_batch, ligand_decomp_index, ligand_atom_mask,
                                     ligand_fc_bond_index, init_ligand_fc_bond_type, num_steps, center_pos_mode,
                                     energy_drift_opt, full_protein_pos, full_batch_protein, noise, seed, keep_traj,
-                                    _drift_norm_batch, start_step)
+                                    _drift_norm_batch, start_step, static=static)
+        if static is None and "static" in chain:
+            self._static_memo_put(key_t, center_pos_mode, chain["static"])
         self._run_chains([chain], num_steps, use_graph)
         out = self._collect_chain(chain, num_steps, keep_traj)
         self._last = (chain["s"], chain["bufs"])
@@ -800,14 +827,19 @@ class DecompScorePosNet3D(nn.Module):
     def _prepare_chain(self, protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, ligand_v_aux,
                        batch_ligand, prior_stds, ligand_decomp_batch, ligand_decomp_index, ligand_atom_mask,
                        ligand_fc_bond_index, init_ligand_fc_bond_type, num_steps, center_pos_mode, energy_drift_opt,
-                       full_protein_pos, full_batch_protein, noise, seed, keep_traj, drift_norm_batch, start_step=0):
-        """Validate one dense batch, centre it, allocate its state / workspace and fill the ``dd_sampler`` struct."""
+                       full_protein_pos, full_batch_protein, noise, seed, keep_traj, drift_norm_batch, start_step=0,
+                       static=None):
+        """Validate one dense batch, centre it, allocate its state / workspace and fill the ``dd_sampler`` struct.
+        ``static``: what an earlier call with the same pocket / batch-vector tensors established (_static_memo_get)."""
         d = self._dense_inputs(protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, ligand_v_aux,
-                               batch_ligand, ligand_fc_bond_index, init_ligand_fc_bond_type, ligand_atom_mask)
+                               batch_ligand, ligand_fc_bond_index, init_ligand_fc_bond_type, ligand_atom_mask,
+                               layout=None if static is None else static["layout"])
         dev = d["protein_pos"].device
         B, NP, NL = d["B"], d["NP"], d["NL"]
         # center_pos (decompdiff.py:20-32): subtract the per-sample protein centroid
-        if center_pos_mode == "protein":
+        if static is not None:
+            offset = static["offset"]
+        elif center_pos_mode == "protein":
             # scatter_mean(protein_pos, batch_protein, dim=0) (decompdiff.py:25): fp32 accumulation in row order / count --
             # the same arithmetic as the CPU scatter, on the host (B*NP*3 floats), so the offset that is re-added to
             # every output is bit-identical to the reference's
@@ -818,7 +850,8 @@ class DecompScorePosNet3D(nn.Module):
             offset = torch.zeros(B, 3, device=dev)
         else:
             raise NotImplementedError(center_pos_mode)
-        d["protein_pos_centered"] = (d["protein_pos"] - offset[:, None, :]).contiguous()
+        d["protein_pos_centered"] = static["protein_pos_centered"] if static is not None else \
+            (d["protein_pos"] - offset[:, None, :]).contiguous()
         d["ligand_pos_centered"] = (d["ligand_pos"] - offset[:, None, :]).contiguous()
         atom_std = prior_stds.to(dev).float()[ligand_decomp_batch.to(dev)].contiguous()           # [B*NL,3]
         decomp = ligand_decomp_index.to(device=dev, dtype=torch.int32).contiguous() if ligand_decomp_index is not None else None
@@ -837,7 +870,8 @@ class DecompScorePosNet3D(nn.Module):
         pw = self._packed_weights()
         s, bufs, ent = self._make_sampler(d, pw, num_steps, t_start, noise, keep_traj, energy_drift_opt, atom_std,
                                           offset.contiguous(), decomp, fpp, seed, drift_norm_batch)
-        return dict(s=s, bufs=bufs, offset=offset, B=B, NL=NL, dev=dev, ent=ent)
+        return dict(s=s, bufs=bufs, offset=offset, B=B, NL=NL, dev=dev, ent=ent,
+                    static=dict(layout=(B, NP, NL), offset=offset, protein_pos_centered=d["protein_pos_centered"]))
 
     def _run_chains(self, chains, num_steps, use_graph):
         """Advance every prepared chain by ``num_steps``.  One chain: the captured step graph replayed on a dedicated

@@ -317,3 +317,34 @@ def test_bench_json_line_contract():
     assert o["bound"] == "hbm" and o["unit"] == "GB/s" and 0.3 < o["frac"] < 1.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "steps" in c["sample"]
+
+
+def test_static_input_memo_is_invalidated_by_in_place_changes():
+    """Validation / centring of the pocket-side inputs is remembered for calls that pass the same tensor objects
+    (model._static_memo_get); an in-place change (version counter) or a new tensor must not see the old centroid."""
+    m = model(0)
+    torch.manual_seed(5)
+    b = to_dev_local(synth.build_sampling_batch(synth.make_pocket(17, 60, (3, 3), 4, num_full_protein=0), 2))
+    kw = dict(num_steps=4, center_pos_mode="protein", seed=77)
+    r0 = m.sample_diffusion(**b, **kw)
+    assert m.__dict__.get("_static_memo") is not None
+    r1 = m.sample_diffusion(**b, **kw)                        # memo hit
+    assert torch.equal(r0["pos"], r1["pos"]) and torch.equal(r0["v"], r1["v"])
+    shift = torch.tensor([1.5, -2.0, 0.25], device=b["protein_pos"].device)
+    b["protein_pos"].add_(shift)                              # in place: same object, new version
+    b["init_ligand_pos"] = b["init_ligand_pos"] + shift
+    r2 = m.sample_diffusion(**b, **kw)
+    assert maxabs(r2["pos"], r0["pos"] + shift) < 1e-5        # translated frame: stale centroid would be off by |shift|
+    b2 = dict(b)
+    b2["protein_pos"] = b["protein_pos"] - shift              # a new tensor object
+    b2["init_ligand_pos"] = b["init_ligand_pos"] - shift
+    r3 = m.sample_diffusion(**b2, **kw)
+    assert maxabs(r3["pos"], r0["pos"]) < 1e-5
+    # a ragged batch never hits the memo of a dense one
+    with pytest.raises((NotImplementedError, ValueError, RuntimeError, AssertionError)):
+        bad = dict(b); bad["batch_ligand"] = b["batch_ligand"].clone(); bad["batch_ligand"][0] = 1
+        m.sample_diffusion(**bad, **kw)
+
+
+def to_dev_local(batch):
+    return {k: (v.to(dev()) if torch.is_tensor(v) else v) for k, v in batch.items()}
