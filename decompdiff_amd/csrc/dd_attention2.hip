@@ -231,20 +231,28 @@ __host__ __device__ inline int ne_blocks_per_sample(int NP, int NL, int NW) { re
 // state lives in registers; LDS only holds the (read-only) weight images shared by the workgroup.
 // PERSIST (modes without Gaussian tables): the workgroup stages its images once and every wave then pulls segments
 // from the global counter a.work_counter until none are left -- no barriers after the first one.
-template <int MODE, int MAXT, int NW, bool PERSIST = false, bool RAG = false>
+// PAIR (coordinate modes): two waves per segment.  The launch is a pure latency chain (one segment per wave, 120
+// workgroups), and its two halves only meet at the very end: wave 0 of a pair runs the query MLP, the fold, the k pass and
+// the softmax, wave 1 meanwhile the v pass (activations and the 16 per-head values of every member); the attention
+// weights cross through LDS behind one workgroup barrier and wave 1 forms the coordinate update.
+template <int MODE, int MAXT, int NW, bool PERSIST = false, bool RAG = false, bool PAIR = false>
 __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, float* smem) {
   constexpr bool KNN = (MODE == M_NE || MODE == M_PE);
   constexpr bool POS = (MODE == M_PE || MODE == M_PB);
   constexpr bool TRIP = (MODE == M_BL);
   constexpr bool BOND = (MODE == M_NB || MODE == M_PB);
-  constexpr int NT = NW * 64;
+  static_assert(!PAIR || (POS && !PERSIST), "wave pairs: coordinate modes");
+  constexpr int NT = (PAIR ? 2 : 1) * NW * 64;
   using L = Lds<MODE>;
   constexpr int LNP = L::LNP, WAO = L::WAO;
   constexpr bool RES = L::RES;
   static_assert(!PERSIST || RES, "persistent workgroups need both weight images resident");
   float* WB = smem;
   float* WV = smem + L::WV;
-  const int wave = threadIdx.x >> 6, lane0 = threadIdx.x & 63;
+  // (pairs: waves p and p + NW -- one k-side and one v-side wave on every SIMD, which want different units at a time)
+  const int wave = PAIR ? ((threadIdx.x >> 6) % NW) : (threadIdx.x >> 6), lane0 = threadIdx.x & 63;
+  const int role = PAIR ? ((threadIdx.x >> 6) / NW) : 0;  // 0: query / k pass / softmax, 1: v pass / coordinate update
+  const bool kside = !PAIR || role == 0, vside = !PAIR || role == 1;
 
   const int N = a.NP + a.NL, NLm1 = a.NL - 1, Eb = a.NL * NLm1;
   // Padded heterogeneous batch (a.nl_real != NULL): sample b's real atoms are the first np_real[b] / nl_real[b] rows of
@@ -398,7 +406,7 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
   float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
   if (PERSIST && it > 0) {
     q0 = qn0; q1 = qn1;                                // requested during the previous trip's epilogue
-  } else if (POS && a.W2q != nullptr) {
+  } else if (POS && a.W2q != nullptr && kside) {
     // coordinate modes: the query MLP's second layer runs here (q = W2q . relu(LN(hidden)) + b2q, one 128x128
     // mat-vec per segment) instead of as a 16-tile GEMM launch on the critical chain.  Lane l owns outputs 2l, 2l+1.
     float* sc = smem + L::TOTAL + wave * 256;
@@ -431,7 +439,7 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
       q0 = *reinterpret_cast<const float4*>(sc + 128 + mm * 8);
       q1 = *reinterpret_cast<const float4*>(sc + 128 + mm * 8 + 4);
     }
-  } else if (active) {
+  } else if (active && kside) {
     q0 = *reinterpret_cast<const float4*>(a.q + (long)seg * 128 + mm * 8);
     q1 = *reinterpret_cast<const float4*>(a.q + (long)seg * 128 + mm * 8 + 4);
   }
@@ -452,7 +460,7 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
       load_row(Pf, a.ke + ((long)b * Eb + sj * NLm1 + (k - (k > sj ? 1 : 0))) * a.ld_ke, cg);
     }
   };
-  if (active) {
+  if (active && kside) {
     load_row(Rc, TRIP ? a.Rk + (long)seg * 128 : a.kd + drow * a.ld_kd, cg);
     fetch_k_rows(0);
     if (TRIP) {
@@ -475,7 +483,7 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
   float Qb[32];
 #pragma unroll
   for (int k = 0; k < 32; ++k) Qb[k] = 0.f;
-  if (active) {
+  if (active && kside) {
     // a real loop (8 LDS reads in flight per trip): fully unrolled, the scheduler hoists all 64 reads = 256 registers.
     // The 8 query values rotate through r0 so that no dynamic register indexing is needed.
     float r0 = q0.x, r1 = q0.y, r2 = q0.z, r3 = q0.w, r4 = q1.x, r5 = q1.y, r6 = q1.z, r7 = q1.w;
@@ -652,7 +660,7 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
   // ---- pass 1: scores S[t][r] = score[member 16t + 4cg + r][head mm] ---------------------------------------
   f32x4 S[MAXT];
   float ssum = 0.f;                                    // sum_m alpha*w for head mm
-  if (active) {
+  if (active && kside) {
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
       if (t < T) {
@@ -712,21 +720,48 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
 
   // ---- pass 2 -----------------------------------------------------------------------------------------------
   if (POS) {
-    if (active) {
+    // wave pairs: the weights go from the k side to the v side through LDS, [tile][r][lane] per pair, behind one barrier
+    float* xw = smem + L::TOTAL + NW * 256 + wave * (MAXT * 4 * 64);
+    f32x4 Vt[MAXT];                                    // V[r] = v16[member 16t+4cg+r][head mm] - bias
+    if (active && vside) {
       float Wv[32];
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) {
         const float4 w = *reinterpret_cast<const float4*>(a.W2v16 + mm * 128 + 16 * nt + 4 * cg);
         Wv[4 * nt] = w.x; Wv[4 * nt + 1] = w.y; Wv[4 * nt + 2] = w.z; Wv[4 * nt + 3] = w.w;
       }
-      const float bv = a.b2v16[mm];
-      float dx = 0.f, dy = 0.f, dz = 0.f;
 #pragma unroll
       for (int t = 0; t < MAXT; ++t) {
         if (t < T) {
           float P[32];
           build_pre(t, 1, P);
-          const f32x4 V = mfma_rows(P, Wv);             // V[r] = v16[member 16t+4cg+r][head mm] - bias
+          Vt[t] = mfma_rows(P, Wv);
+        }
+      }
+    }
+    if (PAIR) {
+      if (active && role == 0) {
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xw[(t * 4 + r) * 64 + lane] = S[t][r];
+      }
+      __syncthreads();
+      if (role == 0) { DD_STAMP(10); return; }
+      if (active) {
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) S[t][r] = xw[(t * 4 + r) * 64 + lane];
+      }
+    }
+    if (active) {
+      const float bv = a.b2v16[mm];
+      float dx = 0.f, dy = 0.f, dz = 0.f;
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t) {
+        if (t < T) {
+          const f32x4 V = Vt[t];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int m = 16 * t + 4 * cg + r;
@@ -868,13 +903,15 @@ __global__ __launch_bounds__(NW * 64) void k_attn2_node(const AttnArgs ne, const
   else attn2_body<M_BL, MAXT, NW, false, RAG>(bl, blk - n_ne - n_nb, smem);
 }
 // Same for the two coordinate sub-layers (both write their own delta buffer; x is updated afterwards).
+// (NW segments = 2 NW waves per workgroup: attn2_body's PAIR)
 template <int MAXT, int NW, bool RAG = false>
-__global__ __launch_bounds__(NW * 64) void k_attn2_pos(const AttnArgs pe, const AttnArgs pb, int n_pe) {
-  constexpr int SZ = imax(Lds<M_PE>::TOTAL, Lds<M_PB>::TOTAL) + NW * 256;   // + per-wave scratch of the in-kernel query MLP
+__global__ __launch_bounds__(NW * 128) void k_attn2_pos(const AttnArgs pe, const AttnArgs pb, int n_pe) {
+  // + per-segment scratch of the in-kernel query MLP + the attention weights handed from the k wave to the v wave
+  constexpr int SZ = imax(Lds<M_PE>::TOTAL, Lds<M_PB>::TOTAL) + NW * 256 + NW * MAXT * 256;
   __shared__ __attribute__((aligned(16))) float smem[SZ];
   const int blk = blockIdx.x;
-  if (blk < n_pe) attn2_body<M_PE, 2, NW, false, RAG>(pe, blk, smem);
-  else attn2_body<M_PB, MAXT, NW, false, RAG>(pb, blk - n_pe, smem);
+  if (blk < n_pe) attn2_body<M_PE, 2, NW, false, RAG, true>(pe, blk, smem);
+  else attn2_body<M_PB, MAXT, NW, false, RAG, true>(pb, blk - n_pe, smem);
   // x update (x += (dx_edge + dx_bond) on the ligand rows, uni_transformer_edge.py:285) by the workgroup that finishes
   // last: ~120 workgroups, so the ticket costs nothing and a launch on the critical chain is saved
   if (pe.work_counter == nullptr) return;
@@ -890,7 +927,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn2_pos(const AttnArgs pe, const 
     const int n = pe.B * pe.NL * 3, N = pe.NP + pe.NL;
     const volatile float* dxe = pe.out;
     const volatile float* dxb = pb.out;
-    for (int idx = threadIdx.x; idx < n; idx += NW * 64) {
+    for (int idx = threadIdx.x; idx < n; idx += NW * 128) {
       const int b = idx / (pe.NL * 3), r = idx % (pe.NL * 3);
       const long xi = ((long)b * N + pe.NP) * 3 + r;
       pe.x_next[xi] = pe.x[xi] + dxe[idx] + dxb[idx];
@@ -1001,12 +1038,12 @@ static int launch_pos_nw(const AttnArgs& pe, const AttnArgs& pb, hipStream_t st)
   using namespace v2;
   const int n = (pe.B * pe.NL + NW - 1) / NW;
   if (pe.nl_real != nullptr) {
-    if (pe.NL > 49) hipLaunchKernelGGL((k_attn2_pos<4, NW, true>), dim3(2 * n), dim3(NW * 64), 0, st, pe, pb, n);
-    else if (pe.NL > 33) hipLaunchKernelGGL((k_attn2_pos<3, NW, true>), dim3(2 * n), dim3(NW * 64), 0, st, pe, pb, n);
-    else hipLaunchKernelGGL((k_attn2_pos<2, NW, true>), dim3(2 * n), dim3(NW * 64), 0, st, pe, pb, n);
-  } else if (pe.NL > 49) hipLaunchKernelGGL((k_attn2_pos<4, NW>), dim3(2 * n), dim3(NW * 64), 0, st, pe, pb, n);
-  else if (pe.NL > 33) hipLaunchKernelGGL((k_attn2_pos<3, NW>), dim3(2 * n), dim3(NW * 64), 0, st, pe, pb, n);
-  else hipLaunchKernelGGL((k_attn2_pos<2, NW>), dim3(2 * n), dim3(NW * 64), 0, st, pe, pb, n);
+    if (pe.NL > 49) hipLaunchKernelGGL((k_attn2_pos<4, NW, true>), dim3(2 * n), dim3(NW * 128), 0, st, pe, pb, n);
+    else if (pe.NL > 33) hipLaunchKernelGGL((k_attn2_pos<3, NW, true>), dim3(2 * n), dim3(NW * 128), 0, st, pe, pb, n);
+    else hipLaunchKernelGGL((k_attn2_pos<2, NW, true>), dim3(2 * n), dim3(NW * 128), 0, st, pe, pb, n);
+  } else if (pe.NL > 49) hipLaunchKernelGGL((k_attn2_pos<4, NW>), dim3(2 * n), dim3(NW * 128), 0, st, pe, pb, n);
+  else if (pe.NL > 33) hipLaunchKernelGGL((k_attn2_pos<3, NW>), dim3(2 * n), dim3(NW * 128), 0, st, pe, pb, n);
+  else hipLaunchKernelGGL((k_attn2_pos<2, NW>), dim3(2 * n), dim3(NW * 128), 0, st, pe, pb, n);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
