@@ -9,6 +9,7 @@ init / barrier / a final gather of per-rank metadata (timings, checksums).
 from __future__ import annotations
 
 import os
+import gc
 import time
 from dataclasses import asdict, dataclass
 from typing import Any, Callable, Dict, List, Optional, Tuple
@@ -54,7 +55,7 @@ def shard_samples(n_samples: int, rank: int, world: int) -> range:
 def barrier(device=None):
     if device is not None and torch.cuda.is_available():
         torch.cuda.synchronize(device)
-    if dist.is_available() and dist.is_initialized():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:      # (one rank: nothing to wait for)
         dist.barrier()
     if device is not None and torch.cuda.is_available():
         torch.cuda.synchronize(device)
@@ -158,6 +159,8 @@ def run_job(units: List[Unit], config: int, rank: int, world: int, prepare: Call
     if warmup > 0:
         for u, st in zip(mine, states):
             checksum(sample(st, warmup, u.noise_seed + 1))      # (also loads the reduction kernels the timed region uses)
+    gc.collect()
+    gc.disable()                                   # no collector pause inside the timed region (re-enabled below)
     barrier(device)
     t0 = time.perf_counter()
     records = []
@@ -168,6 +171,7 @@ def run_job(units: List[Unit], config: int, rank: int, world: int, prepare: Call
                         "checksum": checksum(out), "seconds_enqueue": round(time.perf_counter() - t1, 6), "_out": out})
     barrier(device)
     local = time.perf_counter() - t0
+    gc.enable()
     elapsed = max_over_ranks(local, device)
     last = records[-1].pop("_out") if records else None
     for r in records:
