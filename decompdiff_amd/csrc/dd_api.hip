@@ -145,6 +145,7 @@ static int g_defer_pos = 0;                    // dd_debug_set_option(14, v): re
 static int g_lin_with_pb2 = 1;                 // dd_debug_set_option(16, v): bond projections of the coordinate sub-layer ride with lin_node
 static int g_pb_early = 1;                     // dd_debug_set_option(17, v): next layer's bond projections in the lin_node launch
 static int g_q1_in_gemm = 1;                   // dd_debug_set_option(12, v): bond-layer query hidden row summed inside the query GEMM
+static int g_l0_tables = 1;                    // dd_debug_set_option(22, v): first layer's projection / query rows gathered from tables
 static int g_q_in_pos = 1;                     // dd_debug_set_option(9, v): coordinate query MLPs' second layer inside attn_pos
 // (ev_fork / ev_join: [0..7] per layer, [8] graph construction at the head of a forward)
 // DD_SIDE_PRIO: 1 (default) lowest priority for the side stream, 0 default priority, 2 highest
@@ -187,6 +188,34 @@ struct StepFold {
   const float* xprev = nullptr;          // out: != nullptr when the tail was deferred
 };
 
+// First-Linear projections of layer `ll` from h / h_bond (one launch) and the query MLPs' second layer (one launch):
+// the forward's own launches, also run by dd_layer0_tables on its 16-atom problem.
+static int launch_projections1(const dd_sampler* s, const Workspace& w, int ll, const float* h, float* P, hipStream_t sx) {
+  const int B = s->B, NP = s->NP, NL = s->NL, N = NP + NL;
+  const int nE = B * NL * (NL - 1);
+  const long hN = (long)N * 128;
+  const float* W = s->weights;
+  auto LW = [&](int l, int slot) { return W + s->slot_off[(long)l * DD_NUM_LAYER_SLOTS + slot]; };
+  GemmArgs j[3] = {
+      gemm_args(h, B * N, 0, 128, B * N, LW(ll, DD_W_n1), LW(ll, DD_b_n1), nullptr, P, B * N, 0, 640, 640, 0),
+      gemm_args(h + (long)NP * 128, NL, hN, 128, B * NL, LW(ll, DD_W_l1), LW(ll, DD_b_l1), nullptr, w.PL, B * NL, 0, 1280, 1280, 0),
+      gemm_args(w.hb, nE, 0, 128, nE, LW(ll, DD_W_b1), LW(ll, DD_b_b1), nullptr, w.PB, nE, 0, 640, 640, 0)};
+  return launch_gemm128_batch(j, 3, sx);
+}
+static int launch_queries_q1(const dd_sampler* s, const Workspace& w, int ll, const float* P, float* qn, hipStream_t sx) {
+  const int B = s->B, NP = s->NP, NL = s->NL, N = NP + NL;
+  const long Eb = (long)NL * (NL - 1);
+  const int nE = (int)(B * Eb);
+  const float* W = s->weights;
+  auto LW = [&](int l, int slot) { return W + s->slot_off[(long)l * DD_NUM_LAYER_SLOTS + slot]; };
+  GemmArgs j[3] = {
+      gemm_args(w.PB + 512, nE, 0, 640, nE, LW(ll, DD_BL_W2q), LW(ll, DD_BL_b2q), LW(ll, DD_BL_lnq), w.qb, nE, 0, 128, 128, 0),
+      gemm_args(P + 512, B * N, 0, 640, B * N, LW(ll, DD_NE_W2q), LW(ll, DD_NE_b2q), LW(ll, DD_NE_lnq), qn, B * N, 0, 128, 128, 0),
+      gemm_args(w.PL + 512, B * NL, 0, 1280, B * NL, LW(ll, DD_NB_W2q), LW(ll, DD_NB_b2q), LW(ll, DD_NB_lnq), w.qlnb, B * NL, 0, 128, 128, 0)};
+  j[0].X2 = w.PL + 1152; j[0].x2_N = NL; j[0].x2_Eb = (int)Eb; j[0].x2_NLm1 = NL - 1; j[0].x2_ld = 1280;
+  return launch_gemm128_batch(j, 3, sx);
+}
+
 static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nullptr) {
   DD_TRY(check_shapes(s));
   const int B = s->B, NP = s->NP, NL = s->NL, K = s->K, N = NP + NL;
@@ -208,6 +237,13 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
   DD_TRYP(DD_PROF_MISC, launch_embed_all(s->protein_h, s->protein_pos, s->lig_pos, s->lig_v, s->lig_aux, GW(DD_G_W_lemb),
                                          GW(DD_G_b_lemb), B, NP, NL, w.h, w.xa, w.xb, s->lig_bond, (long)B * Eb, GW(DD_G_W_bemb),
                                          GW(DD_G_b_bemb), w.hb, w.counters, st, (fold && fold->advance) ? s->step_counter : nullptr));
+  // layer-0 tables: the first layer's projection and query rows are gathered (ligand atoms: 16 combinations of class and
+  // arm flag, bonds: type x destination combination; protein rows are static per chain) instead of two GEMM launches
+  const bool l0 = fused && g_l0_tables && g_q1_in_gemm && g_gemm_ksplit_on() && s->l0_tables && s->l0_P && s->l0_qn &&
+                  s->nl_real == nullptr;
+  if (l0)
+    DD_TRYP(DD_PROF_MISC, launch_layer0_rows(s->l0_tables, s->lig_v, s->lig_aux, s->lig_bond, B, NP, NL, s->l0_P, w.PL, s->l0_qn,
+                                              w.qlnb, w.PB, w.qb, st));
   // graph (uni_transformer_edge.py:404-427): only the attention kernels need it, so with two streams it is built
   // beside the bond embedding and the first layer's projections
   bool head_join = false;
@@ -248,13 +284,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     // ---- projections of the old h / h_bond: one launch (the q blocks are the last columns: skipped when fused above).
     //      With the projection-ahead schedule this launch was already issued on the side stream right after the
     //      previous layer's lin_node (it needs h and h_bond only) and is joined before its first consumer.
-    auto launch_batch1 = [&](int ll, hipStream_t sx) -> int {
-      GemmArgs j[3] = {
-          gemm_args(w.h, B * N, 0, 128, B * N, LW(ll, DD_W_n1), LW(ll, DD_b_n1), nullptr, w.P, B * N, 0, 640, 640, 0),
-          gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(ll, DD_W_l1), LW(ll, DD_b_l1), nullptr, w.PL, B * NL, 0, 1280, 1280, 0),
-          gemm_args(w.hb, nE, 0, 128, nE, LW(ll, DD_W_b1), LW(ll, DD_b_b1), nullptr, w.PB, nE, 0, 640, 640, 0)};
-      return launch_gemm128_batch(j, 3, sx);
-    };
+    auto launch_batch1 = [&](int ll, hipStream_t sx) -> int { return launch_projections1(s, w, ll, w.h, w.P, sx); };
     // (schedule 2) the same projections in two launches: the bond part only needs h_bond, final once the node
     // attention is done; the node parts need h (lin_node)
     auto launch_batch1_part = [&](int ll, int part, hipStream_t sx) -> int {
@@ -272,8 +302,9 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     const bool ahead_b2 = overlap && g_sched >= 3 && g_q1_in_gemm && g_gemm_ksplit_on();
     const bool two_joins = ahead_b2 && g_sched >= 4;     // g_ev_qb_fork[l]: layer l's projections done (side stream)
     const bool pb_early = g_pb_early && g_lin_with_pb2 && !ahead;   // next layer's bond projections ride with lin_node
+    const bool l0_here = l0 && l == 0;                  // this layer's projection / query rows came from the tables
     if (pb_early && l > 0) DD_TRYP(DD_PROF_GEMM, launch_batch1_part(l, 1, st));
-    else if (!(ahead && l > 0)) DD_TRYP(DD_PROF_GEMM, launch_batch1(l, st));
+    else if (!(ahead && l > 0) && !l0_here) DD_TRYP(DD_PROF_GEMM, launch_batch1(l, st));
     // ---- queries (second Linear of the q MLPs, LayerNorm+ReLU prologue): one launch.  The bond-layer hidden row is
     //      q_hb[bond] + q_hi[dst atom], summed while the GEMM stages its rows, so this launch depends on the projections
     //      only and runs before the coordinates of the previous layer are joined.
@@ -283,10 +314,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
           gemm_args(w.q1bl, nE, 0, 128, nE, LW(ll, DD_BL_W2q), LW(ll, DD_BL_b2q), LW(ll, DD_BL_lnq), w.qb, nE, 0, 128, 128, 0),
           gemm_args(w.P + 512, B * N, 0, 640, B * N, LW(ll, DD_NE_W2q), LW(ll, DD_NE_b2q), LW(ll, DD_NE_lnq), w.qn, B * N, 0, 128, 128, 0),
           gemm_args(w.PL + 512, B * NL, 0, 1280, B * NL, LW(ll, DD_NB_W2q), LW(ll, DD_NB_b2q), LW(ll, DD_NB_lnq), w.qlnb, B * NL, 0, 128, 128, 0)};
-      if (q1_in_gemm) {
-        j[0] = gemm_args(w.PB + 512, nE, 0, 640, nE, LW(ll, DD_BL_W2q), LW(ll, DD_BL_b2q), LW(ll, DD_BL_lnq), w.qb, nE, 0, 128, 128, 0);
-        j[0].X2 = w.PL + 1152; j[0].x2_N = NL; j[0].x2_Eb = (int)Eb; j[0].x2_NLm1 = NL - 1; j[0].x2_ld = 1280;
-      }
+      if (q1_in_gemm) return launch_queries_q1(s, w, ll, w.P, w.qn, sx);
       return launch_gemm128_batch(j, 3, sx);
     };
     // (schedule 3) the query GEMMs of this layer already ran on the side stream behind its projections
@@ -297,7 +325,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
         if (hipStreamWaitEvent(st, g_ev_join[l], 0) != hipSuccess) return DD_ERR_HIP;
         b1_joined = true;
       }
-      DD_TRYP(DD_PROF_GEMM, launch_b2(l, st));
+      if (!l0_here) DD_TRYP(DD_PROF_GEMM, launch_b2(l, st));
     }
     DD_TRY(flush_pos());                                 // previous layer's coordinate launch (side stream)
     if (pending_join >= 0) {
@@ -325,8 +353,9 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
       ne.np_real = nb.np_real = bl.np_real = s->np_real; ne.nl_real = nb.nl_real = bl.nl_real = s->nl_real;
       bl.bl_prefix = s->bl_prefix;
       ne.B = B; ne.NP = NP; ne.NL = NL; ne.K = K; ne.x = xcur; ne.nbr = w.nbr; ne.ew = w.ew;
-      ne.kd = w.P; ne.ks = w.P + 128; ne.vd = w.P + 256; ne.vs = w.P + 384; ne.ld_kd = ne.ld_ks = ne.ld_vd = ne.ld_vs = 640;
-      ne.q = w.qn; ne.Akp = LW(l, DD_NE_Akp); ne.Avp = LW(l, DD_NE_Avp); ne.lnk = LW(l, DD_NE_lnk); ne.lnv = LW(l, DD_NE_lnv);
+      const float* Pn = l0_here ? s->l0_P : w.P;
+      ne.kd = Pn; ne.ks = Pn + 128; ne.vd = Pn + 256; ne.vs = Pn + 384; ne.ld_kd = ne.ld_ks = ne.ld_vd = ne.ld_vs = 640;
+      ne.q = l0_here ? s->l0_qn : w.qn; ne.Akp = LW(l, DD_NE_Akp); ne.Avp = LW(l, DD_NE_Avp); ne.lnk = LW(l, DD_NE_lnk); ne.lnv = LW(l, DD_NE_lnv);
       ne.W2k = LW(l, DD_NE_W2k); ne.W2v = LW(l, DD_NE_W2v); ne.b2v = LW(l, DD_NE_b2v); ne.out = w.A;
       nb.B = B; nb.NP = NP; nb.NL = NL; nb.K = K; nb.x = xcur;
       nb.kd = w.PL; nb.ks = w.PL + 128; nb.vd = w.PL + 256; nb.vs = w.PL + 384; nb.ld_kd = nb.ld_ks = nb.ld_vd = nb.ld_vs = 1280;
@@ -655,7 +684,52 @@ extern "C" const char* dd_status_string(int status) {
 // 3: tab_v / tab_b carry the class log-prior after the four schedule rows
 // 4: step_counter is the [4] int32 run state (steps done, t_start, seed lo, seed hi) written by dd_sampler_reset
 // 5: np_real / nl_real / bl_prefix (padded heterogeneous batches) appended to dd_sampler
-extern "C" int dd_abi_version(void) { return 5; }
+extern "C" int dd_abi_version(void) { return 6; }
+
+// 6: l0_tables / l0_P / l0_qn (layer-0 tables) appended to dd_sampler
+extern "C" int dd_layer0_tables(const dd_sampler* m, float* tables, void* stream) {
+  if (!m || !tables || !m->weights || !m->slot_off || !m->workspace || !m->lig_v || !m->lig_aux || !m->lig_bond || !m->lig_pos)
+    return DD_ERR_BAD_ARG;
+  if (m->B != 1 || m->NP != 0 || m->NL != 16) return DD_ERR_BAD_ARG;
+  int rc = dd::check_shapes(m);
+  if (rc != DD_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  dd::Workspace w = dd::carve(m->workspace, 1, 0, 16, m->K);
+  const float* W = m->weights;
+  auto GW = [&](int slot) { return W + m->slot_off[(long)m->num_layers * DD_NUM_LAYER_SLOTS + slot]; };
+  rc = dd::launch_embed_all(m->protein_h, m->protein_pos, m->lig_pos, m->lig_v, m->lig_aux, GW(DD_G_W_lemb), GW(DD_G_b_lemb), 1, 0, 16,
+                            w.h, w.xa, w.xb, m->lig_bond, 240, GW(DD_G_W_bemb), GW(DD_G_b_bemb), w.hb, w.counters, st, nullptr);
+  if (rc != DD_OK) return rc;
+  if ((rc = dd::launch_projections1(m, w, 0, w.h, w.P, st)) != DD_OK) return rc;
+  if ((rc = dd::launch_queries_q1(m, w, 0, w.P, w.qn, st)) != DD_OK) return rc;
+  // atom i has combination i; bonds dst*15 + s have type s % 5 (s < 5: type s)
+  auto cp = [&](float* dst, const float* src, size_t n) {
+    return hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess;
+  };
+  bool ok = cp(tables, w.P, 16 * 640) && cp(tables + 16 * 640, w.PL, 16 * 1280) && cp(tables + 16 * 640 + 16 * 1280, w.PB, 5 * 640);
+  float* tq = tables + 16 * 640 + 16 * 1280 + 5 * 640;
+  ok = ok && cp(tq, w.qn, 16 * 128) && cp(tq + 16 * 128, w.qlnb, 16 * 128);
+  for (int c = 0; c < 16 && ok; ++c) ok = cp(tq + 32 * 128 + (size_t)c * 5 * 128, w.qb + (size_t)c * 15 * 128, 5 * 128);
+  return ok ? DD_OK : DD_ERR_HIP;
+}
+
+extern "C" int dd_layer0_prepare(const dd_sampler* s, void* stream) {
+  if (!s || !s->weights || !s->slot_off || !s->l0_P || !s->l0_qn) return DD_ERR_BAD_ARG;
+  if (s->NP <= 0) return DD_OK;
+  if (!s->protein_h) return DD_ERR_BAD_ARG;
+  const int B = s->B, NP = s->NP, N = s->NP + s->NL;
+  const float* W = s->weights;
+  auto LW = [&](int l, int slot) { return W + s->slot_off[(long)l * DD_NUM_LAYER_SLOTS + slot]; };
+  using dd::gemm_args;
+  // the protein rows of the layer-0 node projections and node queries: same GEMM tile code, rows mapped into the [B, N] tables
+  dd::GemmArgs g1 = gemm_args(s->protein_h, NP, (long)NP * 128, 128, B * NP, LW(0, DD_W_n1), LW(0, DD_b_n1), nullptr, s->l0_P, NP,
+                              (long)N * 640, 640, 640, 0);
+  int rc = dd::launch_gemm128_batch(&g1, 1, (hipStream_t)stream);
+  if (rc != DD_OK) return rc;
+  dd::GemmArgs g2 = gemm_args(s->l0_P + 512, NP, (long)N * 640, 640, B * NP, LW(0, DD_NE_W2q), LW(0, DD_NE_b2q), LW(0, DD_NE_lnq),
+                              s->l0_qn, NP, (long)N * 128, 128, 128, 0);
+  return dd::launch_gemm128_batch(&g2, 1, (hipStream_t)stream);
+}
 
 extern "C" int dd_sampler_reset(const dd_sampler* s, void* stream) {
   if (!s || !s->step_counter) return DD_ERR_BAD_ARG;
@@ -1012,6 +1086,7 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 0) return dd_debug_set_fusion(value);
   if (key == 1) { dd::g_gemm_ksplit = value ? 1 : 0; return DD_OK; }
   if (key == 3) { dd::g_attn_persist = value ? 1 : 0; return DD_OK; }
+  if (key == 22) { dd::g_l0_tables = value ? 1 : 0; return DD_OK; }
   if (key == 21) { dd::g_gemm_xcd = value ? 1 : 0; return DD_OK; }
   if (key == 20) { dd::g_step_fold = value ? 1 : 0; return DD_OK; }
   if (key == 19) { dd::g_xup_in_asm = value ? 1 : 0; return DD_OK; }

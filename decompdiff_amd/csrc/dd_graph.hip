@@ -217,6 +217,49 @@ __global__ __launch_bounds__(256) void k_embed_all(const float* __restrict__ pro
   }
 }
 
+// --------------------------------------------------------------------------- layer-0 rows from tables
+// One thread per float4 of an output row.  Ligand atom a = b*NL + i with combination c = 8*(arm flag) + class:
+//   l0_P[b*N + NP + i] = TN[c] (640), PL[a] = TL[c] (1280), l0_qn[b*N + NP + i] = TQN[c], qlnb[a] = TQL[c];
+// bond e = b*Eb + t*(NL-1) + s' of type ty with destination atom t:  PB[e] = TB[ty] (640), qb[e] = TQB[c(t)][ty].
+constexpr int L0_TN = 0, L0_TL = 16 * 640, L0_TB = L0_TL + 16 * 1280, L0_TQN = L0_TB + 5 * 640, L0_TQL = L0_TQN + 16 * 128,
+              L0_TQB = L0_TQL + 16 * 128;
+__global__ __launch_bounds__(256) void k_layer0_rows(const float* __restrict__ tab, const int32_t* __restrict__ lig_v,
+                                                     const float* __restrict__ lig_aux, const int32_t* __restrict__ bond, int B,
+                                                     int NP, int NL, float* __restrict__ l0_P, float* __restrict__ PL,
+                                                     float* __restrict__ l0_qn, float* __restrict__ qlnb, float* __restrict__ PB,
+                                                     float* __restrict__ qb, long atom_f4) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int N = NP + NL, Eb = NL * (NL - 1);
+  auto combo = [&](long a) { return (lig_aux[2 * a + 1] > 0.5f ? 8 : 0) + lig_v[a]; };
+  const float4* t4 = reinterpret_cast<const float4*>(tab);
+  if (idx < atom_f4) {
+    constexpr int PER = 160 + 320 + 32 + 32;             // float4 per atom: 640 + 1280 + 128 + 128 floats
+    const long a = idx / PER;
+    const int k = (int)(idx % PER);
+    const int b = (int)(a / NL), i = (int)(a % NL);
+    const int c = combo(a);
+    const long node = (long)b * N + NP + i;
+    if (k < 160) reinterpret_cast<float4*>(l0_P + node * 640)[k] = t4[(L0_TN + c * 640) / 4 + k];
+    else if (k < 480) reinterpret_cast<float4*>(PL + a * 1280)[k - 160] = t4[(L0_TL + c * 1280) / 4 + (k - 160)];
+    else if (k < 512) reinterpret_cast<float4*>(l0_qn + node * 128)[k - 480] = t4[(L0_TQN + c * 128) / 4 + (k - 480)];
+    else reinterpret_cast<float4*>(qlnb + a * 128)[k - 512] = t4[(L0_TQL + c * 128) / 4 + (k - 512)];
+    return;
+  }
+  constexpr int PERB = 160 + 32;                         // float4 per bond: 640 + 128 floats
+  const long j = idx - atom_f4;
+  const long e = j / PERB;
+  if (e >= (long)B * Eb) return;
+  const int k = (int)(j % PERB);
+  const int ty = bond[e];
+  if (k < 160) {
+    reinterpret_cast<float4*>(PB + e * 640)[k] = t4[(L0_TB + ty * 640) / 4 + k];
+  } else {
+    const int b = (int)(e / Eb), t = (int)((e % Eb) / (NL - 1));
+    const int c = combo((long)b * NL + t);
+    reinterpret_cast<float4*>(qb + e * 128)[k - 160] = t4[(L0_TQB + (c * 5 + ty) * 128) / 4 + (k - 160)];
+  }
+}
+
 // --------------------------------------------------------------------------- bond-layer assemble
 // For bond edge e = (src s -> dst t) of sample b (dst-major id e = t*(NL-1) + s'):
 //   Ek[e] = PB.k_hb[e] + Wg1k . G(d_e) + PL[s].k_hk + PL[t].k_hj        (b1 folded into PB bias)
@@ -388,6 +431,14 @@ int launch_embed_all(const float* protein_h, const float* protein_pos, const flo
   const int node_blocks = (int)((nn + 255) / 256), bond_blocks = (int)((nb + 255) / 256);
   hipLaunchKernelGGL(k_embed_all, dim3(node_blocks + bond_blocks), dim3(256), 0, st, protein_h, protein_pos, lig_pos, lig_v, lig_aux,
                      Wl, bl, B, NP, NL, h, xa, xb, bond, bond_rows, Wb, bb, hb, counters, node_blocks, advance);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+int launch_layer0_rows(const float* tables, const int32_t* lig_v, const float* lig_aux, const int32_t* bond, int B, int NP, int NL,
+                       float* l0_P, float* PL, float* l0_qn, float* qlnb, float* PB, float* qb, hipStream_t st) {
+  const long atom_f4 = (long)B * NL * (160 + 320 + 32 + 32), bond_f4 = (long)B * NL * (NL - 1) * (160 + 32);
+  hipLaunchKernelGGL(k_layer0_rows, dim3((unsigned)((atom_f4 + bond_f4 + 255) / 256)), dim3(256), 0, st, tables, lig_v, lig_aux, bond,
+                     B, NP, NL, l0_P, PL, l0_qn, qlnb, PB, qb, atom_f4);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }

@@ -43,6 +43,9 @@ int launch_edge_weights(const float* x, const int32_t* nbr, int B, int N, int K,
 int launch_bl_assemble(const float* x, const float* PB, const float* PL, const float* Wgp, int B, int NP, int NL, float* Ek, float* Ev,
                        float* q1, float* Rk, float* Rv, hipStream_t st, const float* xprev = nullptr, const float* dxe = nullptr,
                        const float* dxb = nullptr, float* xout = nullptr);
+// layer-0 rows of the ligand atoms / bonds gathered from dd_sampler.l0_tables (see include/decompdiff_hip.h)
+int launch_layer0_rows(const float* tables, const int32_t* lig_v, const float* lig_aux, const int32_t* bond, int B, int NP, int NL,
+                       float* l0_P, float* PL, float* l0_qn, float* qlnb, float* PB, float* qb, hipStream_t st);
 int launch_extract_ligand(const float* x, int B, int NP, int NL, float* out, hipStream_t st);
 
 enum { M_NE = 0, M_NB = 1, M_BL = 2, M_PE = 3, M_PB = 4 };

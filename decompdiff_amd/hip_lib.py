@@ -25,6 +25,7 @@ EXPORTED_SYMBOLS = [
     "dd_drift_clash", "dd_workspace_view", "dd_profile_step", "dd_debug_set_clock_buffer", "dd_debug_set_fusion", "dd_debug_set_option", "dd_debug_node_split",
     "dd_attn_aggregate_node", "dd_attn_aggregate_triplet", "dd_attn_aggregate_pos", "dd_reverse_step", "dd_debug_philox",
     "dd_segment_reduce", "dd_segment_softmax", "dd_sampler_reset", "dd_debug_options_epoch",
+    "dd_layer0_tables", "dd_layer0_prepare",
 ]
 
 
@@ -47,7 +48,11 @@ class DDSampler(ctypes.Structure):
         ("pred_pos", c_void_p), ("pred_v", c_void_p), ("pred_bond", c_void_p),
         ("workspace", c_void_p), ("workspace_floats", c_size_t),
         ("np_real", c_void_p), ("nl_real", c_void_p), ("bl_prefix", c_void_p),
+        ("l0_tables", c_void_p), ("l0_P", c_void_p), ("l0_qn", c_void_p),
     ]
+
+
+L0_TABLE_FLOATS = 16 * 640 + 16 * 1280 + 5 * 640 + 16 * 128 + 16 * 128 + 80 * 128      # DD_L0_TABLE_FLOATS
 
 
 class DDWsView(ctypes.Structure):
@@ -58,7 +63,7 @@ class DDWsView(ctypes.Structure):
 PROF_CATS = ["misc", "gemm", "assemble", "attn_NE", "attn_NB", "attn_BL", "attn_PE", "attn_PB", "step", "event_pair"]
 
 
-ABI_VERSION = 5          # include/decompdiff_hip.h: layout of struct dd_sampler and of the tables it points to
+ABI_VERSION = 6          # include/decompdiff_hip.h: layout of struct dd_sampler and of the tables it points to
 
 
 class HipLibraryError(RuntimeError):
@@ -95,6 +100,8 @@ def load():
     lib.dd_embed_protein.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.dd_forward.argtypes = [POINTER(DDSampler), c_void_p]
     lib.dd_sampler_reset.argtypes = [POINTER(DDSampler), c_void_p]
+    lib.dd_layer0_tables.argtypes = [POINTER(DDSampler), c_void_p, c_void_p]
+    lib.dd_layer0_prepare.argtypes = [POINTER(DDSampler), c_void_p]
     lib.dd_debug_options_epoch.argtypes = []
     lib.dd_sample_steps.argtypes = [POINTER(DDSampler), c_int, c_void_p]
     lib.dd_sample_steps_graph.argtypes = [POINTER(DDSampler), c_int, c_void_p]

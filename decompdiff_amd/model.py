@@ -208,6 +208,39 @@ class DecompScorePosNet3D(nn.Module):
         return self._packed
 
 
+    def _layer0_tables(self, pw, dev):
+        """dd_sampler.l0_tables for this weight set (built once): the first layer's projection / query rows of the 16
+        (class, arm flag) combinations of a ligand atom and of the 5 x 16 (bond type, destination combination) pairs,
+        produced by the forward's own embedding / projection / query kernels on a 16-atom problem (dd_layer0_tables)."""
+        if "l0_tables" in pw:
+            return pw["l0_tables"]
+        pw["l0_tables"] = None
+        if os.environ.get("DD_LAYER0_TABLES", "1") == "0" or self.num_classes != 8 or self.num_bond_classes != 5:
+            return None
+        lib = hip_lib.load()
+        NL, K = 16, 15
+        z = lambda *shape, dtype=torch.float32: torch.zeros(*shape, dtype=dtype, device=dev)
+        i = torch.arange(NL, device=dev)
+        keep = {"lig_pos": z(NL, 3), "lig_v": (i % 8).to(torch.int32).contiguous(),
+                "lig_aux": torch.stack([(i < 8).float(), (i >= 8).float()], 1).contiguous(),
+                "lig_bond": (torch.arange(NL - 1, device=dev) % 5).repeat(NL).to(torch.int32).contiguous(),
+                "protein": z(4)}
+        ws_floats = int(lib.dd_workspace_floats(1, 0, NL, K))
+        keep["workspace"] = z(ws_floats)
+        sm = hip_lib.DDSampler()
+        sm.B, sm.NP, sm.NL, sm.K, sm.NF = 1, 0, NL, K, 0
+        sm.num_layers, sm.T = int(self.config.num_layers), int(self.betas.numel())
+        sm.weights, sm.slot_off = pw["arena"].data_ptr(), pw["offsets"].ctypes.data
+        sm.protein_pos = sm.protein_h = keep["protein"].data_ptr()
+        for k in ("lig_pos", "lig_v", "lig_aux", "lig_bond", "workspace"):
+            setattr(sm, k, keep[k].data_ptr())
+        sm.workspace_floats = ws_floats
+        tables = z(hip_lib.L0_TABLE_FLOATS)
+        hip_lib.check(lib.dd_layer0_tables(ctypes.byref(sm), hip_lib.ptr(tables), hip_lib.stream_ptr(dev)), "dd_layer0_tables")
+        torch.cuda.current_stream(dev).synchronize()           # (the 16-atom problem's buffers die with this frame)
+        pw["l0_tables"] = tables
+        return tables
+
     # ------------------------------------------------------------------------------------------
     # Ragged batches (samples with different atom counts, SURVEY.md 8f-1).  Every sample's chain is independent of the
     # rest of its batch (all graph ops of the reference are segmented by `batch`; tests/test_gpu_parity.py checks that
@@ -479,12 +512,14 @@ class DecompScorePosNet3D(nn.Module):
                 or ligand_v.shape != (n_l,) or ligand_v_aux.shape[0] != n_l:
             raise ValueError("per-atom tensors do not match the batch vectors")
         # class ids out of range: the reference's index_to_log_onehot asserts (transitions.py:66)
-        lo_v, hi_v, lo_b, hi_b = torch.stack([ligand_v.min(), ligand_v.max(), ligand_bond_type.min().to(ligand_v.dtype),
-                                              ligand_bond_type.max().to(ligand_v.dtype)]).tolist()      # (one sync)
+        aux_ok = (((ligand_v_aux == 0) | (ligand_v_aux == 1)).all() & (ligand_v_aux.sum(-1) == 1).all()).to(ligand_v.dtype)
+        lo_v, hi_v, lo_b, hi_b, aux_ok = torch.stack([ligand_v.min(), ligand_v.max(), ligand_bond_type.min().to(ligand_v.dtype),
+                                                      ligand_bond_type.max().to(ligand_v.dtype), aux_ok]).tolist()   # (one sync)
         assert lo_v >= 0 and hi_v < self.num_classes, f"Error: {hi_v} >= {self.num_classes}"
         assert lo_b >= 0 and hi_b < self.num_bond_classes, f"Error: {hi_b} >= {self.num_bond_classes}"
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
-        return dict(B=B, NP=NP, NL=NL, protein_pos=f32(protein_pos).view(B, NP, 3), protein_v=f32(protein_v).view(B, NP, -1),
+        return dict(B=B, NP=NP, NL=NL, aux_onehot=bool(aux_ok),
+                    protein_pos=f32(protein_pos).view(B, NP, 3), protein_v=f32(protein_v).view(B, NP, -1),
                     ligand_pos=f32(ligand_pos).view(B, NL, 3), ligand_v=ligand_v.detach().to(torch.int32).contiguous(),
                     ligand_aux=f32(ligand_v_aux).view(B, NL, -1),
                     bond=ligand_bond_type.detach().to(torch.int32).contiguous())
@@ -598,6 +633,8 @@ class DecompScorePosNet3D(nn.Module):
             bufs["pred_pos"], bufs["pred_v"], bufs["pred_bond"] = z(B * NL, 3), z(B * NL, 8), z(B * Eb, 5)
             ws_floats = int(lib.dd_workspace_floats(B, NP, NL, K))
             bufs["workspace"] = z(ws_floats)
+            if masks is None and self._layer0_tables(pw, dev) is not None:     # layer-0 tables (dd_sampler.l0_*)
+                bufs["l0_P"], bufs["l0_qn"] = z(B * N, 640), z(B * N, 128)
             if keep_traj and n_steps > 0:
                 bufs["traj_pos"] = z(cap, B * NL, 3)
                 bufs["traj_v"] = z(cap, B * NL, dtype=torch.int32)
@@ -643,6 +680,11 @@ class DecompScorePosNet3D(nn.Module):
                 if tuple(t.shape) != shp:
                     raise ValueError(f"noise['{k}'] must have shape {shp}, got {tuple(t.shape)}")
                 bufs[k] = t.to(device=dev, dtype=torch.float32).contiguous()
+        # layer-0 tables: only for arm / scaffold indicator rows that are exactly (1,0) or (0,1) (d["aux_onehot"])
+        use_l0 = bufs.get("l0_P") is not None and bool(d.get("aux_onehot", False))
+        sm.l0_tables = self._layer0_tables(pw, dev).data_ptr() if use_l0 else None
+        sm.l0_P = bufs["l0_P"].data_ptr() if use_l0 else None
+        sm.l0_qn = bufs["l0_qn"].data_ptr() if use_l0 else None
         sm.t_start = int(t_start)
         sm.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         for k in ("protein_pos", "protein_h", "lig_aux", "atom_std", "offset", "decomp_index", "full_protein_pos",
@@ -667,11 +709,13 @@ class DecompScorePosNet3D(nn.Module):
             else:
                 raise ValueError(dr["type"])
         sm.drift_norm_batch = int(drift_norm_batch)
+        if use_l0:                                         # protein rows of the layer-0 tables (this chain's pocket)
+            hip_lib.check(lib.dd_layer0_prepare(ctypes.byref(sm), hip_lib.stream_ptr(dev)), "dd_layer0_prepare")
         if n_steps > 0:
             hip_lib.check(lib.dd_sampler_reset(ctypes.byref(sm), hip_lib.stream_ptr(dev)), "dd_sampler_reset")
         # everything that shapes the captured step graph besides the (cached) pointers
         ent["sig"] = (sm.drift_armsca, sm.armsca_min_d, sm.armsca_max_d, sm.armsca_scale, sm.drift_clash, sm.clash_sigma,
-                      sm.clash_gamma, sm.clash_scale, sm.drift_norm_batch, int(lib.dd_debug_options_epoch()))
+                      sm.clash_gamma, sm.clash_scale, sm.drift_norm_batch, int(lib.dd_debug_options_epoch()), bool(use_l0))
         if cacheable:
             cache[key] = ent                               # (re-inserted: most recently used last)
             self._evict_chain_cache(self._CACHE_MAX)

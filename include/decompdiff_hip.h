@@ -131,7 +131,27 @@ typedef struct dd_sampler {
   const int32_t* nl_real;          /* [B] or NULL */
   const int32_t* bl_prefix;        /* [B+1] prefix sums of nl_real*(nl_real-1) (compact enumeration of the real
                                       bond-layer segments); required when nl_real is given */
+  /* Layer-0 tables (optional; all three NULL = off).  The first layer's projections and query rows are functions of the
+   * embedded inputs alone: a ligand atom's rows depend on its (class, arm flag) -- 16 combinations -- a bond's on its
+   * type (5) and its destination atom's combination, and the protein rows are the same in every step of a chain.  With
+   * the tables set, a step gathers those rows instead of running the first layer's projection and query GEMMs
+   * (models/common.py:85-105 MLP first Linear + the query MLPs of uni_transformer_edge.py:42-167).  Requires
+   * lig_aux rows to be exactly (1,0) or (0,1) (utils/transforms.py arm / scaffold indicator) and a dense batch. */
+  const float* l0_tables;          /* [DD_L0_TABLE_FLOATS], device; filled by dd_layer0_tables() once per weight set */
+  float* l0_P;                     /* [B,N,640] layer-0 node projections; protein rows by dd_layer0_prepare() */
+  float* l0_qn;                    /* [B,N,128] layer-0 node queries; protein rows by dd_layer0_prepare() */
 } dd_sampler;
+
+/* Layout of l0_tables (floats): node projections [16][640], ligand projections [16][1280], bond projections [5][640],
+ * node queries [16][128], node-with-bond queries [16][128], bond-layer queries [16 dst combinations][5 types][128].
+ * Combination = 8 * (arm flag) + class. */
+#define DD_L0_TABLE_FLOATS (16 * 640 + 16 * 1280 + 5 * 640 + 16 * 128 + 16 * 128 + 80 * 128)
+/* Build the tables: `mini` is a sampler with B = 1, NP = 0, NL = 16, K = 15 whose lig_v[i] = i % 8, lig_aux[i] = (i < 8 ?
+ * (1,0) : (0,1)) and lig_bond[dst * 15 + s] = s % 5, with the model's weights and its own workspace; the SAME embedding,
+ * projection and query kernels the forward uses run on it, so a gathered row equals the GEMM's row bit for bit. */
+int dd_layer0_tables(const dd_sampler* mini, float* tables, void* stream);
+/* Per chain (after protein_h is in place): the protein rows of s->l0_P and s->l0_qn. */
+int dd_layer0_prepare(const dd_sampler* s, void* stream);
 
 const char* dd_status_string(int status);
 int dd_abi_version(void);

@@ -348,3 +348,37 @@ def test_static_input_memo_is_invalidated_by_in_place_changes():
 
 def to_dev_local(batch):
     return {k: (v.to(dev()) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+def test_layer0_tables_are_bit_identical_to_the_gemms():
+    """dd_sampler.l0_tables: the first layer's projection / query rows gathered from tables (16 atom combinations, 5 x 16
+    bond combinations, static protein rows) instead of two GEMM launches -- same kernels built the tables, so forward and
+    chain are bit-identical with the option off; rows that are not exactly one-hot in the arm flag switch them off."""
+    lib = hip_lib.load()
+    m = model(0)
+    torch.manual_seed(9)
+    pocket = synth.make_pocket_small(4)
+    b = to_dev_local(synth.build_sampling_batch(pocket, 3))
+    names = ["protein_pos", "protein_v", "batch_protein", "protein_group_idx", "init_ligand_pos", "init_ligand_v", "batch_ligand",
+             "ligand_group_idx", "prior_centers", "prior_stds", "batch_prior", "prior_group_idx", "ligand_fc_bond_index",
+             "init_ligand_fc_bond_type"]
+    fwd = lambda bb: m(init_ligand_v_aux=bb["ligand_v_aux"], **{n: bb[n] for n in names})
+    try:
+        on = fwd(b)
+        assert m._last[0].l0_tables                      # tables in use
+        chain_on = m.sample_diffusion(num_steps=5, center_pos_mode="protein", energy_drift_opt=GU.DRIFT, seed=5, **b)
+        assert lib.dd_debug_set_option(22, 0) == 0
+        off = fwd(b)
+        chain_off = m.sample_diffusion(num_steps=5, center_pos_mode="protein", energy_drift_opt=GU.DRIFT, seed=5, **b)
+    finally:
+        assert lib.dd_debug_set_option(22, 1) == 0
+    for k in ("pred_ligand_pos", "pred_ligand_v", "pred_bond"):
+        assert torch.equal(on[k], off[k]), k
+    for k in ("pos", "v", "bond"):
+        assert torch.equal(chain_on[k], chain_off[k]), k
+    assert all(torch.equal(x, y) for x, y in zip(chain_on["pos_traj"], chain_off["pos_traj"]))
+    soft = dict(b)
+    soft["ligand_v_aux"] = b["ligand_v_aux"] * 0.75 + 0.125          # not an indicator any more: GEMM path
+    r = fwd(soft)
+    assert not m._last[0].l0_tables and torch.isfinite(r["pred_ligand_pos"]).all()
+    assert not torch.equal(r["pred_ligand_v"], on["pred_ligand_v"])
