@@ -112,16 +112,20 @@ def algorithmic_flops_node_launch(B, NP, NL, K):
     return 2.0 * (e * 2 * (21 * 128 + 128 * 128) + eb * 2 * (128 * 128) + e3 * 2 * (13 * 128 + 128 * 128))
 
 
-def gemm_work_per_step(B, NP, NL, num_layers):
-    """(useful FLOPs, 64x64 output tiles) of the dense GEMM launches of one step (dd_api.hip forward_impl)."""
+def gemm_work_per_step(B, NP, NL, num_layers, layer0_tables=True):
+    """(useful FLOPs, 64x64 output tiles) of the dense GEMM launches of one step (dd_api.hip forward_impl).  With the
+    layer-0 tables (dd_sampler.l0_tables) the first layer's projection and query launches do not run."""
     N, Eb = NP + NL, NL * (NL - 1)
-    per_layer = [(B * N, 640), (B * NL, 1280), (B * Eb, 640),                 # projections of the old h / h_bond
-                 (B * Eb, 128), (B * N, 128), (B * NL, 128),                  # query MLPs, second Linear
-                 (B * N, 128), (B * Eb, 256),                                 # lin_node, bond projections (coordinates)
-                 (B * N, 256), (B * NL, 1024)]                                # projections of the new h
+    first = [(B * N, 640), (B * NL, 1280), (B * Eb, 640),                     # projections of the old h / h_bond
+             (B * Eb, 128), (B * N, 128), (B * NL, 128)]                      # query MLPs, second Linear
+    rest = [(B * N, 128), (B * Eb, 256),                                      # lin_node, bond projections (coordinates)
+            (B * N, 256), (B * NL, 1024)]                                     # projections of the new h
     heads = [(B * Eb, 128), (B * NL, 128)]
+    jobs = (first + rest) * num_layers + heads
+    if layer0_tables:
+        jobs = jobs[len(first):]
     flops = tiles = 0
-    for rows, cols in per_layer * num_layers + heads:
+    for rows, cols in jobs:
         flops += 2.0 * rows * 128 * cols
         tiles += ((rows + 63) // 64) * ((cols + 63) // 64)
     return flops, tiles
@@ -294,7 +298,7 @@ def measure_step_rooflines(torch, model, hip_lib, lib, state, cfg, B, NP, NL, K,
                 "The kernel is fused: q / k / v never touch HBM, so it is priced against the fp32 MFMA peak, not HBM.",
         "ms_per_step_by_launch_class": {k: round(v, 4) for k, v in per_cat.items()},
     }
-    g_flops, g_tiles = gemm_work_per_step(B, NP, NL, L)
+    g_flops, g_tiles = gemm_work_per_step(B, NP, NL, L, layer0_tables=bool(s2.l0_tables))
     g_ms = per_cat["gemm"]
     roofline_gemm = {"bound": "mfma", "kernel": "dd::k_gemm128_batch (projection / query / lin_node / head GEMMs, serialised)",
                      "flops_per_step": g_flops, "tiles_64x64_per_step": g_tiles, "ms_per_step": round(g_ms, 4),

@@ -474,7 +474,7 @@ class DecompScorePosNet3D(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def _dense_inputs(self, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, ligand_v_aux, batch_ligand,
-                      ligand_fc_bond_index, ligand_bond_type, ligand_atom_mask, layout=None):
+                      ligand_fc_bond_index, ligand_bond_type, ligand_atom_mask, layout=None, aux_onehot=None):
         """Flat PyG-style batch -> dense [B, ...] tensors (validated, no arithmetic).  ``layout`` = (B, NP, NL) already
         established for these very batch-vector / bond-list tensors by an earlier call: their checks are skipped."""
         for name, t in (("protein_pos", protein_pos), ("ligand_pos", ligand_pos)):
@@ -512,9 +512,13 @@ class DecompScorePosNet3D(nn.Module):
                 or ligand_v.shape != (n_l,) or ligand_v_aux.shape[0] != n_l:
             raise ValueError("per-atom tensors do not match the batch vectors")
         # class ids out of range: the reference's index_to_log_onehot asserts (transitions.py:66)
-        aux_ok = (((ligand_v_aux == 0) | (ligand_v_aux == 1)).all() & (ligand_v_aux.sum(-1) == 1).all()).to(ligand_v.dtype)
-        lo_v, hi_v, lo_b, hi_b, aux_ok = torch.stack([ligand_v.min(), ligand_v.max(), ligand_bond_type.min().to(ligand_v.dtype),
-                                                      ligand_bond_type.max().to(ligand_v.dtype), aux_ok]).tolist()   # (one sync)
+        # (aux_onehot: the arm / scaffold indicator rows are exactly (1,0) or (0,1) -- the layer-0 tables need that)
+        vals = [ligand_v.min(), ligand_v.max(), ligand_bond_type.min().to(ligand_v.dtype), ligand_bond_type.max().to(ligand_v.dtype)]
+        if aux_onehot is None:
+            vals.append((((ligand_v_aux == 0) | (ligand_v_aux == 1)).all() & (ligand_v_aux.sum(-1) == 1).all()).to(ligand_v.dtype))
+        res = torch.stack(vals).tolist()                                                                   # (one sync)
+        lo_v, hi_v, lo_b, hi_b = res[:4]
+        aux_ok = bool(res[4]) if aux_onehot is None else bool(aux_onehot)
         assert lo_v >= 0 and hi_v < self.num_classes, f"Error: {hi_v} >= {self.num_classes}"
         assert lo_b >= 0 and hi_b < self.num_bond_classes, f"Error: {hi_b} >= {self.num_bond_classes}"
         f32 = lambda t: t.detach().to(torch.float32).contiguous()
@@ -842,7 +846,7 @@ class DecompScorePosNet3D(nn.Module):
             num_steps = self.num_timesteps
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
-        key_t = (protein_pos, batch_protein, batch_ligand, ligand_fc_bond_index)
+        key_t = (protein_pos, batch_protein, batch_ligand, ligand_fc_bond_index, ligand_v_aux)
         static = self._static_memo_get(key_t, center_pos_mode)        # (only dense batches are remembered)
         if static is None and self._is_ragged(batch_protein, batch_ligand):
             return self._sample_heterogeneous(
@@ -877,7 +881,8 @@ class DecompScorePosNet3D(nn.Module):
         ``static``: what an earlier call with the same pocket / batch-vector tensors established (_static_memo_get)."""
         d = self._dense_inputs(protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, ligand_v_aux,
                                batch_ligand, ligand_fc_bond_index, init_ligand_fc_bond_type, ligand_atom_mask,
-                               layout=None if static is None else static["layout"])
+                               layout=None if static is None else static["layout"],
+                               aux_onehot=None if static is None else static["aux_onehot"])
         dev = d["protein_pos"].device
         B, NP, NL = d["B"], d["NP"], d["NL"]
         # center_pos (decompdiff.py:20-32): subtract the per-sample protein centroid
@@ -915,7 +920,8 @@ class DecompScorePosNet3D(nn.Module):
         s, bufs, ent = self._make_sampler(d, pw, num_steps, t_start, noise, keep_traj, energy_drift_opt, atom_std,
                                           offset.contiguous(), decomp, fpp, seed, drift_norm_batch)
         return dict(s=s, bufs=bufs, offset=offset, B=B, NL=NL, dev=dev, ent=ent,
-                    static=dict(layout=(B, NP, NL), offset=offset, protein_pos_centered=d["protein_pos_centered"]))
+                    static=dict(layout=(B, NP, NL), offset=offset, protein_pos_centered=d["protein_pos_centered"],
+                                aux_onehot=d["aux_onehot"]))
 
     def _run_chains(self, chains, num_steps, use_graph):
         """Advance every prepared chain by ``num_steps``.  One chain: the captured step graph replayed on a dedicated
