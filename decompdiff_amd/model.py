@@ -381,7 +381,10 @@ class DecompScorePosNet3D(nn.Module):
         return out
 
     def _sample_ragged(self, kw, ligand_atom_mask, num_steps, center_pos_mode, energy_drift_opt, noise, seed, keep_traj,
-                       use_graph, concurrent=None, start_step=0):
+                       use_graph, concurrent=None, start_step=0, split=1):
+        """One dense chain per group of samples of equal size.  ``split`` > 1 additionally cuts every group into that many
+        sub-batches (measurement aid, tools/split_bench.py: two concurrent half-batches were measured slower than one
+        chain)."""
         _check_ligand_atom_mask(ligand_atom_mask, kw["batch_ligand"].numel())
         dev = kw["protein_pos"].device
         bp, bl, bpr = kw["batch_protein"], kw["batch_ligand"], kw["batch_prior"]
@@ -404,14 +407,14 @@ class DecompScorePosNet3D(nn.Module):
         o_p, o_l, o_pr, o_b, o_f = off(n_p), off(n_l), off(n_pr), off(n_b), off(n_f)
         groups: Dict[tuple, list] = {}
         for b in range(B):
-            groups.setdefault((n_p[b], n_l[b], n_pr[b], n_f[b]), []).append(b)
+            groups.setdefault((n_p[b], n_l[b], n_pr[b], n_f[b], (b * split) // B), []).append(b)
         n_lig, n_bond = sum(n_l), sum(n_b)
         out = {"pos": torch.empty(n_lig, 3, device=dev), "v": torch.empty(n_lig, dtype=torch.long, device=dev),
                "bond": torch.empty(n_bond, dtype=torch.long, device=dev)}
         traj: Dict[str, Optional[torch.Tensor]] = {k: None for k in ("pos_traj", "v_traj", "bond_traj", "v0_traj", "vt_traj", "bt_traj")}
         rng = lambda o, c, ids: torch.cat([torch.arange(o[b], o[b] + c[b]) for b in ids])
         prepared = []
-        for gi, ((np_, nl_, npr_, nf_), ids) in enumerate(sorted(groups.items(), key=lambda kv: kv[1][0])):
+        for gi, ((np_, nl_, npr_, nf_, _part), ids) in enumerate(sorted(groups.items(), key=lambda kv: kv[1][0])):
             G = len(ids)
             r_p, r_l, r_pr, r_b = rng(o_p, n_p, ids), rng(o_l, n_l, ids), rng(o_pr, n_pr, ids), rng(o_b, n_b, ids)
             d_p, d_l, d_pr, d_b = r_p.to(dev), r_l.to(dev), r_pr.to(dev), r_b.to(dev)
@@ -445,7 +448,8 @@ class DecompScorePosNet3D(nn.Module):
                 sub["ligand_v_aux"], sub["batch_ligand"], sub["prior_stds"], sub["ligand_decomp_batch"],
                 sub["ligand_decomp_index"], None, sub["ligand_fc_bond_index"], sub["init_ligand_fc_bond_type"], num_steps,
                 center_pos_mode, energy_drift_opt, sub.get("full_protein_pos"), sub.get("full_batch_protein"), sub_noise,
-                seed + 7919 * gi, keep_traj, B, start_step)        # (the armsca loss is averaged over the whole batch)
+                seed + 7919 * gi, keep_traj, B, start_step,        # (the armsca loss is averaged over the whole batch)
+                cache_slot=_part)                                  # (sub-batches of one shape: own cached buffers each)
             prepared.append((chain, d_l, d_b, r_l, r_b))
         if concurrent is None:
             # measured on MI355X (tools/ragged_bench.py): with the runtime's default 4 hardware queues the
@@ -603,7 +607,7 @@ class DecompScorePosNet3D(nn.Module):
         return memo[key]
 
     def _make_sampler(self, d, pw, n_steps, t_start, noise, keep_traj, drift, atom_std, offset, decomp_index,
-                      full_protein_pos, seed, drift_norm_batch=0, masks=None):
+                      full_protein_pos, seed, drift_norm_batch=0, masks=None, cache_slot=0):
         lib = hip_lib.load()
         dev = d["protein_pos"].device
         B, NP, NL = d["B"], d["NP"], d["NL"]
@@ -617,7 +621,7 @@ class DecompScorePosNet3D(nn.Module):
         if cacheable and keep_traj:
             cap = max(32, 1 << (int(n_steps) - 1).bit_length())        # trajectory capacity: 5 and 20 steps share buffers
         key = (str(dev), B, NP, NL, K, NF, cap if keep_traj else 0, bool(keep_traj), decomp_index is not None, arena.data_ptr(),
-               masks is not None)
+               masks is not None, int(cache_slot))     # cache_slot: chains of ONE call that share a shape need separate buffers
         cache = DecompScorePosNet3D._chain_cache
         ent = cache.pop(key, None) if cacheable else None
         if ent is None:
@@ -876,7 +880,7 @@ class DecompScorePosNet3D(nn.Module):
                        batch_ligand, prior_stds, ligand_decomp_batch, ligand_decomp_index, ligand_atom_mask,
                        ligand_fc_bond_index, init_ligand_fc_bond_type, num_steps, center_pos_mode, energy_drift_opt,
                        full_protein_pos, full_batch_protein, noise, seed, keep_traj, drift_norm_batch, start_step=0,
-                       static=None):
+                       static=None, cache_slot=0):
         """Validate one dense batch, centre it, allocate its state / workspace and fill the ``dd_sampler`` struct.
         ``static``: what an earlier call with the same pocket / batch-vector tensors established (_static_memo_get)."""
         d = self._dense_inputs(protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, ligand_v_aux,
@@ -918,7 +922,7 @@ class DecompScorePosNet3D(nn.Module):
             raise ValueError("num_steps (+ start_step) exceeds num_timesteps")
         pw = self._packed_weights()
         s, bufs, ent = self._make_sampler(d, pw, num_steps, t_start, noise, keep_traj, energy_drift_opt, atom_std,
-                                          offset.contiguous(), decomp, fpp, seed, drift_norm_batch)
+                                          offset.contiguous(), decomp, fpp, seed, drift_norm_batch, cache_slot=cache_slot)
         return dict(s=s, bufs=bufs, offset=offset, B=B, NL=NL, dev=dev, ent=ent,
                     static=dict(layout=(B, NP, NL), offset=offset, protein_pos_centered=d["protein_pos_centered"],
                                 aux_onehot=d["aux_onehot"]))
