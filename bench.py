@@ -222,6 +222,7 @@ def main():
             "config": {"workload": wl, "baseline_config_index": args.config, "batch_per_unit": B, "units": len(units),
                        "sample_steps_per_s": round(steps_per_s * B, 2),
                        "parallelism": f"{world} rank(s), independent pocket batches (no data-path collective)",
+                       "control_plane": ddist.control_backend() or "single process",
                        "launch": "eager" if args.eager else "hipGraph replay", "noise": "device Philox",
                        "node_launch_split_cus": int(lib.dd_debug_node_split(B, NP, NL, K))},
             "roofline": roofline, "roofline_gemm": roofline_gemm, "roofline_op_level": op_roofline, "cpu_baseline": cpu,

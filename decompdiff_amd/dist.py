@@ -8,8 +8,10 @@ init / barrier / a final gather of per-rank metadata (timings, checksums).
 """
 from __future__ import annotations
 
-import os
+import datetime
 import gc
+import os
+import sys
 import time
 from dataclasses import asdict, dataclass
 from typing import Any, Callable, Dict, List, Optional, Tuple
@@ -36,8 +38,28 @@ def init_from_env(backend: str = None, device_index: int = None) -> bool:
     if backend == "nccl":
         torch.cuda.set_device(local_rank if device_index is None else device_index)
     if not dist.is_initialized():
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+        if backend == "nccl" and os.environ.get("DD_DIST_NO_FALLBACK") != "1":
+            # The job exchanges control messages only (two barriers, one all-reduce of a scalar, one object gather), so a
+            # box whose RCCL cannot start (IPC / topology trouble shows up in the first collective, symmetrically on every
+            # rank) still measures the same thing over gloo: probe once, fall back loudly.
+            try:
+                dist.barrier()
+                torch.cuda.synchronize()
+            except Exception as e:                                   # noqa: BLE001 -- whatever RCCL raises
+                print(f"[decompdiff_amd.dist] rank {rank}: RCCL start-up failed ({type(e).__name__}: {str(e)[:200]}); "
+                      "control plane falls back to gloo", file=sys.stderr, flush=True)
+                try:
+                    dist.destroy_process_group()
+                except Exception:                                    # noqa: BLE001
+                    pass
+                dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
     return True
+
+
+def control_backend() -> Optional[str]:
+    """Backend the control plane ended up on ('nccl' = RCCL, 'gloo'), None for a single process."""
+    return dist.get_backend() if dist.is_available() and dist.is_initialized() else None
 
 
 def shard_units(n_units: int, rank: int, world: int) -> List[int]:
@@ -64,7 +86,8 @@ def barrier(device=None):
 def max_over_ranks(value: float, device=None) -> float:
     if not (dist.is_available() and dist.is_initialized()):
         return float(value)
-    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    on_dev = device is not None and dist.get_backend() == "nccl"          # (gloo control plane: host tensor)
+    t = torch.tensor([value], dtype=torch.float64, device=device if on_dev else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
