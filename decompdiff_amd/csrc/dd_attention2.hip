@@ -235,7 +235,7 @@ __host__ __device__ inline int ne_blocks_per_sample(int NP, int NL, int NW) { re
 // workgroups), and its two halves only meet at the very end: wave 0 of a pair runs the query MLP, the fold, the k pass and
 // the softmax, wave 1 meanwhile the v pass (activations and the 16 per-head values of every member); the attention
 // weights cross through LDS behind one workgroup barrier and wave 1 forms the coordinate update.
-template <int MODE, int MAXT, int NW, bool PERSIST = false, bool RAG = false, bool PAIR = false>
+template <int MODE, int MAXT, int NW, bool PERSIST = false, bool RAG = false, bool PAIR = false, bool STAMPS = true>
 __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, float* smem) {
   constexpr bool KNN = (MODE == M_NE || MODE == M_PE);
   constexpr bool POS = (MODE == M_PE || MODE == M_PB);
@@ -282,7 +282,9 @@ __device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, f
     const int first = wg_protein ? ne_rb * NW : (ne_rb - ne_nbp) * NW;
     if (first >= (wg_protein ? (a.np_real ? a.np_real[ne_b] : a.NP) : a.nl_real[ne_b])) return;
   }
-  long long* dbg = a.dbg_clock ? a.dbg_clock + (long)block * 16 : nullptr;
+  // (STAMPS = false in the fused launches, which never run with a clock buffer: the stamp branches split the k pass of
+  // tile 0 into five basic blocks the scheduler cannot move instructions across; -1.4 % step time, bit-identical)
+  long long* dbg = (STAMPS && a.dbg_clock) ? a.dbg_clock + (long)block * 16 : nullptr;
 #define DD_STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
   DD_STAMP(0);
 
@@ -891,16 +893,16 @@ __global__ __launch_bounds__(NW * 64) void k_attn2_node(const AttnArgs ne, const
   // n_bl_first > 0: the persistent bond-layer workgroups come first in dispatch order and keep their CUs for the whole
   // launch, the node blocks cycle through the remaining CUs -- both parts then end together (see launch_node_nw)
   if (n_bl_first > 0) {
-    if (blk < n_bl_first) { attn2_body<M_BL, MAXT, NW, true, RAG>(bl, blk, smem); return; }
+    if (blk < n_bl_first) { attn2_body<M_BL, MAXT, NW, true, RAG, false, false>(bl, blk, smem); return; }
     blk -= n_bl_first;
-    if (blk < n_ne) attn2_body<M_NE, 2, NW, false, RAG>(ne, blk, smem);
-    else attn2_body<M_NB, MAXT, NW, false, RAG>(nb, blk - n_ne, smem);
+    if (blk < n_ne) attn2_body<M_NE, 2, NW, false, RAG, false, false>(ne, blk, smem);
+    else attn2_body<M_NB, MAXT, NW, false, RAG, false, false>(nb, blk - n_ne, smem);
     return;
   }
-  if (blk < n_ne) attn2_body<M_NE, 2, NW, false, RAG>(ne, blk, smem);
-  else if (blk < n_ne + n_nb) attn2_body<M_NB, MAXT, NW, false, RAG>(nb, blk - n_ne, smem);
-  else if (persist) attn2_body<M_BL, MAXT, NW, true, RAG>(bl, blk - n_ne - n_nb, smem);
-  else attn2_body<M_BL, MAXT, NW, false, RAG>(bl, blk - n_ne - n_nb, smem);
+  if (blk < n_ne) attn2_body<M_NE, 2, NW, false, RAG, false, false>(ne, blk, smem);
+  else if (blk < n_ne + n_nb) attn2_body<M_NB, MAXT, NW, false, RAG, false, false>(nb, blk - n_ne, smem);
+  else if (persist) attn2_body<M_BL, MAXT, NW, true, RAG, false, false>(bl, blk - n_ne - n_nb, smem);
+  else attn2_body<M_BL, MAXT, NW, false, RAG, false, false>(bl, blk - n_ne - n_nb, smem);
 }
 // Same for the two coordinate sub-layers (both write their own delta buffer; x is updated afterwards).
 // (NW segments = 2 NW waves per workgroup: attn2_body's PAIR)
@@ -910,8 +912,8 @@ __global__ __launch_bounds__(NW * 128) void k_attn2_pos(const AttnArgs pe, const
   constexpr int SZ = imax(Lds<M_PE>::TOTAL, Lds<M_PB>::TOTAL) + NW * 256 + NW * MAXT * 256;
   __shared__ __attribute__((aligned(16))) float smem[SZ];
   const int blk = blockIdx.x;
-  if (blk < n_pe) attn2_body<M_PE, 2, NW, false, RAG, true>(pe, blk, smem);
-  else attn2_body<M_PB, MAXT, NW, false, RAG, true>(pb, blk - n_pe, smem);
+  if (blk < n_pe) attn2_body<M_PE, 2, NW, false, RAG, true, false>(pe, blk, smem);
+  else attn2_body<M_PB, MAXT, NW, false, RAG, true, false>(pb, blk - n_pe, smem);
   // x update (x += (dx_edge + dx_bond) on the ligand rows, uni_transformer_edge.py:285) by the workgroup that finishes
   // last: ~120 workgroups, so the ticket costs nothing and a launch on the critical chain is saved
   if (pe.work_counter == nullptr) return;

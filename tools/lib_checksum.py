@@ -1,0 +1,19 @@
+#!/usr/bin/env python
+"""Checksums of a short seeded chain (C-small B=8 and a 37-atom-ligand batch) -- to confirm that two builds of the library
+(DD_HIP_LIB=...) give bit-identical results.  usage: DD_HIP_LIB=path python tools/lib_checksum.py [steps]"""
+import sys, hashlib, torch
+sys.path.insert(0, ".")
+from decompdiff_amd import DecompScorePosNet3D, shipped_config, synth
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+dev = torch.device("cuda:0"); cfg = shipped_config()
+m = DecompScorePosNet3D(cfg, 29, 10, 8); sd = m.state_dict(); sd.update(synth.synthetic_state_dict(cfg, 0)); m.load_state_dict(sd); m = m.to(dev)
+for name, pocket, B in (("small", synth.make_pocket_small(0), 8), ("mid37", synth.make_pocket(5, 347, (12, 12), 13, num_full_protein=360), 4),
+                        ("large", synth.make_pocket_large(0), 2)):
+    torch.manual_seed(0)
+    b = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synth.build_sampling_batch(pocket, B).items()}
+    r = m.sample_diffusion(num_steps=steps, center_pos_mode="protein", seed=7, **b)
+    h = hashlib.sha256()
+    for k in ("pos", "v", "bond"):
+        h.update(r[k].cpu().numpy().tobytes())
+    h.update(torch.stack(r["v0_traj"]).numpy().tobytes())
+    print(name, h.hexdigest()[:16], flush=True)
