@@ -291,6 +291,32 @@ def test_padded_heterogeneous_batch_equals_size_groups(monkeypatch):
     assert torch.isfinite(r1["pos"]).all() and torch.equal(r1["pos"], r3["pos"]) and torch.equal(r1["bond"], r3["bond"])
 
 
+def test_same_shape_sub_batches_equal_the_whole_batch():
+    """A dense batch cut into sub-batches of ONE shape (each a chain of its own with its own cached buffers -- the cache
+    key carries a slot, otherwise two chains of a call would share device memory), run one after the other and as
+    concurrent graphs on separate streams, reproduces the one-chain result bit for bit on the same injected noise
+    (every sample's chain is independent of its batch; tools/split_bench.py times the same path)."""
+    m = model(0)
+    torch.manual_seed(3)
+    b = synth.build_sampling_batch(synth.make_pocket_small(2), 4)
+    steps = 3
+    noise = synth.draw_step_noise(steps, b["init_ligand_pos"].size(0), b["init_ligand_fc_bond_type"].size(0))
+    whole = _sample_hip(m, b, steps, None, noise)
+    kw = {k: (v.to(dev()) if torch.is_tensor(v) else v) for k, v in b.items() if k != "ligand_atom_mask"}
+    for concurrent in (False, True):
+        for rep in range(2):                                   # second pass: every sub-batch finds its own cache entry
+            part = m._sample_ragged(kw, None, steps, "protein", None, noise, 1, True, True, concurrent=concurrent, split=2)
+            for k in ("pos", "v", "bond"):
+                assert torch.equal(part[k].cpu(), whole[k].cpu()), (concurrent, rep, k)
+            assert torch.equal(torch.stack(part["bt_traj"]), torch.stack(whole["bt_traj"]))
+    # production noise: the two sub-batches of a call must not share buffers (identical halves would be the symptom)
+    r = m._sample_ragged(kw, None, 5, "protein", None, None, 11, True, True, concurrent=True, split=2)
+    r2 = m._sample_ragged(kw, None, 5, "protein", None, None, 11, True, True, concurrent=False, split=2)   # cached entries re-used
+    nl = r["pos"].shape[0] // 4
+    assert torch.isfinite(r["pos"]).all() and not torch.equal(r["pos"][:2 * nl], r["pos"][2 * nl:])
+    assert torch.equal(r["pos"], r2["pos"]) and torch.equal(r["bond"], r2["bond"])
+
+
 def test_bench_json_line_contract():
     """The driver's contract for bench.py: ONE JSON line from rank 0 with the metric of BASELINE.json, the whole-job value,
     and the roofline / cpu_baseline objects."""
