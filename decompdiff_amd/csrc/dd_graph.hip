@@ -11,33 +11,10 @@ namespace dd {
 
 // ------------------------------------------------------------------------------------ kNN
 // One wave per centre.  Each lane owns candidates c = lane, lane+64, ... (<= 16 per lane,
-// N <= 1024).  Key = (bits(d2) << 32) | index is monotone in (d2, index) because d2 >= 0, so
-// K rounds of wave-min give neighbours in ascending (distance, index) — the same total order
-// the oracle's stable sort uses.  d2 = (dx*dx + dy*dy) + dz*dz with no FMA contraction.
-// The wave-min runs on DPP / permlane-swap exchanges of the two key halves (no LDS round trips), and the per-lane
-// candidate count is a template parameter (ceil(N / 64), not the maximum 16).
-template <int CTRL>
-__device__ __forceinline__ unsigned dpp_mov_u(unsigned v) {
-  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
-}
-// wave-wide minimum of an unsigned value: 4 DPP steps + 2 permlane swaps, one v_min_u32 each
-__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
-  v = min(v, dpp_mov_u<0xB1>(v));
-  v = min(v, dpp_mov_u<0x4E>(v));
-  v = min(v, dpp_mov_u<0x141>(v));
-  v = min(v, dpp_mov_u<0x140>(v));
-  {
-    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-    const unsigned r0 = r[0], r1 = r[1];
-    v = min(r0, r1);
-  }
-  {
-    auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    const unsigned r0 = r[0], r1 = r[1];
-    v = min(r0, r1);
-  }
-  return v;
-}
+// N <= 1024).  Key = (bits(d2) << 32) | index is monotone in (d2, index) because d2 >= 0: the K
+// smallest keys in ascending order are the neighbours in ascending (distance, index) — the same
+// total order the oracle's stable sort uses.  d2 = (dx*dx + dy*dy) + dz*dz with no FMA contraction.
+// The per-lane candidate count is a template parameter (ceil(N / 64), not the maximum 16).
 
 // atom n of sample b is real (not padding): protein rows n < NP count up to np_real[b], ligand rows up to nl_real[b]
 __device__ __forceinline__ bool atom_is_real(int n, int NP, int npb, int nlb) { return n < NP ? n < npb : (n - NP) < nlb; }
@@ -68,21 +45,45 @@ __global__ __launch_bounds__(256) void k_knn(const float* __restrict__ x, int B,
       khi[t] = __float_as_uint(d2); klo[t] = (unsigned)c;
     }
   }
-  // K rounds: minimum distance first (32-bit), then the lowest index among the candidates at that distance -- the
-  // (d2, index) lexicographic minimum with two cheap 32-bit wave reductions instead of one 64-bit one
-  for (int s = 0; s < K; ++s) {
-    unsigned bh = khi[0];
-#pragma unroll
-    for (int t = 1; t < CAND; ++t) bh = min(bh, khi[t]);
-    const unsigned mh = wave_min_u32(bh);
-    unsigned bl = ~0u;
-#pragma unroll
-    for (int t = 0; t < CAND; ++t) bl = min(bl, khi[t] == mh ? klo[t] : ~0u);
-    const unsigned ml = wave_min_u32(bl);
+  // Selection without K serial wave-min rounds:
+  //  (1) radix select on the distance bits: the K-th smallest d2 (with multiplicity), one bit per trip from the top;
+  //      a trip is CAND ballots + scalar popcounts, no cross-lane dependency chain;
+  //  (2) every candidate below that distance is a neighbour, and of those AT it the `need` lowest indices (candidate
+  //      c = lane + 64 t, so index order is (t, lane) order: ballot prefix counts);
+  //  (3) the K selected keys go to LDS, one per slot, and lane j ranks key j among them: its position in ascending
+  //      (d2, index) order -- the order K rounds of wave-min produced (and the oracle's stable sort).
+  __shared__ unsigned long long sel[4][64];
+  const int w = threadIdx.x >> 6;
+  unsigned prefix = 0;
+  int need = K;
+  for (int bit = 31; bit >= 0; --bit) {
+    int c0 = 0;                                          // keys that agree with the prefix above `bit` and have this bit clear
 #pragma unroll
     for (int t = 0; t < CAND; ++t)
-      if (khi[t] == mh && klo[t] == ml) { khi[t] = ~0u; klo[t] = ~0u; }
-    if (lane == 0) nbr[(long)centre * K + s] = (int32_t)ml;
+      c0 += __builtin_popcountll(__builtin_amdgcn_ballot_w64((khi[t] >> bit) == (prefix >> bit)));
+    if (c0 < need) { need -= c0; prefix |= 1u << bit; }
+  }
+  int base = 0, ties = 0;
+#pragma unroll
+  for (int t = 0; t < CAND; ++t) {
+    const bool eq = khi[t] == prefix;
+    const unsigned long long meq = __builtin_amdgcn_ballot_w64(eq);
+    const int tie_rank = ties + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(meq >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)meq, 0u));
+    const bool take = khi[t] < prefix || (eq && tie_rank < need);
+    const unsigned long long mtk = __builtin_amdgcn_ballot_w64(take);
+    const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mtk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mtk, 0u));
+    if (take && slot < 64) sel[w][slot] = ((unsigned long long)khi[t] << 32) | klo[t];
+    base += __builtin_popcountll(mtk);
+    ties += __builtin_popcountll(meq);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's LDS writes before its reads below (one wave owns sel[w])
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  if (lane < K) {
+    const unsigned long long mine = sel[w][lane];
+    int rank = 0;
+    for (int j = 0; j < K; ++j) rank += sel[w][j] < mine ? 1 : 0;   // same address for every lane: an LDS broadcast
+    nbr[(long)centre * K + rank] = (int32_t)(unsigned)(mine & 0xffffffffull);
   }
 }
 
