@@ -146,6 +146,7 @@ static int g_lin_with_pb2 = 1;                 // dd_debug_set_option(16, v): bo
 static int g_pb_early = 1;                     // dd_debug_set_option(17, v): next layer's bond projections in the lin_node launch
 static int g_q1_in_gemm = 1;                   // dd_debug_set_option(12, v): bond-layer query hidden row summed inside the query GEMM
 static int g_l0_tables = 1;                    // dd_debug_set_option(22, v): first layer's projection / query rows gathered from tables
+static int g_head_fused = 2;                   // dd_debug_set_option(24, v): head of a forward, see forward_impl (0 = four launches)
 static int g_q_in_pos = 1;                     // dd_debug_set_option(9, v): coordinate query MLPs' second layer inside attn_pos
 // (ev_fork / ev_join: [0..7] per layer, [8] graph construction at the head of a forward)
 // DD_SIDE_PRIO: 1 (default) lowest priority for the side stream, 0 default priority, 2 highest
@@ -233,21 +234,45 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
   const bool overlap = fused && g_overlap && g_prof == nullptr && s->num_layers <= 8;
   if (overlap) DD_TRY(ensure_side_stream());
 
-  // embeddings + context (decompdiff.py:219-297) and the zeroed work counters: one launch
-  DD_TRYP(DD_PROF_MISC, launch_embed_all(s->protein_h, s->protein_pos, s->lig_pos, s->lig_v, s->lig_aux, GW(DD_G_W_lemb),
-                                         GW(DD_G_b_lemb), B, NP, NL, w.h, w.xa, w.xb, s->lig_bond, (long)B * Eb, GW(DD_G_W_bemb),
-                                         GW(DD_G_b_bemb), w.hb, w.counters, st, (fold && fold->advance) ? s->step_counter : nullptr));
   // layer-0 tables: the first layer's projection and query rows are gathered (ligand atoms: 16 combinations of class and
   // arm flag, bonds: type x destination combination; protein rows are static per chain) instead of two GEMM launches
   const bool l0 = fused && g_l0_tables && g_q1_in_gemm && g_gemm_ksplit_on() && s->l0_tables && s->l0_P && s->l0_qn &&
                   s->nl_real == nullptr;
-  if (l0)
-    DD_TRYP(DD_PROF_MISC, launch_layer0_rows(s->l0_tables, s->lig_v, s->lig_aux, s->lig_bond, B, NP, NL, s->l0_P, w.PL, s->l0_qn,
-                                              w.qlnb, w.PB, w.qb, st));
-  // graph (uni_transformer_edge.py:404-427): only the attention kernels need it, so with two streams it is built
-  // beside the bond embedding and the first layer's projections
+  int32_t* advance = (fold && fold->advance) ? s->step_counter : nullptr;
   bool head_join = false;
-  {
+  if (overlap && g_head_fused) {
+    // dd_graph.hip::k_head_all: the graph (kNN + edge weights, one wave per centre, reading x_t from the sampler's position
+    // buffers) and the embeddings / context / counters / layer-0 rows as ONE launch each instead of two.
+    //   1: everything in one launch (assemble then waits for the graph it does not need: measured +2.1 % step time)
+    //   2: graph launch forked to the side stream first, embeddings + layer-0 rows on the main stream beside it
+    //   3: embeddings + layer-0 rows first, then the graph launch on the side stream
+    auto head = [&](hipStream_t sx, int parts) -> int {
+      return launch_head_all(s->protein_h, s->protein_pos, s->lig_pos, s->lig_v, s->lig_aux, GW(DD_G_W_lemb), GW(DD_G_b_lemb), B, NP, NL,
+                             K, w.h, w.xa, w.xb, s->lig_bond, (long)B * Eb, GW(DD_G_W_bemb), GW(DD_G_b_bemb), w.hb, w.counters, advance,
+                             w.nbr, w.ew, GW(DD_G_EW_W1T), GW(DD_G_EW_b1), GW(DD_G_EW_ln), GW(DD_G_EW_w2), GW(DD_G_EW_b2),
+                             s->np_real, s->nl_real, l0 ? s->l0_tables : nullptr, s->l0_P, w.PL, s->l0_qn, w.qlnb, w.PB, w.qb, sx,
+                             parts);
+    };
+    if (g_head_fused == 1) {
+      DD_TRYP(DD_PROF_MISC, head(st, 3));
+    } else {
+      if (g_head_fused == 3) DD_TRYP(DD_PROF_MISC, head(st, 2));
+      if (hipEventRecord(g_ev_fork[8], st) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_fork[8], 0) != hipSuccess) return DD_ERR_HIP;
+      DD_TRYP(DD_PROF_MISC, head(g_side, 1));
+      if (hipEventRecord(g_ev_join[8], g_side) != hipSuccess) return DD_ERR_HIP;
+      head_join = true;
+      if (g_head_fused == 2) DD_TRYP(DD_PROF_MISC, head(st, 2));
+    }
+  } else {
+    // embeddings + context (decompdiff.py:219-297) and the zeroed work counters: one launch
+    DD_TRYP(DD_PROF_MISC, launch_embed_all(s->protein_h, s->protein_pos, s->lig_pos, s->lig_v, s->lig_aux, GW(DD_G_W_lemb),
+                                           GW(DD_G_b_lemb), B, NP, NL, w.h, w.xa, w.xb, s->lig_bond, (long)B * Eb, GW(DD_G_W_bemb),
+                                           GW(DD_G_b_bemb), w.hb, w.counters, st, advance));
+    if (l0)
+      DD_TRYP(DD_PROF_MISC, launch_layer0_rows(s->l0_tables, s->lig_v, s->lig_aux, s->lig_bond, B, NP, NL, s->l0_P, w.PL, s->l0_qn,
+                                                w.qlnb, w.PB, w.qb, st));
+    // graph (uni_transformer_edge.py:404-427): only the attention kernels need it, so with two streams it is built
+    // beside the bond embedding and the first layer's projections
     hipStream_t gs = st;
     if (overlap) {
       if (hipEventRecord(g_ev_fork[8], st) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_fork[8], 0) != hipSuccess) return DD_ERR_HIP;
@@ -1086,6 +1111,7 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 0) return dd_debug_set_fusion(value);
   if (key == 1) { dd::g_gemm_ksplit = value ? 1 : 0; return DD_OK; }
   if (key == 3) { dd::g_attn_persist = value ? 1 : 0; return DD_OK; }
+  if (key == 24) { if (value < 0 || value > 3) return DD_ERR_BAD_ARG; dd::g_head_fused = value; return DD_OK; }
   if (key == 22) { dd::g_l0_tables = value ? 1 : 0; return DD_OK; }
   if (key == 21) { dd::g_gemm_xcd = value ? 1 : 0; return DD_OK; }
   if (key == 20) { dd::g_step_fold = value ? 1 : 0; return DD_OK; }

@@ -19,28 +19,29 @@ namespace dd {
 // atom n of sample b is real (not padding): protein rows n < NP count up to np_real[b], ligand rows up to nl_real[b]
 __device__ __forceinline__ bool atom_is_real(int n, int NP, int npb, int nlb) { return n < NP ? n < npb : (n - NP) < nlb; }
 
+// Positions of one sample, either one [N,3] block (the workspace copy: l = p + 3 NP) or the sampler's separate protein /
+// ligand blocks (the fused head launch reads x_t where the step kernel left it: same values, other addresses).
+struct PosView {
+  const float* p;
+  const float* l;
+  int NP;
+  __device__ __forceinline__ float get(int n, int c) const { return n < NP ? p[3 * n + c] : l[3 * (n - NP) + c]; }
+};
+
+// One wave: the K nearest neighbours of centre i, ascending (d2, index), to nbr_row[0..K) (global) and -- when srt is
+// given -- to srt[0..K) (this wave's LDS slice: the edge-weight pass of the fused head launch reads them from there).
 template <int CAND>
-__global__ __launch_bounds__(256) void k_knn(const float* __restrict__ x, int B, int N, int K, int32_t* __restrict__ nbr, int NP,
-                                             const int32_t* __restrict__ np_real, const int32_t* __restrict__ nl_real) {
+__device__ __forceinline__ void knn_wave(const PosView& pv, int i, int N, int K, int32_t* __restrict__ nbr_row, bool masked, int npb,
+                                         int nlb, unsigned long long* sel /*LDS, 64 per wave*/, int32_t* srt /*LDS or nullptr*/) {
   const int lane = threadIdx.x & 63;
-  const int centre = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (centre >= B * N) return;
-  const int b = centre / N, i = centre % N;
-  const bool masked = nl_real != nullptr;
-  const int npb = masked && np_real ? np_real[b] : NP, nlb = masked ? nl_real[b] : N - NP;
-  if (masked && !atom_is_real(i, NP, npb, nlb)) {          // a padding atom is no centre: its list is never read
-    if (lane < K) nbr[(long)centre * K + lane] = 0;
-    return;
-  }
-  const float* xb = x + (long)b * N * 3;
-  const float cx = xb[3 * i], cy = xb[3 * i + 1], cz = xb[3 * i + 2];
+  const float cx = pv.get(i, 0), cy = pv.get(i, 1), cz = pv.get(i, 2);
   unsigned khi[CAND], klo[CAND];                         // key = (bits(d2), index): d2 >= 0, so unsigned order = float order
 #pragma unroll
   for (int t = 0; t < CAND; ++t) {
     const int c = lane + 64 * t;
     khi[t] = ~0u; klo[t] = ~0u;
-    if (c < N && c != i && (!masked || atom_is_real(c, NP, npb, nlb))) {
-      float dx = __fsub_rn(cx, xb[3 * c]), dy = __fsub_rn(cy, xb[3 * c + 1]), dz = __fsub_rn(cz, xb[3 * c + 2]);
+    if (c < N && c != i && (!masked || atom_is_real(c, pv.NP, npb, nlb))) {
+      float dx = __fsub_rn(cx, pv.get(c, 0)), dy = __fsub_rn(cy, pv.get(c, 1)), dz = __fsub_rn(cz, pv.get(c, 2));
       float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
       khi[t] = __float_as_uint(d2); klo[t] = (unsigned)c;
     }
@@ -52,8 +53,6 @@ __global__ __launch_bounds__(256) void k_knn(const float* __restrict__ x, int B,
   //      c = lane + 64 t, so index order is (t, lane) order: ballot prefix counts);
   //  (3) the K selected keys go to LDS, one per slot, and lane j ranks key j among them: its position in ascending
   //      (d2, index) order -- the order K rounds of wave-min produced (and the oracle's stable sort).
-  __shared__ unsigned long long sel[4][64];
-  const int w = threadIdx.x >> 6;
   unsigned prefix = 0;
   int need = K;
   for (int bit = 31; bit >= 0; --bit) {
@@ -72,19 +71,45 @@ __global__ __launch_bounds__(256) void k_knn(const float* __restrict__ x, int B,
     const bool take = khi[t] < prefix || (eq && tie_rank < need);
     const unsigned long long mtk = __builtin_amdgcn_ballot_w64(take);
     const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mtk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mtk, 0u));
-    if (take && slot < 64) sel[w][slot] = ((unsigned long long)khi[t] << 32) | klo[t];
+    if (take && slot < 64) sel[slot] = ((unsigned long long)khi[t] << 32) | klo[t];
     base += __builtin_popcountll(mtk);
     ties += __builtin_popcountll(meq);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's LDS writes before its reads below (one wave owns sel[w])
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's LDS writes before its reads below (one wave owns the slice)
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   if (lane < K) {
-    const unsigned long long mine = sel[w][lane];
+    const unsigned long long mine = sel[lane];
     int rank = 0;
-    for (int j = 0; j < K; ++j) rank += sel[w][j] < mine ? 1 : 0;   // same address for every lane: an LDS broadcast
-    nbr[(long)centre * K + rank] = (int32_t)(unsigned)(mine & 0xffffffffull);
+    for (int j = 0; j < K; ++j) rank += sel[j] < mine ? 1 : 0;     // same address for every lane: an LDS broadcast
+    const int32_t idx = (int32_t)(unsigned)(mine & 0xffffffffull);
+    nbr_row[rank] = idx;
+    if (srt) srt[rank] = idx;
   }
+  if (srt) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+}
+
+template <int CAND>
+__global__ __launch_bounds__(256) void k_knn(const float* __restrict__ x, int B, int N, int K, int32_t* __restrict__ nbr, int NP,
+                                             const int32_t* __restrict__ np_real, const int32_t* __restrict__ nl_real) {
+  __shared__ unsigned long long sel[4][64];
+  const int lane = threadIdx.x & 63;
+  const int centre = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (centre >= B * N) return;
+  const int b = centre / N, i = centre % N;
+  const bool masked = nl_real != nullptr;
+  const int npb = masked && np_real ? np_real[b] : NP, nlb = masked ? nl_real[b] : N - NP;
+  if (masked && !atom_is_real(i, NP, npb, nlb)) {          // a padding atom is no centre: its list is never read
+    if (lane < K) nbr[(long)centre * K + lane] = 0;
+    return;
+  }
+  const float* xb = x + (long)b * N * 3;
+  const PosView pv{xb, xb + 3 * (long)NP, NP};
+  knn_wave<CAND>(pv, i, N, K, nbr + (long)centre * K, masked, npb, nlb, sel[threadIdx.x >> 6], nullptr);
 }
 
 // ------------------------------------------------------------------------------ edge weights
@@ -93,19 +118,12 @@ __global__ __launch_bounds__(256) void k_knn(const float* __restrict__ x, int B,
 // v_mfma_f32_16x16x4_f32 with the weights as A operands held in 40 registers; LayerNorm + ReLU and the 128 -> 1
 // output layer reduce over the 4 lanes of a member with permlane swaps.
 typedef float f32x4e __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void k_edge_weights2(const float* __restrict__ x, const int32_t* __restrict__ nbr, int B,
-                                                       int N, int K, const float* __restrict__ W1T,
-                                                       const float* __restrict__ b1, const float* __restrict__ ln,
-                                                       const float* __restrict__ w2, const float* __restrict__ b2,
-                                                       float* __restrict__ ew, int NP, const int32_t* __restrict__ np_real,
-                                                       const int32_t* __restrict__ nl_real) {
+// One wave: e_w of the K edges of node i.  nbr_row: the node's neighbour list (global memory, or the LDS copy knn_wave left).
+__device__ __forceinline__ void ew_wave(const PosView& pv, int i, int K, const int32_t* nbr_row, const float* __restrict__ W1T,
+                                        const float* __restrict__ b1, const float* __restrict__ ln, const float* __restrict__ w2,
+                                        const float* __restrict__ b2, float* __restrict__ ew_row) {
   const int lane = threadIdx.x & 63, mm = lane & 15, cg = lane >> 4;
-  const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (node >= B * N) return;
-  const int b = node / N, i = node % N;
-  if (nl_real != nullptr && !atom_is_real(i, NP, np_real ? np_real[b] : NP, nl_real[b])) return;   // padding atom
-  const float* xb = x + (long)b * N * 3;
-  const float cx = xb[3 * i], cy = xb[3 * i + 1], cz = xb[3 * i + 2];
+  const float cx = pv.get(i, 0), cy = pv.get(i, 1), cz = pv.get(i, 2);
   float Wa[5][8];                                        // A operands: W1T[4s + cg][16nt + mm]
 #pragma unroll
   for (int s = 0; s < 5; ++s)
@@ -123,8 +141,8 @@ __global__ __launch_bounds__(256) void k_edge_weights2(const float* __restrict__
   auto quad = [](float v) { v = swap16_sum(v, v); return swap32_sum(v, v); };
   for (int t0 = 0; t0 < K; t0 += 16) {
     const int m = t0 + mm;
-    const int j = nbr[(long)node * K + (m < K ? m : K - 1)];
-    const float dx = cx - xb[3 * j], dy = cy - xb[3 * j + 1], dz = cz - xb[3 * j + 2];
+    const int j = nbr_row[m < K ? m : K - 1];
+    const float dx = cx - pv.get(j, 0), dy = cy - pv.get(j, 1), dz = cz - pv.get(j, 2);
     const float d = sqrtf(dx * dx + dy * dy + dz * dz);
     f32x4e acc[8];
 #pragma unroll
@@ -154,8 +172,22 @@ __global__ __launch_bounds__(256) void k_edge_weights2(const float* __restrict__
       dot = fmaf(fmaxf(fmaf(acc[nt][3] * rstd, gm[nt].w, bt[nt].w), 0.f), ww[nt].w, dot);
     }
     const float logit = quad(dot) + bias2;
-    if (cg == 0 && m < K) ew[(long)node * K + m] = 1.0f / (1.0f + expf(-logit));
+    if (cg == 0 && m < K) ew_row[m] = 1.0f / (1.0f + expf(-logit));
   }
+}
+__global__ __launch_bounds__(256) void k_edge_weights2(const float* __restrict__ x, const int32_t* __restrict__ nbr, int B,
+                                                       int N, int K, const float* __restrict__ W1T,
+                                                       const float* __restrict__ b1, const float* __restrict__ ln,
+                                                       const float* __restrict__ w2, const float* __restrict__ b2,
+                                                       float* __restrict__ ew, int NP, const int32_t* __restrict__ np_real,
+                                                       const int32_t* __restrict__ nl_real) {
+  const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (node >= B * N) return;
+  const int b = node / N, i = node % N;
+  if (nl_real != nullptr && !atom_is_real(i, NP, np_real ? np_real[b] : NP, nl_real[b])) return;   // padding atom
+  const float* xb = x + (long)b * N * 3;
+  const PosView pv{xb, xb + 3 * (long)NP, NP};
+  ew_wave(pv, i, K, nbr + (long)node * K, W1T, b1, ln, w2, b2, ew + (long)node * K);
 }
 
 // -------------------------------------------------------------------------------- embeddings
@@ -175,7 +207,7 @@ __global__ void k_embed_protein(const float* __restrict__ feat, int rows, const 
 
 // One launch at the head of a step: node embedding / context, bond embedding, and the per-forward work counters
 // of the persistent kernels (64 ints) set to zero.
-__global__ __launch_bounds__(256) void k_embed_all(const float* __restrict__ protein_h, const float* __restrict__ protein_pos,
+__device__ __forceinline__ void embed_block(const unsigned blk, const float* __restrict__ protein_h, const float* __restrict__ protein_pos,
                                                    const float* __restrict__ lig_pos, const int32_t* __restrict__ lig_v,
                                                    const float* __restrict__ lig_aux, const float* __restrict__ Wl,
                                                    const float* __restrict__ bl, int B, int NP, int NL, float* __restrict__ h,
@@ -184,13 +216,13 @@ __global__ __launch_bounds__(256) void k_embed_all(const float* __restrict__ pro
                                                    const float* __restrict__ Wb, const float* __restrict__ bb,
                                                    float* __restrict__ hb, int32_t* __restrict__ counters, int node_blocks,
                                                    int32_t* __restrict__ advance) {
-  if (blockIdx.x == 0 && threadIdx.x < 64 && counters) counters[threadIdx.x] = 0;
+  if (blk == 0 && threadIdx.x < 64 && counters) counters[threadIdx.x] = 0;
   // the step index moves on with the first launch of a step's forward (nothing before the step kernels reads it): the
   // step kernels use *advance - 1, and no one-thread launch sits at the end of a step
-  if (blockIdx.x == 0 && threadIdx.x == 64 && advance) *advance += 1;
-  if ((int)blockIdx.x < node_blocks) {
+  if (blk == 0 && threadIdx.x == 64 && advance) *advance += 1;
+  if ((int)blk < node_blocks) {
     const int N = NP + NL;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long idx = (long)blk * 256 + threadIdx.x;
     if (idx >= (long)B * N * 128) return;
     const int c = idx & 127;
     const long node = idx >> 7;
@@ -210,12 +242,24 @@ __global__ __launch_bounds__(256) void k_embed_all(const float* __restrict__ pro
       xb[node * 3 + c] = p;
     }
   } else {
-    const long idx = (long)(blockIdx.x - node_blocks) * 256 + threadIdx.x;
+    const long idx = (long)(blk - node_blocks) * 256 + threadIdx.x;
     if (idx >= bond_rows * 128) return;
     const int c = idx & 127;
     const long e = idx >> 7;
     hb[idx] = Wb[c * 5 + bond[e]] + bb[c];
   }
+}
+__global__ __launch_bounds__(256) void k_embed_all(const float* __restrict__ protein_h, const float* __restrict__ protein_pos,
+                                                   const float* __restrict__ lig_pos, const int32_t* __restrict__ lig_v,
+                                                   const float* __restrict__ lig_aux, const float* __restrict__ Wl,
+                                                   const float* __restrict__ bl, int B, int NP, int NL, float* __restrict__ h,
+                                                   float* __restrict__ xa, float* __restrict__ xb,
+                                                   const int32_t* __restrict__ bond, long bond_rows,
+                                                   const float* __restrict__ Wb, const float* __restrict__ bb,
+                                                   float* __restrict__ hb, int32_t* __restrict__ counters, int node_blocks,
+                                                   int32_t* __restrict__ advance) {
+  embed_block(blockIdx.x, protein_h, protein_pos, lig_pos, lig_v, lig_aux, Wl, bl, B, NP, NL, h, xa, xb, bond, bond_rows, Wb, bb, hb,
+              counters, node_blocks, advance);
 }
 
 // --------------------------------------------------------------------------- layer-0 rows from tables
@@ -224,12 +268,12 @@ __global__ __launch_bounds__(256) void k_embed_all(const float* __restrict__ pro
 // bond e = b*Eb + t*(NL-1) + s' of type ty with destination atom t:  PB[e] = TB[ty] (640), qb[e] = TQB[c(t)][ty].
 constexpr int L0_TN = 0, L0_TL = 16 * 640, L0_TB = L0_TL + 16 * 1280, L0_TQN = L0_TB + 5 * 640, L0_TQL = L0_TQN + 16 * 128,
               L0_TQB = L0_TQL + 16 * 128;
-__global__ __launch_bounds__(256) void k_layer0_rows(const float* __restrict__ tab, const int32_t* __restrict__ lig_v,
+__device__ __forceinline__ void layer0_rows_block(const unsigned blk, const float* __restrict__ tab, const int32_t* __restrict__ lig_v,
                                                      const float* __restrict__ lig_aux, const int32_t* __restrict__ bond, int B,
                                                      int NP, int NL, float* __restrict__ l0_P, float* __restrict__ PL,
                                                      float* __restrict__ l0_qn, float* __restrict__ qlnb, float* __restrict__ PB,
                                                      float* __restrict__ qb, long atom_f4) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long idx = (long)blk * 256 + threadIdx.x;
   const int N = NP + NL, Eb = NL * (NL - 1);
   auto combo = [&](long a) { return (lig_aux[2 * a + 1] > 0.5f ? 8 : 0) + lig_v[a]; };
   const float4* t4 = reinterpret_cast<const float4*>(tab);
@@ -259,6 +303,75 @@ __global__ __launch_bounds__(256) void k_layer0_rows(const float* __restrict__ t
     const int c = combo((long)b * NL + t);
     reinterpret_cast<float4*>(qb + e * 128)[k - 160] = t4[(L0_TQB + (c * 5 + ty) * 128) / 4 + (k - 160)];
   }
+}
+__global__ __launch_bounds__(256) void k_layer0_rows(const float* __restrict__ tab, const int32_t* __restrict__ lig_v,
+                                                     const float* __restrict__ lig_aux, const int32_t* __restrict__ bond, int B,
+                                                     int NP, int NL, float* __restrict__ l0_P, float* __restrict__ PL,
+                                                     float* __restrict__ l0_qn, float* __restrict__ qlnb, float* __restrict__ PB,
+                                                     float* __restrict__ qb, long atom_f4) {
+  layer0_rows_block(blockIdx.x, tab, lig_v, lig_aux, bond, B, NP, NL, l0_P, PL, l0_qn, qlnb, PB, qb, atom_f4);
+}
+
+// ------------------------------------------------------------------------------ head of a forward: two launches
+// Everything the first attention layer waits for that only depends on the state the previous reverse step left:
+// k_head_graph -- the kNN graph + edge weights, one wave per centre (the bodies of k_knn and k_edge_weights2, the list
+// handed over through LDS; x_t is read from the sampler's protein / ligand position buffers, so the launch does not
+// wait for the workspace copy the embedding blocks write); k_head_rows -- the embeddings / context (with the zeroed work
+// counters and the step index) and the layer-0 rows (the bodies of k_embed_all and k_layer0_rows as two block ranges).
+// Outputs bit-identical to the four separate launches.
+struct HeadArgs {
+  // graph
+  int B, NP, NL, K;
+  const float *protein_pos, *lig_pos;
+  int32_t* nbr;
+  float* ew;
+  const float *EW_W1T, *EW_b1, *EW_ln, *EW_w2, *EW_b2;
+  const int32_t *np_real, *nl_real;
+  // embeddings
+  const float* protein_h;
+  const int32_t* lig_v;
+  const float* lig_aux;
+  const float *Wl, *bl;
+  float *h, *xa, *xb;
+  const int32_t* bond;
+  long bond_rows;
+  const float *Wb, *bb;
+  float* hb;
+  int32_t *counters, *advance;
+  // layer-0 rows (tab == nullptr: none)
+  const float* tab;
+  float *l0_P, *PL, *l0_qn, *qlnb, *PB, *qb;
+  long atom_f4;
+  int n_graph, n_embed_nodes, n_embed;
+};
+template <int CAND>
+__global__ __launch_bounds__(256) void k_head_graph(const HeadArgs a) {
+  __shared__ unsigned long long sel[4][64];
+  __shared__ int32_t srt[4][32];
+  const int N = a.NP + a.NL, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int centre = (int)blockIdx.x * 4 + w;
+  if (centre >= a.B * N) return;
+  const int b = centre / N, i = centre % N;
+  const bool masked = a.nl_real != nullptr;
+  const int npb = masked && a.np_real ? a.np_real[b] : a.NP, nlb = masked ? a.nl_real[b] : a.NL;
+  if (masked && !atom_is_real(i, a.NP, npb, nlb)) {        // a padding atom is no centre: its list is never read
+    if (lane < a.K) a.nbr[(long)centre * a.K + lane] = 0;
+    return;
+  }
+  const PosView pv{a.protein_pos + (long)b * a.NP * 3, a.lig_pos + (long)b * a.NL * 3, a.NP};
+  knn_wave<CAND>(pv, i, N, a.K, a.nbr + (long)centre * a.K, masked, npb, nlb, sel[w], srt[w]);
+  ew_wave(pv, i, a.K, srt[w], a.EW_W1T, a.EW_b1, a.EW_ln, a.EW_w2, a.EW_b2, a.ew + (long)centre * a.K);
+}
+// (a kernel of its own: the copy blocks need many waves per SIMD, the graph blocks ~200 registers per lane)
+__global__ __launch_bounds__(256) void k_head_rows(const HeadArgs a) {
+  const unsigned blk = blockIdx.x;
+  if ((int)blk < a.n_embed) {
+    embed_block(blk, a.protein_h, a.protein_pos, a.lig_pos, a.lig_v, a.lig_aux, a.Wl, a.bl, a.B, a.NP, a.NL, a.h, a.xa, a.xb, a.bond,
+                a.bond_rows, a.Wb, a.bb, a.hb, a.counters, a.n_embed_nodes, a.advance);
+    return;
+  }
+  layer0_rows_block(blk - a.n_embed, a.tab, a.lig_v, a.lig_aux, a.bond, a.B, a.NP, a.NL, a.l0_P, a.PL, a.l0_qn, a.qlnb, a.PB, a.qb,
+                    a.atom_f4);
 }
 
 // --------------------------------------------------------------------------- bond-layer assemble
@@ -432,6 +545,43 @@ int launch_embed_all(const float* protein_h, const float* protein_pos, const flo
   const int node_blocks = (int)((nn + 255) / 256), bond_blocks = (int)((nb + 255) / 256);
   hipLaunchKernelGGL(k_embed_all, dim3(node_blocks + bond_blocks), dim3(256), 0, st, protein_h, protein_pos, lig_pos, lig_v, lig_aux,
                      Wl, bl, B, NP, NL, h, xa, xb, bond, bond_rows, Wb, bb, hb, counters, node_blocks, advance);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+int launch_head_all(const float* protein_h, const float* protein_pos, const float* lig_pos, const int32_t* lig_v,
+                    const float* lig_aux, const float* Wl, const float* bl, int B, int NP, int NL, int K, float* h, float* xa, float* xb,
+                    const int32_t* bond, long bond_rows, const float* Wb, const float* bb, float* hb, int32_t* counters,
+                    int32_t* advance, int32_t* nbr, float* ew, const float* EW_W1T, const float* EW_b1, const float* EW_ln,
+                    const float* EW_w2, const float* EW_b2, const int32_t* np_real, const int32_t* nl_real, const float* l0_tables,
+                    float* l0_P, float* PL, float* l0_qn, float* qlnb, float* PB, float* qb, hipStream_t st, int parts) {
+  if (K > 32 || (parts & 3) == 0) return DD_ERR_UNSUPPORTED_SHAPE;
+  const int N = NP + NL;
+  HeadArgs a;
+  a.B = B; a.NP = NP; a.NL = NL; a.K = K;
+  a.protein_pos = protein_pos; a.lig_pos = lig_pos; a.nbr = nbr; a.ew = ew;
+  a.EW_W1T = EW_W1T; a.EW_b1 = EW_b1; a.EW_ln = EW_ln; a.EW_w2 = EW_w2; a.EW_b2 = EW_b2;
+  a.np_real = np_real; a.nl_real = nl_real;
+  a.protein_h = protein_h; a.lig_v = lig_v; a.lig_aux = lig_aux; a.Wl = Wl; a.bl = bl; a.h = h; a.xa = xa; a.xb = xb;
+  a.bond = bond; a.bond_rows = bond_rows; a.Wb = Wb; a.bb = bb; a.hb = hb; a.counters = counters; a.advance = advance;
+  a.tab = l0_tables; a.l0_P = l0_P; a.PL = PL; a.l0_qn = l0_qn; a.qlnb = qlnb; a.PB = PB; a.qb = qb;
+  const long nn = (long)B * N * 128, nb = bond_rows * 128;
+  a.n_embed_nodes = (int)((nn + 255) / 256);
+  a.n_embed = a.n_embed_nodes + (int)((nb + 255) / 256);
+  a.n_graph = (B * N + 3) / 4;
+  a.atom_f4 = (long)B * NL * (160 + 320 + 32 + 32);
+  const long bond_f4 = (long)B * NL * (NL - 1) * (160 + 32);
+  const int n_l0 = l0_tables ? (int)((a.atom_f4 + bond_f4 + 255) / 256) : 0;
+  const dim3 block(256);
+  if (parts & 2) hipLaunchKernelGGL(k_head_rows, dim3((unsigned)(a.n_embed + n_l0)), block, 0, st, a);   // parts: 2 = embedding + layer-0 rows
+  if (parts & 1) {                                                                                        //        1 = graph
+    const dim3 grid((unsigned)a.n_graph);
+    const int cand = (N + 63) / 64;
+    if (cand <= 2) hipLaunchKernelGGL(k_head_graph<2>, grid, block, 0, st, a);
+    else if (cand <= 4) hipLaunchKernelGGL(k_head_graph<4>, grid, block, 0, st, a);
+    else if (cand <= 6) hipLaunchKernelGGL(k_head_graph<6>, grid, block, 0, st, a);
+    else if (cand <= 11) hipLaunchKernelGGL(k_head_graph<11>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(k_head_graph<DD_N_MAX / 64>, grid, block, 0, st, a);
+  }
   DD_CHECK_LAUNCH();
   return DD_OK;
 }

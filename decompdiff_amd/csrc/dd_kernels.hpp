@@ -46,6 +46,13 @@ int launch_bl_assemble(const float* x, const float* PB, const float* PL, const f
 // layer-0 rows of the ligand atoms / bonds gathered from dd_sampler.l0_tables (see include/decompdiff_hip.h)
 int launch_layer0_rows(const float* tables, const int32_t* lig_v, const float* lig_aux, const int32_t* bond, int B, int NP, int NL,
                        float* l0_P, float* PL, float* l0_qn, float* qlnb, float* PB, float* qb, hipStream_t st);
+// head of a forward: kNN graph + edge weights (parts & 1), embeddings / context + layer-0 rows (parts & 2; l0_tables may be NULL)
+int launch_head_all(const float* protein_h, const float* protein_pos, const float* lig_pos, const int32_t* lig_v,
+                    const float* lig_aux, const float* Wl, const float* bl, int B, int NP, int NL, int K, float* h, float* xa, float* xb,
+                    const int32_t* bond, long bond_rows, const float* Wb, const float* bb, float* hb, int32_t* counters,
+                    int32_t* advance, int32_t* nbr, float* ew, const float* EW_W1T, const float* EW_b1, const float* EW_ln,
+                    const float* EW_w2, const float* EW_b2, const int32_t* np_real, const int32_t* nl_real, const float* l0_tables,
+                    float* l0_P, float* PL, float* l0_qn, float* qlnb, float* PB, float* qb, hipStream_t st, int parts = 3);
 int launch_extract_ligand(const float* x, int B, int NP, int NL, float* out, hipStream_t st);
 
 enum { M_NE = 0, M_NB = 1, M_BL = 2, M_PE = 3, M_PB = 4 };
