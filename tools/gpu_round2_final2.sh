@@ -3,7 +3,7 @@
 set -x
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-O=gpurun_out/r2fin2; mkdir -p $O
+O=gpurun_out/r2fin3; mkdir -p $O
 python -X faulthandler -m pytest tests -m gpu -q -s > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee $O/pytest.rc
 grep -E "passed|failed|FAILED|Fatal|Error" $O/pytest.log | tail -5
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
@@ -34,7 +34,7 @@ done
 rocprofv3 --kernel-trace -d /tmp/tl -- python $GRAFT_REPO_ROOT/tools/run_steps.py 30 > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
 f=$(find /tmp/tl -name "*.db" | head -1); [ -n "$f" ] && python tools/timeline.py $f 20 60 > $O/timeline_small.txt
-for d in small large b16 drift; do f=$(find $O/prof_$d -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_summary.py "$f" "(round 2 final, stamps compiled out, $d)" > $O/kernel_trace_$d.md; done
+for d in small large b16 drift; do f=$(find $O/prof_$d -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_summary.py "$f" "(round 2 final, head in two launches, $d)" > $O/kernel_trace_$d.md; done
 for d in $O/pmc_*; do [ -d "$d" ] || continue; f=$(find $d -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_pmc.py "$f" 6 > $d.md; done
 find $O -name "*.db" -delete; find $O -type d -empty -delete
 python -c "
