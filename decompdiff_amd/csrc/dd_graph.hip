@@ -118,10 +118,18 @@ __global__ __launch_bounds__(256) void k_knn(const float* __restrict__ x, int B,
 // v_mfma_f32_16x16x4_f32 with the weights as A operands held in 40 registers; LayerNorm + ReLU and the 128 -> 1
 // output layer reduce over the 4 lanes of a member with permlane swaps.
 typedef float f32x4e __attribute__((ext_vector_type(4)));
+// The 128-channel vectors of the edge-weight MLP (first-layer bias, LayerNorm gamma / beta, output weights) in LDS, once per
+// workgroup: kept in registers they cost 128 VGPRs per lane for two uses each, which left the kernel at ONE wave per SIMD.
+__device__ __forceinline__ void ew_stage(float* lw /*LDS, 512 floats*/, const float* __restrict__ b1, const float* __restrict__ ln,
+                                         const float* __restrict__ w2) {
+  const int t = threadIdx.x;                             // 256 threads: 128 float4
+  if (t < 32) reinterpret_cast<float4*>(lw)[t] = reinterpret_cast<const float4*>(b1)[t];
+  else if (t < 96) reinterpret_cast<float4*>(lw + 128)[t - 32] = reinterpret_cast<const float4*>(ln)[t - 32];   // gamma | beta
+  else if (t < 128) reinterpret_cast<float4*>(lw + 384)[t - 96] = reinterpret_cast<const float4*>(w2)[t - 96];
+}
 // One wave: e_w of the K edges of node i.  nbr_row: the node's neighbour list (global memory, or the LDS copy knn_wave left).
 __device__ __forceinline__ void ew_wave(const PosView& pv, int i, int K, const int32_t* nbr_row, const float* __restrict__ W1T,
-                                        const float* __restrict__ b1, const float* __restrict__ ln, const float* __restrict__ w2,
-                                        const float* __restrict__ b2, float* __restrict__ ew_row) {
+                                        const float* lw /*LDS: ew_stage*/, const float* __restrict__ b2, float* __restrict__ ew_row) {
   const int lane = threadIdx.x & 63, mm = lane & 15, cg = lane >> 4;
   const float cx = pv.get(i, 0), cy = pv.get(i, 1), cz = pv.get(i, 2);
   float Wa[5][8];                                        // A operands: W1T[4s + cg][16nt + mm]
@@ -129,24 +137,21 @@ __device__ __forceinline__ void ew_wave(const PosView& pv, int i, int K, const i
   for (int s = 0; s < 5; ++s)
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) Wa[s][nt] = W1T[(4 * s + cg) * 128 + 16 * nt + mm];
-  float4 bb[8], gm[8], bt[8], ww[8];                     // channels 16nt + 4cg .. +3
-#pragma unroll
-  for (int nt = 0; nt < 8; ++nt) {
-    bb[nt] = *reinterpret_cast<const float4*>(b1 + 16 * nt + 4 * cg);
-    gm[nt] = *reinterpret_cast<const float4*>(ln + 16 * nt + 4 * cg);
-    bt[nt] = *reinterpret_cast<const float4*>(ln + 128 + 16 * nt + 4 * cg);
-    ww[nt] = *reinterpret_cast<const float4*>(w2 + 16 * nt + 4 * cg);
-  }
   const float bias2 = b2[0];
   auto quad = [](float v) { v = swap16_sum(v, v); return swap32_sum(v, v); };
   for (int t0 = 0; t0 < K; t0 += 16) {
+    // (the LDS offset is made opaque per trip: the vectors are loop-invariant, and hoisted out of the loop they are the
+    // 128 registers per lane this layout is there to avoid)
+    int o4 = 4 * cg;
+    asm volatile("" : "+v"(o4));
+    auto vec = [&](int which, int nt) { return *reinterpret_cast<const float4*>(lw + which * 128 + 16 * nt + o4); };   // channels 16nt + 4cg .. +3
     const int m = t0 + mm;
     const int j = nbr_row[m < K ? m : K - 1];
     const float dx = cx - pv.get(j, 0), dy = cy - pv.get(j, 1), dz = cz - pv.get(j, 2);
     const float d = sqrtf(dx * dx + dy * dy + dz * dz);
     f32x4e acc[8];
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt) acc[nt] = f32x4e{bb[nt].x, bb[nt].y, bb[nt].z, bb[nt].w};
+    for (int nt = 0; nt < 8; ++nt) { const float4 bb = vec(0, nt); acc[nt] = f32x4e{bb.x, bb.y, bb.z, bb.w}; }
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
       const float fk = gauss_feat(d, 4 * s + cg);
@@ -166,28 +171,32 @@ __device__ __forceinline__ void ew_wave(const PosView& pv, int i, int K, const i
     float dot = 0.f;
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) {
-      dot = fmaf(fmaxf(fmaf(acc[nt][0] * rstd, gm[nt].x, bt[nt].x), 0.f), ww[nt].x, dot);
-      dot = fmaf(fmaxf(fmaf(acc[nt][1] * rstd, gm[nt].y, bt[nt].y), 0.f), ww[nt].y, dot);
-      dot = fmaf(fmaxf(fmaf(acc[nt][2] * rstd, gm[nt].z, bt[nt].z), 0.f), ww[nt].z, dot);
-      dot = fmaf(fmaxf(fmaf(acc[nt][3] * rstd, gm[nt].w, bt[nt].w), 0.f), ww[nt].w, dot);
+      const float4 gm = vec(1, nt), bt = vec(2, nt), ww = vec(3, nt);
+      dot = fmaf(fmaxf(fmaf(acc[nt][0] * rstd, gm.x, bt.x), 0.f), ww.x, dot);
+      dot = fmaf(fmaxf(fmaf(acc[nt][1] * rstd, gm.y, bt.y), 0.f), ww.y, dot);
+      dot = fmaf(fmaxf(fmaf(acc[nt][2] * rstd, gm.z, bt.z), 0.f), ww.z, dot);
+      dot = fmaf(fmaxf(fmaf(acc[nt][3] * rstd, gm.w, bt.w), 0.f), ww.w, dot);
     }
     const float logit = quad(dot) + bias2;
     if (cg == 0 && m < K) ew_row[m] = 1.0f / (1.0f + expf(-logit));
   }
 }
-__global__ __launch_bounds__(256) void k_edge_weights2(const float* __restrict__ x, const int32_t* __restrict__ nbr, int B,
-                                                       int N, int K, const float* __restrict__ W1T,
-                                                       const float* __restrict__ b1, const float* __restrict__ ln,
-                                                       const float* __restrict__ w2, const float* __restrict__ b2,
-                                                       float* __restrict__ ew, int NP, const int32_t* __restrict__ np_real,
-                                                       const int32_t* __restrict__ nl_real) {
+__global__ __launch_bounds__(256, 3) void k_edge_weights2(const float* __restrict__ x, const int32_t* __restrict__ nbr, int B,
+                                                          int N, int K, const float* __restrict__ W1T,
+                                                          const float* __restrict__ b1, const float* __restrict__ ln,
+                                                          const float* __restrict__ w2, const float* __restrict__ b2,
+                                                          float* __restrict__ ew, int NP, const int32_t* __restrict__ np_real,
+                                                          const int32_t* __restrict__ nl_real) {
+  __shared__ __attribute__((aligned(16))) float lw[512];
+  ew_stage(lw, b1, ln, w2);
+  __syncthreads();                                       // (before any wave leaves)
   const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (node >= B * N) return;
   const int b = node / N, i = node % N;
   if (nl_real != nullptr && !atom_is_real(i, NP, np_real ? np_real[b] : NP, nl_real[b])) return;   // padding atom
   const float* xb = x + (long)b * N * 3;
   const PosView pv{xb, xb + 3 * (long)NP, NP};
-  ew_wave(pv, i, K, nbr + (long)node * K, W1T, b1, ln, w2, b2, ew + (long)node * K);
+  ew_wave(pv, i, K, nbr + (long)node * K, W1T, lw, b2, ew + (long)node * K);
 }
 
 // -------------------------------------------------------------------------------- embeddings
@@ -345,9 +354,12 @@ struct HeadArgs {
   int n_graph, n_embed_nodes, n_embed;
 };
 template <int CAND>
-__global__ __launch_bounds__(256) void k_head_graph(const HeadArgs a) {
+__global__ __launch_bounds__(256, 3) void k_head_graph(const HeadArgs a) {
   __shared__ unsigned long long sel[4][64];
   __shared__ int32_t srt[4][32];
+  __shared__ __attribute__((aligned(16))) float lw[512];
+  ew_stage(lw, a.EW_b1, a.EW_ln, a.EW_w2);
+  __syncthreads();                                       // (before any wave leaves)
   const int N = a.NP + a.NL, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int centre = (int)blockIdx.x * 4 + w;
   if (centre >= a.B * N) return;
@@ -360,7 +372,7 @@ __global__ __launch_bounds__(256) void k_head_graph(const HeadArgs a) {
   }
   const PosView pv{a.protein_pos + (long)b * a.NP * 3, a.lig_pos + (long)b * a.NL * 3, a.NP};
   knn_wave<CAND>(pv, i, N, a.K, a.nbr + (long)centre * a.K, masked, npb, nlb, sel[w], srt[w]);
-  ew_wave(pv, i, a.K, srt[w], a.EW_W1T, a.EW_b1, a.EW_ln, a.EW_w2, a.EW_b2, a.ew + (long)centre * a.K);
+  ew_wave(pv, i, a.K, srt[w], a.EW_W1T, lw, a.EW_b2, a.ew + (long)centre * a.K);
 }
 // (a kernel of its own: the copy blocks need many waves per SIMD, the graph blocks ~200 registers per lane)
 __global__ __launch_bounds__(256) void k_head_rows(const HeadArgs a) {
