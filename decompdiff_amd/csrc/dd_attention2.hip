@@ -235,8 +235,8 @@ __host__ __device__ inline int ne_blocks_per_sample(int NP, int NL, int NW) { re
 // workgroups), and its two halves only meet at the very end: wave 0 of a pair runs the query MLP, the fold, the k pass and
 // the softmax, wave 1 meanwhile the v pass (activations and the 16 per-head values of every member); the attention
 // weights cross through LDS behind one workgroup barrier and wave 1 forms the coordinate update.
-template <int MODE, int MAXT, int NW, bool PERSIST = false, bool RAG = false, bool PAIR = false, bool STAMPS = true>
-__device__ __forceinline__ void attn2_body(const AttnArgs& a, const int block, float* smem) {
+template <int MODE, int MAXT, int NW, bool PERSIST = false, bool RAG = false, bool PAIR = false, bool STAMPS = true, typename ARGS = AttnArgs>
+__device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float* smem) {
   constexpr bool KNN = (MODE == M_NE || MODE == M_PE);
   constexpr bool POS = (MODE == M_PE || MODE == M_PB);
   constexpr bool TRIP = (MODE == M_BL);
@@ -890,19 +890,31 @@ __global__ __launch_bounds__(NW * 64) void k_attn2_node(const AttnArgs ne, const
   constexpr int SZ = imax(imax(Lds<M_NE>::TOTAL, Lds<M_NB>::TOTAL), Lds<M_BL>::TOTAL) + 4;
   __shared__ __attribute__((aligned(16))) float smem[SZ];
   int blk = blockIdx.x;
+  // Each body reads ITS argument block through the kernarg pointer with an offset the compiler cannot see through: with
+  // the three by-value structs used directly, their scalar loads are hoisted in front of the branch below and stay live
+  // across all bodies (104 SGPRs + 80 spilled to VGPR lanes, which in turn pushed the 256-register node body into
+  // scratch); read in place, a body holds only its own pointers.
+  typedef const __attribute__((address_space(4))) AttnArgs KArgs;
+  auto args = [](unsigned k) -> KArgs& {
+    unsigned off = k * (unsigned)sizeof(AttnArgs);       // kernel parameters: ne at 0, nb and bl behind it
+    asm volatile("" : "+s"(off));
+    return *reinterpret_cast<KArgs*>((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + off);
+  };
+  static_assert(sizeof(AttnArgs) % 8 == 0, "kernel parameter layout");
+  (void)ne; (void)nb; (void)bl;
   // n_bl_first > 0: the persistent bond-layer workgroups come first in dispatch order and keep their CUs for the whole
   // launch, the node blocks cycle through the remaining CUs -- both parts then end together (see launch_node_nw)
   if (n_bl_first > 0) {
-    if (blk < n_bl_first) { attn2_body<M_BL, MAXT, NW, true, RAG, false, false>(bl, blk, smem); return; }
+    if (blk < n_bl_first) { attn2_body<M_BL, MAXT, NW, true, RAG, false, false>(args(2), blk, smem); return; }
     blk -= n_bl_first;
-    if (blk < n_ne) attn2_body<M_NE, 2, NW, false, RAG, false, false>(ne, blk, smem);
-    else attn2_body<M_NB, MAXT, NW, false, RAG, false, false>(nb, blk - n_ne, smem);
+    if (blk < n_ne) attn2_body<M_NE, 2, NW, false, RAG, false, false>(args(0), blk, smem);
+    else attn2_body<M_NB, MAXT, NW, false, RAG, false, false>(args(1), blk - n_ne, smem);
     return;
   }
-  if (blk < n_ne) attn2_body<M_NE, 2, NW, false, RAG, false, false>(ne, blk, smem);
-  else if (blk < n_ne + n_nb) attn2_body<M_NB, MAXT, NW, false, RAG, false, false>(nb, blk - n_ne, smem);
-  else if (persist) attn2_body<M_BL, MAXT, NW, true, RAG, false, false>(bl, blk - n_ne - n_nb, smem);
-  else attn2_body<M_BL, MAXT, NW, false, RAG, false, false>(bl, blk - n_ne - n_nb, smem);
+  if (blk < n_ne) attn2_body<M_NE, 2, NW, false, RAG, false, false>(args(0), blk, smem);
+  else if (blk < n_ne + n_nb) attn2_body<M_NB, MAXT, NW, false, RAG, false, false>(args(1), blk - n_ne, smem);
+  else if (persist) attn2_body<M_BL, MAXT, NW, true, RAG, false, false>(args(2), blk - n_ne - n_nb, smem);
+  else attn2_body<M_BL, MAXT, NW, false, RAG, false, false>(args(2), blk - n_ne - n_nb, smem);
 }
 // Same for the two coordinate sub-layers (both write their own delta buffer; x is updated afterwards).
 // (NW segments = 2 NW waves per workgroup: attn2_body's PAIR)

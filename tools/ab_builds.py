@@ -2,23 +2,26 @@
 """Compare two builds of the library on ONE box: alternating subprocesses, each timing the shipped workload.
 usage: python tools/ab_builds.py libA.so libB.so [libC.so ...] [rounds]   (paths relative to the repo root)
 
-Note: packed-weight slot layouts must be compatible with the Python package for both builds.
+DD_WORKLOAD=small|mid|large and DD_B select the batch.  Note: packed-weight slot layouts must be compatible with the Python package for both builds.
 """
 import os, subprocess, sys, statistics
 CHILD = r'''
-import sys, time, torch
+import os, sys, time, torch
 sys.path.insert(0, ".")
 from decompdiff_amd import DecompScorePosNet3D, shipped_config, synth
 dev = torch.device("cuda:0"); cfg = shipped_config()
 m = DecompScorePosNet3D(cfg, 29, 10, 8); sd = m.state_dict(); sd.update(synth.synthetic_state_dict(cfg, 0)); m.load_state_dict(sd); m = m.to(dev)
-pocket = synth.make_pocket_small(0); torch.manual_seed(0)
-b = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synth.build_sampling_batch(pocket, 8).items()}
+wl = os.environ.get("DD_WORKLOAD", "small")               # small (300 + 30), mid (347 + 37: 3-tile kernels), large (600 + 60: 4-tile)
+pocket = {"small": lambda: synth.make_pocket_small(0), "mid": lambda: synth.make_pocket(5, 347, (12, 12), 13, num_full_protein=360),
+          "large": lambda: synth.make_pocket_large(0)}[wl](); torch.manual_seed(0)
+b = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synth.build_sampling_batch(pocket, int(os.environ.get("DD_B", "8"))).items()}
 def run(steps):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     m.sample_diffusion(num_steps=steps, center_pos_mode="protein", keep_traj=True, use_graph=True, **b)
     torch.cuda.synchronize(); return 1e3 * (time.perf_counter() - t0) / steps
 run(20)
-print(min(run(200) for _ in range(3)))
+n = 60 if wl == "large" else 200
+print(min(run(n) for _ in range(3)))
 '''
 args = sys.argv[1:]; rounds = int(args.pop()) if args and args[-1].isdigit() else 3; libs = args
 res = {l: [] for l in libs}
