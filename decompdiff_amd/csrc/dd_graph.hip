@@ -398,7 +398,9 @@ __global__ __launch_bounds__(256) void k_head_rows(const HeadArgs a) {
 // (20 Gaussians = 5 k-steps of v_mfma_f32_16x16x4_f32) take the tables as A operands from a channel-permuted LDS image
 // (packing.py BL_Wgp, 40 KB) and the per-lane Gaussians as B; the gathered projection rows enter as the accumulator.
 typedef float f32x4a __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void k_bl_assemble3(const float* __restrict__ x, const float* __restrict__ PB,
+// (two waves per SIMD asked for: left alone, the compiler takes 216 VGPRs + 60 AGPRs = one wave per SIMD, i.e. ONE workgroup per
+// CU and 2.1 rounds for the 545 workgroups of a C-small batch; -1.0 % step time, no spills, bit-identical)
+__global__ __launch_bounds__(256, 2) void k_bl_assemble3(const float* __restrict__ x, const float* __restrict__ PB,
                                                       const float* __restrict__ PL, const float* __restrict__ Wgp /*[4,20,128]*/,
                                                       int B, int NP, int NL, float* __restrict__ Ek, float* __restrict__ Ev,
                                                       float* __restrict__ q1, float* __restrict__ Rk, float* __restrict__ Rv,
