@@ -156,6 +156,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int bx, const
 // image (4 workgroups/CU instead of 2); the second half's global loads are in flight while the first half is
 // multiplied.  Same MFMA order per output element as gemm_tile (k ascending), hence bit-identical results.
 constexpr int GPH = 66;       // LDS pitch of a K-half tile: (66*row) mod 64 = 2*row -> conflict-free ds_read_b64
+template <bool STAMPS = false>
 __device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx, const int by, float* smh /*>= 2*GT*GPH floats*/) {
   float* Xh = smh;
   float* Wh = smh + GT * GPH;
@@ -219,7 +220,8 @@ __device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  long long* dbg = a.dbg ? a.dbg + ((long)by * gridDim.x + bx) * 8 : nullptr;
+  // (phase stamps only in the stand-alone kernel tools/gemm_clocks.py drives: compiled out of the batched launches)
+  long long* dbg = (STAMPS && a.dbg) ? a.dbg + ((long)by * gridDim.x + bx) * 8 : nullptr;
 #define GSTAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
   GSTAMP(0);
   if (a.ln != nullptr) {
@@ -300,7 +302,7 @@ __device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx
 __global__ __launch_bounds__(256) void k_gemm128(GemmArgs a) { gemm_tile(a, blockIdx.x, blockIdx.y); }
 __global__ __launch_bounds__(256) void k_gemm128_ks(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float sm[2 * GT * GPH];
-  gemm_tile_ksplit(a, blockIdx.x, blockIdx.y, sm);
+  gemm_tile_ksplit<true>(a, blockIdx.x, blockIdx.y, sm);
 }
 
 struct GemmBatch { GemmArgs job[4]; int end[4]; int nbx[4]; int big[4]; int njobs; };
@@ -318,7 +320,7 @@ __device__ __forceinline__ void gemm_job(const GemmArgs& a, int lb, int nbx, int
     by = k % nby;
     if (bx >= nbx) return;
   }
-  if (KS) gemm_tile_ksplit(a, bx, by, sm);
+  if (KS) gemm_tile_ksplit<false>(a, bx, by, sm);
   else gemm_tile(a, bx, by);
 }
 template <bool KS>
