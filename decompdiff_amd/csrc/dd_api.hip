@@ -146,7 +146,7 @@ static int g_lin_with_pb2 = 1;                 // dd_debug_set_option(16, v): bo
 static int g_pb_early = 1;                     // dd_debug_set_option(17, v): next layer's bond projections in the lin_node launch
 static int g_q1_in_gemm = 1;                   // dd_debug_set_option(12, v): bond-layer query hidden row summed inside the query GEMM
 static int g_l0_tables = 1;                    // dd_debug_set_option(22, v): first layer's projection / query rows gathered from tables
-static int g_head_fused = 2;                   // dd_debug_set_option(24, v): head of a forward, see forward_impl (0 = four launches)
+static int g_head_fused = 1;                   // dd_debug_set_option(24, v): head of a forward in two launches (0 = four, the cross-check)
 static int g_q_in_pos = 1;                     // dd_debug_set_option(9, v): coordinate query MLPs' second layer inside attn_pos
 // (ev_fork / ev_join: [0..7] per layer, [8] graph construction at the head of a forward)
 // DD_SIDE_PRIO: 1 (default) lowest priority for the side stream, 0 default priority, 2 highest
@@ -241,11 +241,11 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
   int32_t* advance = (fold && fold->advance) ? s->step_counter : nullptr;
   bool head_join = false;
   if (overlap && g_head_fused) {
-    // dd_graph.hip::k_head_all: the graph (kNN + edge weights, one wave per centre, reading x_t from the sampler's position
-    // buffers) and the embeddings / context / counters / layer-0 rows as ONE launch each instead of two.
-    //   1: everything in one launch (assemble then waits for the graph it does not need: measured +2.1 % step time)
-    //   2: graph launch forked to the side stream first, embeddings + layer-0 rows on the main stream beside it
-    //   3: embeddings + layer-0 rows first, then the graph launch on the side stream
+    // dd_graph.hip: the graph (k_head_graph: kNN + edge weights, one wave per centre, reading x_t from the sampler's
+    // position buffers) forked to the side stream FIRST, the embeddings / context / counters / layer-0 rows (k_head_rows)
+    // on the main stream beside it -- two launches instead of four.  (Measured and dropped: all four bodies in one
+    // kernel, +2.5 % step time -- one register allocation for every block kind, and assemble then waits for a graph it
+    // does not need; rows first and the graph forked after them, +1 %.)
     auto head = [&](hipStream_t sx, int parts) -> int {
       return launch_head_all(s->protein_h, s->protein_pos, s->lig_pos, s->lig_v, s->lig_aux, GW(DD_G_W_lemb), GW(DD_G_b_lemb), B, NP, NL,
                              K, w.h, w.xa, w.xb, s->lig_bond, (long)B * Eb, GW(DD_G_W_bemb), GW(DD_G_b_bemb), w.hb, w.counters, advance,
@@ -253,16 +253,11 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
                              s->np_real, s->nl_real, l0 ? s->l0_tables : nullptr, s->l0_P, w.PL, s->l0_qn, w.qlnb, w.PB, w.qb, sx,
                              parts);
     };
-    if (g_head_fused == 1) {
-      DD_TRYP(DD_PROF_MISC, head(st, 3));
-    } else {
-      if (g_head_fused == 3) DD_TRYP(DD_PROF_MISC, head(st, 2));
-      if (hipEventRecord(g_ev_fork[8], st) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_fork[8], 0) != hipSuccess) return DD_ERR_HIP;
-      DD_TRYP(DD_PROF_MISC, head(g_side, 1));
-      if (hipEventRecord(g_ev_join[8], g_side) != hipSuccess) return DD_ERR_HIP;
-      head_join = true;
-      if (g_head_fused == 2) DD_TRYP(DD_PROF_MISC, head(st, 2));
-    }
+    if (hipEventRecord(g_ev_fork[8], st) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_fork[8], 0) != hipSuccess) return DD_ERR_HIP;
+    DD_TRYP(DD_PROF_MISC, head(g_side, 1));
+    if (hipEventRecord(g_ev_join[8], g_side) != hipSuccess) return DD_ERR_HIP;
+    head_join = true;
+    DD_TRYP(DD_PROF_MISC, head(st, 2));
   } else {
     // embeddings + context (decompdiff.py:219-297) and the zeroed work counters: one launch
     DD_TRYP(DD_PROF_MISC, launch_embed_all(s->protein_h, s->protein_pos, s->lig_pos, s->lig_v, s->lig_aux, GW(DD_G_W_lemb),
@@ -1111,7 +1106,7 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 0) return dd_debug_set_fusion(value);
   if (key == 1) { dd::g_gemm_ksplit = value ? 1 : 0; return DD_OK; }
   if (key == 3) { dd::g_attn_persist = value ? 1 : 0; return DD_OK; }
-  if (key == 24) { if (value < 0 || value > 3) return DD_ERR_BAD_ARG; dd::g_head_fused = value; return DD_OK; }
+  if (key == 24) { dd::g_head_fused = value ? 1 : 0; return DD_OK; }
   if (key == 22) { dd::g_l0_tables = value ? 1 : 0; return DD_OK; }
   if (key == 21) { dd::g_gemm_xcd = value ? 1 : 0; return DD_OK; }
   if (key == 20) { dd::g_step_fold = value ? 1 : 0; return DD_OK; }

@@ -408,3 +408,25 @@ def test_layer0_tables_are_bit_identical_to_the_gemms():
     r = fwd(soft)
     assert not m._last[0].l0_tables and torch.isfinite(r["pred_ligand_pos"]).all()
     assert not torch.equal(r["pred_ligand_v"], on["pred_ligand_v"])
+
+
+def test_two_launch_head_is_bit_identical_to_the_four_launches():
+    """Head of a forward: k_head_graph (kNN by radix select + edge weights in one wave per centre, x_t read from the
+    sampler's position buffers) beside k_head_rows (embeddings / context / counters + layer-0 rows) against the four
+    separate launches (dd_debug_set_option(24, 0)) -- forward and chain bit-identical, dense and padded batches."""
+    lib = hip_lib.load()
+    m = model(0)
+    torch.manual_seed(11)
+    b = to_dev_local(synth.build_sampling_batch(synth.make_pocket_small(7), 3))
+    hb = to_dev_local(_hetero_batch([9, 20, 33], [150, 120, 200], seed=6))
+    run = lambda bb: m.sample_diffusion(num_steps=4, center_pos_mode="protein", energy_drift_opt=GU.DRIFT, seed=21, **bb)
+    try:
+        two, two_h = run(b), run(hb)
+        assert lib.dd_debug_set_option(24, 0) == 0
+        four, four_h = run(b), run(hb)
+    finally:
+        assert lib.dd_debug_set_option(24, 1) == 0
+    for x, y in ((two, four), (two_h, four_h)):
+        for k in ("pos", "v", "bond"):
+            assert torch.equal(x[k], y[k]), k
+        assert all(torch.equal(p, q) for p, q in zip(x["v0_traj"], y["v0_traj"]))
