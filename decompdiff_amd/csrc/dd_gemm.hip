@@ -270,7 +270,7 @@ __device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx
     GSTAMP(1);
     fetch(1);
   }
-#pragma unroll 8
+#pragma unroll
   for (int kk = 0; kk < 16; ++kk) {
     float2 av = *reinterpret_cast<const float2*>(xa + 4 * kk);
     float2 bv = *reinterpret_cast<const float2*>(wb + 4 * kk);
@@ -283,7 +283,7 @@ __device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx
   commit();
   __syncthreads();
   GSTAMP(3);
-#pragma unroll 8
+#pragma unroll
   for (int kk = 0; kk < 16; ++kk) {
     float2 av = *reinterpret_cast<const float2*>(xa + 4 * kk);
     float2 bv = *reinterpret_cast<const float2*>(wb + 4 * kk);
