@@ -3,7 +3,7 @@
 set -x
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-O=gpurun_out/r2fin4; mkdir -p $O
+O=gpurun_out/r2fin5; mkdir -p $O
 python -X faulthandler -m pytest tests -m gpu -q -s > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee $O/pytest.rc
 grep -E "passed|failed|FAILED|Fatal|Error" $O/pytest.log | tail -5
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
