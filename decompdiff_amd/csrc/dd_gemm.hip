@@ -63,6 +63,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, float* sm /*>= 
   }
 }
 
+// Variant: the accumulators straight to global memory -- for a fixed register, the 32 lanes of a half wave hold 32
+// consecutive columns of one output row (128 contiguous bytes), so 16 dword stores per lane write whole 128-byte row
+// pieces without the LDS round trip and its barrier.  Same arithmetic per element (acc + bias (+ old)).
+__device__ __forceinline__ void gemm_epilogue_direct(const GemmArgs& a, const f32x16& acc, int row0, int col0) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1, li = lane & 31, hh = lane >> 5;
+  const int gc = col0 + wc * 32 + li;
+  if (gc >= a.ncols) return;
+  const bool plain = a.y_rows_per_b >= a.rows;
+  const float bv = a.bias ? a.bias[gc] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int gr = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+    if (gr >= a.rows) continue;
+    float* dst = a.Y + row_offset(gr, a.y_rows_per_b, a.y_stride_b, a.ldy, plain) + gc;
+    float x = a.bias ? acc[r] + bv : acc[r];
+    if (a.accumulate) x += *dst;
+    *dst = x;
+  }
+}
 
 __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int bx, const int by) {
   __shared__ __attribute__((aligned(16))) float smg[2 * GT * GP];
@@ -292,8 +312,12 @@ __device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx
   }
   asm volatile("" : "+v"(acc));
   GSTAMP(4);
+#if defined(DD_GEMM_DIRECT_EPILOGUE) && DD_GEMM_DIRECT_EPILOGUE
+  gemm_epilogue_direct(a, acc, row0, col0);
+#else
   __syncthreads();                                     // operands dead: the tile buffer becomes the output stage
   gemm_epilogue(a, smh, acc, row0, col0);
+#endif
   if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); GSTAMP(5); }
 #undef GSTAMP
 }
