@@ -24,7 +24,9 @@ __device__ __forceinline__ long row_offset(int r, int rows_per_b, long stride_b,
 }
 
 // Epilogue: the four 32x32 accumulators go through an LDS tile (pitch 68) so that every thread writes whole
-// 16-byte pieces of output rows (4 x global_store_dwordx4 instead of 16 scalar stores).
+// 16-byte pieces of output rows (4 x global_store_dwordx4 instead of 16 scalar stores).  (Re-measured at the end of
+// round 2: 16 dword stores straight from the accumulators -- 128 contiguous bytes per half wave and register, no LDS
+// round trip, no barrier -- cost +2.3 % step time at B = 8 and +1.3 % at B = 16.)
 constexpr int EP = 68;
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, float* sm /*>= 64*EP floats, free*/, const f32x16& acc,
                                               int row0, int col0) {
@@ -60,27 +62,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, float* sm /*>= 
           dst[e] = x;
         }
     }
-  }
-}
-
-// Variant: the accumulators straight to global memory -- for a fixed register, the 32 lanes of a half wave hold 32
-// consecutive columns of one output row (128 contiguous bytes), so 16 dword stores per lane write whole 128-byte row
-// pieces without the LDS round trip and its barrier.  Same arithmetic per element (acc + bias (+ old)).
-__device__ __forceinline__ void gemm_epilogue_direct(const GemmArgs& a, const f32x16& acc, int row0, int col0) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 1, wc = wave & 1, li = lane & 31, hh = lane >> 5;
-  const int gc = col0 + wc * 32 + li;
-  if (gc >= a.ncols) return;
-  const bool plain = a.y_rows_per_b >= a.rows;
-  const float bv = a.bias ? a.bias[gc] : 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int gr = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-    if (gr >= a.rows) continue;
-    float* dst = a.Y + row_offset(gr, a.y_rows_per_b, a.y_stride_b, a.ldy, plain) + gc;
-    float x = a.bias ? acc[r] + bv : acc[r];
-    if (a.accumulate) x += *dst;
-    *dst = x;
   }
 }
 
@@ -312,12 +293,8 @@ __device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx
   }
   asm volatile("" : "+v"(acc));
   GSTAMP(4);
-#if defined(DD_GEMM_DIRECT_EPILOGUE) && DD_GEMM_DIRECT_EPILOGUE
-  gemm_epilogue_direct(a, acc, row0, col0);
-#else
   __syncthreads();                                     // operands dead: the tile buffer becomes the output stage
   gemm_epilogue(a, smh, acc, row0, col0);
-#endif
   if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); GSTAMP(5); }
 #undef GSTAMP
 }
