@@ -14,7 +14,9 @@ for name, pocket, B in (("small", synth.make_pocket_small(0), 8), ("mid37", synt
                         ("large", synth.make_pocket_large(0), 2)):
     torch.manual_seed(0)
     b = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synth.build_sampling_batch(pocket, B).items()}
-    r = m.sample_diffusion(num_steps=steps, center_pos_mode="protein", seed=7, **b)
+    drift = ([dict(type="armsca_prox", min_d=1.2, max_d=1.9), dict(type="clash", sigma=2.0, gamma=4.0)]
+             if os.environ.get("DD_DRIFT") == "1" else None)      # (configs/sampling_drift.yml values)
+    r = m.sample_diffusion(num_steps=steps, center_pos_mode="protein", seed=7, energy_drift_opt=drift, **b)
     h = hashlib.sha256()
     for k in ("pos", "v", "bond"):
         h.update(r[k].cpu().numpy().tobytes())
