@@ -63,6 +63,10 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo lets several "
                                                     "ranks share one GPU for testing)")
+    ap.add_argument("--oversubscribe", action="store_true", help="allow more ranks than visible devices (several ranks share a "
+                                                                 "GPU; testing only: n_gpus then reports the DISTINCT devices)")
+    ap.add_argument("--allow-gloo-fallback", action="store_true", help="if RCCL cannot start, run the control plane over gloo "
+                                                                       "instead of failing (the job exchanges no data)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rooflines", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=20)
@@ -148,11 +152,14 @@ def main():
     n_dev = torch.cuda.device_count()
     if n_dev == 0:
         raise SystemExit("bench.py needs a HIP device (the sampling hot path has no CPU implementation)")
+    ddist.check_world_fits_devices(world, n_dev, args.oversubscribe)        # one rank per GPU unless asked otherwise
     dev_index = local_rank % n_dev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     backend = args.backend or "nccl"
-    distributed = ddist.init_from_env(backend=backend, device_index=dev_index)   # RCCL on ROCm; no-op for one process
+    # RCCL on ROCm; no-op for one process.  An RCCL that cannot start is an error unless the fall-back is asked for.
+    distributed = ddist.init_from_env(backend=backend, device_index=dev_index,
+                                      allow_fallback=True if args.allow_gloo_fallback else None)
 
     cfg = shipped_config()
     model = DecompScorePosNet3D(cfg, 29, 10, 8)
@@ -204,25 +211,29 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(torch, synth, cfg, cpu_batches[u0.uid], DRIFT if u0.drift else None, B, args.cpu_steps, args.cpu_warmup)
-        wl = {1: "configs[1]: single pocket ref_prior", 2: "configs[2]: single pocket + armsca_prox/clash drift guidance",
+        wl = {1: "configs[1]: single pocket ref_prior",
+              2: "configs[2]: single pocket + armsca_prox/clash drift guidance (batch assembled as ref_prior with unit std "
+                 "scales; the beta_prior harness mode only changes the initial state and prior stds, not the per-step work)",
               3: f"configs[3]: {len(units)} pockets (NP in [250,350], NL in [20,40])", 4: "configs[4]: C-large pocket, "
               f"{args.num_samples} samples in shards"}[args.config]
         if args.config in (1, 2):
             wl += f", {NP} protein + {NL} ligand atoms, batch={B} per GPU"
         elif args.config == 3:
-            wl += f", batch={B} each, pocket p -> rank p mod {world}"
+            wl += f", batch={B} each, pockets assigned longest-first to the least loaded of {world} rank(s)"
         else:
             wl += f" of {B} (600 protein + 60 ligand atoms), contiguous shards over {world} rank(s)"
         wl += ", trajectories recorded and streamed to the host"
         result = {
             "metric": "denoising steps/sec (1000-step reverse) per pocket", "value": round(steps_per_s, 3),
-            "unit": "denoising steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "denoising steps/s", "n_gpus": job["distinct_devices"], "ranks": world,
+            "devices": job["devices"], "distinct_devices": job["distinct_devices"], "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / max(1, job["n_local_units"] * args.steps), 4), "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "baseline_config_index": args.config, "batch_per_unit": B, "units": len(units),
                        "sample_steps_per_s": round(steps_per_s * B, 2),
                        "parallelism": f"{world} rank(s), independent pocket batches (no data-path collective)",
                        "control_plane": ddist.control_backend() or "single process",
+                       "control_plane_note": ddist.control_note(), "imbalance_max_over_mean_busy": job["imbalance"],
                        "launch": "eager" if args.eager else "hipGraph replay", "noise": "device Philox",
                        "node_launch_split_cus": int(lib.dd_debug_node_split(B, NP, NL, K))},
             "roofline": roofline, "roofline_gemm": roofline_gemm, "roofline_op_level": op_roofline, "cpu_baseline": cpu,

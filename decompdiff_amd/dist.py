@@ -25,8 +25,24 @@ def env_world():
     return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def init_from_env(backend: str = None, device_index: int = None) -> bool:
-    """Initialise torch.distributed from torchrun's environment.  Returns True if world_size > 1."""
+class ControlPlaneError(RuntimeError):
+    """RCCL could not start and the gloo fall-back was not asked for."""
+
+
+_CTL: Dict[str, Any] = {"group": None, "backend": None, "note": None}      # the group the barriers / reductions use
+
+
+def init_from_env(backend: str = None, device_index: int = None, allow_fallback: Optional[bool] = None) -> bool:
+    """Initialise the control plane from torchrun's environment.  Returns True if world_size > 1.
+
+    The default process group is ALWAYS gloo (host sockets: it starts wherever torchrun does).  With backend "nccl"
+    (= RCCL; the default on a GPU box) a second group over RCCL is created on top and probed with one barrier; every
+    rank then all-reduces (MIN) its success flag over gloo, so all ranks take the SAME decision -- a rank whose RCCL
+    failed alone cannot leave the others waiting inside an RCCL collective.  If any rank failed:
+      * allow_fallback False (default; env DD_DIST_ALLOW_FALLBACK=1 turns it on): ControlPlaneError on every rank --
+        a `--gpus N` run whose RCCL does not start is an error, not a silent backend swap;
+      * allow_fallback True: the job runs its control messages over gloo (it exchanges no data) and
+        control_backend() / control_note() say so."""
     world, rank, local_rank = env_world()
     if world <= 1:
         return False
@@ -35,31 +51,86 @@ def init_from_env(backend: str = None, device_index: int = None) -> bool:
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver only supports dmabuf IPC (RCCL init)
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if backend == "nccl":
-        torch.cuda.set_device(local_rank if device_index is None else device_index)
-    if not dist.is_initialized():
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
-        if backend == "nccl" and os.environ.get("DD_DIST_NO_FALLBACK") != "1":
-            # The job exchanges control messages only (two barriers, one all-reduce of a scalar, one object gather), so a
-            # box whose RCCL cannot start (IPC / topology trouble shows up in the first collective, symmetrically on every
-            # rank) still measures the same thing over gloo: probe once, fall back loudly.
-            try:
-                dist.barrier()
-                torch.cuda.synchronize()
-            except Exception as e:                                   # noqa: BLE001 -- whatever RCCL raises
-                print(f"[decompdiff_amd.dist] rank {rank}: RCCL start-up failed ({type(e).__name__}: {str(e)[:200]}); "
-                      "control plane falls back to gloo", file=sys.stderr, flush=True)
-                try:
-                    dist.destroy_process_group()
-                except Exception:                                    # noqa: BLE001
-                    pass
-                dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+    if allow_fallback is None:
+        allow_fallback = os.environ.get("DD_DIST_ALLOW_FALLBACK") == "1"
+    if dist.is_initialized():
+        return True
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+    _CTL.update(group=None, backend="gloo", note=None)
+    if backend != "nccl":
+        return True
+    dev = local_rank if device_index is None else device_index
+    ok, err, group = 1, "", None
+
+    def all_ok(mine: int) -> bool:                                   # gloo: every rank sees the same verdict
+        flag = torch.tensor([mine], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+    try:
+        torch.cuda.set_device(dev)
+    except Exception as e:                                           # noqa: BLE001
+        ok, err = 0, f"{type(e).__name__}: {str(e)[:200]}"
+    try:
+        group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=300))      # (every rank must call this)
+    except Exception as e:                                           # noqa: BLE001 -- whatever RCCL raises
+        ok, err = 0, err or f"{type(e).__name__}: {str(e)[:200]}"
+    started = all_ok(ok)
+    if started:                                                      # only enter an RCCL collective if every rank can
+        try:
+            dist.barrier(group=group, device_ids=[dev])
+            torch.cuda.synchronize(dev)
+        except Exception as e:                                       # noqa: BLE001
+            ok, err = 0, f"{type(e).__name__}: {str(e)[:200]}"
+        started = all_ok(ok)
+    flag = torch.tensor([1 if started else 0])
+    if int(flag.item()) == 1:
+        _CTL.update(group=group, backend="nccl", note=None)
+        return True
+    msg = f"RCCL start-up failed on rank {rank}: {err}" if not ok else "RCCL start-up failed on another rank"
+    if not allow_fallback:
+        try:
+            dist.destroy_process_group()
+        except Exception:                                            # noqa: BLE001
+            pass
+        raise ControlPlaneError(msg + " (DD_DIST_ALLOW_FALLBACK=1 / bench.py --allow-gloo-fallback runs the control "
+                                      "plane over gloo instead; the job exchanges no data)")
+    print(f"[decompdiff_amd.dist] {msg}; control plane stays on gloo", file=sys.stderr, flush=True)
+    _CTL.update(group=None, backend="gloo", note="RCCL start-up failed; gloo fall-back requested by the caller")
     return True
 
 
 def control_backend() -> Optional[str]:
-    """Backend the control plane ended up on ('nccl' = RCCL, 'gloo'), None for a single process."""
-    return dist.get_backend() if dist.is_available() and dist.is_initialized() else None
+    """Backend the control plane runs on ('nccl' = RCCL, 'gloo'), None for a single process."""
+    return _CTL["backend"] if dist.is_available() and dist.is_initialized() else None
+
+
+def control_note() -> Optional[str]:
+    return _CTL["note"]
+
+
+def device_identity(device=None) -> Dict[str, Any]:
+    """What physically runs this rank: the HIP device's UUID / PCI bus id (distinct per GPU of a node)."""
+    if device is None or not torch.cuda.is_available():
+        return {"host": os.uname().nodename, "device": None, "uuid": f"cpu:{os.uname().nodename}:{os.getpid()}"}
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    prop = torch.cuda.get_device_properties(idx)
+    uuid = str(getattr(prop, "uuid", "")) or None
+    bus = None
+    for attr in ("pci_bus_id", "pci_device_id", "pci_domain_id"):
+        if hasattr(prop, attr):
+            bus = (bus or "") + f"{attr[4:-3]}={getattr(prop, attr)} "
+    ident = uuid or (bus.strip() if bus else None) or f"index{idx}"
+    return {"host": os.uname().nodename, "device": idx, "name": prop.name, "uuid": f"{os.uname().nodename}:{ident}",
+            "pci": bus.strip() if bus else None}
+
+
+def check_world_fits_devices(world: int, n_devices: int, oversubscribe: bool = False) -> None:
+    """One rank per GPU: more ranks than visible devices is refused unless the caller explicitly shares GPUs (tests)."""
+    if world > n_devices and not oversubscribe:
+        raise SystemExit(f"bench.py: {world} ranks but only {n_devices} visible HIP device(s): refusing to put several ranks on "
+                         "one GPU and report them as GPUs (pass --oversubscribe to share devices on purpose; the JSON line then "
+                         "reports n_gpus = distinct devices)")
 
 
 def shard_units(n_units: int, rank: int, world: int) -> List[int]:
@@ -78,7 +149,10 @@ def barrier(device=None):
     if device is not None and torch.cuda.is_available():
         torch.cuda.synchronize(device)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:      # (one rank: nothing to wait for)
-        dist.barrier()
+        if _CTL["backend"] == "nccl":
+            dist.barrier(group=_CTL["group"], device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
     if device is not None and torch.cuda.is_available():
         torch.cuda.synchronize(device)
 
@@ -86,9 +160,9 @@ def barrier(device=None):
 def max_over_ranks(value: float, device=None) -> float:
     if not (dist.is_available() and dist.is_initialized()):
         return float(value)
-    on_dev = device is not None and dist.get_backend() == "nccl"          # (gloo control plane: host tensor)
+    on_dev = device is not None and _CTL["backend"] == "nccl"             # (gloo control plane: host tensor)
     t = torch.tensor([value], dtype=torch.float64, device=device if on_dev else "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_CTL["group"] if on_dev else None)
     return float(t.item())
 
 
@@ -162,11 +236,37 @@ def plan_job(config: int, world: int, batch: Optional[int] = None, n_pockets: in
     raise ValueError(f"config {config}: expected 1..4 (index into BASELINE.json configs)")
 
 
+def unit_cost(u: Unit) -> float:
+    """Relative cost of one reverse step of a unit (for load balancing only): per sample, node-attention blocks of 8
+    centres at 1.0 and bond-layer batches of 8 segments at 0.1 + 0.35 per 16-member tile (the unit costs the node-launch
+    split measurement starts from, dd_api.hip::autotune_node_split) -- the NL^3 term dominates: the 100 pockets of configs[3] spread 3.5x."""
+    n_l = sum(u.arm_atoms) + u.scaffold_atoms
+    n = u.num_protein + n_l
+    tiles = (max(n_l - 2, 1) + 15) // 16
+    return u.n_samples * (n / 8.0 + n_l / 8.0 + n_l * (n_l - 1) / 8.0 * (0.1 + 0.35 * tiles))
+
+
+def assign_lpt(units: List[Unit], world: int) -> List[List[int]]:
+    """Longest-processing-time-first: units in descending cost, each to the least loaded rank so far (ties: lowest rank).
+    Deterministic and a function of (units, world) only, so every rank computes the same table without talking."""
+    order = sorted(range(len(units)), key=lambda i: (-unit_cost(units[i]), i))
+    load = [0.0] * world
+    out: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        out[r].append(i)
+        load[r] += unit_cost(units[i])
+    return out
+
+
 def units_of_rank(units: List[Unit], config: int, rank: int, world: int) -> List[Unit]:
-    """configs 1-3: unit u -> rank u mod world (pockets are independent; round-robin balances the pocket sizes);
+    """configs 1-2: unit u -> rank u (one identical unit per rank); config 3: the pockets differ 3.5x in cost (NL^3 bond-layer term), so
+    they are assigned longest-first to the least loaded rank (assign_lpt; SURVEY.md 8e) instead of p mod N;
     config 4: contiguous shards of one pocket's samples (shard_samples)."""
     if config == 4:
         return [units[i] for i in shard_samples(len(units), rank, world)]
+    if config == 3:
+        return [units[i] for i in assign_lpt(units, world)[rank]]
     return [units[i] for i in shard_units(len(units), rank, world)]
 
 
@@ -184,23 +284,34 @@ def run_job(units: List[Unit], config: int, rank: int, world: int, prepare: Call
             checksum(sample(st, warmup, u.noise_seed + 1))      # (also loads the reduction kernels the timed region uses)
     gc.collect()
     gc.disable()                                   # no collector pause inside the timed region (re-enabled below)
-    barrier(device)
-    t0 = time.perf_counter()
-    records = []
-    for u, st in zip(mine, states):
-        t1 = time.perf_counter()
-        out = sample(st, steps, u.noise_seed)
-        records.append({"unit": u.uid, "rank": rank, "pocket_seed": u.pocket_seed, "n_samples": u.n_samples,
-                        "checksum": checksum(out), "seconds_enqueue": round(time.perf_counter() - t1, 6), "_out": out})
-    barrier(device)
-    local = time.perf_counter() - t0
-    gc.enable()
+    try:
+        barrier(device)
+        t0 = time.perf_counter()
+        records = []
+        for u, st in zip(mine, states):
+            t1 = time.perf_counter()
+            out = sample(st, steps, u.noise_seed)
+            records.append({"unit": u.uid, "rank": rank, "pocket_seed": u.pocket_seed, "n_samples": u.n_samples,
+                            "checksum": checksum(out), "seconds_enqueue": round(time.perf_counter() - t1, 6), "_out": out})
+        if device is not None and torch.cuda.is_available():
+            torch.cuda.synchronize(device)                     # this rank's own work, without the wait for the others
+        busy = time.perf_counter() - t0
+        barrier(device)
+        local = time.perf_counter() - t0
+    finally:
+        gc.enable()
     elapsed = max_over_ranks(local, device)
     last = records[-1].pop("_out") if records else None
     for r in records:
         r.pop("_out", None)
-    gathered = gather_metadata({"rank": rank, "seconds": round(local, 6), "units": records})
+    gathered = gather_metadata({"rank": rank, "seconds": round(local, 6), "busy_seconds": round(busy, 6), "units": records,
+                                "device": device_identity(device), "cost": round(sum(unit_cost(u) for u in mine), 1)})
     per_unit = sorted((r for g in gathered for r in g["units"]), key=lambda r: r["unit"])
-    return {"elapsed": elapsed, "unit_steps": len(units) * steps, "per_rank": [{"rank": g["rank"], "seconds": g["seconds"],
-            "units": [r["unit"] for r in g["units"]]} for g in gathered], "per_unit": per_unit, "last_out": last,
-            "n_local_units": len(mine)}
+    busy_all = [g["busy_seconds"] for g in gathered]
+    devices = [g["device"]["uuid"] for g in gathered]
+    return {"elapsed": elapsed, "unit_steps": len(units) * steps,
+            "per_rank": [{"rank": g["rank"], "seconds": g["seconds"], "busy_seconds": g["busy_seconds"], "planned_cost": g["cost"],
+                          "units": [r["unit"] for r in g["units"]], "device": g["device"]} for g in gathered],
+            "imbalance": round(max(busy_all) / (sum(busy_all) / len(busy_all)), 4) if min(busy_all) > 0 else None,
+            "devices": devices, "distinct_devices": len(set(devices)),
+            "per_unit": per_unit, "last_out": last, "n_local_units": len(mine)}

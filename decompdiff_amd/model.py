@@ -187,9 +187,14 @@ class DecompScorePosNet3D(nn.Module):
     def _packed_weights(self):
         dev = self._device()
         key = str(dev)
-        if os.environ.get("DD_CHECK_PARAM_VERSIONS", "0") == "1":           # (0.4 ms per call over the 600 tensors)
+        # in-place parameter updates (optimizer.step on a loss of the caller's own, an EMA copy, param.data.copy_) bump the
+        # tensors' version counters: the packed copy is rebuilt when their sum moves (0.4 ms per call over the 600 tensors;
+        # DD_CHECK_PARAM_VERSIONS=0 turns the check off)
+        if os.environ.get("DD_CHECK_PARAM_VERSIONS", "1") != "0":
             key = (key, sum(int(p._version) for p in self.parameters()))
         if self._packed is None or self._packed_key != key:
+            if self._packed is not None:
+                self._evict_chain_cache(0)                                  # cached chains point into the old arena
             sd = {k: v for k, v in self.state_dict().items()}
             arena, offsets, _ = packing.pack_model(sd, self.config)
             tab_pos = torch.stack([self.posterior_mean_c0_coef, self.posterior_mean_ct_coef,
@@ -794,14 +799,13 @@ class DecompScorePosNet3D(nn.Module):
         With autograd enabled the network runs through :mod:`decompdiff_amd.training` (torch dense layers + the HIP graph
         ops with analytic backward passes), so ``results['losses']`` can be back-propagated into all parameters.  Under
         ``torch.no_grad()`` (the reference's validation loop) the network output comes from the fused ``dd_forward``
-        kernels instead.  Dense batches only (equal atom counts per sample)."""
+        kernels instead.  The batch layout (sorted batch vectors, dst-major fully connected bond lists) is validated
+        on every call for both paths (`training.check_batch_layout`); samples of different sizes -- the reference's
+        training batches -- run as one dense sub-batch per distinct size (`training.network_grouped`)."""
         from . import training
         _check_ligand_atom_mask(ligand_atom_mask, batch_ligand.numel())
         if ligand_fc_bond_index is None or ligand_fc_bond_type is None or batch_ligand_bond is None:
             raise NotImplementedError("the uni_o2_bond path needs the fully connected ligand bond graph")
-        if self._is_ragged(batch_protein, batch_ligand):
-            raise NotImplementedError("get_diffusion_loss: batch samples of equal size (the padded heterogeneous layout is a "
-                                      "sampling-path feature)")
         hip_lib.require_gpu(protein_pos, "protein_pos")
         grad = torch.is_grad_enabled()
         if grad:

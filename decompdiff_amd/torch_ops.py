@@ -104,6 +104,80 @@ def _(src, index, dim=-1, dim_size=None):
     return torch.empty_like(src)
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# Autograd formulas (the reference differentiates through these ops: drift guidance calls torch.autograd.grad through
+# scatter_min, utils/guidance_funcs.py:52-60; training goes through scatter_softmax / scatter_sum / scatter_mean).
+# Backward passes reuse the registered ops (so they run on the HIP kernels too); the index is never differentiated.
+# ------------------------------------------------------------------------------------------------------------------
+def _index_1d(index):
+    return index if index.dim() == 1 else index.reshape(index.size(0), -1)[:, 0]
+
+
+def _setup_sum(ctx, inputs, output):
+    src, index, dim, dim_size = inputs
+    ctx.save_for_backward(_index_1d(index))
+
+
+def _bw_sum(ctx, g):
+    (index,) = ctx.saved_tensors
+    return g.index_select(0, index), None, None, None
+
+
+scatter_sum.register_autograd(_bw_sum, setup_context=_setup_sum)
+
+
+def _setup_mean(ctx, inputs, output):
+    src, index, dim, dim_size = inputs
+    idx = _index_1d(index)
+    ctx.save_for_backward(idx, torch.bincount(idx, minlength=output.size(0)).clamp(min=1))
+
+
+def _bw_mean(ctx, g):
+    index, cnt = ctx.saved_tensors
+    scale = (1.0 / cnt.to(g.dtype)).view((-1,) + (1,) * (g.dim() - 1))
+    return (g * scale).index_select(0, index), None, None, None
+
+
+scatter_mean.register_autograd(_bw_mean, setup_context=_setup_mean)
+
+
+def _setup_softmax(ctx, inputs, output):
+    src, index, dim, dim_size = inputs
+    idx = _index_1d(index)
+    ctx.save_for_backward(output, idx)
+    ctx.n_seg = int(dim_size) if dim_size is not None else (int(idx.max().item()) + 1 if idx.numel() else 0)
+
+
+def _bw_softmax(ctx, g):
+    y, index = ctx.saved_tensors
+    yg = y * g
+    tot = torch.ops.decompdiff_amd.scatter_sum(yg.contiguous(), index, 0, ctx.n_seg)
+    return yg - y * tot.index_select(0, index), None, None, None
+
+
+scatter_softmax.register_autograd(_bw_softmax, setup_context=_setup_softmax)
+
+
+def _setup_min(ctx, inputs, output):
+    src, index, dim, dim_size = inputs
+    ctx.save_for_backward(output[1])
+    ctx.src_shape = tuple(src.shape)
+
+
+def _bw_min(ctx, g_val, g_arg):
+    (arg,) = ctx.saved_tensors
+    E = ctx.src_shape[0]
+    a = arg.reshape(arg.size(0), -1)
+    g = g_val.reshape(arg.size(0), -1)
+    valid = a < E                                                        # empty destinations point at row E
+    grad = torch.zeros((E + 1, a.size(1)), dtype=g.dtype, device=g.device)
+    grad.scatter_add_(0, torch.where(valid, a, torch.full_like(a, E)), g * valid.to(g.dtype))
+    return grad[:E].reshape(ctx.src_shape), None, None, None
+
+
+scatter_min.register_autograd(_bw_min, setup_context=_setup_min)
+
+
 def patch_reference_imports(force: bool = False) -> None:
     """Make ``import torch_scatter`` / ``from torch_geometric.nn import knn_graph``-style imports of a host that keeps the
     reference's Python resolve to these ops.  Existing real packages are left alone unless ``force``."""

@@ -118,10 +118,83 @@ def _edge_mlp_pre(P, name, W_off, dst_tab, src_tab, dst, src, extra):
     return dst_tab.index_select(0, dst) + src_tab.index_select(0, src) + extra + P.b(name + ".net.0")
 
 
+def check_batch_layout(batch_protein, batch_ligand, ligand_fc_bond_index, batch_ligand_bond=None):
+    """The layout both network paths assume, checked once per call (never silently wrong triplets / gradients): sorted
+    PyG batch vectors and, per sample, the dst-major fully connected bond list of FeaturizeLigandBond('fc')
+    (utils/transforms.py:331-337) offset by the sample's first ligand row (utils/data.py:443-444).
+    Returns (n_p, n_l) per sample as python lists."""
+    for name, t in (("batch_protein", batch_protein), ("batch_ligand", batch_ligand)):
+        if t.numel() == 0:
+            raise ValueError("empty batch")
+        if t.numel() > 1 and bool((t[1:] < t[:-1]).any().item()):
+            raise NotImplementedError(f"{name} must be sorted (PyG Batch order)")
+    B = int(batch_protein.max().item()) + 1
+    n_p = torch.bincount(batch_protein, minlength=B).tolist()
+    n_l = torch.bincount(batch_ligand, minlength=B).tolist()
+    if len(n_l) != B or min(n_p) < 1 or min(n_l) < 2:
+        raise NotImplementedError("every sample needs protein atoms and at least 2 ligand atoms")
+    dev = ligand_fc_bond_index.device
+    exp, off = [], 0
+    for n in n_l:
+        dst = torch.arange(n, device=dev).repeat_interleave(n - 1)
+        sp = torch.arange(n - 1, device=dev).repeat(n)
+        exp.append(torch.stack([sp + (sp >= dst).long(), dst], 0) + off)
+        off += n
+    exp = torch.cat(exp, 1)
+    if ligand_fc_bond_index.shape != exp.shape or not torch.equal(ligand_fc_bond_index, exp):
+        raise NotImplementedError("ligand_fc_bond_index must be the dst-major fully connected graph ('fc' mode)")
+    if batch_ligand_bond is not None:
+        want = torch.repeat_interleave(torch.arange(B, device=dev), torch.tensor([n * (n - 1) for n in n_l], device=dev))
+        if batch_ligand_bond.shape != want.shape or not torch.equal(batch_ligand_bond, want):
+            raise NotImplementedError("batch_ligand_bond does not match the fully connected bond lists")
+    return n_p, n_l
+
+
+def network_grouped(net, model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, ligand_v_aux, batch_ligand,
+                    ligand_fc_bond_index, ligand_bond_type, sizes=None) -> Dict[str, torch.Tensor]:
+    """``net`` (``network`` or the fused forward) on a batch whose samples differ in size -- what the reference's training
+    batches are (batch_size 4 of different complexes, configs/training.yml:62): samples of equal (protein, ligand) size
+    form one dense sub-batch each, the outputs are put back in the caller's row order (differentiable: cat + index_select).
+    Exact because every graph op of the network is segmented by sample."""
+    n_p, n_l = sizes if sizes is not None else check_batch_layout(batch_protein, batch_ligand, ligand_fc_bond_index)
+    B, dev = len(n_p), protein_pos.device
+    if len(set(zip(n_p, n_l))) == 1:
+        return net(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, ligand_v_aux, batch_ligand,
+                   ligand_fc_bond_index, ligand_bond_type)
+    o_p = [0] + list(torch.tensor(n_p).cumsum(0).tolist())
+    o_l = [0] + list(torch.tensor(n_l).cumsum(0).tolist())
+    n_b = [n * (n - 1) for n in n_l]
+    o_b = [0] + list(torch.tensor(n_b).cumsum(0).tolist())
+    groups: Dict = {}
+    for b in range(B):
+        groups.setdefault((n_p[b], n_l[b]), []).append(b)
+    outs, rows_l, rows_b = [], [], []
+    ar = lambda a, n: torch.arange(a, a + n, device=dev)
+    for (np_, nl_), members in groups.items():
+        rp = torch.cat([ar(o_p[b], np_) for b in members])
+        rl = torch.cat([ar(o_l[b], nl_) for b in members])
+        rb = torch.cat([ar(o_b[b], nl_ * (nl_ - 1)) for b in members])
+        g = len(members)
+        _, _, fc = model._expected_layout(g, np_, nl_, dev)
+        outs.append(net(model, protein_pos[rp], protein_v[rp], torch.arange(g, device=dev).repeat_interleave(np_),
+                        ligand_pos[rl], ligand_v[rl], ligand_v_aux[rl], torch.arange(g, device=dev).repeat_interleave(nl_),
+                        fc, ligand_bond_type[rb]))
+        rows_l.append(rl)
+        rows_b.append(rb)
+    inv_l = torch.empty(o_l[-1], dtype=torch.long, device=dev)
+    inv_l[torch.cat(rows_l)] = torch.arange(o_l[-1], device=dev)
+    inv_b = torch.empty(o_b[-1], dtype=torch.long, device=dev)
+    inv_b[torch.cat(rows_b)] = torch.arange(o_b[-1], device=dev)
+    cat = lambda k, inv: torch.cat([o[k] for o in outs], 0).index_select(0, inv)
+    return {"pred_ligand_pos": cat("pred_ligand_pos", inv_l), "pred_ligand_v": cat("pred_ligand_v", inv_l),
+            "pred_bond": cat("pred_bond", inv_b)}
+
+
 def network(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, ligand_v_aux, batch_ligand,
             ligand_fc_bond_index, ligand_bond_type) -> Dict[str, torch.Tensor]:
     """DecompScorePosNet3D.forward for the shipped configuration, differentiable w.r.t. the model's parameters.
-    Dense batches (equal sizes per sample, sorted batch vectors, dst-major fc bond index) as in the sampling path."""
+    Dense batches (equal sizes per sample, sorted batch vectors, dst-major fc bond index -- `check_batch_layout`, run by
+    `diffusion_loss`; samples of different sizes go through `network_grouped`)."""
     cfg = model.config
     P = _P(model)
     dev = protein_pos.device
@@ -312,7 +385,8 @@ def diffusion_loss(model, protein_pos, protein_v, batch_protein, ligand_pos, lig
     (time steps, position noise, atom-type Gumbel uniforms, bond-type Gumbel uniforms) and moved to the device, so a
     seeded call reproduces the reference's CPU run."""
     dev = protein_pos.device
-    B = int(batch_protein.max().item()) + 1
+    sizes = check_batch_layout(batch_protein, batch_ligand, ligand_fc_bond_index, batch_ligand_bond)
+    B = len(sizes[0])
     if time_step is None:
         time_step, _ = sample_time(model, B, dev)
     time_step = time_step.to(dev)
@@ -336,8 +410,11 @@ def diffusion_loss(model, protein_pos, protein_v, batch_protein, ligand_pos, lig
     log_bt = _log_onehot(b_pert, model.num_bond_classes)
     # center_pos (decompdiff.py:20-32)
     if model.center_pos_mode == "protein":
-        NP = batch_protein.numel() // B
-        offset = protein_pos.view(B, NP, 3).mean(1)
+        if len(set(sizes[0])) == 1:
+            offset = protein_pos.view(B, sizes[0][0], 3).mean(1)
+        else:                                                               # scatter_mean(protein_pos, batch_protein)
+            cnt = torch.tensor(sizes[0], dtype=protein_pos.dtype, device=dev).view(B, 1)
+            offset = torch.zeros(B, 3, dtype=protein_pos.dtype, device=dev).index_add_(0, batch_protein, protein_pos) / cnt
     elif model.center_pos_mode == "none":
         offset = torch.zeros(B, 3, device=dev)
     else:
@@ -346,7 +423,8 @@ def diffusion_loss(model, protein_pos, protein_v, batch_protein, ligand_pos, lig
     x_t = pos_pert - offset[batch_ligand]
     x_0 = ligand_pos - offset[batch_ligand]
     net = network_fn or network
-    preds = net(model, p_pos, protein_v, batch_protein, x_t, v_pert, ligand_v_aux, batch_ligand, ligand_fc_bond_index, b_pert)
+    preds = network_grouped(net, model, p_pos, protein_v, batch_protein, x_t, v_pert, ligand_v_aux, batch_ligand,
+                            ligand_fc_bond_index, b_pert, sizes=sizes)
     pred_pos, pred_v = preds["pred_ligand_pos"], preds["pred_ligand_v"]
     log_v_recon = F.log_softmax(pred_v, dim=-1)
     kl_v = _v_loss(tv.posterior(log_v_recon, log_vt, time_step, batch_ligand), log_v0,

@@ -266,14 +266,20 @@ GRAD_KEYS = ["protein_atom_emb.weight", "ligand_atom_emb.weight", "ligand_bond_e
              "v_inference.2.bias", "bond_inference.0.weight"]
 
 
-def gen_loss(ref, cfg):
+def gen_loss(ref, cfg, ragged=False):
     """Training objective: the reference's get_diffusion_loss + backward on a small dense batch, fixed
     time steps, noise from torch.manual_seed on the CPU generator.  Stored: the three losses, the network outputs, the
     gradient of a spread of parameters (full tensors) and the gradient norm of EVERY parameter."""
-    pocket = synth.make_pocket(31, 90, (4, 3), 5, num_full_protein=0)
-    torch.manual_seed(77)
-    batch = synth.build_sampling_batch(pocket, 3, per_sample_std_scale=[1.0, 0.9, 1.1])
-    time_step = torch.tensor([700, 12, 0])
+    if ragged:
+        # what the reference's training batches are (batch_size 4 of different complexes, configs/training.yml:62):
+        # samples of two pocket / ligand sizes, interleaved (48 + 8, 40 + 6, 40 + 6, 48 + 8 atoms)
+        batch = synth.ragged_demo_batch(78)
+        time_step = torch.tensor([700, 12, 0, 400])
+    else:
+        pocket = synth.make_pocket(31, 90, (4, 3), 5, num_full_protein=0)
+        torch.manual_seed(77)
+        batch = synth.build_sampling_batch(pocket, 3, per_sample_std_scale=[1.0, 0.9, 1.1])
+        time_step = torch.tensor([700, 12, 0])
     kw = dict(protein_pos=batch["protein_pos"], protein_v=batch["protein_v"], batch_protein=batch["batch_protein"],
               protein_group_idx=batch["protein_group_idx"], ligand_pos=batch["init_ligand_pos"], ligand_v=batch["init_ligand_v"],
               ligand_v_aux=batch["ligand_v_aux"], batch_ligand=batch["batch_ligand"], ligand_group_idx=batch["ligand_group_idx"],
@@ -300,8 +306,9 @@ def gen_loss(ref, cfg):
     names = sorted(k for k, p_ in params.items() if p_.requires_grad and p_.grad is not None)
     out["grad_norm_names"] = np.array(names)
     out["grad_norms"] = np.array([float(params[k].grad.double().norm()) for k in names])
-    np.savez_compressed(os.path.join(GOLDEN, "loss_grad.npz"), **out)
-    print(f"[loss_grad] losses pos {float(res['losses']['pos']):.6g} v {float(res['losses']['v']):.6g} bond "
+    name = "loss_grad_ragged" if ragged else "loss_grad"
+    np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **out)
+    print(f"[{name}] losses pos {float(res['losses']['pos']):.6g} v {float(res['losses']['v']):.6g} bond "
           f"{float(res['losses']['bond']):.6g}; {len(names)} parameter gradients, total norm {float(np.linalg.norm(out['grad_norms'])):.6g}")
 
 
@@ -337,6 +344,8 @@ def main():
         gen_traj_ragged(ref, sd, cfg, "traj10_ragged", 10, DRIFT, 2023)
     if want("loss"):
         gen_loss(ref, cfg)
+    if want("loss_ragged"):
+        gen_loss(ref, cfg, ragged=True)
     if want("scale"):
         # `scale: True` of the drift terms (decompdiff.py:656-657,667-668), mid-chain where pos_score_coef is not tiny
         drift_scale = [dict(DRIFT[0], scale=True), dict(DRIFT[1], scale=True)]
@@ -345,6 +354,12 @@ def main():
     if want("b16"):
         # configs[3]-style unit: a pocket of the 100-pocket job's size range (NP = 347, NL = 37), batch of 16
         gen_traj(ref, sd, cfg, "traj3_b16", synth.make_pocket(7, 347, (9, 9), 19, num_full_protein=0), 16, 3, None, 2031)
+    if want("b8"):
+        # configs[1] at its exact shape: C-small (300 + 30 atoms), batch of 8 -- the batch the metric is quoted on --
+        # 3 reverse steps, plain (configs[1]) and with armsca + clash drift (configs[2])
+        gen_traj(ref, sd, cfg, "traj3_b8_plain", synth.make_pocket_small(8), 8, 3, None, 2041)
+        gen_traj(ref, sd, cfg, "traj3_b8_drift", synth.make_pocket_small(8), 8, 3, DRIFT, 2042,
+                 std_scale=[1.0, 0.9, 0.8, 1.1, 1.0, 0.95, 1.05, 0.85])
     if want("large"):
         # configs[4] size (600 + 60 atoms) with drift guidance, batch of 2
         gen_traj(ref, sd, cfg, "traj3_large_drift", synth.make_pocket_large(6), 2, 3, DRIFT, 2032, std_scale=[1.0, 0.9])

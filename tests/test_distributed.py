@@ -130,7 +130,10 @@ def test_sharded_job_two_ranks_equals_one_rank():
         assert [u["unit"] for u in units2] == list(range(len(units2)))
         assert sorted(u for r in ranks2 for u in r["units"]) == list(range(len(units2)))
         if config == 3:
-            assert ranks2[0]["units"] == [0, 2, 4, 6] and ranks2[1]["units"] == [1, 3, 5]      # pocket p -> rank p mod N
+            units, _ = ddist.plan_job(3, 2, n_pockets=7)
+            want = ddist.assign_lpt(units, 2)                                                  # longest-first, least loaded rank
+            assert [r["units"] for r in ranks2] == want and sorted(want[0] + want[1]) == list(range(7))
+            assert ranks2[0]["planned_cost"] > 0 and "busy_seconds" in ranks2[0] and ranks2[0]["device"]["uuid"] != ranks2[1]["device"]["uuid"]
         else:
             assert len(units2) == 5 and units2[-1]["n_samples"] == 8                           # 40 samples = 5 shards of 8
             assert ranks2[0]["units"] == [0, 1, 2] and ranks2[1]["units"] == [3, 4]            # contiguous sample shards
@@ -148,3 +151,68 @@ def test_plan_job_weak_configs_scale_with_world():
     assert all(250 <= u.num_protein <= 350 and 20 <= sum(u.arm_atoms) + u.scaffold_atoms <= 40 for u in units)
     units, _ = ddist.plan_job(4, 8)
     assert len(units) == 8 and all(u.num_protein == 600 and sum(u.arm_atoms) + u.scaffold_atoms == 60 for u in units)
+
+
+def test_lpt_assignment_balances_the_pocket_costs():
+    """configs[3]: pocket costs spread 3.5x (the NL^3 bond-layer term); longest-first assignment keeps the planned per-rank load within a few
+    per cent where p mod N does not have to, covers every pocket once, and is a pure function of (units, world)."""
+    units, _ = ddist.plan_job(3, 8)
+    cost = [ddist.unit_cost(u) for u in units]
+    assert max(cost) / min(cost) > 3.0
+    for world in (2, 4, 8):
+        table = ddist.assign_lpt(units, world)
+        assert sorted(i for r in table for i in r) == list(range(100))
+        assert table == ddist.assign_lpt(list(units), world)
+        load = [sum(cost[i] for i in r) for r in table]
+        naive = [sum(cost[i] for i in range(r, 100, world)) for r in range(world)]
+        assert max(load) / (sum(load) / world) < 1.03
+        assert max(load) <= max(naive) + 1e-9
+        assert [u.uid for u in ddist.units_of_rank(units, 3, 1, world)] == table[1]
+    # the heaviest pocket goes first, to rank 0
+    assert ddist.assign_lpt(units, 8)[0][0] == max(range(100), key=lambda i: (cost[i], -i))
+
+
+def test_more_ranks_than_devices_is_refused():
+    import pytest
+    with pytest.raises(SystemExit) as e:
+        ddist.check_world_fits_devices(8, 1)
+    assert "8 ranks but only 1 visible" in str(e.value)
+    ddist.check_world_fits_devices(8, 1, oversubscribe=True)
+    ddist.check_world_fits_devices(8, 8)
+
+
+def _fallback_worker(rank, world, port, allow, q):
+    """backend 'nccl' on a box without a GPU: the RCCL group cannot start on any rank -> every rank takes the same branch."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    try:
+        ddist.init_from_env(backend="nccl", device_index=0, allow_fallback=allow)
+        ddist.barrier()
+        t = ddist.max_over_ranks(1.0 + rank)
+        q.put((rank, "ok", ddist.control_backend(), ddist.control_note(), t))
+        dist.destroy_process_group()
+    except ddist.ControlPlaneError as e:
+        q.put((rank, "error", str(e), None, None))
+
+
+def _run_fallback(allow):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fallback_worker, args=(r, 2, port, allow, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_rccl_failure_is_an_error_unless_the_fallback_is_requested():
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("needs a box where RCCL cannot start (no GPU)")
+    res = _run_fallback(False)
+    assert [r[1] for r in res] == ["error", "error"] and "RCCL start-up failed" in res[0][2]
+    res = _run_fallback(True)
+    assert [r[1] for r in res] == ["ok", "ok"] and all(r[2] == "gloo" and "fall-back" in r[3] and r[4] == 2.0 for r in res)

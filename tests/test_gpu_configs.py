@@ -41,6 +41,17 @@ def _check_chain(name, r, g, steps):
     assert np.array_equal(r["v"].cpu().numpy(), g["out_v"]) and np.array_equal(r["bond"].cpu().numpy(), g["out_bond"])
 
 
+@pytest.mark.parametrize("name,std_scale", [("traj3_b8_plain", None), ("traj3_b8_drift", [1.0, 0.9, 0.8, 1.1, 1.0, 0.95, 1.05, 0.85])])
+def test_config1_config2_exact_bench_shape_reference_golden(name, std_scale):
+    """BASELINE configs[1] (and configs[2]: + armsca / clash drift) at the EXACT shape the metric is quoted on -- C-small
+    300 + 30 atoms, batch of 8 -- 3 reverse steps against the reference's own output (oracle/make_golden.py --only b8)."""
+    g, b, noise = _fixture_chain(name, synth.make_pocket_small(8), 8, std_scale)
+    assert b["init_ligand_pos"].shape[0] == 8 * 30 and b["protein_pos"].shape[0] == 8 * 300
+    r = _sample_hip(model(0), b, 3, json.loads(str(g["drift"])), noise)
+    _check_chain(f"configs[1/2] exact shape ({name}: NP=300, NL=30, B=8)", r, g, 3)
+    assert hip_lib.load().dd_debug_node_split(8, 300, 30, 32) >= 0          # the per-shape launch measurement ran
+
+
 def test_config3_unit_batch16_reference_golden():
     """BASELINE configs[3]: one unit of the 100-pocket job -- a pocket in its size range (347 protein + 37 ligand atoms:
     the 3-tile kernel variants), batch of 16 -- 3 reverse steps against the reference's own output."""
@@ -176,7 +187,8 @@ def test_default_seed_is_fresh_per_call_and_follows_torch_manual_seed():
 def test_bench_two_ranks_equal_one_rank():
     """`python bench.py --gpus 2` (no torchrun environment) spawns two ranks itself; over gloo both may share this box's
     one GPU.  The per-unit checksums of the 2-rank job must equal those of the 1-rank job (units are defined without
-    reference to the world size) and n_gpus / per_rank must say 2."""
+    reference to the world size); the line reports 2 ranks on ONE distinct device (n_gpus counts devices, not ranks).
+    Without --oversubscribe the same command is refused: more ranks than visible devices."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     common = ["--config", "4", "--num-samples", "16", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-rooflines"]
 
@@ -188,8 +200,15 @@ def test_bench_two_ranks_equal_one_rank():
         return json.loads(line)
 
     one = run(["--gpus", "1"])
-    two = run(["--gpus", "2", "--backend", "gloo"])
-    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and len(two["per_rank"]) == 2
+    n_dev = torch.cuda.device_count()
+    two = run(["--gpus", "2", "--backend", "gloo", "--oversubscribe"])
+    assert one["n_gpus"] == 1 and one["ranks"] == 1 and two["ranks"] == 2 and len(two["per_rank"]) == 2
+    assert two["n_gpus"] == two["distinct_devices"] == min(2, n_dev) and len(two["devices"]) == 2
+    if n_dev == 1:
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, capture_output=True, text=True,
+                           env=env, timeout=900)
+        assert p.returncode != 0 and "2 ranks but only 1 visible" in (p.stdout + p.stderr)
+        assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert [r["units"] for r in two["per_rank"]] == [[0], [1]]
     strip = lambda rs: [(r["unit"], r["checksum"]) for r in rs]
     assert strip(one["per_unit"]) == strip(two["per_unit"])

@@ -212,3 +212,36 @@ def test_torch_ops_registered_with_reference_signatures():
     assert float((tot - 1).abs().max()) < 1e-5
     with pytest.raises(Exception):                                  # CPU tensors: no fallback
         torch.ops.decompdiff_amd.scatter_sum(torch.randn(4, 2), torch.tensor([0, 0, 1, 1]), 0, 2)
+
+
+def test_torch_ops_backward_matches_autograd_of_the_oracle_ops():
+    """register_autograd formulas of torch.ops.decompdiff_amd.scatter_{sum,mean,softmax,min} (the reference differentiates
+    through them: guidance_funcs.py:52-60 takes torch.autograd.grad through scatter_min; training goes through
+    scatter_softmax / scatter_sum) against torch autograd through the oracle's CPU restatement, fp64."""
+    import decompdiff_amd.torch_ops  # noqa: F401
+    dev = torch.device("cuda:0")
+    for n_seg, sizes, trail in ((40, [0, 3, 17], (16,)), (25, [5, 9], (3,)), (12, [4, 33], ())):
+        ptr, dst, g = _segments(n_seg, sizes, 11)
+        E = int(ptr[-1])
+        src = torch.randn((E,) + trail, generator=g) * 2
+        w = torch.randn((n_seg,) + trail, generator=g)
+        w_e = torch.randn((E,) + trail, generator=g)
+        for name in ("sum", "mean", "softmax", "min"):
+            a = src.clone().double().requires_grad_(True)
+            b = src.clone().to(dev).requires_grad_(True)
+            if name == "softmax":
+                (ops.scatter_softmax(a, dst, 0, dim_size=n_seg) * w_e.double()).sum().backward()
+                (torch.ops.decompdiff_amd.scatter_softmax(b, dst.to(dev), 0, n_seg) * w_e.to(dev)).sum().backward()
+            elif name == "min":
+                big = torch.full((n_seg,) + trail, float("inf"), dtype=torch.float64).scatter_reduce(
+                    0, dst.view([-1] + [1] * len(trail)).expand_as(a), a, "amin", include_self=True)
+                big = torch.where(torch.isinf(big), torch.zeros_like(big), big)
+                (big * w.double()).sum().backward()
+                (torch.ops.decompdiff_amd.scatter_min(b, dst.to(dev), 0, n_seg)[0] * w.to(dev)).sum().backward()
+            else:
+                f_ref = ops.scatter_sum if name == "sum" else ops.scatter_mean
+                f_op = torch.ops.decompdiff_amd.scatter_sum if name == "sum" else torch.ops.decompdiff_amd.scatter_mean
+                (f_ref(a, dst, 0, dim_size=n_seg) * w.double()).sum().backward()
+                (f_op(b, dst.to(dev), 0, n_seg) * w.to(dev)).sum().backward()
+            err = float((b.grad.cpu().double() - a.grad).abs().max()) if E else 0.0
+            assert b.grad.shape == src.shape and err < 2e-5, (name, n_seg, trail, err)

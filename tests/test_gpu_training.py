@@ -35,8 +35,11 @@ def _loss_kwargs(g):
                 batch_ligand_bond=d(b["batch_ligand_bond"]), time_step=torch.from_numpy(g["time_step"]).to(dev()))
 
 
-def test_diffusion_loss_and_gradients_match_reference():
-    g = GU.load("loss_grad")
+@pytest.mark.parametrize("fixture", ["loss_grad", "loss_grad_ragged"])
+def test_diffusion_loss_and_gradients_match_reference(fixture):
+    """`loss_grad_ragged`: samples of different sizes in one batch (48 + 8, 40 + 6, 40 + 6, 48 + 8 atoms) -- what the
+    reference's training batches are; run as one dense sub-batch per distinct size (training.network_grouped)."""
+    g = GU.load(fixture)
     m = _fresh_model()
     m.train()
     kw = _loss_kwargs(g)
@@ -68,9 +71,10 @@ def test_diffusion_loss_and_gradients_match_reference():
     assert all(params[n].grad is not None for n in names)
 
 
-def test_validation_loss_uses_the_fused_forward_and_agrees():
+@pytest.mark.parametrize("fixture", ["loss_grad", "loss_grad_ragged"])
+def test_validation_loss_uses_the_fused_forward_and_agrees(fixture):
     """torch.no_grad() (the reference's validate()): the network output comes from the fused dd_forward kernels."""
-    g = GU.load("loss_grad")
+    g = GU.load(fixture)
     m = _fresh_model()
     kw = _loss_kwargs(g)
     torch.manual_seed(int(g["noise_seed"]))
@@ -108,3 +112,46 @@ def test_optimizer_steps_reduce_the_loss_and_sampling_sees_the_new_weights():
     torch.manual_seed(5)
     auto = m.get_diffusion_loss(**kw)
     assert abs(float(fused["losses"]["pos"]) - float(auto["losses"]["pos"])) < 1e-5 * max(1.0, float(auto["losses"]["pos"]))
+
+
+def test_loss_rejects_layouts_it_would_get_wrong():
+    """Unsorted batch vectors / a differently ordered bond list raise in BOTH paths (autograd and fused) instead of giving
+    silently wrong triplets and gradients."""
+    g = GU.load("loss_grad")
+    m = _fresh_model()
+    kw = _loss_kwargs(g)
+    bad = dict(kw)
+    bad["ligand_fc_bond_index"] = kw["ligand_fc_bond_index"].flip(0)            # src-major instead of dst-major
+    for grad in (True, False):
+        with torch.set_grad_enabled(grad), pytest.raises(NotImplementedError, match="dst-major"):
+            m.get_diffusion_loss(**bad)
+    bad = dict(kw)
+    bl = kw["batch_ligand"].clone()
+    bl[0], bl[-1] = bl[-1].item(), bl[0].item()
+    bad["batch_ligand"] = bl
+    for grad in (True, False):
+        with torch.set_grad_enabled(grad), pytest.raises(NotImplementedError, match="sorted"):
+            m.get_diffusion_loss(**bad)
+
+
+def test_in_place_parameter_update_is_seen_by_the_fused_path():
+    """Parameters changed in place after a fused call (an optimizer step on the caller's own loss, an EMA copy): the packed
+    weight arena is keyed on the parameters' version counters, so the next fused call runs on the new values."""
+    g = GU.load("loss_grad")
+    m = _fresh_model()
+    kw = _loss_kwargs(g)
+    with torch.no_grad():
+        torch.manual_seed(5)
+        a = m.get_diffusion_loss(**kw)
+        m.v_inference[2].weight.mul_(1.5)                          # in place: no train()/load_state_dict in between
+        dict(m.named_parameters())["refine_net.base_block.3.lin_node.bias"].add_(0.05)
+        torch.manual_seed(5)
+        b = m.get_diffusion_loss(**kw)
+    assert maxabs(a["pred_ligand_v"], b["pred_ligand_v"]) > 1e-3 and maxabs(a["pred_ligand_pos"], b["pred_ligand_pos"]) > 1e-6
+    m2 = _fresh_model()
+    with torch.no_grad():
+        m2.v_inference[2].weight.mul_(1.5)
+        dict(m2.named_parameters())["refine_net.base_block.3.lin_node.bias"].add_(0.05)
+        torch.manual_seed(5)
+        c = m2.get_diffusion_loss(**kw)
+    assert torch.equal(b["pred_ligand_v"], c["pred_ligand_v"]) and torch.equal(b["pred_ligand_pos"], c["pred_ligand_pos"])

@@ -219,3 +219,19 @@ def test_result_pt_round_trip_and_reconstruction_hand_off(tmp_path):
             assert np.array_equal(back[0][k], v), k
         else:
             assert back[0][k] == v, k
+
+
+def test_training_batch_layout_check():
+    """training.check_batch_layout (run by get_diffusion_loss for both network paths): sizes of a ragged batch, and the
+    layouts that would give wrong triplets are refused."""
+    import pytest
+    from decompdiff_amd import training
+    b = synth.ragged_demo_batch(3)
+    n_p, n_l = training.check_batch_layout(b["batch_protein"], b["batch_ligand"], b["ligand_fc_bond_index"], b["batch_ligand_bond"])
+    assert n_p == [48, 40, 40, 48] and n_l == [8, 6, 6, 8]
+    with pytest.raises(NotImplementedError, match="dst-major"):
+        training.check_batch_layout(b["batch_protein"], b["batch_ligand"], b["ligand_fc_bond_index"].flip(0))
+    with pytest.raises(NotImplementedError, match="sorted"):
+        training.check_batch_layout(b["batch_protein"], b["batch_ligand"].flip(0), b["ligand_fc_bond_index"])
+    with pytest.raises(NotImplementedError, match="batch_ligand_bond"):
+        training.check_batch_layout(b["batch_protein"], b["batch_ligand"], b["ligand_fc_bond_index"], b["batch_ligand_bond"].flip(0))

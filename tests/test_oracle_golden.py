@@ -113,6 +113,7 @@ def _pocket_for(name):
             "traj1000_drift": synth.make_pocket_small(5),
             "traj3_scale": synth.make_pocket(41, 80, (3, 3), 4, num_full_protein=200),
             "traj3_b16": synth.make_pocket(7, 347, (9, 9), 19, num_full_protein=0),
+            "traj3_b8_plain": synth.make_pocket_small(8), "traj3_b8_drift": synth.make_pocket_small(8),
             "traj3_large_drift": synth.make_pocket_large(6)}[name]
 
 
@@ -148,9 +149,14 @@ def test_trajectory_drift_scale_option():
     assert np.array_equal(g["out_v"], r["v"].numpy()) and np.array_equal(g["out_bond"], r["bond"].numpy())
 
 
-@pytest.mark.parametrize("name,std_scale", [("traj3_b16", None), ("traj3_large_drift", [1.0, 0.9])])
+B8_STD = [1.0, 0.9, 0.8, 1.1, 1.0, 0.95, 1.05, 0.85]
+
+
+@pytest.mark.parametrize("name,std_scale", [("traj3_b16", None), ("traj3_large_drift", [1.0, 0.9]),
+                                            ("traj3_b8_plain", None), ("traj3_b8_drift", B8_STD)])
 def test_trajectory_bench_config_shapes_first_step(name, std_scale):
-    """BASELINE configs[3] / configs[4] shapes (NP=347, NL=37, B=16; 600 + 60 atoms with drift): the first step of the
+    """BASELINE configs[1] / configs[2] at the exact bench shape (C-small 300 + 30, B=8, plain / drift), configs[3] /
+    configs[4] shapes (NP=347, NL=37, B=16; 600 + 60 atoms with drift): the first step of the
     reference's 3-step fixtures (the full 3 steps are replayed by the HIP path in tests/test_gpu_configs.py; the oracle
     reproduced all 3 bit for bit when the fixture was generated: `oracle_vs_reference_maxabs` = 0)."""
     g, r = _replay_traj(name, 1, std_scale=std_scale)
