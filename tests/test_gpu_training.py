@@ -143,14 +143,14 @@ def test_in_place_parameter_update_is_seen_by_the_fused_path():
     with torch.no_grad():
         torch.manual_seed(5)
         a = m.get_diffusion_loss(**kw)
-        m.v_inference[2].weight.mul_(1.5)                          # in place: no train()/load_state_dict in between
+        dict(m.named_parameters())["v_inference.2.weight"].mul_(1.5)     # in place: no train()/load_state_dict in between
         dict(m.named_parameters())["refine_net.base_block.3.lin_node.bias"].add_(0.05)
         torch.manual_seed(5)
         b = m.get_diffusion_loss(**kw)
     assert maxabs(a["pred_ligand_v"], b["pred_ligand_v"]) > 1e-3 and maxabs(a["pred_ligand_pos"], b["pred_ligand_pos"]) > 1e-6
     m2 = _fresh_model()
     with torch.no_grad():
-        m2.v_inference[2].weight.mul_(1.5)
+        dict(m2.named_parameters())["v_inference.2.weight"].mul_(1.5)
         dict(m2.named_parameters())["refine_net.base_block.3.lin_node.bias"].add_(0.05)
         torch.manual_seed(5)
         c = m2.get_diffusion_loss(**kw)
