@@ -54,7 +54,7 @@ static Workspace carve(float* base, int B, int NP, int NL, int K) {
   w.dxb = take((size_t)B * NL * 3);
   w.ga = take((size_t)B * NL * 3);
   w.gc = take((size_t)B * NL * 3);
-  w.counters = reinterpret_cast<int32_t*>(take(64));
+  w.counters = reinterpret_cast<int32_t*>(take(DD_NUM_COUNTERS + DD_NUM_FLAGS));   // (+ the layer-tail queue's flag words)
   w.total = off;
   return w;
 }
@@ -105,6 +105,8 @@ struct ProfScope {
 // second stream for the coordinate sub-layers (they only feed the NEXT layer's geometry, so they overlap its
 // projection GEMMs); fork/join through events, which stream capture turns into graph edges
 extern int g_gemm_ksplit;                      // dd_gemm.hip
+extern int g_tail_variant;
+extern int g_long_waves;
 static bool g_gemm_ksplit_on() { return g_gemm_ksplit != 0; }   // (the addend form above lives in the K-split tile)
 // Side stream and fork / join events, one set per device (a process may drive several devices; multi-GPU runs use one
 // process per GPU, where this is a single entry).  They only shape a graph while it is being captured, and captures are
@@ -129,7 +131,8 @@ static int g_step_fused = 1;                   // dd_debug_set_option(7, v): row
 static int g_step_fold = 1;                    // dd_debug_set_option(20, v): step boundary folded (counter advanced by the forward's
                                                // first launch; last x update + x0 extraction inside the step kernel)
 static int g_xup_in_asm = 1;                   // dd_debug_set_option(19, v): x += dx applied by the next layer's assemble launch
-static int g_sched = 4;                        // dd_debug_set_option(8, v): 0 = coordinate sub-layers on the side stream,
+static int g_sched = 4;                        // dd_debug_set_option(8, v): 5 = tile queues with in-launch hand-offs (forward_tail;
+                                               // measured slower, EXPERIMENTS.md round 3); 0 = coordinate sub-layers on the side stream,
                                                // 1 = next layer's projections ahead on the side stream, 2 = the same in two
                                                // launches (bond part forked at the node attention), 3 (-3 % in the
                                                // in-process A/B) = 2 + the next layer's query GEMMs on the side stream too,
@@ -217,6 +220,213 @@ static int launch_queries_q1(const dd_sampler* s, const Workspace& w, int ll, co
   return launch_gemm128_batch(j, 3, sx);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Schedule 5 (default): per layer THREE launches on the main stream -- assemble, node attention, coordinate attention --
+// and ONE on the side stream, the persistent layer-tail queue (dd_gemm.hip::k_gemm_tail) with every dense GEMM between
+// two node attentions: lin_node, the coordinate sub-layers' projections, the next layer's projections and query MLPs
+// (last layer: the heads' first Linear).  The queue is forked behind the node attention; what the main stream reads from
+// it is handed over through device counters instead of graph edges: the coordinate attention starts beside the queue
+// (weights staged, then it polls "P2 + PL2 + PB2 tiles done"), the next assemble polls "next PB / PL done", the next node
+// attention "queue finished".  The side stream is joined once, at the end of the forward.  The main-stream successor of
+// the node attention (the coordinate launch, 1 workgroup per CU through its LDS) is dispatched before the forked queue
+// arrives, so it gets its CUs; the queue's workgroups fill the rest.  `two_streams` false (profiling, DD overlap off):
+// the same launches on one stream -- every wait is then satisfied when it is reached.
+static int forward_tail(const dd_sampler* s, hipStream_t st, StepFold* fold, bool two_streams) {
+  const int B = s->B, NP = s->NP, NL = s->NL, K = s->K, N = NP + NL, L = s->num_layers;
+  const long Eb = (long)NL * (NL - 1);
+  const int nE = (int)(B * Eb);
+  Workspace w = carve(s->workspace, B, NP, NL, K);
+  const float* W = s->weights;
+  const int64_t* off = s->slot_off;
+  auto LW = [&](int l, int slot) { return W + off[(long)l * DD_NUM_LAYER_SLOTS + slot]; };
+  auto GW = [&](int slot) { return W + off[(long)L * DD_NUM_LAYER_SLOTS + slot]; };
+  int32_t* flags = w.counters + DD_NUM_COUNTERS;
+  auto FL = [&](int l, int f) { return (l * DD_FLAGS_PER_LAYER + f) * DD_FLAG_STRIDE; };
+  const long hN = (long)N * 128;
+  if (two_streams) DD_TRY(ensure_side_stream());
+  const bool l0 = g_l0_tables && s->l0_tables && s->l0_P && s->l0_qn && s->nl_real == nullptr;
+  int32_t* advance = (fold && fold->advance) ? s->step_counter : nullptr;
+
+  // ---- head of the forward: kNN graph + edge weights (side stream) beside embeddings / context / zeroed counters and
+  //      flags / layer-0 rows (main stream); decompdiff.py:219-297, uni_transformer_edge.py:404-427
+  auto head = [&](hipStream_t sx, int parts) -> int {
+    return launch_head_all(s->protein_h, s->protein_pos, s->lig_pos, s->lig_v, s->lig_aux, GW(DD_G_W_lemb), GW(DD_G_b_lemb), B, NP, NL,
+                           K, w.h, w.xa, w.xb, s->lig_bond, (long)B * Eb, GW(DD_G_W_bemb), GW(DD_G_b_bemb), w.hb, w.counters, advance,
+                           w.nbr, w.ew, GW(DD_G_EW_W1T), GW(DD_G_EW_b1), GW(DD_G_EW_ln), GW(DD_G_EW_w2), GW(DD_G_EW_b2),
+                           s->np_real, s->nl_real, l0 ? s->l0_tables : nullptr, s->l0_P, w.PL, s->l0_qn, w.qlnb, w.PB, w.qb, sx, parts);
+  };
+  bool head_join = false;
+  if (two_streams) {
+    if (hipEventRecord(g_ev_fork[8], st) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_fork[8], 0) != hipSuccess) return DD_ERR_HIP;
+    DD_TRY(head(g_side, 1));
+    if (hipEventRecord(g_ev_join[8], g_side) != hipSuccess) return DD_ERR_HIP;
+    head_join = true;
+    DD_TRY(head(st, 2));
+  } else {
+    DD_TRYP(DD_PROF_MISC, head(st, 2));
+    DD_TRYP(DD_PROF_MISC, head(st, 1));
+  }
+  if (!l0) {                                             // first layer's projections / queries as GEMMs (no tables)
+    DD_TRYP(DD_PROF_GEMM, launch_projections1(s, w, 0, w.h, w.P, st));
+    DD_TRYP(DD_PROF_GEMM, launch_queries_q1(s, w, 0, w.P, w.qn, st));
+  }
+  // tile counts of the queue's jobs (targets of the counters)
+  const int n_lin = gemm_tiles(B * N, 128), n_p2 = gemm_tiles(B * N, 256), n_pl2 = gemm_tiles(B * NL, 1024), n_pb2 = gemm_tiles(nE, 256);
+  const int n_pl1 = gemm_tiles(B * NL, 1280), n_p1q = gemm_tiles(B * N, 128), n_p1r = gemm_tiles(B * N, 512);
+  const int n_pbq = gemm_tiles(nE, 128), n_pb1r = gemm_tiles(nE, 512);
+  const int n_q = gemm_tiles(B * N, 128) + gemm_tiles(B * NL, 128) + gemm_tiles(nE, 128);
+  const int total_mid = n_lin + n_p2 + n_pl2 + n_pb2 + n_pl1 + n_p1q + n_p1r + n_pbq + n_pb1r + n_q;
+
+  float* xcur = w.xa;
+  float* xnext = w.xb;
+  const float* xup_prev = nullptr;
+  for (int l = 0; l < L; ++l) {
+    // ---- assemble (bond_layer first-Linear partial sums; applies the previous layer's coordinate update)
+    FlagWait fw = no_wait();
+    if (l > 0) fw = FlagWait{flags, FL(l - 1, DD_FLAG_PB1R), n_pb1r, FL(l - 1, DD_FLAG_PL1), n_pl1};
+    DD_TRYP(DD_PROF_ASSEMBLE, launch_bl_assemble(xcur, w.PB, w.PL, LW(l, DD_BL_Wgp), B, NP, NL, w.Ek, w.Ev, nullptr, w.Rk, w.Rv, st,
+                                                  xup_prev, w.dxe, w.dxb, xup_prev ? xcur : nullptr, fw));
+    xup_prev = nullptr;
+    if (head_join) {                                     // kNN graph + edge weights: first needed by the node attention
+      if (hipStreamWaitEvent(st, g_ev_join[8], 0) != hipSuccess) return DD_ERR_HIP;
+      head_join = false;
+    }
+    // ---- node_layer_with_edge + node_layer_with_bond + bond_layer: one launch (uni_transformer_edge.py:42-167)
+    {
+      const bool l0_here = l0 && l == 0;
+      AttnArgs ne, nb, bl;
+      memset(&ne, 0, sizeof(ne)); memset(&nb, 0, sizeof(nb)); memset(&bl, 0, sizeof(bl));
+      ne.np_real = nb.np_real = bl.np_real = s->np_real; ne.nl_real = nb.nl_real = bl.nl_real = s->nl_real;
+      bl.bl_prefix = s->bl_prefix;
+      ne.B = B; ne.NP = NP; ne.NL = NL; ne.K = K; ne.x = xcur; ne.nbr = w.nbr; ne.ew = w.ew;
+      const float* Pn = l0_here ? s->l0_P : w.P;
+      ne.kd = Pn; ne.ks = Pn + 128; ne.vd = Pn + 256; ne.vs = Pn + 384; ne.ld_kd = ne.ld_ks = ne.ld_vd = ne.ld_vs = 640;
+      ne.q = l0_here ? s->l0_qn : w.qn; ne.Akp = LW(l, DD_NE_Akp); ne.Avp = LW(l, DD_NE_Avp); ne.lnk = LW(l, DD_NE_lnk); ne.lnv = LW(l, DD_NE_lnv);
+      ne.W2k = LW(l, DD_NE_W2k); ne.W2v = LW(l, DD_NE_W2v); ne.b2v = LW(l, DD_NE_b2v); ne.out = w.A;
+      nb.B = B; nb.NP = NP; nb.NL = NL; nb.K = K; nb.x = xcur;
+      nb.kd = w.PL; nb.ks = w.PL + 128; nb.vd = w.PL + 256; nb.vs = w.PL + 384; nb.ld_kd = nb.ld_ks = nb.ld_vd = nb.ld_vs = 1280;
+      nb.ke = w.PB; nb.ve = w.PB + 128; nb.ld_ke = nb.ld_ve = 640;
+      nb.q = w.qlnb; nb.lnk = LW(l, DD_NB_lnk); nb.lnv = LW(l, DD_NB_lnv);
+      nb.W2k = LW(l, DD_NB_W2k); nb.W2v = LW(l, DD_NB_W2v); nb.b2v = LW(l, DD_NB_b2v); nb.out = w.Anb; nb.out_assign = 1;
+      bl.B = B; bl.NP = NP; bl.NL = NL; bl.K = K; bl.x = xcur;
+      bl.ke = w.Ek; bl.ve = w.Ev; bl.ld_ke = bl.ld_ve = 128;
+      bl.q = w.qb; bl.Wakp = LW(l, DD_BL_Wakp); bl.Wavp = LW(l, DD_BL_Wavp);
+      bl.lnk = LW(l, DD_BL_lnk); bl.lnv = LW(l, DD_BL_lnv);
+      bl.W2k = LW(l, DD_BL_W2k); bl.W2v = LW(l, DD_BL_W2v); bl.b2v = LW(l, DD_BL_b2v); bl.out = w.hb;
+      bl.Rk = w.Rk; bl.Rv = w.Rv;
+      bl.work_counter = w.counters + l;
+      if (l > 0) {                                       // (its other inputs -- PB, PL -- were awaited by this layer's assemble)
+        ne.wait_flags = flags; ne.wait_idx = FL(l - 1, DD_FLAG_NODE); ne.wait_n = n_q + n_p1r;
+      }
+      DD_TRYP(DD_PROF_ATTN_BL, launch_attn2_node(ne, nb, bl, st));
+    }
+    // ---- the two tile queues of the layer: `ta` (lin_node + the coordinate sub-layers' projections: what the coordinate
+    //      attention needs) on the main stream, `tb` (next layer's projections / queries, or the heads) on the side stream
+    TailArgs ta, tb;
+    {
+      memset(&ta, 0, sizeof(ta));
+      memset(&tb, 0, sizeof(tb));
+      ta.flags = tb.flags = flags;
+      ta.ticket = FL(l, DD_FLAG_TICKET);
+      tb.ticket = FL(l, DD_FLAG_TICKET2);
+      const int fLIN = FL(l, DD_FLAG_LIN), fNODE = FL(l, DD_FLAG_NODE);
+      const int fPOS = -1;                               // (the coordinate launch follows `ta` in stream order)
+      int n = 0;
+      GemmArgs g = gemm_args(w.A, B * N, 0, 128, B * N, LW(l, DD_W_lin), LW(l, DD_b_lin), nullptr, w.h, B * N, 0, 128, 128, 1);
+      g.X2 = w.Anb; g.x2_N = N; g.x2_NP = NP;                                           // h += lin_node(A + A_nb on ligand rows)
+      ta.job[n++] = tail_job(g, -1, 0, fLIN);
+      // (independent tiles right behind lin_node: the workgroups of the first wave work instead of polling for it)
+      ta.job[n++] = tail_job(gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b2), LW(l, DD_b_b2), nullptr, w.PB2, nE, 0, 256, 256, 0),
+                             -1, 0, fPOS);
+      ta.job[n++] = tail_job(gemm_args(w.h, B * N, 0, 128, B * N, LW(l, DD_W_n2), LW(l, DD_b_n2), nullptr, w.P2, B * N, 0, 256, 256, 0),
+                             fLIN, n_lin, fPOS);
+      ta.job[n++] = tail_job(gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(l, DD_W_l2), LW(l, DD_b_l2), nullptr, w.PL2, B * NL,
+                                       0, 1024, 1024, 0), fLIN, n_lin, fPOS);
+      ta.njobs = n;
+      n = 0;
+      if (l + 1 < L) {
+        const int ll = l + 1;
+        const int fPL1 = FL(l, DD_FLAG_PL1), fP1Q = FL(l, DD_FLAG_P1Q), fPBQ = FL(l, DD_FLAG_PBQ), fPB1R = FL(l, DD_FLAG_PB1R);
+        // next layer's projections: the query-hidden column blocks first (their consumers sit at the end of the list)
+        tb.job[n++] = tail_job(gemm_args(w.hb, nE, 0, 128, nE, LW(ll, DD_W_b1) + 512 * 128, LW(ll, DD_b_b1) + 512, nullptr, w.PB + 512,
+                                         nE, 0, 640, 128, 0), -1, 0, fPBQ);
+        tb.job[n++] = tail_job(gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(ll, DD_W_l1), LW(ll, DD_b_l1), nullptr, w.PL,
+                                         B * NL, 0, 1280, 1280, 0), fLIN, n_lin, fPL1);
+        tb.job[n++] = tail_job(gemm_args(w.h, B * N, 0, 128, B * N, LW(ll, DD_W_n1) + 512 * 128, LW(ll, DD_b_n1) + 512, nullptr,
+                                         w.P + 512, B * N, 0, 640, 128, 0), fLIN, n_lin, fP1Q);
+        tb.job[n++] = tail_job(gemm_args(w.hb, nE, 0, 128, nE, LW(ll, DD_W_b1), LW(ll, DD_b_b1), nullptr, w.PB, nE, 0, 640, 512, 0),
+                               -1, 0, fPB1R);
+        tb.job[n++] = tail_job(gemm_args(w.h, B * N, 0, 128, B * N, LW(ll, DD_W_n1), LW(ll, DD_b_n1), nullptr, w.P, B * N, 0, 640, 512, 0),
+                               fLIN, n_lin, fNODE);
+        // next layer's query MLPs, second Linear (LayerNorm + ReLU prologue); the bond-layer hidden row is
+        // q_hb[bond] + q_hi[destination atom], summed while the tile stages its rows
+        tb.job[n++] = tail_job(gemm_args(w.P + 512, B * N, 0, 640, B * N, LW(ll, DD_NE_W2q), LW(ll, DD_NE_b2q), LW(ll, DD_NE_lnq), w.qn,
+                                         B * N, 0, 128, 128, 0), fP1Q, n_p1q, fNODE);
+        tb.job[n++] = tail_job(gemm_args(w.PL + 512, B * NL, 0, 1280, B * NL, LW(ll, DD_NB_W2q), LW(ll, DD_NB_b2q), LW(ll, DD_NB_lnq),
+                                         w.qlnb, B * NL, 0, 128, 128, 0), fPL1, n_pl1, fNODE);
+        GemmArgs qb = gemm_args(w.PB + 512, nE, 0, 640, nE, LW(ll, DD_BL_W2q), LW(ll, DD_BL_b2q), LW(ll, DD_BL_lnq), w.qb, nE, 0, 128, 128, 0);
+        qb.X2 = w.PL + 1152; qb.x2_N = NL; qb.x2_Eb = (int)Eb; qb.x2_NLm1 = NL - 1; qb.x2_ld = 1280;
+        tb.job[n++] = tail_job(qb, fPBQ, n_pbq, fNODE, fPL1, n_pl1);
+      } else {
+        // heads, first Linear (decompdiff.py:194-211): bond head on h_bond, v head on the ligand rows of the new h
+        tb.job[n++] = tail_job(gemm_args(w.hb, nE, 0, 128, nE, GW(DD_G_BH_W1), GW(DD_G_BH_b1), nullptr, w.qb, nE, 0, 128, 128, 0),
+                               -1, 0, fNODE);
+        tb.job[n++] = tail_job(gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, GW(DD_G_VH_W1), GW(DD_G_VH_b1), nullptr, w.qn,
+                                         B * NL, 0, 128, 128, 0), fLIN, n_lin, fNODE);
+      }
+      tb.njobs = n;
+    }
+    // ---- pos_layer_with_edge + pos_layer_with_bond: one launch (uni_transformer_edge.py:188-210), query MLPs inside
+    {
+      AttnArgs pe, pb;
+      memset(&pe, 0, sizeof(pe)); memset(&pb, 0, sizeof(pb));
+      pe.np_real = pb.np_real = s->np_real; pe.nl_real = pb.nl_real = s->nl_real;
+      pe.B = B; pe.NP = NP; pe.NL = NL; pe.K = K; pe.x = xcur; pe.nbr = w.nbr; pe.ew = w.ew;
+      pe.kd = w.PL2; pe.vd = w.PL2 + 128; pe.ld_kd = pe.ld_vd = 1024; pe.ks = w.P2; pe.vs = w.P2 + 128; pe.ld_ks = pe.ld_vs = 256;
+      pe.q = w.ql; pe.Akp = LW(l, DD_PE_Akp); pe.Avp = LW(l, DD_PE_Avp); pe.lnk = LW(l, DD_PE_lnk); pe.lnv = LW(l, DD_PE_lnv);
+      pe.W2k = LW(l, DD_PE_W2k); pe.W2v16 = LW(l, DD_PE_W2v); pe.b2v16 = LW(l, DD_PE_b2v); pe.out = w.dxe;
+      pb.B = B; pb.NP = NP; pb.NL = NL; pb.K = K; pb.x = xcur;
+      pb.kd = w.PL2 + 384; pb.ks = w.PL2 + 512; pb.vd = w.PL2 + 640; pb.vs = w.PL2 + 768; pb.ld_kd = pb.ld_ks = pb.ld_vd = pb.ld_vs = 1024;
+      pb.ke = w.PB2; pb.ve = w.PB2 + 128; pb.ld_ke = pb.ld_ve = 256;
+      pb.q = w.ql2; pb.lnk = LW(l, DD_PB_lnk); pb.lnv = LW(l, DD_PB_lnv);
+      pb.W2k = LW(l, DD_PB_W2k); pb.W2v16 = LW(l, DD_PB_W2v); pb.b2v16 = LW(l, DD_PB_b2v); pb.out = w.dxb; pb.x_next = nullptr;
+      pe.qhid = w.PL2 + 256; pe.ld_qhid = 1024; pe.lnq = LW(l, DD_PE_lnq); pe.W2q = LW(l, DD_PE_W2qT); pe.b2q = LW(l, DD_PE_b2q);
+      pb.qhid = w.PL2 + 896; pb.ld_qhid = 1024; pb.lnq = LW(l, DD_PB_lnq); pb.W2q = LW(l, DD_PB_W2qT); pb.b2q = LW(l, DD_PB_b2q);
+      if (two_streams) {
+        // Recording order matters: the graph runtime keeps the FIRST-recorded successor of a node on that node's hardware
+        // queue and pays the cross-queue latency (7-12 us) on the others -- `ta`, which gates the coordinate attention,
+        // is recorded first; `tb` has ~50 us of slack before its first consumer (the next assemble) polls its counters.
+        if (hipEventRecord(g_ev_fork[l], st) != hipSuccess) return DD_ERR_HIP;
+        DD_TRY(launch_gemm_tail(ta, st));
+        if (hipStreamWaitEvent(g_side, g_ev_fork[l], 0) != hipSuccess) return DD_ERR_HIP;
+        DD_TRY(launch_gemm_tail(tb, g_side));
+        if (l + 1 == L && hipEventRecord(g_ev_join[l], g_side) != hipSuccess) return DD_ERR_HIP;
+        DD_TRY(launch_attn2_pos(pe, pb, st));
+      } else {
+        DD_TRYP(DD_PROF_GEMM, launch_gemm_tail(ta, st));
+        DD_TRYP(DD_PROF_GEMM, launch_gemm_tail(tb, st));
+        DD_TRYP(DD_PROF_ATTN_PE, launch_attn2_pos(pe, pb, st));
+      }
+      if (l + 1 < L && ta.total + tb.total != total_mid) return DD_ERR_BAD_ARG;       // (the counters' targets follow the job lists)
+      // x += dx_edge + dx_bond (ligand rows, :285) is applied by the next consumer of x: the next layer's assemble launch,
+      // or the step kernel behind the last layer (folded step boundary); a plain forward runs the 3-block update launch
+      const bool deferred = l + 1 < L || (fold && fold->fold_tail);
+      if (deferred) xup_prev = xcur;
+      else DD_TRYP(DD_PROF_MISC, launch_xupdate(xcur, w.dxe, w.dxb, B, NP, NL, xnext, st));
+    }
+    float* t = xcur; xcur = xnext; xnext = t;
+  }
+  if (head_join && hipStreamWaitEvent(st, g_ev_join[8], 0) != hipSuccess) return DD_ERR_HIP;
+  if (two_streams && hipStreamWaitEvent(st, g_ev_join[L - 1], 0) != hipSuccess) return DD_ERR_HIP;   // last queue: the heads' hidden rows
+  if (!s->pred_pos) return DD_ERR_BAD_ARG;
+  if (xup_prev != nullptr) {                             // folded tail: the step kernel applies the update and extracts x0
+    fold->xprev = xup_prev;
+    return DD_OK;
+  }
+  DD_TRYP(DD_PROF_MISC, launch_extract_ligand(xcur, B, NP, NL, s->pred_pos, st));
+  return DD_OK;
+}
+
 static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nullptr) {
   DD_TRY(check_shapes(s));
   const int B = s->B, NP = s->NP, NL = s->NL, K = s->K, N = NP + NL;
@@ -232,6 +442,9 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
   const long hN = (long)N * 128;
   const bool fused = g_fuse && NL <= g_fused_max_nl && g_dbg_clock == nullptr;
   const bool overlap = fused && g_overlap && g_prof == nullptr && s->num_layers <= 8;
+  if (fused && g_sched >= 5 && s->num_layers <= DD_FLAG_LAYERS && g_q1_in_gemm && g_gemm_ksplit_on() && g_q_in_pos && g_head_fused &&
+      g_xup_in_asm && !g_xup_in_pos)
+    return forward_tail(s, st, fold, overlap);
   if (overlap) DD_TRY(ensure_side_stream());
 
   // layer-0 tables: the first layer's projection and query rows are gathered (ligand atoms: 16 combinations of class and
@@ -704,7 +917,8 @@ extern "C" const char* dd_status_string(int status) {
 // 3: tab_v / tab_b carry the class log-prior after the four schedule rows
 // 4: step_counter is the [4] int32 run state (steps done, t_start, seed lo, seed hi) written by dd_sampler_reset
 // 5: np_real / nl_real / bl_prefix (padded heterogeneous batches) appended to dd_sampler
-extern "C" int dd_abi_version(void) { return 6; }
+// 7: dd_queue_error; the workspace carries the layer-tail queue's flag words (dd_workspace_floats grew)
+extern "C" int dd_abi_version(void) { return 7; }
 
 // 6: l0_tables / l0_P / l0_qn (layer-0 tables) appended to dd_sampler
 extern "C" int dd_layer0_tables(const dd_sampler* m, float* tables, void* stream) {
@@ -1099,6 +1313,21 @@ extern "C" int dd_debug_set_fusion(int mode) {
 namespace dd { extern int g_gemm_ksplit; extern int g_attn_waves; extern int g_attn_persist; extern int g_pos_waves; extern int g_bl_first; extern int g_gemm_xcd; }
 // Measurement aid: runtime switches for A/B timing inside one process.  key 0: attention launch structure (same
 // values as dd_debug_set_fusion), key 1: K-split projection GEMM tiles (1 = on).
+// First bounded spin of the layer-tail hand-offs that gave up (0 = none) since the word was last read (sticky; the
+// workspace must be zero-initialised once): 100+j / 200+j a queue tile of job j, 300/301 assemble, 400 coordinate attention, 500 node attention.
+// Synchronises the stream.  A non-zero code means the launches did not overlap as the schedule assumes (results invalid).
+extern "C" int dd_queue_error(const dd_sampler* s, void* stream, int* code) {
+  if (!s || !s->workspace || !code) return DD_ERR_BAD_ARG;
+  dd::Workspace w = dd::carve(s->workspace, s->B, s->NP, s->NL, s->K);
+  int32_t v = 0;
+  if (hipMemcpyAsync(&v, w.counters + dd::DD_NUM_COUNTERS + dd::DD_FLAG_ERR, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+      hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+    return DD_ERR_HIP;
+  *code = (int)v;
+  if (v != 0 && hipMemsetAsync(w.counters + dd::DD_NUM_COUNTERS + dd::DD_FLAG_ERR, 0, sizeof(v), (hipStream_t)stream) != hipSuccess) return DD_ERR_HIP;
+  return DD_OK;
+}
+
 extern "C" int dd_debug_node_split(int B, int NP, int NL, int K) { return dd::node_split_lookup(B, NP, NL, K); }
 
 extern "C" int dd_debug_set_option(int key, int value) {
@@ -1119,7 +1348,9 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 12) { dd::g_q1_in_gemm = value ? 1 : 0; return DD_OK; }
   if (key == 11) { dd::g_xup_in_pos = value ? 1 : 0; return DD_OK; }
   if (key == 9) { dd::g_q_in_pos = value ? 1 : 0; return DD_OK; }
-  if (key == 8) { if (value < 0 || value > 4) return DD_ERR_BAD_ARG; dd::g_sched = value; return DD_OK; }
+  if (key == 8) { if (value < 0 || value > 5) return DD_ERR_BAD_ARG; dd::g_sched = value; return DD_OK; }
+  if (key == 25) { dd::g_tail_variant = value; return DD_OK; }
+  if (key == 26) { if (value != 4 && value != 8) return DD_ERR_BAD_ARG; dd::g_long_waves = value; return DD_OK; }
   if (key == 7) { dd::g_step_fused = value ? 1 : 0; return DD_OK; }
   if (key == 5) { if (value != 2 && value != 4 && value != 8) return DD_ERR_BAD_ARG; dd::g_pos_waves = value; return DD_OK; }
   if (key == 2) { if (value != 8) return DD_ERR_BAD_ARG; dd::g_attn_waves = value; return DD_OK; }

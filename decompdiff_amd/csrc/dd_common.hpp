@@ -32,6 +32,35 @@ __device__ __forceinline__ float dd_rsqrt(float x) {
 #endif
 }
 
+// ---- consumer side of an in-flight hand-off (guide section 6, Guideline 16): ONE lane polls the counter with relaxed
+// agent-scope loads, ONE agent-scope acquire drops this CU's stale L1 lines, the barrier releases the workgroup, plain
+// loads follow.  The producers (dd_gemm.hip::k_gemm_tail) store write-through (sc1) and bump the counter after their
+// stores have drained.  Spins are bounded (~0.1 s): a waiter that gives up records `code` in the error word and goes on.
+__device__ __forceinline__ void dd_poll_flag(const int32_t* flags, int idx, int target, int err_idx, int code) {
+  if (idx < 0) return;
+  // (polls back off: 0.4, 0.8, 1.6 us, ... capped at 3.3 us -- hundreds of waiters polling one line at full rate saturate
+  //  its memory channel, which every tile's loads cross)
+  for (unsigned spins = 0; __hip_atomic_load(flags + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spins) {
+    if (spins == 0) __builtin_amdgcn_s_sleep(16);
+    else if (spins == 1) __builtin_amdgcn_s_sleep(32);
+    else if (spins == 2) __builtin_amdgcn_s_sleep(64);
+    else __builtin_amdgcn_s_sleep(127);
+    if (spins > (1u << 15)) {
+      __hip_atomic_store(const_cast<int32_t*>(flags) + err_idx, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+  }
+}
+__device__ __forceinline__ void dd_wait_flags(const int32_t* flags, int idx0, int n0, int idx1, int n1, int err_idx, int code) {
+  if (flags == nullptr) return;                          // (kernel-uniform)
+  if (threadIdx.x == 0) {
+    dd_poll_flag(flags, idx0, n0, err_idx, code);
+    dd_poll_flag(flags, idx1, n1, err_idx, code + 1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+
 // ---- cross-lane primitives on the VALU (DPP + v_permlane{16,32}_swap): no LDS round trips ------------
 // DPP controls: quad_perm[1,0,3,2]=0xB1 (lane^1), quad_perm[2,3,0,1]=0x4E (lane^2), row_half_mirror=0x141
 // (i -> 7-i within 8 lanes), row_mirror=0x140 (i -> 15-i within 16), row_ror:8=0x128 (lane^8).

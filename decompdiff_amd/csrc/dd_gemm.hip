@@ -28,6 +28,22 @@ __device__ __forceinline__ long row_offset(int r, int rows_per_b, long stride_b,
 // round 2: 16 dword stores straight from the accumulators -- 128 contiguous bytes per half wave and register, no LDS
 // round trip, no barrier -- cost +2.3 % step time at B = 8 and +1.3 % at B = 16.)
 constexpr int EP = 68;
+// Write-through (sc1) 16-byte accesses through a buffer descriptor: what a tile of the persistent layer-tail queue uses for
+// everything another workgroup of the SAME launch (or of a concurrently running one) produced or will consume -- an sc1
+// store is visible device-wide once the wave's vmcnt has drained, an sc1 load bypasses this CU's L1 (guide section 6,
+// Guideline 16, form R1): no release / acquire fences in the tile path.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_sc1(const float* base, long off) {
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, -1, 0x00020000);
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off * 4), 0, 16);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void st4_sc1(float* base, long off, const float4& v) {
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, -1, 0x00020000);
+  const u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(u, rs, (int)(off * 4), 0, 16);
+}
+template <bool SC1 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, float* sm /*>= 64*EP floats, free*/, const f32x16& acc,
                                               int row0, int col0) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -48,11 +64,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, float* sm /*>= 
     if (gr >= a.rows || gc >= a.ncols) continue;
     const float4 v = *reinterpret_cast<const float4*>(&sm[r * EP + c4]);
     float o[4] = {v.x, v.y, v.z, v.w};
-    float* dst = a.Y + row_offset(gr, a.y_rows_per_b, a.y_stride_b, a.ldy, plain) + gc;
+    const long yoff = row_offset(gr, a.y_rows_per_b, a.y_stride_b, a.ldy, plain) + gc;
+    float* dst = a.Y + yoff;
     if (vec_ok && gc + 3 < a.ncols) {
       if (a.bias) { const float4 bb = *reinterpret_cast<const float4*>(a.bias + gc); o[0] += bb.x; o[1] += bb.y; o[2] += bb.z; o[3] += bb.w; }
-      if (a.accumulate) { const float4 old = *reinterpret_cast<const float4*>(dst); o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w; }
-      *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+      if (a.accumulate) {
+        const float4 old = SC1 ? ld4_sc1(a.Y, yoff) : *reinterpret_cast<const float4*>(dst);
+        o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w;
+      }
+      if (SC1) st4_sc1(a.Y, yoff, make_float4(o[0], o[1], o[2], o[3]));
+      else *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -150,15 +171,19 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int bx, const
   }
 
   __syncthreads();                                     // operands dead: the tile buffer becomes the output stage
-  gemm_epilogue(a, smg, acc, row0, col0);
+  gemm_epilogue<false>(a, smg, acc, row0, col0);
 }
 
 // K-split variant for jobs without the LayerNorm prologue: the two 64-wide halves of K go through a 33 KB LDS
 // image (4 workgroups/CU instead of 2); the second half's global loads are in flight while the first half is
 // multiplied.  Same MFMA order per output element as gemm_tile (k ascending), hence bit-identical results.
 constexpr int GPH = 66;       // LDS pitch of a K-half tile: (66*row) mod 64 = 2*row -> conflict-free ds_read_b64
-template <bool STAMPS = false>
-__device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx, const int by, float* smh /*>= 2*GT*GPH floats*/) {
+// `ticket` (persistent queue): the workgroup's NEXT ticket is drawn by thread 0 right after the second K-half went to LDS --
+// every load of the wave has been consumed by then, so the returning atomic (which retires in order with loads) stalls
+// nothing: it is in flight over the second half's MFMAs and the epilogue and is collected at the end-of-tile drain.
+template <bool STAMPS = false, bool SC1 = false>
+__device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx, const int by, float* smh /*>= 2*GT*GPH floats*/,
+                                                 int32_t* ticket = nullptr, int ticket_step = 0, int* ticket_out = nullptr) {
   float* Xh = smh;
   float* Wh = smh + GT * GPH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -173,16 +198,17 @@ __device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx
       const int gr = row0 + r;
       dst[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (gr < a.rows) {
-        const float* src = a.X + row_offset(gr, a.x_rows_per_b, a.x_stride_b, a.ldx, xplain) + c4;
-        dst[k] = *reinterpret_cast<const float4*>(src);
+        const long xoff = row_offset(gr, a.x_rows_per_b, a.x_stride_b, a.ldx, xplain) + c4;
+        dst[k] = SC1 ? ld4_sc1(a.X, xoff) : *reinterpret_cast<const float4*>(a.X + xoff);
         if (a.X2 != nullptr && a.x2_Eb > 0) {              // bond row -> row of its destination atom
           const long r2 = (long)(gr / a.x2_Eb) * a.x2_N + (gr % a.x2_Eb) / a.x2_NLm1;
-          const float4 t = *reinterpret_cast<const float4*>(a.X2 + r2 * a.x2_ld + c4);
+          const float4 t = SC1 ? ld4_sc1(a.X2, r2 * a.x2_ld + c4) : *reinterpret_cast<const float4*>(a.X2 + r2 * a.x2_ld + c4);
           dst[k].x += t.x; dst[k].y += t.y; dst[k].z += t.z; dst[k].w += t.w;
         } else if (a.X2 != nullptr) {
           const int bb = gr / a.x2_N, n = gr % a.x2_N;
           if (n >= a.x2_NP) {
-            const float4 t = *reinterpret_cast<const float4*>(a.X2 + ((long)bb * (a.x2_N - a.x2_NP) + (n - a.x2_NP)) * 128 + c4);
+            const long o2 = ((long)bb * (a.x2_N - a.x2_NP) + (n - a.x2_NP)) * 128 + c4;
+            const float4 t = SC1 ? ld4_sc1(a.X2, o2) : *reinterpret_cast<const float4*>(a.X2 + o2);
             dst[k].x += t.x; dst[k].y += t.y; dst[k].z += t.z; dst[k].w += t.w;
           }
         }
@@ -282,6 +308,8 @@ __device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx
   GSTAMP(2);
   __syncthreads();
   commit();
+  if (ticket != nullptr && threadIdx.x == 0)
+    *ticket_out = __hip_atomic_fetch_add(ticket, ticket_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   GSTAMP(3);
 #pragma unroll
@@ -294,7 +322,7 @@ __device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx
   asm volatile("" : "+v"(acc));
   GSTAMP(4);
   __syncthreads();                                     // operands dead: the tile buffer becomes the output stage
-  gemm_epilogue(a, smh, acc, row0, col0);
+  gemm_epilogue<SC1>(a, smh, acc, row0, col0);
   if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); GSTAMP(5); }
 #undef GSTAMP
 }
@@ -337,6 +365,111 @@ __global__ __launch_bounds__(256) void k_gemm128_batch(GemmBatch gb) {
   // code.  (One inlined copy per job made this kernel 70 KB -- more than the 64 KB instruction cache two CUs share.)
   const GemmArgs a = gb.job[j];
   gemm_job<KS>(a, lb, gb.nbx[j], gb.big[j], sm);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Persistent layer-tail queue: every dense GEMM between two node-attention launches -- lin_node, the projections of the
+// coordinate sub-layers, the NEXT layer's projections and its query MLPs' second Linear (the ATen addmm chain of
+// models/common.py:85-105 per uni_transformer_edge.py:259-287) -- as ONE launch.  The tiles of all jobs form one list in
+// dependency order; a workgroup draws tickets from a device counter (the next ticket is drawn while the current tile is
+// multiplied), waits -- one lane, relaxed polls -- until the counters its job names have reached their targets, runs the
+// K-split 64 x 64 tile with write-through (sc1) stores and L1-bypassing (sc1) loads, and bumps the job's counters once
+// the workgroup's stores have drained.  Tickets are handed out in list order and a tile only waits for counters fed by
+// tiles EARLIER in the list, which were therefore drawn by workgroups that are resident and never wait for later
+// tickets: progress does not depend on dispatch order, placement or the number of resident workgroups.  The same
+// counters let the kernels around the queue start without a graph edge: the coordinate attention and the next assemble
+// run on the other stream and poll them (dd_attention2.hip / dd_graph.hip: wait_flags).
+// Spins are bounded: after ~0.1 s a waiter records an error code in flags[DD_FLAG_ERR] and goes on (the host reads the
+// word at the end of a chain) instead of hanging the device.
+template <bool SC1, bool WAITS, bool STATIC = false>
+__global__ __launch_bounds__(256) void k_gemm_tail(TailArgs ta) {
+  __shared__ __attribute__((aligned(16))) float sm[2 * GT * GPH + 4];
+  int* s_t = reinterpret_cast<int*>(sm + 2 * GT * GPH);
+  int32_t* flags = ta.flags;
+  if (STATIC) {                                          // timing only: tiles dealt round-robin, no ticket counter
+    for (int t0 = blockIdx.x * DD_TAIL_CHUNK; t0 < ta.total; t0 += gridDim.x * DD_TAIL_CHUNK)
+      for (int t = t0; t < t0 + DD_TAIL_CHUNK && t < ta.total; ++t) {
+        int j = 0, base = 0;
+        for (int i = 0; i + 1 < ta.njobs; ++i)
+          if (j == i && t >= ta.end[i]) { base = ta.end[i]; j = i + 1; }
+        const TailJob q = ta.job[j];
+        const int lb = t - base;
+        if (WAITS && threadIdx.x == 0) {
+          dd_poll_flag(flags, q.wait0, q.wait0_n, DD_FLAG_ERR, 100 + j);
+          dd_poll_flag(flags, q.wait1, q.wait1_n, DD_FLAG_ERR, 200 + j);
+        }
+        __syncthreads();
+        gemm_tile_ksplit<false, SC1>(q.g, lb % q.nbx, lb / q.nbx, sm);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0 && q.sig >= 0) __hip_atomic_fetch_add(flags + q.sig, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    return;
+  }
+  if (threadIdx.x == 0) s_t[0] = __hip_atomic_fetch_add(flags + ta.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  int t = s_t[0];
+  while (t < ta.total) {
+    int j = 0, base = 0;
+    for (int i = 0; i + 1 < ta.njobs; ++i)
+      if (j == i && t >= ta.end[i]) { base = ta.end[i]; j = i + 1; }
+    const TailJob q = ta.job[j];                         // (uniform index: scalar loads from the kernel arguments)
+    const int lb = t - base;
+    if (WAITS && threadIdx.x == 0) {
+      dd_poll_flag(flags, q.wait0, q.wait0_n, DD_FLAG_ERR, 100 + j);
+      dd_poll_flag(flags, q.wait1, q.wait1_n, DD_FLAG_ERR, 200 + j);
+    }
+    __syncthreads();
+    int nxt = 0;
+    gemm_tile_ksplit<false, SC1>(q.g, lb % q.nbx, lb / q.nbx, sm, ta.persist ? flags + ta.ticket : nullptr, 1, &nxt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its write-through stores ...
+    __syncthreads();                                     // ... before ONE lane publishes (and before sm is reused)
+    if (threadIdx.x == 0) {
+      if (q.sig >= 0) __hip_atomic_fetch_add(flags + q.sig, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_t[0] = nxt;
+    }
+    if (!ta.persist) return;
+    __syncthreads();
+    t = s_t[0];
+  }
+}
+
+int g_tail_variant = 0;   // dd_debug_set_option(25, v): timing-only variants of the queue (results invalid for v != 0)
+int launch_gemm_tail(TailArgs& ta, hipStream_t st) {
+  if (ta.njobs <= 0 || ta.njobs > DD_TAIL_MAX_JOBS || !ta.flags) return DD_ERR_BAD_ARG;
+  int total = 0;
+  for (int i = 0; i < ta.njobs; ++i) {
+    TailJob& q = ta.job[i];
+    q.nbx = (q.g.rows + GT - 1) / GT;
+    q.tiles = q.nbx * ((q.g.ncols + GT - 1) / GT);
+    total += q.tiles;
+    ta.end[i] = total;
+  }
+  for (int i = ta.njobs; i < DD_TAIL_MAX_JOBS; ++i) ta.end[i] = total;
+  ta.total = total;
+  ta.persist = g_tail_variant == 7 ? 1 : 0;
+  if (total <= 0) return DD_OK;
+  static int slots = 0;
+  if (slots == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    slots = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                ? 4 * prop.multiProcessorCount : 1024;
+  }
+  // one ticket per workgroup (grid = tiles): workgroups leave when their tile is done, so a launch with a large per-CU
+  // footprint on the other stream (the coordinate attention: one workgroup per CU through its LDS) still finds CUs --
+  // persistent workgroups (g_tail_variant 7: grid = resident slots, tickets drawn in a loop) hold theirs until the queue is empty
+  const dim3 grid(g_tail_variant == 7 ? (total < slots ? total : slots) : total);
+  if (g_tail_variant == 1) hipLaunchKernelGGL((k_gemm_tail<true, false>), grid, dim3(256), 0, st, ta);        // timing only: no waits
+  else if (g_tail_variant == 2) hipLaunchKernelGGL((k_gemm_tail<false, true>), grid, dim3(256), 0, st, ta);   // timing only: plain memory ops
+  else if (g_tail_variant == 3) hipLaunchKernelGGL((k_gemm_tail<false, false>), grid, dim3(256), 0, st, ta);
+  else if (g_tail_variant == 4) hipLaunchKernelGGL((k_gemm_tail<true, false, true>), grid, dim3(256), 0, st, ta);    // static, no waits
+  else if (g_tail_variant == 5) hipLaunchKernelGGL((k_gemm_tail<true, true, true>), grid, dim3(256), 0, st, ta);     // static + waits (serialized runs only)
+  else if (g_tail_variant == 6) hipLaunchKernelGGL((k_gemm_tail<true, true, true>), dim3(total / DD_TAIL_CHUNK + 1), dim3(256), 0, st, ta);   // one chunk per workgroup
+  else hipLaunchKernelGGL((k_gemm_tail<true, true>), grid, dim3(256), 0, st, ta);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
 }
 
 long long* g_gemm_dbg = nullptr;

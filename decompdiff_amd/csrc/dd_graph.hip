@@ -225,7 +225,9 @@ __device__ __forceinline__ void embed_block(const unsigned blk, const float* __r
                                                    const float* __restrict__ Wb, const float* __restrict__ bb,
                                                    float* __restrict__ hb, int32_t* __restrict__ counters, int node_blocks,
                                                    int32_t* __restrict__ advance) {
-  if (blk == 0 && threadIdx.x < 64 && counters) counters[threadIdx.x] = 0;
+  // (+ the layer-tail queue's flag words; the error word behind them is sticky: dd_queue_error reads and clears it)
+  if (blk == 0 && counters)
+    for (int i = threadIdx.x; i < DD_NUM_COUNTERS + DD_FLAG_ERR; i += 256) counters[i] = 0;
   // the step index moves on with the first launch of a step's forward (nothing before the step kernels reads it): the
   // step kernels use *advance - 1, and no one-thread launch sits at the end of a step
   if (blk == 0 && threadIdx.x == 64 && advance) *advance += 1;
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void k_bl_assemble3(const float* __restrict
                                                       float* __restrict__ q1, float* __restrict__ Rk, float* __restrict__ Rv,
                                                       int blocks_per_output, const float* __restrict__ xprev,
                                                       const float* __restrict__ dxe, const float* __restrict__ dxb,
-                                                      float* __restrict__ xout) {
+                                                      float* __restrict__ xout, const FlagWait fw) {
   // Deferred coordinate update (xprev != nullptr): the previous layer's x += dx_edge + dx_bond (uni_transformer_edge.py:285)
   // has not been applied yet -- every lane forms its two ligand positions from xprev + deltas (same association as
   // k_xupdate, so bit-identical) and workgroup 0 writes the updated rows for the kernels that follow.
@@ -426,7 +428,10 @@ __global__ __launch_bounds__(256, 2) void k_bl_assemble3(const float* __restrict
     const float4* src = reinterpret_cast<const float4*>(Wgp + q * DD_NGAUSS * 128);
     for (int i = threadIdx.x; i < DD_NGAUSS * 32; i += 256) reinterpret_cast<float4*>(tab)[i] = src[i];
   }
-  __syncthreads();
+  // PB / PL of this layer come from the layer-tail queue on the other stream: no graph edge, the counters are polled here
+  // (the table above is staged meanwhile); ends with the barrier that also publishes the table
+  if (fw.flags != nullptr) dd_wait_flags(fw.flags, fw.idx0, fw.n0, fw.idx1, fw.n1, DD_FLAG_ERR, 300);
+  else __syncthreads();
   const int lane = threadIdx.x & 63, mm = lane & 15, cg = lane >> 4;
   const int Eb = NL * (NL - 1), N = NP + NL;
   const long nrows = (long)B * Eb;
@@ -609,13 +614,13 @@ int launch_layer0_rows(const float* tables, const int32_t* lig_v, const float* l
 }
 int launch_bl_assemble(const float* x, const float* PB, const float* PL, const float* Wgp, int B, int NP, int NL, float* Ek, float* Ev,
                        float* q1, float* Rk, float* Rv, hipStream_t st, const float* xprev, const float* dxe, const float* dxb,
-                       float* xout) {
+                       float* xout, FlagWait fw) {
   if (Wgp == nullptr) return DD_ERR_BAD_ARG;
   const long rows = (long)B * NL * (NL - 1);
   const long tiles = (rows + 15) / 16;
   const int bpo = (int)((tiles + 3) / 4);                            // blocks per output (4 tiles each)
   hipLaunchKernelGGL(k_bl_assemble3, dim3((unsigned)(bpo * (q1 ? 5 : 4))), dim3(256), 0, st, x, PB, PL, Wgp, B, NP, NL, Ek, Ev, q1,
-                     Rk, Rv, bpo, xprev, dxe, dxb, xout);
+                     Rk, Rv, bpo, xprev, dxe, dxb, xout, fw);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }

@@ -4,6 +4,9 @@
 
 namespace dd {
 
+struct FlagWait { const int32_t* flags; int idx0, n0, idx1, n1; };       // up to two counters (idx < 0: none)
+inline FlagWait no_wait() { return FlagWait{nullptr, -1, 0, -1, 0}; }
+
 struct GemmArgs {
   const float* X; int x_rows_per_b; long x_stride_b; int ldx; int rows;
   const float* W; const float* bias; const float* ln;
@@ -22,6 +25,38 @@ inline GemmArgs gemm_args(const float* X, int x_rows_per_b, long x_stride_b, int
              nullptr, 0, 0, 0, 0, 0, nullptr};
   return g;
 }
+// Persistent layer-tail queue (dd_gemm.hip::k_gemm_tail): jobs in dependency order, counters in the workspace.
+// Flag words (int32, zeroed by the first launch of every forward), per layer DD_FLAGS_PER_LAYER of them, EACH ON ITS OWN
+// 128-byte line (DD_FLAG_STRIDE ints apart): agent-scope atomics on one word retire at ~12 ns each device-wide
+// (tools/bench_atomics.hip) and every poll of a word on the same line queues with them -- with all of a layer's words in
+// one line the queue took 330 us instead of 40.
+enum { DD_FLAG_TICKET = 0, DD_FLAG_LIN = 1, DD_FLAG_TICKET2 = 2, DD_FLAG_PL1 = 3, DD_FLAG_P1Q = 4, DD_FLAG_PBQ = 5, DD_FLAG_PB1R = 6,
+       DD_FLAG_NODE = 7, DD_FLAGS_PER_LAYER = 8 };
+constexpr int DD_FLAG_LAYERS = 8;
+constexpr int DD_FLAG_STRIDE = 32;
+constexpr int DD_FLAG_ERR = DD_FLAG_LAYERS * DD_FLAGS_PER_LAYER * DD_FLAG_STRIDE;   // first spin that timed out (0 = none); sticky
+constexpr int DD_NUM_FLAGS = DD_FLAG_ERR + DD_FLAG_STRIDE;
+constexpr int DD_NUM_COUNTERS = 64;                                     // work counters of the persistent attention workgroups
+constexpr int DD_TAIL_CHUNK = 2;                                        // consecutive tiles drawn per ticket
+constexpr int DD_TAIL_MAX_JOBS = 14;
+struct TailJob {
+  GemmArgs g;
+  int nbx, tiles;                        // filled by launch_gemm_tail
+  int wait0, wait0_n, wait1, wait1_n;    // flag index (-1: none) that must have reached the target before a tile starts
+  int sig;                               // flag index bumped by every finished tile (-1: none)
+};
+struct TailArgs {
+  TailJob job[DD_TAIL_MAX_JOBS];
+  int end[DD_TAIL_MAX_JOBS];             // cumulative tile counts
+  int njobs, total, ticket, persist;     // ticket: index of this launch's ticket counter; persist: workgroups loop over tickets
+  int32_t* flags;
+};
+inline TailJob tail_job(const GemmArgs& g, int wait0 = -1, int wait0_n = 0, int sig = -1, int wait1 = -1, int wait1_n = 0) {
+  TailJob q{g, 0, 0, wait0, wait0_n, wait1, wait1_n, sig};
+  return q;
+}
+inline int gemm_tiles(int rows, int cols) { return ((rows + 63) / 64) * ((cols + 63) / 64); }
+int launch_gemm_tail(TailArgs& ta, hipStream_t st);
 int launch_gemm128(const GemmArgs& a, hipStream_t st);
 // up to 4 independent projections in one launch (small ones ride along with the big ones)
 int launch_gemm128_batch(const GemmArgs* jobs, int njobs, hipStream_t st);
@@ -42,7 +77,7 @@ int launch_edge_weights(const float* x, const int32_t* nbr, int B, int N, int K,
                         const int32_t* np_real = nullptr, const int32_t* nl_real = nullptr);
 int launch_bl_assemble(const float* x, const float* PB, const float* PL, const float* Wgp, int B, int NP, int NL, float* Ek, float* Ev,
                        float* q1, float* Rk, float* Rv, hipStream_t st, const float* xprev = nullptr, const float* dxe = nullptr,
-                       const float* dxb = nullptr, float* xout = nullptr);
+                       const float* dxb = nullptr, float* xout = nullptr, FlagWait fw = FlagWait{nullptr, -1, 0, -1, 0});
 // layer-0 rows of the ligand atoms / bonds gathered from dd_sampler.l0_tables (see include/decompdiff_hip.h)
 int launch_layer0_rows(const float* tables, const int32_t* lig_v, const float* lig_aux, const int32_t* bond, int B, int NP, int NL,
                        float* l0_P, float* PL, float* l0_qn, float* qlnb, float* PB, float* qb, hipStream_t st);
@@ -83,9 +118,13 @@ struct AttnArgs {
   int out_assign;          // NB: 1 = write (=) rows [B*NL,128] of `out` instead of accumulating into the node table
   // padded heterogeneous batches (dd_sampler.np_real / nl_real / bl_prefix), all NULL for dense batches
   const int32_t *np_real, *nl_real, *bl_prefix;
+  // inputs produced by the layer-tail queue running on the other stream (dd_gemm.hip::k_gemm_tail): the launch starts
+  // without a graph edge and polls flags[wait_idx] >= wait_n before its first read of them (NULL: ordinary stream order)
+  const int32_t* wait_flags; int wait_idx, wait_n;
 };
+
 int launch_attn2(int mode, const AttnArgs& a, hipStream_t st);   // one sub-layer: 16-member tiles, scores/aggregation on MFMA
-int launch_attn2_node(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs& bl, hipStream_t st);   // NE+NB+BL, one launch
+int launch_attn2_node(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs& bl, hipStream_t st);   // NE+NB+BL, one launch (ne.wait_*)
 int launch_attn2_pos(const AttnArgs& pe, const AttnArgs& pb, hipStream_t st);                        // PE+PB, one launch
 int launch_xupdate(const float* x, const float* dxe, const float* dxb, int B, int NP, int NL, float* x_next, hipStream_t st);
 

@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "dd_drift_clash", "dd_workspace_view", "dd_profile_step", "dd_debug_set_clock_buffer", "dd_debug_set_fusion", "dd_debug_set_option", "dd_debug_node_split",
     "dd_attn_aggregate_node", "dd_attn_aggregate_triplet", "dd_attn_aggregate_pos", "dd_reverse_step", "dd_debug_philox",
     "dd_segment_reduce", "dd_segment_softmax", "dd_sampler_reset", "dd_debug_options_epoch",
-    "dd_layer0_tables", "dd_layer0_prepare",
+    "dd_layer0_tables", "dd_layer0_prepare", "dd_queue_error",
 ]
 
 
@@ -63,7 +63,7 @@ class DDWsView(ctypes.Structure):
 PROF_CATS = ["misc", "gemm", "assemble", "attn_NE", "attn_NB", "attn_BL", "attn_PE", "attn_PB", "step", "event_pair"]
 
 
-ABI_VERSION = 6          # include/decompdiff_hip.h: layout of struct dd_sampler and of the tables it points to
+ABI_VERSION = 7          # include/decompdiff_hip.h: layout of struct dd_sampler and of the tables it points to
 
 
 class HipLibraryError(RuntimeError):
@@ -103,6 +103,7 @@ def load():
     lib.dd_layer0_tables.argtypes = [POINTER(DDSampler), c_void_p, c_void_p]
     lib.dd_layer0_prepare.argtypes = [POINTER(DDSampler), c_void_p]
     lib.dd_debug_options_epoch.argtypes = []
+    lib.dd_queue_error.argtypes = [POINTER(DDSampler), c_void_p, POINTER(c_int)]
     lib.dd_sample_steps.argtypes = [POINTER(DDSampler), c_int, c_void_p]
     lib.dd_sample_steps_graph.argtypes = [POINTER(DDSampler), c_int, c_void_p]
     lib.dd_graph_create.argtypes = [POINTER(DDSampler), c_int, c_void_p, POINTER(c_void_p)]

@@ -47,6 +47,16 @@ def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor, kind: str):
 GAUSS_OFFSETS = [0, 1, 1.25, 1.5, 1.75, 2, 2.25, 2.5, 2.75, 3, 3.5, 4, 4.5, 5, 5.5, 6, 7, 8, 9, 10]
 
 
+def _check_queue(sampler, dev):
+    """The default launch schedule hands data from the layer-tail GEMM queue to the attention launches through device
+    counters with bounded polls.  A poll that gave up means the results are invalid: raise."""
+    code = ctypes.c_int(0)
+    hip_lib.check(hip_lib.load().dd_queue_error(ctypes.byref(sampler), hip_lib.stream_ptr(dev), ctypes.byref(code)), "dd_queue_error")
+    if code.value != 0:
+        raise RuntimeError(f"decompdiff_hip: an in-launch hand-off of the layer-tail queue timed out (waiter {code.value}); the "
+                           "results are invalid (dd_debug_set_option(8, 4) selects the graph-edge schedule)")
+
+
 def log_sample_categorical(logits: torch.Tensor) -> torch.Tensor:
     """Gumbel-argmax sampling, re-exported because the reference's script imports it from
     models.decompdiff (scripts/sample_diffusion_decomp.py:25; models/transitions.py:78-84).
@@ -777,6 +787,7 @@ class DecompScorePosNet3D(nn.Module):
             s, bufs, _ = self._make_sampler(d, pw, 0, 0, None, False, None, dummy3,
                                             torch.zeros(B, 3, device=dev), None, None, 0)
             hip_lib.check(hip_lib.load().dd_forward(ctypes.byref(s), hip_lib.stream_ptr(dev)), "dd_forward")
+            _check_queue(s, dev)
             preds = {"pred_ligand_pos": bufs["pred_pos"].view(B * NL, 3),
                      "pred_ligand_v": bufs["pred_v"].view(B * NL, 8)}
             if self.bond_diffusion:
@@ -1066,6 +1077,7 @@ class DecompScorePosNet3D(nn.Module):
         bufs, B, NL, offset = chain["bufs"], chain["B"], chain["NL"], chain["offset"]
         ligand_pos = bufs["lig_pos"].view(B, NL, 3) + offset[:, None, :]
         dev = chain["dev"]
+        _check_queue(chain["s"], dev)
         pick_a = (lambda t: t) if rows_atoms is None else (lambda t, r=rows_atoms.to(dev): t.index_select(0, r))
         pick_b = (lambda t: t) if rows_bonds is None else (lambda t, r=rows_bonds.to(dev): t.index_select(0, r))
         out = {

@@ -281,6 +281,13 @@ int dd_debug_options_epoch(void);
 /* Measured split of the fused node launch for a shape (dd_debug_set_option key 18 = 1): number of CUs kept by the
  * persistent bond-layer workgroups, 0 = node blocks first, -1 = not measured yet. */
 int dd_debug_node_split(int B, int NP, int NL, int K);
+/* Health word of the in-launch hand-offs of the default launch schedule ("layer-tail queue"): the
+ * coordinate attention, the next assemble and the next node attention start beside the persistent GEMM queue of their
+ * layer and poll its device counters instead of waiting for a graph edge; every poll is bounded (~0.1 s).  *code = 0:
+ * no poll gave up since the last forward started; otherwise the id of the first waiter that did (100+j / 200+j a queue
+ * tile of job j, 300/301 assemble, 400 coordinate attention, 500 node attention) -- the results of that forward are then
+ * invalid.  Synchronises `stream`.  (ABI 7.) */
+int dd_queue_error(const dd_sampler* s, void* stream, int* code);
 
 /* Test aid: the production (Philox4x32-10) noise of one step exactly as the step kernels draw it -- kind 1: uniforms
  * [rows,8] of the atom-type stream (transitions.py:79 rand_like), 2: uniforms [rows,5] of the bond-type stream,

@@ -102,7 +102,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(hip_lib.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.dd_abi_version() == hip_lib.ABI_VERSION == 6
+    assert lib.dd_abi_version() == hip_lib.ABI_VERSION == 7
     assert lib.dd_status_string(0) == b"ok" and b"workspace" in lib.dd_status_string(-3)
     # pure host helper: workspace size grows with the batch and is non-zero
     w1, w8 = lib.dd_workspace_floats(1, 300, 30, 32), lib.dd_workspace_floats(8, 300, 30, 32)
