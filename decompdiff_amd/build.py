@@ -36,7 +36,7 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True, exact: bool = False) -> str:
+def build(force: bool = False, verbose: bool = True, exact: bool = False, debug_options: bool = False) -> str:
     """``exact``: the -DDD_EXACT_MATH=1 variant (correctly rounded 1/sqrt and softmax division instead of v_rsq_f32 and
     one reciprocal per head) as lib/libdecompdiff_hip_exact.so -- a measurement aid for the parity study of DESIGN.md
     section 2, selected at run time with DD_HIP_LIB; the default library is unaffected."""
@@ -44,13 +44,17 @@ def build(force: bool = False, verbose: bool = True, exact: bool = False) -> str
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs, jobs = [], []
-    lib = LIB.replace(".so", "_exact.so") if exact else LIB
+    # debug_options: the measurement build (-DDD_DEBUG_OPTIONS=1) with the alternative launch schedules / kernel variants behind
+    # dd_debug_set_option, as lib/libdecompdiff_hip_dbg.so (tools/ab_*.py and the variant cross-check tests select it with
+    # DD_HIP_LIB); the default library compiles none of them
+    tag = "_exact" if exact else ("_dbg" if debug_options else "")
+    lib = LIB.replace(".so", tag + ".so")
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(LIBDIR, src.replace(".hip", "_exact.o" if exact else ".o"))
+        o = os.path.join(LIBDIR, src.replace(".hip", tag + ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([hipcc] + FLAGS + (["-DDD_EXACT_MATH=1"] if exact else []) + ["-c", s, "-o", o])
+            jobs.append([hipcc] + FLAGS + (["-DDD_EXACT_MATH=1"] if exact else []) + (["-DDD_DEBUG_OPTIONS=1"] if debug_options else []) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -66,4 +70,4 @@ def build(force: bool = False, verbose: bool = True, exact: bool = False) -> str
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, exact="--exact" in sys.argv))
+    print(build(force="--force" in sys.argv, exact="--exact" in sys.argv, debug_options="--debug-options" in sys.argv))

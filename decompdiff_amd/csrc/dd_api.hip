@@ -59,11 +59,15 @@ static Workspace carve(float* base, int B, int NP, int NL, int K) {
   return w;
 }
 
+static inline int num_v(const dd_sampler* s) { return s->num_v > 0 ? s->num_v : DD_NUM_V; }
+
 static int check_shapes(const dd_sampler* s) {
   if (!s || !s->weights || !s->slot_off || !s->workspace) return DD_ERR_BAD_ARG;
   if (s->B <= 0 || s->NP < 0 || s->NL < 2 || s->K <= 0 || s->num_layers < 1 || s->num_layers > 64) return DD_ERR_BAD_ARG;
   const int N = s->NP + s->NL;
   if (s->NL > DD_NL_MAX || N > DD_N_MAX || s->K > DD_KNN_MAX || s->K > N - 1) return DD_ERR_UNSUPPORTED_SHAPE;
+  if (s->num_v != 0 && s->num_v != 8 && s->num_v != 13 && s->num_v != 23) return DD_ERR_UNSUPPORTED_SHAPE;   // utils/transforms.py:138-151
+  if (num_v(s) != DD_NUM_V && s->l0_tables != nullptr) return DD_ERR_BAD_ARG;
   if (s->workspace_floats < dd_workspace_floats(s->B, s->NP, s->NL, s->K)) return DD_ERR_WORKSPACE_TOO_SMALL;
   if ((s->nl_real != nullptr) != (s->bl_prefix != nullptr) || (s->np_real != nullptr && s->nl_real == nullptr)) return DD_ERR_BAD_ARG;
   return DD_OK;
@@ -105,8 +109,9 @@ struct ProfScope {
 // second stream for the coordinate sub-layers (they only feed the NEXT layer's geometry, so they overlap its
 // projection GEMMs); fork/join through events, which stream capture turns into graph edges
 extern int g_gemm_ksplit;                      // dd_gemm.hip
+#if defined(DD_DEBUG_OPTIONS) && DD_DEBUG_OPTIONS
 extern int g_tail_variant;
-extern int g_long_waves;
+#endif
 static bool g_gemm_ksplit_on() { return g_gemm_ksplit != 0; }   // (the addend form above lives in the K-split tile)
 // Side stream and fork / join events, one set per device (a process may drive several devices; multi-GPU runs use one
 // process per GPU, where this is a single entry).  They only shape a graph while it is being captured, and captures are
@@ -127,11 +132,20 @@ static DevCtx& dev_ctx() {
 #define g_ev_qb_fork (dev_ctx().ev_qb_fork)
 #define g_ev_fork (dev_ctx().ev_fork)
 #define g_ev_join (dev_ctx().ev_join)
-static int g_step_fused = 1;                   // dd_debug_set_option(7, v): rows + coordinates + counter in one launch
-static int g_step_fold = 1;                    // dd_debug_set_option(20, v): step boundary folded (counter advanced by the forward's
+// Launch-schedule / kernel alternatives kept for A/B measurements (EXPERIMENTS.md).  They exist only in the measurement
+// build (`python -m decompdiff_amd.build --debug-options` -> lib/libdecompdiff_hip_dbg.so, -DDD_DEBUG_OPTIONS=1, selected
+// with DD_HIP_LIB); in the default library the values below are compile-time constants, the alternative paths are not
+// compiled, and dd_debug_set_option only knows key 0 (one launch per sub-layer: the cross-check).
+#if defined(DD_DEBUG_OPTIONS) && DD_DEBUG_OPTIONS
+#define DD_OPT static int
+#else
+#define DD_OPT static constexpr int
+#endif
+DD_OPT g_step_fused = 1;                   // dd_debug_set_option(7, v): rows + coordinates + counter in one launch
+DD_OPT g_step_fold = 1;                    // dd_debug_set_option(20, v): step boundary folded (counter advanced by the forward's
                                                // first launch; last x update + x0 extraction inside the step kernel)
-static int g_xup_in_asm = 1;                   // dd_debug_set_option(19, v): x += dx applied by the next layer's assemble launch
-static int g_sched = 4;                        // dd_debug_set_option(8, v): 5 = tile queues with in-launch hand-offs (forward_tail;
+DD_OPT g_xup_in_asm = 1;                   // dd_debug_set_option(19, v): x += dx applied by the next layer's assemble launch
+DD_OPT g_sched = 4;                        // dd_debug_set_option(8, v): 5 = tile queues with in-launch hand-offs (forward_tail;
                                                // measured slower, EXPERIMENTS.md round 3); 0 = coordinate sub-layers on the side stream,
                                                // 1 = next layer's projections ahead on the side stream, 2 = the same in two
                                                // launches (bond part forked at the node attention), 3 (-3 % in the
@@ -139,18 +153,18 @@ static int g_sched = 4;                        // dd_debug_set_option(8, v): 5 =
                                                // 4 (default, another -2 %) = 3 with two joins: assemble waits for the
                                                // projections only and runs beside the query GEMMs, which are joined at the
                                                // node attention
-static int g_xup_in_pos = 0;                   // dd_debug_set_option(11, v): x update inside the coordinate launch (last workgroup);
+DD_OPT g_xup_in_pos = 0;                   // dd_debug_set_option(11, v): x update inside the coordinate launch (last workgroup);
                                                // measured 1 % slower than the separate 3-block launch, off
-static int g_fused_max_nl = 64;                // dd_debug_set_option(13, v): largest ligand handled by the fused launches
-static int g_defer_pos = 0;                    // dd_debug_set_option(14, v): record the coordinate launch after the next layer's GEMMs
+DD_OPT g_fused_max_nl = 64;                // dd_debug_set_option(13, v): largest ligand handled by the fused launches
+DD_OPT g_defer_pos = 0;                    // dd_debug_set_option(14, v): record the coordinate launch after the next layer's GEMMs
                                                // (keeps the GEMM chain on the main queue; measured 1.3 % slower: the coordinate
                                                // launch then starves behind the projections' workgroups)
-static int g_lin_with_pb2 = 1;                 // dd_debug_set_option(16, v): bond projections of the coordinate sub-layer ride with lin_node
-static int g_pb_early = 1;                     // dd_debug_set_option(17, v): next layer's bond projections in the lin_node launch
-static int g_q1_in_gemm = 1;                   // dd_debug_set_option(12, v): bond-layer query hidden row summed inside the query GEMM
-static int g_l0_tables = 1;                    // dd_debug_set_option(22, v): first layer's projection / query rows gathered from tables
-static int g_head_fused = 1;                   // dd_debug_set_option(24, v): head of a forward in two launches (0 = four, the cross-check)
-static int g_q_in_pos = 1;                     // dd_debug_set_option(9, v): coordinate query MLPs' second layer inside attn_pos
+DD_OPT g_lin_with_pb2 = 1;                 // dd_debug_set_option(16, v): bond projections of the coordinate sub-layer ride with lin_node
+DD_OPT g_pb_early = 1;                     // dd_debug_set_option(17, v): next layer's bond projections in the lin_node launch
+DD_OPT g_q1_in_gemm = 1;                   // dd_debug_set_option(12, v): bond-layer query hidden row summed inside the query GEMM
+DD_OPT g_l0_tables = 1;                    // dd_debug_set_option(22, v): first layer's projection / query rows gathered from tables
+DD_OPT g_head_fused = 1;                   // dd_debug_set_option(24, v): head of a forward in two launches (0 = four, the cross-check)
+DD_OPT g_q_in_pos = 1;                     // dd_debug_set_option(9, v): coordinate query MLPs' second layer inside attn_pos
 // (ev_fork / ev_join: [0..7] per layer, [8] graph construction at the head of a forward)
 // DD_SIDE_PRIO: 1 (default) lowest priority for the side stream, 0 default priority, 2 highest
 static int g_side_low_priority = [] { const char* e = getenv("DD_SIDE_PRIO"); return (e && e[0] == '0') ? 0 : ((e && e[0] == '2') ? 2 : 1); }();
@@ -220,17 +234,16 @@ static int launch_queries_q1(const dd_sampler* s, const Workspace& w, int ll, co
   return launch_gemm128_batch(j, 3, sx);
 }
 
+#if defined(DD_DEBUG_OPTIONS) && DD_DEBUG_OPTIONS
 // ---------------------------------------------------------------------------------------------------------------------
-// Schedule 5 (default): per layer THREE launches on the main stream -- assemble, node attention, coordinate attention --
-// and ONE on the side stream, the persistent layer-tail queue (dd_gemm.hip::k_gemm_tail) with every dense GEMM between
-// two node attentions: lin_node, the coordinate sub-layers' projections, the next layer's projections and query MLPs
-// (last layer: the heads' first Linear).  The queue is forked behind the node attention; what the main stream reads from
-// it is handed over through device counters instead of graph edges: the coordinate attention starts beside the queue
-// (weights staged, then it polls "P2 + PL2 + PB2 tiles done"), the next assemble polls "next PB / PL done", the next node
-// attention "queue finished".  The side stream is joined once, at the end of the forward.  The main-stream successor of
-// the node attention (the coordinate launch, 1 workgroup per CU through its LDS) is dispatched before the forked queue
-// arrives, so it gets its CUs; the queue's workgroups fill the rest.  `two_streams` false (profiling, DD overlap off):
-// the same launches on one stream -- every wait is then satisfied when it is reached.
+// Schedule 5 (measurement build only; EXPERIMENTS.md, round 3): the dense GEMMs between two node attentions as TWO ordered
+// tile queues per layer (dd_gemm.hip::k_gemm_tail: tickets in dependency order, write-through tiles, device counters) --
+// `ta` = lin_node + the coordinate sub-layers' projections on the main stream in front of the coordinate attention, `tb`
+// = the next layer's projections and query MLPs (last layer: the heads' first Linear) on the side stream -- and device
+// counters instead of graph edges towards the next assemble / node attention (they poll; the side stream is joined once
+// per forward).  Bit-identical to schedule 4, 31 instead of 51 launches per step, and SLOWER (1.41 vs 1.24 ms/step): a
+// polling consumer with a large per-CU footprint keeps the producers' workgroups off the chip.  `two_streams` false
+// (profiling): the same launches on one stream -- every wait is then satisfied when it is reached.
 static int forward_tail(const dd_sampler* s, hipStream_t st, StepFold* fold, bool two_streams) {
   const int B = s->B, NP = s->NP, NL = s->NL, K = s->K, N = NP + NL, L = s->num_layers;
   const long Eb = (long)NL * (NL - 1);
@@ -253,7 +266,7 @@ static int forward_tail(const dd_sampler* s, hipStream_t st, StepFold* fold, boo
     return launch_head_all(s->protein_h, s->protein_pos, s->lig_pos, s->lig_v, s->lig_aux, GW(DD_G_W_lemb), GW(DD_G_b_lemb), B, NP, NL,
                            K, w.h, w.xa, w.xb, s->lig_bond, (long)B * Eb, GW(DD_G_W_bemb), GW(DD_G_b_bemb), w.hb, w.counters, advance,
                            w.nbr, w.ew, GW(DD_G_EW_W1T), GW(DD_G_EW_b1), GW(DD_G_EW_ln), GW(DD_G_EW_w2), GW(DD_G_EW_b2),
-                           s->np_real, s->nl_real, l0 ? s->l0_tables : nullptr, s->l0_P, w.PL, s->l0_qn, w.qlnb, w.PB, w.qb, sx, parts);
+                           s->np_real, s->nl_real, l0 ? s->l0_tables : nullptr, s->l0_P, w.PL, s->l0_qn, w.qlnb, w.PB, w.qb, sx, parts, num_v(s));
   };
   bool head_join = false;
   if (two_streams) {
@@ -427,6 +440,8 @@ static int forward_tail(const dd_sampler* s, hipStream_t st, StepFold* fold, boo
   return DD_OK;
 }
 
+#endif
+
 static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nullptr) {
   DD_TRY(check_shapes(s));
   const int B = s->B, NP = s->NP, NL = s->NL, K = s->K, N = NP + NL;
@@ -442,9 +457,11 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
   const long hN = (long)N * 128;
   const bool fused = g_fuse && NL <= g_fused_max_nl && g_dbg_clock == nullptr;
   const bool overlap = fused && g_overlap && g_prof == nullptr && s->num_layers <= 8;
+#if defined(DD_DEBUG_OPTIONS) && DD_DEBUG_OPTIONS
   if (fused && g_sched >= 5 && s->num_layers <= DD_FLAG_LAYERS && g_q1_in_gemm && g_gemm_ksplit_on() && g_q_in_pos && g_head_fused &&
       g_xup_in_asm && !g_xup_in_pos)
     return forward_tail(s, st, fold, overlap);
+#endif
   if (overlap) DD_TRY(ensure_side_stream());
 
   // layer-0 tables: the first layer's projection and query rows are gathered (ligand atoms: 16 combinations of class and
@@ -464,7 +481,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
                              K, w.h, w.xa, w.xb, s->lig_bond, (long)B * Eb, GW(DD_G_W_bemb), GW(DD_G_b_bemb), w.hb, w.counters, advance,
                              w.nbr, w.ew, GW(DD_G_EW_W1T), GW(DD_G_EW_b1), GW(DD_G_EW_ln), GW(DD_G_EW_w2), GW(DD_G_EW_b2),
                              s->np_real, s->nl_real, l0 ? s->l0_tables : nullptr, s->l0_P, w.PL, s->l0_qn, w.qlnb, w.PB, w.qb, sx,
-                             parts);
+                             parts, num_v(s));
     };
     if (hipEventRecord(g_ev_fork[8], st) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_fork[8], 0) != hipSuccess) return DD_ERR_HIP;
     DD_TRYP(DD_PROF_MISC, head(g_side, 1));
@@ -475,7 +492,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     // embeddings + context (decompdiff.py:219-297) and the zeroed work counters: one launch
     DD_TRYP(DD_PROF_MISC, launch_embed_all(s->protein_h, s->protein_pos, s->lig_pos, s->lig_v, s->lig_aux, GW(DD_G_W_lemb),
                                            GW(DD_G_b_lemb), B, NP, NL, w.h, w.xa, w.xb, s->lig_bond, (long)B * Eb, GW(DD_G_W_bemb),
-                                           GW(DD_G_b_bemb), w.hb, w.counters, st, advance));
+                                           GW(DD_G_b_bemb), w.hb, w.counters, st, advance, num_v(s)));
     if (l0)
       DD_TRYP(DD_PROF_MISC, launch_layer0_rows(s->l0_tables, s->lig_v, s->lig_aux, s->lig_bond, B, NP, NL, s->l0_P, w.PL, s->l0_qn,
                                                 w.qlnb, w.PB, w.qb, st));
@@ -797,7 +814,7 @@ static int heads_and_step(const dd_sampler* s, hipStream_t st, const StepFold* f
   auto GW = [&](int slot) { return W + off[(long)s->num_layers * DD_NUM_LAYER_SLOTS + slot]; };
   StepRowsArgs r;
   memset(&r, 0, sizeof(r));
-  r.hid = w.qn; r.W2 = GW(DD_G_VH_W2); r.b2 = GW(DD_G_VH_b2); r.rows = B * NL; r.NC = DD_NUM_V; r.rows_per_sample = NL;
+  r.hid = w.qn; r.W2 = GW(DD_G_VH_W2); r.b2 = GW(DD_G_VH_b2); r.rows = B * NL; r.NC = num_v(s); r.rows_per_sample = NL;
   r.tab = s->tab_v; r.T = s->T; r.step_counter = s->step_counter;
   r.counter_bias = (fold && fold->advance) ? 1 : 0;
   r.state = s->lig_v; r.uniforms = s->u_v; r.stream_id = 1;
@@ -850,7 +867,7 @@ static int reverse_step_from_logits(const dd_sampler* s, const float* logits_v, 
   Workspace w = carve(s->workspace, B, s->NP, NL, s->K);
   StepRowsArgs r;
   memset(&r, 0, sizeof(r));
-  r.logits_in = logits_v; r.rows = B * NL; r.NC = DD_NUM_V; r.rows_per_sample = NL;
+  r.logits_in = logits_v; r.rows = B * NL; r.NC = num_v(s); r.rows_per_sample = NL;
   r.tab = s->tab_v; r.T = s->T; r.step_counter = s->step_counter;
   r.state = s->lig_v; r.uniforms = s->u_v; r.stream_id = 1;
   r.logits_out = nullptr; r.traj_recon = s->traj_v0; r.traj_prob = s->traj_vt; r.traj_state = s->traj_v;
@@ -997,7 +1014,7 @@ extern "C" int dd_forward(const dd_sampler* s, void* stream) {
   const int rows_v = s->B * s->NL;
   const long rows_b = (long)s->B * s->NL * (s->NL - 1);
   hipLaunchKernelGGL(dd::k_head_logits, dim3((rows_v + 3) / 4), dim3(256), 0, st, w.qn, GW(DD_G_VH_W2), GW(DD_G_VH_b2),
-                     rows_v, DD_NUM_V, s->pred_v);
+                     rows_v, dd::num_v(s), s->pred_v);
   hipLaunchKernelGGL(dd::k_head_logits, dim3((unsigned)((rows_b + 3) / 4)), dim3(256), 0, st, w.qb, GW(DD_G_BH_W2),
                      GW(DD_G_BH_b2), (int)rows_b, DD_NUM_B, s->pred_bond);
   DD_CHECK_LAUNCH();
@@ -1333,6 +1350,7 @@ extern "C" int dd_debug_node_split(int B, int NP, int NL, int K) { return dd::no
 extern "C" int dd_debug_set_option(int key, int value) {
   ++g_options_epoch;
   if (key == 0) return dd_debug_set_fusion(value);
+#if defined(DD_DEBUG_OPTIONS) && DD_DEBUG_OPTIONS
   if (key == 1) { dd::g_gemm_ksplit = value ? 1 : 0; return DD_OK; }
   if (key == 3) { dd::g_attn_persist = value ? 1 : 0; return DD_OK; }
   if (key == 24) { dd::g_head_fused = value ? 1 : 0; return DD_OK; }
@@ -1350,9 +1368,12 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 9) { dd::g_q_in_pos = value ? 1 : 0; return DD_OK; }
   if (key == 8) { if (value < 0 || value > 5) return DD_ERR_BAD_ARG; dd::g_sched = value; return DD_OK; }
   if (key == 25) { dd::g_tail_variant = value; return DD_OK; }
-  if (key == 26) { if (value != 4 && value != 8) return DD_ERR_BAD_ARG; dd::g_long_waves = value; return DD_OK; }
   if (key == 7) { dd::g_step_fused = value ? 1 : 0; return DD_OK; }
   if (key == 5) { if (value != 2 && value != 4 && value != 8) return DD_ERR_BAD_ARG; dd::g_pos_waves = value; return DD_OK; }
   if (key == 2) { if (value != 8) return DD_ERR_BAD_ARG; dd::g_attn_waves = value; return DD_OK; }
   return DD_ERR_BAD_ARG;
+#else
+  (void)value;
+  return DD_ERR_BAD_ARG;                                 // (the alternatives live in the measurement build only)
+#endif
 }

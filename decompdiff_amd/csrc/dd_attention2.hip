@@ -23,9 +23,6 @@
 #include <type_traits>
 
 #include "dd_kernels.hpp"
-#ifndef DD_ROLL
-#define DD_ROLL 0
-#endif
 
 namespace dd {
 
@@ -245,11 +242,6 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
   constexpr bool TRIP = (MODE == M_BL);
   constexpr bool BOND = (MODE == M_NB || MODE == M_PB);
   static_assert(!PAIR || (POS && !PERSIST), "wave pairs: coordinate modes");
-  // Long segments (3 / 4 tiles; bond-graph modes of ligands with more than 33 atoms): the tile loops of both passes are
-  // ROLLED over chunks of two tiles.  Fully unrolled, the scheduler hoists the next tiles' gathers and table operands
-  // across the whole pass (135 spilled registers in the 4-tile node launch, ~290 MiB of scratch traffic per launch at
-  // C-large); a chunk is scheduled like the spill-free two-tile body, the scores of the other chunk just stay live.
-  constexpr bool ROLL = (DD_ROLL == 1 && !POS && !KNN && MAXT > 2) || (DD_ROLL == 2 && TRIP && MAXT > 2) || (DD_ROLL == 3 && BOND && !POS && MAXT > 2);
   constexpr int NT = (PAIR ? 2 : 1) * NW * 64;
   using L = Lds<MODE>;
   constexpr int LNP = L::LNP, WAO = L::WAO;
@@ -553,15 +545,7 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
     } else if (TRIP) {
       const float* tb = smem + WAO + pass * 12 * 128 + cg * 128 + mm * 4;
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        float cv = cod[ROLL ? 0 : (t < MAXT ? t : 0)][s];
-        if (ROLL) {                                      // t is a (wave-uniform) run-time value inside the rolled chunk loops
-          if (MAXT > 1 && t == 1) cv = cod[1][s];
-          if (MAXT > 2 && t == 2) cv = cod[MAXT > 2 ? 2 : 0][s];
-          if (MAXT > 3 && t == 3) cv = cod[MAXT > 3 ? 3 : 0][s];
-        }
-        mfma_table_step<TR>(acc, tb + s * 512, cv);
-      }
+      for (int s = 0; s < 3; ++s) mfma_table_step<TR>(acc, tb + s * 512, cod[t][s]);
     }
   };
 
@@ -679,27 +663,6 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
   f32x4 S[MAXT];
   float ssum = 0.f;                                    // sum_m alpha*w for head mm
   if (active && kside) {
-    if (ROLL) {
-#pragma nounroll
-      for (int c = 0; c < (MAXT + 1) / 2; ++c) {
-        f32x4 Sc[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int t = 2 * c + u;
-          Sc[u] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-          if (t < T && t < MAXT) {
-            float P[32];
-            build_pre(t, 0, P);
-            Sc[u] = mfma_rows(P, Qb);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (16 * t + 4 * cg + r >= M) Sc[u][r] = -INFINITY;
-          }
-        }
-        if (c == 0) { S[0] = Sc[0]; S[1] = Sc[1]; }
-        else { S[MAXT > 2 ? 2 : 0] = Sc[0]; if (MAXT > 3) S[MAXT > 3 ? 3 : 0] = Sc[1]; }
-      }
-    } else {
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
       if (t < T) {
@@ -713,7 +676,6 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
       } else {
         S[t] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
       }
-    }
     }
     DD_STAMP(5);
     if (!POS) fetch_T(0);                              // v-pass rows of tile 0 arrive during the softmax
@@ -842,26 +804,6 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
 #pragma unroll
   for (int nt = 0; nt < 8; ++nt) Z[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (active) {
-    if (ROLL) {
-#pragma nounroll
-      for (int c = 0; c < (MAXT + 1) / 2; ++c) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int t = 2 * c + u;
-          if (t < T && t < MAXT) {
-            f32x4 St = S[u];
-            if (c != 0) St = S[(2 + u) < MAXT ? 2 + u : 0];
-            float Tz[32];
-            finish_T(t, Tz);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-              for (int nt = 0; nt < 8; ++nt)
-                Z[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Tz[4 * nt + ks], St[ks], Z[nt], 0, 0, 0);
-          }
-        }
-      }
-    } else {
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
       if (t < T) {
@@ -873,7 +815,6 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
           for (int nt = 0; nt < 8; ++nt)
             Z[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Tz[4 * nt + ks], S[t][ks], Z[nt], 0, 0, 0);
       }
-    }
     }
   }
   DD_STAMP(8);
@@ -1104,15 +1045,8 @@ static int launch_node_nw(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
-int g_long_waves = 8;        // dd_debug_set_option(26, v): waves per workgroup of the 3- / 4-tile node launches (8 or 4)
 int launch_attn2_node(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs& bl, hipStream_t st) {
   if (ne.NL > 65) return DD_ERR_UNSUPPORTED_SHAPE;
-  if (g_long_waves == 4) {
-    // one wave per SIMD: the compiler may use all 512 registers of a lane (256 VGPRs + 256 AGPRs), so what the 8-wave
-    // build spills to scratch memory (135 / 56 registers) lives in AGPRs instead
-    if (ne.NL > 49) return launch_node_nw<4, 4>(ne, nb, bl, st);
-    if (ne.NL > 33) return launch_node_nw<4, 3>(ne, nb, bl, st);
-  }
   if (ne.NL > 49) return launch_node_nw<8, 4>(ne, nb, bl, st);    // up to 64 members per segment: 4 tiles
   if (ne.NL > 33) return launch_node_nw<8, 3>(ne, nb, bl, st);    // up to 48 members: 3 tiles (fewer live registers than 4)
   return launch_node_nw<8, 2>(ne, nb, bl, st);             // (12- and 16-wave workgroups were tried: register spills)

@@ -368,6 +368,7 @@ __global__ __launch_bounds__(256) void k_gemm128_batch(GemmBatch gb) {
 }
 
 
+#if defined(DD_DEBUG_OPTIONS) && DD_DEBUG_OPTIONS
 // ---------------------------------------------------------------------------------------------------------------------
 // Persistent layer-tail queue: every dense GEMM between two node-attention launches -- lin_node, the projections of the
 // coordinate sub-layers, the NEXT layer's projections and its query MLPs' second Linear (the ATen addmm chain of
@@ -471,6 +472,8 @@ int launch_gemm_tail(TailArgs& ta, hipStream_t st) {
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
+
+#endif
 
 long long* g_gemm_dbg = nullptr;
 int g_gemm_ksplit = 1;   // dd_debug_set_option(1, v): K-split tiles for jobs without a LayerNorm prologue

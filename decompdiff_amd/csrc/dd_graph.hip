@@ -224,7 +224,7 @@ __device__ __forceinline__ void embed_block(const unsigned blk, const float* __r
                                                    const int32_t* __restrict__ bond, long bond_rows,
                                                    const float* __restrict__ Wb, const float* __restrict__ bb,
                                                    float* __restrict__ hb, int32_t* __restrict__ counters, int node_blocks,
-                                                   int32_t* __restrict__ advance) {
+                                                   int32_t* __restrict__ advance, int nv) {
   // (+ the layer-tail queue's flag words; the error word behind them is sticky: dd_queue_error reads and clears it)
   if (blk == 0 && counters)
     for (int i = threadIdx.x; i < DD_NUM_COUNTERS + DD_FLAG_ERR; i += 256) counters[i] = 0;
@@ -243,8 +243,8 @@ __device__ __forceinline__ void embed_block(const unsigned blk, const float* __r
       val = protein_h[((long)b * NP + n) * 128 + c];
     } else {
       const long a = (long)b * NL + (n - NP);
-      const float* w = Wl + c * 10;
-      val = w[lig_v[a]] + w[8] * lig_aux[2 * a] + w[9] * lig_aux[2 * a + 1] + bl[c];
+      const float* w = Wl + c * (nv + 2);                // ligand_atom_emb row: nv class columns + 2 arm / scaffold indicators
+      val = w[lig_v[a]] + w[nv] * lig_aux[2 * a] + w[nv + 1] * lig_aux[2 * a + 1] + bl[c];
     }
     h[idx] = val;
     if (c < 3) {
@@ -268,9 +268,9 @@ __global__ __launch_bounds__(256) void k_embed_all(const float* __restrict__ pro
                                                    const int32_t* __restrict__ bond, long bond_rows,
                                                    const float* __restrict__ Wb, const float* __restrict__ bb,
                                                    float* __restrict__ hb, int32_t* __restrict__ counters, int node_blocks,
-                                                   int32_t* __restrict__ advance) {
+                                                   int32_t* __restrict__ advance, int nv) {
   embed_block(blockIdx.x, protein_h, protein_pos, lig_pos, lig_v, lig_aux, Wl, bl, B, NP, NL, h, xa, xb, bond, bond_rows, Wb, bb, hb,
-              counters, node_blocks, advance);
+              counters, node_blocks, advance, nv);
 }
 
 // --------------------------------------------------------------------------- layer-0 rows from tables
@@ -349,6 +349,7 @@ struct HeadArgs {
   const float *Wb, *bb;
   float* hb;
   int32_t *counters, *advance;
+  int nv;                   // atom classes (columns of the ligand embedding before the two indicators)
   // layer-0 rows (tab == nullptr: none)
   const float* tab;
   float *l0_P, *PL, *l0_qn, *qlnb, *PB, *qb;
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(256) void k_head_rows(const HeadArgs a) {
   const unsigned blk = blockIdx.x;
   if ((int)blk < a.n_embed) {
     embed_block(blk, a.protein_h, a.protein_pos, a.lig_pos, a.lig_v, a.lig_aux, a.Wl, a.bl, a.B, a.NP, a.NL, a.h, a.xa, a.xb, a.bond,
-                a.bond_rows, a.Wb, a.bb, a.hb, a.counters, a.n_embed_nodes, a.advance);
+                a.bond_rows, a.Wb, a.bb, a.hb, a.counters, a.n_embed_nodes, a.advance, a.nv);
     return;
   }
   layer0_rows_block(blk - a.n_embed, a.tab, a.lig_v, a.lig_aux, a.bond, a.B, a.NP, a.NL, a.l0_P, a.PL, a.l0_qn, a.qlnb, a.PB, a.qb,
@@ -559,11 +560,11 @@ int launch_edge_weights(const float* x, const int32_t* nbr, int B, int N, int K,
 int launch_embed_all(const float* protein_h, const float* protein_pos, const float* lig_pos, const int32_t* lig_v,
                      const float* lig_aux, const float* Wl, const float* bl, int B, int NP, int NL, float* h, float* xa, float* xb,
                      const int32_t* bond, long bond_rows, const float* Wb, const float* bb, float* hb, int32_t* counters,
-                     hipStream_t st, int32_t* advance) {
+                     hipStream_t st, int32_t* advance, int nv) {
   const long nn = (long)B * (NP + NL) * 128, nb = bond_rows * 128;
   const int node_blocks = (int)((nn + 255) / 256), bond_blocks = (int)((nb + 255) / 256);
   hipLaunchKernelGGL(k_embed_all, dim3(node_blocks + bond_blocks), dim3(256), 0, st, protein_h, protein_pos, lig_pos, lig_v, lig_aux,
-                     Wl, bl, B, NP, NL, h, xa, xb, bond, bond_rows, Wb, bb, hb, counters, node_blocks, advance);
+                     Wl, bl, B, NP, NL, h, xa, xb, bond, bond_rows, Wb, bb, hb, counters, node_blocks, advance, nv);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
@@ -572,8 +573,8 @@ int launch_head_all(const float* protein_h, const float* protein_pos, const floa
                     const int32_t* bond, long bond_rows, const float* Wb, const float* bb, float* hb, int32_t* counters,
                     int32_t* advance, int32_t* nbr, float* ew, const float* EW_W1T, const float* EW_b1, const float* EW_ln,
                     const float* EW_w2, const float* EW_b2, const int32_t* np_real, const int32_t* nl_real, const float* l0_tables,
-                    float* l0_P, float* PL, float* l0_qn, float* qlnb, float* PB, float* qb, hipStream_t st, int parts) {
-  if (K > 32 || (parts & 3) == 0) return DD_ERR_UNSUPPORTED_SHAPE;
+                    float* l0_P, float* PL, float* l0_qn, float* qlnb, float* PB, float* qb, hipStream_t st, int parts, int nv) {
+  if (K > 32 || (parts & 3) == 0 || (l0_tables != nullptr && nv != DD_NUM_V)) return DD_ERR_UNSUPPORTED_SHAPE;
   const int N = NP + NL;
   HeadArgs a;
   a.B = B; a.NP = NP; a.NL = NL; a.K = K;
@@ -582,6 +583,7 @@ int launch_head_all(const float* protein_h, const float* protein_pos, const floa
   a.np_real = np_real; a.nl_real = nl_real;
   a.protein_h = protein_h; a.lig_v = lig_v; a.lig_aux = lig_aux; a.Wl = Wl; a.bl = bl; a.h = h; a.xa = xa; a.xb = xb;
   a.bond = bond; a.bond_rows = bond_rows; a.Wb = Wb; a.bb = bb; a.hb = hb; a.counters = counters; a.advance = advance;
+  a.nv = nv;
   a.tab = l0_tables; a.l0_P = l0_P; a.PL = PL; a.l0_qn = l0_qn; a.qlnb = qlnb; a.PB = PB; a.qb = qb;
   const long nn = (long)B * N * 128, nb = bond_rows * 128;
   a.n_embed_nodes = (int)((nn + 255) / 256);

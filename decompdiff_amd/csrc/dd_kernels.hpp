@@ -64,7 +64,7 @@ int launch_gemm128_batch(const GemmArgs* jobs, int njobs, hipStream_t st);
 int launch_embed_all(const float* protein_h, const float* protein_pos, const float* lig_pos, const int32_t* lig_v,
                      const float* lig_aux, const float* Wl, const float* bl, int B, int NP, int NL, float* h, float* xa, float* xb,
                      const int32_t* bond, long bond_rows, const float* Wb, const float* bb, float* hb, int32_t* counters,
-                     hipStream_t st, int32_t* advance = nullptr);
+                     hipStream_t st, int32_t* advance = nullptr, int nv = DD_NUM_V);
 int launch_drift_armsca(const float* lig_pos, const int32_t* decomp_index, int B, int NL, float min_d, float max_d,
                         float* grad, int accumulate, int norm_B, hipStream_t st);
 // (NP, np_real, nl_real: padded heterogeneous batches -- padding atoms are neither centres nor candidates)
@@ -87,7 +87,8 @@ int launch_head_all(const float* protein_h, const float* protein_pos, const floa
                     const int32_t* bond, long bond_rows, const float* Wb, const float* bb, float* hb, int32_t* counters,
                     int32_t* advance, int32_t* nbr, float* ew, const float* EW_W1T, const float* EW_b1, const float* EW_ln,
                     const float* EW_w2, const float* EW_b2, const int32_t* np_real, const int32_t* nl_real, const float* l0_tables,
-                    float* l0_P, float* PL, float* l0_qn, float* qlnb, float* PB, float* qb, hipStream_t st, int parts = 3);
+                    float* l0_P, float* PL, float* l0_qn, float* qlnb, float* PB, float* qb, hipStream_t st, int parts = 3,
+                    int nv = DD_NUM_V);
 int launch_extract_ligand(const float* x, int B, int NP, int NL, float* out, hipStream_t st);
 
 enum { M_NE = 0, M_NB = 1, M_BL = 2, M_PE = 3, M_PB = 4 };

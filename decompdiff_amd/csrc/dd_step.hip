@@ -13,7 +13,8 @@
 namespace dd {
 
 // Production noise (Philox4x32-10, counter = (row, row >> 32, t, stream id)): one uniform per (row, class) for the
-// Gumbel draws -- classes 0..3 from the block of stream `sid`, 4..7 from the block of `sid | 0x100` -- and one
+// Gumbel draws -- classes 4k..4k+3 from the block of stream `sid | (k << 8)` (8 classes: two blocks, up to 23 classes of
+// ligand_atom_mode 'full': six) -- and one
 // Box-Muller normal per coordinate (stream 7).  Streams: 1 atom types, 2 bond types, 7 coordinates; distinct
 // (row, t, stream) never share a counter.  `t` is the diffusion time index of the step (t_start - steps done), not the
 // step number of the call: a chain resumed with start_step and the same seed continues the noise of the unsplit chain
@@ -21,12 +22,14 @@ namespace dd {
 template <int NC>
 __device__ __forceinline__ float philox_uniform(uint64_t seed, long row, int step, uint32_t sid, int c) {
   Philox ph(seed);
-  uint32_t r[4], r2[4];
-  ph.gen((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)step, sid, r);
-  ph.gen((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)step, sid | 0x100u, r2);
-  uint32_t bits = r[0];
+  uint32_t bits = 0u;
 #pragma unroll
-  for (int k = 1; k < NC; ++k) bits = (c == k) ? (k < 4 ? r[k] : r2[k - 4]) : bits;
+  for (int blk = 0; blk < (NC + 3) / 4; ++blk) {
+    uint32_t r[4];
+    ph.gen((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)step, sid | ((uint32_t)blk << 8), r);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bits = (c == 4 * blk + k) ? r[k] : bits;
+  }
   return u01(bits);
 }
 __device__ __forceinline__ float philox_normal(uint64_t seed, int idx, int step) {
@@ -115,12 +118,8 @@ __global__ __launch_bounds__(256) void k_step_rows(const StepRowsArgs a) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) u[c] = a.uniforms[((long)step * a.rows + row) * NC + c];
   } else {
-    Philox ph(rs.seed);
-    uint32_t r[4], r2[4];
-    ph.gen((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)step, a.stream_id, r);
-    ph.gen((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)step, a.stream_id | 0x100u, r2);
 #pragma unroll
-    for (int c = 0; c < NC; ++c) u[c] = u01(c < 4 ? r[c] : r2[c - 4]);
+    for (int c = 0; c < NC; ++c) u[c] = philox_uniform<NC>(rs.seed, row, t, a.stream_id, c);
   }
   int best = 0;
   float bestv = -INFINITY;
@@ -396,6 +395,7 @@ __device__ __forceinline__ void step_pos_elem(const StepPosArgs& a, const int id
   if (a.traj_pos) a.traj_pos[(long)step * n + idx] = nxt + a.offset[b * 3 + c];
 }
 
+template <int NV>
 __global__ __launch_bounds__(256) void k_step_all(const StepRowsArgs rb, const StepRowsArgs rv, const StepPosArgs p, int nb_b, int nb_v) {
   const int blk = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const RunState rs = load_run_state(rb.step_counter, rb.counter_bias);
@@ -404,16 +404,20 @@ __global__ __launch_bounds__(256) void k_step_all(const StepRowsArgs rb, const S
     if (row < rb.rows) step_row<DD_NUM_B>(rb, row, lane, rs);
   } else if (blk < nb_b + nb_v) {
     const long row = (long)(blk - nb_b) * 4 + wave;
-    if (row < rv.rows) step_row<DD_NUM_V>(rv, row, lane, rs);
+    if (row < rv.rows) step_row<NV>(rv, row, lane, rs);
   } else {
     step_pos_elem(p, (blk - nb_b - nb_v) * 256 + threadIdx.x, rs);
   }
 }
 
 int launch_step_all(const StepRowsArgs& rb, const StepRowsArgs& rv, const StepPosArgs& p, hipStream_t st) {
-  if (rb.NC != DD_NUM_B || rv.NC != DD_NUM_V) return DD_ERR_UNSUPPORTED_SHAPE;
+  if (rb.NC != DD_NUM_B || (rv.NC != 8 && rv.NC != 13 && rv.NC != 23)) return DD_ERR_UNSUPPORTED_SHAPE;
   const int nb_b = (rb.rows + 3) / 4, nb_v = (rv.rows + 3) / 4, nb_p = (p.B * p.NL * 3 + 255) / 256;
-  hipLaunchKernelGGL(k_step_all, dim3(nb_b + nb_v + nb_p), dim3(256), 0, st, rb, rv, p, nb_b, nb_v);
+  const dim3 grid(nb_b + nb_v + nb_p);
+  // atom classes: 8 (ligand_atom_mode 'basic'), 13 ('add_aromatic'), 23 ('full') -- utils/transforms.py:15-64,138-151
+  if (rv.NC == 8) hipLaunchKernelGGL(k_step_all<8>, grid, dim3(256), 0, st, rb, rv, p, nb_b, nb_v);
+  else if (rv.NC == 13) hipLaunchKernelGGL(k_step_all<13>, grid, dim3(256), 0, st, rb, rv, p, nb_b, nb_v);
+  else hipLaunchKernelGGL(k_step_all<23>, grid, dim3(256), 0, st, rb, rv, p, nb_b, nb_v);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
@@ -421,7 +425,9 @@ int launch_step_all(const StepRowsArgs& rb, const StepRowsArgs& rv, const StepPo
 int launch_step_rows(const StepRowsArgs& a, hipStream_t st) {
   if (a.rows <= 0) return DD_OK;
   dim3 grid((a.rows + 3) / 4);
-  if (a.NC == DD_NUM_V) hipLaunchKernelGGL(k_step_rows<DD_NUM_V>, grid, dim3(256), 0, st, a);
+  if (a.NC == 8) hipLaunchKernelGGL(k_step_rows<8>, grid, dim3(256), 0, st, a);
+  else if (a.NC == 13) hipLaunchKernelGGL(k_step_rows<13>, grid, dim3(256), 0, st, a);
+  else if (a.NC == 23) hipLaunchKernelGGL(k_step_rows<23>, grid, dim3(256), 0, st, a);
   else if (a.NC == DD_NUM_B) hipLaunchKernelGGL(k_step_rows<DD_NUM_B>, grid, dim3(256), 0, st, a);
   else return DD_ERR_UNSUPPORTED_SHAPE;
   DD_CHECK_LAUNCH();

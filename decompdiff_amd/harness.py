@@ -145,11 +145,39 @@ def _accepts_extras(model) -> bool:
 
 # index -> atomic number of the 8 atom classes, ligand_atom_mode 'basic' (utils/transforms.py:41-50,73-75)
 ATOMIC_NUMBER_OF_CLASS = (1, 6, 7, 8, 9, 15, 16, 17)
+# ligand_atom_mode 'add_aromatic': class -> (atomic number, aromatic), 13 classes (utils/transforms.py:52-66)
+AROMATIC_CLASSES = ((1, False), (6, False), (6, True), (7, False), (7, True), (8, False), (8, True), (9, False), (15, False), (15, True),
+                    (16, False), (16, True), (17, False))
+# ligand_atom_mode 'full': class -> (atomic number, hybridisation, aromatic), 23 classes (utils/transforms.py:15-39)
+FULL_CLASSES = ((1, "S", False), (6, "SP", False), (6, "SP2", False), (6, "SP2", True), (6, "SP3", False), (7, "SP", False),
+                (7, "SP2", False), (7, "SP2", True), (7, "SP3", False), (8, "SP2", False), (8, "SP2", True), (8, "SP3", False),
+                (9, "SP3", False), (15, "SP2", False), (15, "SP2", True), (15, "SP3", False), (15, "SP3D", False), (16, "SP2", False),
+                (16, "SP2", True), (16, "SP3", False), (16, "SP3D", False), (16, "SP3D2", False), (17, "SP3", False))
+NUM_CLASSES_OF_MODE = {"basic": 8, "add_aromatic": 13, "full": 23}
 
 
-def atomic_numbers_from_index(pred_v) -> List[int]:
-    """trans.get_atomic_number_from_index(pred_v, mode='basic') (utils/transforms.py:73-75)."""
-    return [ATOMIC_NUMBER_OF_CLASS[int(i)] for i in np.asarray(pred_v).tolist()]
+def atomic_numbers_from_index(pred_v, mode: str = "basic") -> List[int]:
+    """trans.get_atomic_number_from_index(pred_v, mode) (utils/transforms.py:73-83)."""
+    idx = [int(i) for i in np.asarray(pred_v).tolist()]
+    if mode == "basic":
+        return [ATOMIC_NUMBER_OF_CLASS[i] for i in idx]
+    if mode == "add_aromatic":
+        return [AROMATIC_CLASSES[i][0] for i in idx]
+    if mode == "full":
+        return [FULL_CLASSES[i][0] for i in idx]
+    raise ValueError(mode)
+
+
+def is_aromatic_from_index(pred_v, mode: str = "basic"):
+    """trans.is_aromatic_from_index(pred_v, mode) (utils/transforms.py:86-95): None for 'basic'."""
+    idx = [int(i) for i in np.asarray(pred_v).tolist()]
+    if mode == "add_aromatic":
+        return [AROMATIC_CLASSES[i][1] for i in idx]
+    if mode == "full":
+        return [FULL_CLASSES[i][2] for i in idx]
+    if mode == "basic":
+        return None
+    raise ValueError(mode)
 
 
 def bond_graph(pred_bond_index, pred_bond_type):
@@ -173,7 +201,8 @@ def bond_graph(pred_bond_index, pred_bond_type):
     return bonds, len({find(a) for a in range(n)})
 
 
-def to_result_records(out: Dict[str, list], ligand_filename: Optional[str] = None, reconstruct=None) -> List[dict]:
+def to_result_records(out: Dict[str, list], ligand_filename: Optional[str] = None, reconstruct=None,
+                      atom_enc_mode: str = "basic") -> List[dict]:
     """Per-sample records in the layout of the reference's ``result.pt`` (scripts/sample_diffusion_decomp.py:416-457,
     609-619): ``mol, smiles, pred_pos, pred_v, pred_pos_traj, pred_v_traj, decomp_mask, pred_bond_index (list),
     pred_bond_type`` (+ ``ligand_filename``), so that ``evaluate_mol_from_meta_full.py`` can consume them unchanged.
@@ -183,14 +212,16 @@ def to_result_records(out: Dict[str, list], ligand_filename: Optional[str] = Non
     signature ``reconstruct(pred_pos, atomic_numbers, pred_bond_index, pred_bond_type) -> mol`` -- where those packages
     exist; a ``(mol, smiles)`` return is accepted too, otherwise ``smiles`` comes from ``Chem.MolToSmiles`` when RDKit is
     importable.  An exception from the callable is a failed reconstruction: ``mol`` None and ``smiles`` '' -- exactly
-    what the reference stores (:440-443).  Without a callable the same placeholders are stored."""
+    what the reference stores (:440-443).  Without a callable the same placeholders are stored.  ``atom_enc_mode``: the
+    ``ligand_atom_mode`` of the checkpoint (``basic`` / ``add_aromatic`` / ``full``: 8 / 13 / 23 atom classes, :422)."""
     records = []
     for i in range(len(out["pred_pos"])):
         bond_index = np.asarray(out["pred_bond_index"][i]).tolist()
         mol, smiles = None, ""
         if reconstruct is not None:
             try:
-                r = reconstruct(out["pred_pos"][i], atomic_numbers_from_index(out["pred_v"][i]), bond_index, out["pred_bond_type"][i])
+                r = reconstruct(out["pred_pos"][i], atomic_numbers_from_index(out["pred_v"][i], atom_enc_mode), bond_index,
+                                out["pred_bond_type"][i])
                 if isinstance(r, tuple):
                     mol, smiles = r
                 else:

@@ -49,6 +49,7 @@ class DDSampler(ctypes.Structure):
         ("workspace", c_void_p), ("workspace_floats", c_size_t),
         ("np_real", c_void_p), ("nl_real", c_void_p), ("bl_prefix", c_void_p),
         ("l0_tables", c_void_p), ("l0_P", c_void_p), ("l0_qn", c_void_p),
+        ("num_v", c_int32), ("reserved0", c_int32),
     ]
 
 

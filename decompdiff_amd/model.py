@@ -169,8 +169,10 @@ class DecompScorePosNet3D(nn.Module):
         need(getattr(config, "h_node_in_bond_net", False), "h_node_in_bond_net=True")
         need(not config.x2h_out_fc and config.norm and config.act_fn == "relu", "x2h_out_fc=False, norm, relu")
         need(getattr(config, "num_bond_classes", 1) == 5, "num_bond_classes=5")
-        need(pdim == 29 and ldim == 10, "protein/ligand feature dims 29/10")
-        need(num_classes == 8, "num_classes=8 (ligand_atom_mode 'basic'; the step kernels and buffers are 8 classes wide)")
+        # ligand_atom_mode basic / add_aromatic / full: 8 / 13 / 23 atom classes (utils/transforms.py:15-64,138-151;
+        # scripts/sample_diffusion_decomp.py:538-540: feature dim = classes + the 2 arm / scaffold indicators)
+        need(num_classes in (8, 13, 23), "num_classes in {8, 13, 23} (ligand_atom_mode basic / add_aromatic / full)")
+        need(pdim == 29 and ldim == num_classes + 2, "protein feature dim 29, ligand feature dim num_classes + 2")
         need(not getattr(config, "sync_twoup", False), "sync_twoup=False")
         need(config.knn <= 32, "knn<=32")
 
@@ -374,11 +376,11 @@ class DecompScorePosNet3D(nn.Module):
         pad_noise = None
         if noise is not None:
             n_lig, n_bond = sum(n_l), sum(n_b)
-            for k, shp in (("u_v", (num_steps, n_lig, 8)), ("u_b", (num_steps, n_bond, 5)), ("eps", (num_steps, n_lig, 3))):
+            for k, shp in (("u_v", (num_steps, n_lig, self.num_classes)), ("u_b", (num_steps, n_bond, 5)), ("eps", (num_steps, n_lig, 3))):
                 if tuple(noise[k].shape) != shp:
                     raise ValueError(f"noise['{k}'] must have shape {shp}, got {tuple(noise[k].shape)}")
             pad_noise = {
-                "u_v": torch.full((num_steps, B * NL, 8), 0.5, device=dev).index_copy_(1, d_l, f32(noise["u_v"])),
+                "u_v": torch.full((num_steps, B * NL, self.num_classes), 0.5, device=dev).index_copy_(1, d_l, f32(noise["u_v"])),
                 "u_b": torch.full((num_steps, B * Eb, 5), 0.5, device=dev).index_copy_(1, d_b, f32(noise["u_b"])),
                 "eps": zeros(num_steps, B * NL, 3).index_copy_(1, d_l, f32(noise["eps"]))}
         prefix = np.concatenate([[0], np.cumsum(n_b)]).astype(np.int32)
@@ -653,7 +655,7 @@ class DecompScorePosNet3D(nn.Module):
             if masks is not None:                                      # padded heterogeneous batch (dd_sampler.np_real ...)
                 bufs["np_real"], bufs["nl_real"] = z(B, dtype=torch.int32), z(B, dtype=torch.int32)
                 bufs["bl_prefix"] = z(B + 1, dtype=torch.int32)
-            bufs["pred_pos"], bufs["pred_v"], bufs["pred_bond"] = z(B * NL, 3), z(B * NL, 8), z(B * Eb, 5)
+            bufs["pred_pos"], bufs["pred_v"], bufs["pred_bond"] = z(B * NL, 3), z(B * NL, self.num_classes), z(B * Eb, 5)
             ws_floats = int(lib.dd_workspace_floats(B, NP, NL, K))
             bufs["workspace"] = z(ws_floats)
             if masks is None and self._layer0_tables(pw, dev) is not None:     # layer-0 tables (dd_sampler.l0_*)
@@ -662,12 +664,13 @@ class DecompScorePosNet3D(nn.Module):
                 bufs["traj_pos"] = z(cap, B * NL, 3)
                 bufs["traj_v"] = z(cap, B * NL, dtype=torch.int32)
                 bufs["traj_bond"] = z(cap, B * Eb, dtype=torch.int32)
-                bufs["traj_v0"] = z(cap, B * NL, 8)
-                bufs["traj_vt"] = z(cap, B * NL, 8)
+                bufs["traj_v0"] = z(cap, B * NL, self.num_classes)
+                bufs["traj_vt"] = z(cap, B * NL, self.num_classes)
                 bufs["traj_bt"] = z(cap, B * Eb, 5)
             sm = hip_lib.DDSampler()
             sm.B, sm.NP, sm.NL, sm.K, sm.NF = B, NP, NL, K, NF
             sm.num_layers, sm.T = int(self.config.num_layers), int(self.betas.numel())
+            sm.num_v = int(self.num_classes)
             sm.weights = arena.data_ptr()
             sm.slot_off = offs.ctypes.data
             sm.tab_pos, sm.tab_v, sm.tab_b = pw["tab_pos"].data_ptr(), pw["tab_v"].data_ptr(), pw["tab_b"].data_ptr()
@@ -698,7 +701,7 @@ class DecompScorePosNet3D(nn.Module):
         for k in ("u_v", "u_b", "eps"):
             bufs[k] = None
         if noise is not None:
-            for k, shp in (("u_v", (n_steps, B * NL, 8)), ("u_b", (n_steps, B * Eb, 5)), ("eps", (n_steps, B * NL, 3))):
+            for k, shp in (("u_v", (n_steps, B * NL, self.num_classes)), ("u_b", (n_steps, B * Eb, 5)), ("eps", (n_steps, B * NL, 3))):
                 t = noise[k]
                 if tuple(t.shape) != shp:
                     raise ValueError(f"noise['{k}'] must have shape {shp}, got {tuple(t.shape)}")
@@ -789,7 +792,7 @@ class DecompScorePosNet3D(nn.Module):
             hip_lib.check(hip_lib.load().dd_forward(ctypes.byref(s), hip_lib.stream_ptr(dev)), "dd_forward")
             _check_queue(s, dev)
             preds = {"pred_ligand_pos": bufs["pred_pos"].view(B * NL, 3),
-                     "pred_ligand_v": bufs["pred_v"].view(B * NL, 8)}
+                     "pred_ligand_v": bufs["pred_v"].view(B * NL, self.num_classes)}
             if self.bond_diffusion:
                 preds["pred_bond"] = bufs["pred_bond"]
             self._last = (s, bufs)

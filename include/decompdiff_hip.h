@@ -33,7 +33,9 @@ extern "C" {
 #define DD_KNN_MAX 32
 #define DD_NL_MAX 64      /* ligand atoms per sample supported by the fused kernels */
 #define DD_N_MAX 1024     /* atoms per sample supported by the kNN kernel */
-#define DD_NUM_V 8        /* atom classes  (scripts/sample_diffusion_decomp.py:540) */
+#define DD_NUM_V 8        /* atom classes of ligand_atom_mode 'basic' (scripts/sample_diffusion_decomp.py:540); dd_sampler.num_v
+                             selects 13 ('add_aromatic') or 23 ('full') instead (utils/transforms.py:15-64,138-151) */
+#define DD_NUM_V_MAX 23
 #define DD_NUM_B 5        /* bond classes  (configs/training.yml:33) */
 
 typedef enum dd_status {
@@ -140,6 +142,11 @@ typedef struct dd_sampler {
   const float* l0_tables;          /* [DD_L0_TABLE_FLOATS], device; filled by dd_layer0_tables() once per weight set */
   float* l0_P;                     /* [B,N,640] layer-0 node projections; protein rows by dd_layer0_prepare() */
   float* l0_qn;                    /* [B,N,128] layer-0 node queries; protein rows by dd_layer0_prepare() */
+  /* ABI 7: atom-class count of the checkpoint (0 = DD_NUM_V = 8; 13; 23): width of lig_v's range, of u_v, pred_v,
+   * traj_v0 / traj_vt, of the v head's second Linear and (num_v + 2) of the ligand embedding's rows.  The layer-0 tables
+   * exist for 8 classes only (l0_tables must be NULL otherwise). */
+  int32_t num_v;
+  int32_t reserved0;
 } dd_sampler;
 
 /* Layout of l0_tables (floats): node projections [16][640], ligand projections [16][1280], bond projections [5][640],

@@ -208,17 +208,20 @@ def gen_steps(ref, sd, cfg):
     print(f"[steps] oracle maxabs diff = {worst:g}")
 
 
-def gen_traj(ref, sd, cfg, name, pocket, n_data, num_steps, drift, seed, every=1, std_scale=None, priors=None, t_start=None):
+def gen_traj(ref, sd, cfg, name, pocket, n_data, num_steps, drift, seed, every=1, std_scale=None, priors=None, t_start=None,
+             num_classes=8):
     torch.manual_seed(seed)
-    batch = synth.build_sampling_batch(pocket, n_data, per_sample_std_scale=std_scale)
+    batch = synth.build_sampling_batch(pocket, n_data, per_sample_std_scale=std_scale, num_classes=num_classes)
     state = torch.get_rng_state()
     t0 = time.time()
     r = run_ref_sampling(ref, batch, num_steps, drift, t_start)
     t_ref = time.time() - t0
     torch.set_rng_state(state)
-    noise = synth.draw_step_noise(num_steps, batch["init_ligand_pos"].size(0), batch["init_ligand_fc_bond_type"].size(0))
+    noise = synth.draw_step_noise(num_steps, batch["init_ligand_pos"].size(0), batch["init_ligand_fc_bond_type"].size(0),
+                                  num_classes=num_classes)
     t0 = time.time()
-    ro = run_oracle_sampling(sd, cfg, batch, num_steps, drift, noise, t_start, **(priors or {}))
+    ro = run_oracle_sampling(sd, cfg, batch, num_steps, drift, noise, t_start, **(priors or {}),
+                             **({"num_classes": num_classes} if num_classes != 8 else {}))
     t_or = time.time() - t0
     w = max(maxabs(r["pos"], ro["pos"]), maxabs(r["v"], ro["v"]), maxabs(r["bond"], ro["bond"]))
     out = np_inputs(batch)
@@ -228,6 +231,8 @@ def gen_traj(ref, sd, cfg, name, pocket, n_data, num_steps, drift, seed, every=1
     out["noise_checksum"] = np.array([float(noise["u_v"].double().sum()), float(noise["u_b"].double().sum()),
                                       float(noise["eps"].double().sum())])
     out["weight_seed"] = np.array(0)
+    if num_classes != 8:
+        out["num_classes"] = np.array(num_classes)
     if t_start is not None:
         out["t_start"] = np.array(t_start)
     for k, v in (priors or {}).items():
@@ -360,6 +365,15 @@ def main():
         gen_traj(ref, sd, cfg, "traj3_b8_plain", synth.make_pocket_small(8), 8, 3, None, 2041)
         gen_traj(ref, sd, cfg, "traj3_b8_drift", synth.make_pocket_small(8), 8, 3, DRIFT, 2042,
                  std_scale=[1.0, 0.9, 0.8, 1.1, 1.0, 0.95, 1.05, 0.85])
+    if want("classes"):
+        # ligand_atom_mode add_aromatic / full: 13 / 23 atom classes (utils/transforms.py:15-64,138-151; the sampling script
+        # passes num_classes = ligand_feature_dim and ligand feature dim = classes + 2, :538-540): reference models of
+        # those widths with synthetic weights, 4 reverse steps with armsca + clash drift
+        for nc, tag in ((13, "aromatic13"), (23, "full23")):
+            sd_c = synth.synthetic_state_dict(cfg, seed=0, ligand_atom_feature_dim=nc + 2, num_classes=nc)
+            ref_c = ref_shims.load_reference_model(cfg.to_dict(), sd_c, ligand_dim=nc + 2, num_classes=nc)
+            gen_traj(ref_c, sd_c, cfg, "traj4_" + tag, synth.make_pocket_small(9), 2, 4, DRIFT, 2050 + nc, std_scale=[1.0, 0.9],
+                     num_classes=nc)
     if want("large"):
         # configs[4] size (600 + 60 atoms) with drift guidance, batch of 2
         gen_traj(ref, sd, cfg, "traj3_large_drift", synth.make_pocket_large(6), 2, 3, DRIFT, 2032, std_scale=[1.0, 0.9])

@@ -52,6 +52,37 @@ def test_config1_config2_exact_bench_shape_reference_golden(name, std_scale):
     assert hip_lib.load().dd_debug_node_split(8, 300, 30, 32) >= 0          # the per-shape launch measurement ran
 
 
+@pytest.mark.parametrize("name,nc", [("traj4_aromatic13", 13), ("traj4_full23", 23)])
+def test_atom_vocabularies_of_the_other_ligand_atom_modes_reference_golden(name, nc):
+    """ligand_atom_mode add_aromatic / full (utils/transforms.py:15-64,138-151; the sampling script passes
+    num_classes = ligand_feature_dim, :538-540): 13 / 23 atom classes -- wider ligand embedding, v head, class posterior and
+    Gumbel draw -- 4 reverse steps with drift against a reference model of that width, injected noise; and a chain on the
+    device Philox streams (classes 8.. come from further counter blocks) keeps every class reachable and finite."""
+    from decompdiff_amd import DecompScorePosNet3D, shipped_config
+    g = GU.load(name)
+    assert int(g["num_classes"]) == nc
+    b = GU.batch_from_npz(g)
+    torch.manual_seed(int(g["seed"]))
+    synth.build_sampling_batch(synth.make_pocket_small(9), 2, per_sample_std_scale=[1.0, 0.9], num_classes=nc)
+    noise = synth.draw_step_noise(4, b["init_ligand_pos"].size(0), b["init_ligand_fc_bond_type"].size(0), num_classes=nc)
+    assert np.array_equal(GU.checksum(noise), g["noise_checksum"])
+    cfg = shipped_config()
+    m = DecompScorePosNet3D(cfg, 29, nc + 2, nc)
+    sd = m.state_dict()
+    sd.update(synth.synthetic_state_dict(cfg, 0, ligand_atom_feature_dim=nc + 2, num_classes=nc))
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev())
+    assert int(b["init_ligand_v"].max()) >= 8                     # the fixture really uses the upper classes
+    r = _sample_hip(m, b, 4, json.loads(str(g["drift"])), noise)
+    _check_chain(f"{nc} atom classes ({name})", r, g, 4)
+    assert r["vt_traj"][0].shape[-1] == nc and r["v0_traj"][0].shape[-1] == nc
+    p = _sample_hip(m, b, 12, None, None, seed=5)
+    v = torch.stack(p["v_traj"])
+    assert torch.isfinite(p["pos"]).all() and int(v.min()) >= 0 and int(v.max()) < nc and int(v.max()) >= 8
+    with pytest.raises(NotImplementedError):
+        DecompScorePosNet3D(cfg, 29, 12, 10)                          # not one of the reference's three vocabularies
+
+
 def test_config3_unit_batch16_reference_golden():
     """BASELINE configs[3]: one unit of the 100-pocket job -- a pocket in its size range (347 protein + 37 ligand atoms:
     the 3-tile kernel variants), batch of 16 -- 3 reverse steps against the reference's own output."""
@@ -249,9 +280,9 @@ def test_chain_cache_reuses_buffers_and_graph_without_changing_results(monkeypat
         outs = []
         for i, (b, drift, seed, start) in enumerate(runs):
             if i == 5:
-                assert lib.dd_debug_set_option(8, 0) == 0            # another launch schedule: the cached graph is stale
+                assert lib.dd_debug_set_fusion(3) == 0               # another launch structure (no second stream): the cached graph is stale
             outs.append(_sample_hip(m, b, 6 if i % 2 else 9, drift, None, seed=seed, start_step=start))
-        assert lib.dd_debug_set_option(8, 4) == 0
+        assert lib.dd_debug_set_fusion(1) == 0
         return outs
 
     cached, fresh = go(True), go(False)
@@ -395,10 +426,12 @@ def to_dev_local(batch):
     return {k: (v.to(dev()) if torch.is_tensor(v) else v) for k, v in batch.items()}
 
 
-def test_layer0_tables_are_bit_identical_to_the_gemms():
+def test_layer0_tables_are_bit_identical_to_the_gemms(debug_options):
     """dd_sampler.l0_tables: the first layer's projection / query rows gathered from tables (16 atom combinations, 5 x 16
     bond combinations, static protein rows) instead of two GEMM launches -- same kernels built the tables, so forward and
     chain are bit-identical with the option off; rows that are not exactly one-hot in the arm flag switch them off."""
+    if not debug_options:
+        return
     lib = hip_lib.load()
     m = model(0)
     torch.manual_seed(9)
@@ -429,10 +462,12 @@ def test_layer0_tables_are_bit_identical_to_the_gemms():
     assert not torch.equal(r["pred_ligand_v"], on["pred_ligand_v"])
 
 
-def test_two_launch_head_is_bit_identical_to_the_four_launches():
+def test_two_launch_head_is_bit_identical_to_the_four_launches(debug_options):
     """Head of a forward: k_head_graph (kNN by radix select + edge weights in one wave per centre, x_t read from the
     sampler's position buffers) beside k_head_rows (embeddings / context / counters + layer-0 rows) against the four
     separate launches (dd_debug_set_option(24, 0)) -- forward and chain bit-identical, dense and padded batches."""
+    if not debug_options:
+        return
     lib = hip_lib.load()
     m = model(0)
     torch.manual_seed(11)
@@ -449,3 +484,31 @@ def test_two_launch_head_is_bit_identical_to_the_four_launches():
         for k in ("pos", "v", "bond"):
             assert torch.equal(x[k], y[k]), k
         assert all(torch.equal(p, q) for p, q in zip(x["v0_traj"], y["v0_traj"]))
+
+
+def test_tile_queue_schedule_is_bit_identical_to_the_graph_edge_schedule(debug_options):
+    """Schedule 5 of the measurement build (EXPERIMENTS.md, round 3): the GEMMs between two node attentions as two ordered
+    tile queues per layer (tickets, write-through tiles, device counters polled by the next assemble / node attention instead
+    of graph edges).  Slower than the shipped schedule 4, kept as a measured alternative -- and it must not change a bit:
+    dense, drift, long ligands, padded batch; graph replay and eager; no hand-off may time out (dd_queue_error)."""
+    if not debug_options:
+        return
+    lib = hip_lib.load()
+    m = model(0)
+    torch.manual_seed(3)
+    cases = [(synth.build_sampling_batch(synth.make_pocket_small(0), 4), None),
+             (synth.build_sampling_batch(synth.make_pocket_small(1), 2), GU.DRIFT),
+             (synth.build_sampling_batch(synth.make_pocket(7, 347, (9, 9), 19, num_full_protein=0), 2), None),
+             (_hetero_batch([9, 20, 33], [150, 120, 200], seed=6), GU.DRIFT)]
+    try:
+        for b, drift in cases:
+            outs = {}
+            for sched, graph in ((4, True), (5, True), (5, False)):
+                assert lib.dd_debug_set_option(8, sched) == 0
+                outs[(sched, graph)] = _sample_hip(m, b, 5, drift, None, seed=9, use_graph=graph)
+            for key in ((5, True), (5, False)):
+                for k in ("pos", "v", "bond"):
+                    assert torch.equal(outs[(4, True)][k], outs[key][k]), (key, k)
+                assert all(torch.equal(x, y) for x, y in zip(outs[(4, True)]["bt_traj"], outs[key]["bt_traj"]))
+    finally:
+        assert lib.dd_debug_set_option(8, 4) == 0

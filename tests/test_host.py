@@ -235,3 +235,22 @@ def test_training_batch_layout_check():
         training.check_batch_layout(b["batch_protein"], b["batch_ligand"].flip(0), b["ligand_fc_bond_index"])
     with pytest.raises(NotImplementedError, match="batch_ligand_bond"):
         training.check_batch_layout(b["batch_protein"], b["batch_ligand"], b["ligand_fc_bond_index"], b["batch_ligand_bond"].flip(0))
+
+
+def test_sensitivity_fixture_and_class_tables():
+    """The oracle self-divergence fixture behind the bound of the free-running 1000-step drift chain (8 replays of the
+    oracle with +-1 ulp nudges per step, oracle/make_sensitivity.py), and the class tables of the three ligand_atom_modes
+    (utils/transforms.py:15-95; checked against the reference's functions when the fixture was added)."""
+    g = GU.load("sens_traj1000_drift")
+    e = g["pos_err"]
+    assert e.shape == (8, 20) and str(g["fixture"]) == "traj1000_drift" and int(g["every"]) == 50
+    assert np.array_equal(g["pos_err_median"], np.median(e, 0)) and (e[:, 0] < 1e-5).all()
+    assert np.median(e, 0)[-1] > 1e-3 > np.median(e, 0)[5]          # chaotic tail: 1 ulp per step ends > 1e-3 from the reference
+    assert int(g["v_mismatch"].sum()) == 0 and int(g["bond_mismatch"].sum(1).max()) > 0      # (one replay flips bond types)
+    from decompdiff_amd import harness as H
+    assert H.atomic_numbers_from_index(np.arange(8)) == [1, 6, 7, 8, 9, 15, 16, 17]
+    assert H.atomic_numbers_from_index(np.arange(13), "add_aromatic") == [1, 6, 6, 7, 7, 8, 8, 9, 15, 15, 16, 16, 17]
+    assert H.is_aromatic_from_index(np.arange(13), "add_aromatic") == [False, False, True, False, True, False, True, False, False, True,
+                                                                        False, True, False]
+    assert len(H.FULL_CLASSES) == 23 and H.atomic_numbers_from_index([0, 3, 12, 22], "full") == [1, 6, 9, 17]
+    assert H.is_aromatic_from_index([3, 4], "full") == [True, False] and H.is_aromatic_from_index([1], "basic") is None

@@ -96,11 +96,18 @@ def _replay_traj(name, num_steps, std_scale=None):
     n_data = int(b["batch_ligand"].max()) + 1
     torch.manual_seed(int(g["seed"]))
     synth.build_sampling_batch(_pocket_for(name), n_data, per_sample_std_scale=std_scale)
+    nc = int(g["num_classes"]) if "num_classes" in g.files else 8
+    if nc != 8:                                    # ligand_atom_mode add_aromatic / full: wider embedding + v head
+        sd = synth.synthetic_state_dict(cfg, seed=int(g["weight_seed"]), ligand_atom_feature_dim=nc + 2, num_classes=nc)
+        torch.manual_seed(int(g["seed"]))
+        synth.build_sampling_batch(_pocket_for(name), n_data, per_sample_std_scale=std_scale, num_classes=nc)
     noise = synth.draw_step_noise(int(g["num_steps"]), b["init_ligand_pos"].size(0),
-                                  b["init_ligand_fc_bond_type"].size(0))
+                                  b["init_ligand_fc_bond_type"].size(0), num_classes=nc)
     assert np.array_equal(GU.checksum(noise), g["noise_checksum"])
     noise = {k: v[:num_steps] for k, v in noise.items()}
     priors = {k: g[k] for k in ("prior_atom_types", "prior_bond_types") if k in g.files}
+    if nc != 8:
+        priors["num_classes"] = nc
     t_start = int(g["t_start"]) if "t_start" in g.files else cfg.num_diffusion_timesteps - 1
     r = OD.sample_diffusion(sd, cfg, num_steps=num_steps, energy_drift_opt=drift, noise=noise,
                             t_start=t_start, **priors, **b)
@@ -114,6 +121,7 @@ def _pocket_for(name):
             "traj3_scale": synth.make_pocket(41, 80, (3, 3), 4, num_full_protein=200),
             "traj3_b16": synth.make_pocket(7, 347, (9, 9), 19, num_full_protein=0),
             "traj3_b8_plain": synth.make_pocket_small(8), "traj3_b8_drift": synth.make_pocket_small(8),
+            "traj4_aromatic13": synth.make_pocket_small(9), "traj4_full23": synth.make_pocket_small(9),
             "traj3_large_drift": synth.make_pocket_large(6)}[name]
 
 
@@ -153,10 +161,12 @@ B8_STD = [1.0, 0.9, 0.8, 1.1, 1.0, 0.95, 1.05, 0.85]
 
 
 @pytest.mark.parametrize("name,std_scale", [("traj3_b16", None), ("traj3_large_drift", [1.0, 0.9]),
-                                            ("traj3_b8_plain", None), ("traj3_b8_drift", B8_STD)])
+                                            ("traj3_b8_plain", None), ("traj3_b8_drift", B8_STD),
+                                            ("traj4_aromatic13", [1.0, 0.9]), ("traj4_full23", [1.0, 0.9])])
 def test_trajectory_bench_config_shapes_first_step(name, std_scale):
     """BASELINE configs[1] / configs[2] at the exact bench shape (C-small 300 + 30, B=8, plain / drift), configs[3] /
-    configs[4] shapes (NP=347, NL=37, B=16; 600 + 60 atoms with drift): the first step of the
+    configs[4] shapes (NP=347, NL=37, B=16; 600 + 60 atoms with drift), and the 13- / 23-class atom vocabularies of
+    ligand_atom_mode add_aromatic / full (reference models of those widths): the first step of the
     reference's 3-step fixtures (the full 3 steps are replayed by the HIP path in tests/test_gpu_configs.py; the oracle
     reproduced all 3 bit for bit when the fixture was generated: `oracle_vs_reference_maxabs` = 0)."""
     g, r = _replay_traj(name, 1, std_scale=std_scale)

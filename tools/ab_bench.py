@@ -2,6 +2,8 @@
 """Interleaved A/B timing of runtime variants inside ONE process (box-to-box variation is ~8%, so variants must be
 compared within a run).  usage: python tools/ab_bench.py "0=1" "0=3" "1=0" ...   (key=value settings of
 dd_debug_set_option; the baseline is always included)"""
+import os as _os; _os.environ.setdefault("DD_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "decompdiff_amd", "lib", "libdecompdiff_hip_dbg.so"))  # measurement build: dd_debug_set_option
+
 import sys, time, statistics, torch
 sys.path.insert(0, ".")
 from decompdiff_amd import DecompScorePosNet3D, hip_lib, shipped_config, synth

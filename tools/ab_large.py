@@ -1,5 +1,7 @@
 #!/usr/bin/env python
 """In-process A/B on the C-large workload (600 + 60 atoms, B=8): usage python tools/ab_large.py "13=33" ..."""
+import os as _os; _os.environ.setdefault("DD_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "decompdiff_amd", "lib", "libdecompdiff_hip_dbg.so"))  # measurement build: dd_debug_set_option
+
 import sys, time, statistics, torch
 sys.path.insert(0, ".")
 from decompdiff_amd import DecompScorePosNet3D, hip_lib, shipped_config, synth

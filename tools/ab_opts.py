@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """Compare dd_debug_set_option settings in alternating subprocesses (each timing the shipped workload, min of 3 x 200 steps).
 usage: python tools/ab_opts.py "24=0" "24=2" "24=3,8=4" [rounds]"""
+import os as _os; _os.environ.setdefault("DD_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "decompdiff_amd", "lib", "libdecompdiff_hip_dbg.so"))  # measurement build: dd_debug_set_option
+
 import os, subprocess, sys, statistics
 CHILD = r'''
 import os, sys, time, torch

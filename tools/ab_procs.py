@@ -2,6 +2,8 @@
 """Compare dd_debug_set_option variants in SEPARATE processes, alternating (each process measures its own per-shape CU
 split of the node launch first -- ab_bench.py keeps the split of the first variant, which hides changes that speed up
 only one part of that launch).  usage: python tools/ab_procs.py "" "22=0" "8=2,22=0" [rounds]   (DD_B = batch)"""
+import os as _os; _os.environ.setdefault("DD_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "decompdiff_amd", "lib", "libdecompdiff_hip_dbg.so"))  # measurement build: dd_debug_set_option
+
 import os, subprocess, sys, statistics
 CHILD = r'''
 import os, sys, time, torch

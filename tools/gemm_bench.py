@@ -1,5 +1,7 @@
 #!/usr/bin/env python
 """Time dd_gemm128 on the projection shapes of the shipped workload (profiling aid, needs a GPU)."""
+import os as _os; _os.environ.setdefault("DD_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "decompdiff_amd", "lib", "libdecompdiff_hip_dbg.so"))  # measurement build: dd_debug_set_option
+
 import ctypes, sys, torch
 sys.path.insert(0, ".")
 from decompdiff_amd import hip_lib

@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """Layer-tail queue schedule (option 8 = 5) against the graph-edge schedule (8 = 4) in one process: bit-equality of a short
 chain (plain and with drift, dense and padded), then interleaved timing.  usage: python tools/r3_tail_check.py [B] [steps]"""
+import os as _os; _os.environ.setdefault("DD_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "decompdiff_amd", "lib", "libdecompdiff_hip_dbg.so"))  # measurement build: dd_debug_set_option
+
 import os, sys, time, statistics, torch
 sys.path.insert(0, ".")
 from decompdiff_amd import DecompScorePosNet3D, hip_lib, shipped_config, synth

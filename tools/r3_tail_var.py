@@ -1,5 +1,7 @@
 #!/usr/bin/env python
 """Timing-only variants of the layer-tail queue (option 25) + serialized per-class times.  usage: python tools/r3_tail_var.py"""
+import os as _os; _os.environ.setdefault("DD_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "decompdiff_amd", "lib", "libdecompdiff_hip_dbg.so"))  # measurement build: dd_debug_set_option
+
 import os, sys, time, ctypes, torch
 sys.path.insert(0, ".")
 from decompdiff_amd import DecompScorePosNet3D, hip_lib, shipped_config, synth

@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """A dense batch run as k concurrent sub-batches (one captured graph, stream and launching host thread each) against the
 one-chain run.  usage: python tools/split_bench.py [steps] [fusion_mode for the split runs: 1 two streams per chain, 3 one]"""
+import os as _os; _os.environ.setdefault("DD_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "decompdiff_amd", "lib", "libdecompdiff_hip_dbg.so"))  # measurement build: dd_debug_set_option
+
 import os, sys, time, torch
 sys.path.insert(0, ".")
 from decompdiff_amd import DecompScorePosNet3D, hip_lib, shipped_config, synth
