@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Checksums of a short seeded chain (C-small B=8 and a 37-atom-ligand batch) -- to confirm that two builds of the library
 (DD_HIP_LIB=...) give bit-identical results.  usage: DD_HIP_LIB=path python tools/lib_checksum.py [steps]"""
-import os as _os; _os.environ.setdefault("DD_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "decompdiff_amd", "lib", "libdecompdiff_hip_dbg.so"))  # measurement build: dd_debug_set_option
+import os as _os
+if _os.environ.get("DD_OPTS"): _os.environ.setdefault("DD_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "decompdiff_amd", "lib", "libdecompdiff_hip_dbg.so"))  # measurement build: dd_debug_set_option
 
 import os, sys, hashlib, torch
 sys.path.insert(0, ".")

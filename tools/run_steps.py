@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Run N sampling steps of the shipped workload with optional dd_debug_set_option settings (profiling aid).
 usage: python tools/run_steps.py [steps] [key=value ...]"""
-import os as _os; _os.environ.setdefault("DD_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "decompdiff_amd", "lib", "libdecompdiff_hip_dbg.so"))  # measurement build: dd_debug_set_option
+import os as _os, sys as _sys
+if len(_sys.argv) > 2: _os.environ.setdefault("DD_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "decompdiff_amd", "lib", "libdecompdiff_hip_dbg.so"))  # measurement build: dd_debug_set_option
 
 import sys, torch
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
