@@ -1063,24 +1063,50 @@ static int autotune_node_split(const dd_sampler* s, hipStream_t st) {
   };
   int best_n = 0;
   float best_t = 0.f, t = 0.f;
-  time_split(0, best_t);
   // scan around the work-proportional share (rough unit costs: a node block of 8 centres 1.0, a bond-layer batch of 8
   // segments 0.1 + 0.35 per 16-member tile) -- far from it a candidate only costs time (a starved part runs for ms)
   const int tiles = (s->NL - 2 + 15) / 16;
   const double w_bl = ((double)s->B * s->NL * (s->NL - 1) / 8.0) * (0.1 + 0.35 * tiles);
   const double w_node = (double)s->B * ((s->NP + 7) / 8 + (s->NL + 7) / 8) + (double)s->B * s->NL / 8.0;
   const int centre = (int)(n_cu * w_bl / (w_bl + w_node)) / 8 * 8;
-  const int lo = centre - 32 < n_cu / 4 ? n_cu / 4 : centre - 32, hi = centre + 16 > n_cu - 16 ? n_cu - 16 : centre + 16;
-  for (int n = lo; n <= hi && rc == DD_OK; n += 16) {
-    time_split(n, t);
-    if (t < best_t) { best_t = t; best_n = n; }
+  // A job of many pockets (configs[3]: 100 shapes) does not scan for every shape: the measured optimum sits at a stable
+  // offset from the work-proportional share within one kernel variant (tile class) and batch size, so a shape whose class
+  // has been scanned before only times that prediction and its two neighbours (9 forward passes instead of ~33).
+  struct Seen { int B, K, tiles, offset; };
+  static std::vector<Seen> seen;
+  static std::mutex seen_mutex;
+  int predicted = -1;
+  {
+    std::lock_guard<std::mutex> lock(seen_mutex);
+    for (const Seen& e : seen)
+      if (e.B == s->B && e.K == s->K && e.tiles == tiles) predicted = centre + e.offset;
   }
-  if (best_n > 0)
-    for (int n : {best_n - 8, best_n + 8}) {
+  if (predicted >= 0) {
+    predicted = predicted < 16 ? 16 : (predicted > n_cu - 16 ? n_cu - 16 : predicted);
+    best_t = 1e30f;
+    for (int n : {predicted, predicted - 8, predicted + 8}) {
       if (rc != DD_OK || n < 16 || n > n_cu - 16) continue;
       time_split(n, t);
       if (t < best_t) { best_t = t; best_n = n; }
     }
+  } else {
+    time_split(0, best_t);
+    const int lo = centre - 32 < n_cu / 4 ? n_cu / 4 : centre - 32, hi = centre + 16 > n_cu - 16 ? n_cu - 16 : centre + 16;
+    for (int n = lo; n <= hi && rc == DD_OK; n += 16) {
+      time_split(n, t);
+      if (t < best_t) { best_t = t; best_n = n; }
+    }
+    if (best_n > 0)
+      for (int n : {best_n - 8, best_n + 8}) {
+        if (rc != DD_OK || n < 16 || n > n_cu - 16) continue;
+        time_split(n, t);
+        if (t < best_t) { best_t = t; best_n = n; }
+      }
+    if (rc == DD_OK && best_n > 0) {
+      std::lock_guard<std::mutex> lock(seen_mutex);
+      seen.push_back(Seen{s->B, s->K, tiles, best_n - centre});
+    }
+  }
   dd::g_node_split_trial = -1;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
