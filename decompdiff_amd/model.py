@@ -184,6 +184,7 @@ class DecompScorePosNet3D(nn.Module):
         """Forget the packed weight arena (and with it the cached chain resources that point into it).  Called by
         load_state_dict / .to() / train(); call it by hand after modifying parameters in place."""
         self._packed = None
+        self.__dict__["_param_list"] = None
         self._evict_chain_cache(0)
 
     def load_state_dict(self, *args, **kwargs):
@@ -194,16 +195,20 @@ class DecompScorePosNet3D(nn.Module):
     def _apply(self, fn, *args, **kwargs):
         r = super()._apply(fn, *args, **kwargs)
         self.__dict__["_packed"] = None
+        self.__dict__["_param_list"] = None                 # (.to() may replace the parameter tensors)
         return r
 
     def _packed_weights(self):
         dev = self._device()
         key = str(dev)
         # in-place parameter updates (optimizer.step on a loss of the caller's own, an EMA copy, param.data.copy_) bump the
-        # tensors' version counters: the packed copy is rebuilt when their sum moves (0.4 ms per call over the 600 tensors;
-        # DD_CHECK_PARAM_VERSIONS=0 turns the check off)
+        # tensors' version counters: the packed copy is rebuilt when their sum moves (the tensor list is kept: walking the
+        # module tree costs 0.4 ms per call, the 600 attribute reads 0.05; DD_CHECK_PARAM_VERSIONS=0 turns the check off)
         if os.environ.get("DD_CHECK_PARAM_VERSIONS", "1") != "0":
-            key = (key, sum(int(p._version) for p in self.parameters()))
+            plist = self.__dict__.get("_param_list")
+            if plist is None:
+                plist = self.__dict__["_param_list"] = list(self.parameters())
+            key = (key, sum(p._version for p in plist), id(plist))
         if self._packed is None or self._packed_key != key:
             if self._packed is not None:
                 self._evict_chain_cache(0)                                  # cached chains point into the old arena
@@ -1044,8 +1049,12 @@ class DecompScorePosNet3D(nn.Module):
 
         pending = []
         try:
-            for c, lo in enumerate(range(0, num_steps, chunk)):
-                hi = min(num_steps, lo + chunk)
+            # a chain shorter than one chunk is still drained in ~3 pieces: only the last piece's copy is exposed
+            piece = min(chunk, max(8, -(-num_steps // 3)))
+            if spg > 1:
+                piece = max(spg, piece // spg * spg)
+            for c, lo in enumerate(range(0, num_steps, piece)):
+                hi = min(num_steps, lo + piece)
                 hip_lib.check(lib.dd_graph_launch(graph, (hi - lo) // spg, side.cuda_stream), "dd_graph_launch")
                 ev = torch.cuda.Event()
                 ev.record(side)
@@ -1058,7 +1067,7 @@ class DecompScorePosNet3D(nn.Module):
                 done.record(copy_st)
                 pending.append((lo, hi, c % 2, done))
                 if c == 0 and not dbg & 4:
-                    tail = ((num_steps - 1) // chunk) * chunk
+                    tail = ((num_steps - 1) // piece) * piece
                     for k in keys:                     # first touch of the pages the un-hidden last drain writes
                         final_np[k][tail:].fill(0)
                 if len(pending) == 2:
