@@ -69,5 +69,33 @@ def build(force: bool = False, verbose: bool = True, exact: bool = False, debug_
     return lib
 
 
+def build_torch_ext(force: bool = False, verbose: bool = True) -> str:
+    """The compiled torch extension csrc/torch_ext.cpp -> lib/decompdiff_torch_ext.so (host-only C++: TORCH_LIBRARY
+    registration of the op-level C-ABI entry points; g++ against the installed torch headers, linked to the default
+    libdecompdiff_hip.so through $ORIGIN).  Build the default library first."""
+    import torch
+    from torch.utils import cpp_extension as ce
+    src = os.path.join(CSRC, "torch_ext.cpp")
+    out = os.path.join(LIBDIR, "decompdiff_torch_ext.so")
+    hdr = os.path.join(HERE, "..", "include", "decompdiff_hip.h")
+    if not force and not _stale(out, [src, hdr, LIB]):
+        return out
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-I", "/opt/rocm/include"]
+    for p in ce.include_paths():
+        cmd += ["-I", p]
+    cmd += [src, "-o", out, "-L", tlib, "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch", "-L", LIBDIR, "-ldecompdiff_hip",
+            "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib]
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"g++ failed:\n{r.stdout}\n{r.stderr}")
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, exact="--exact" in sys.argv, debug_options="--debug-options" in sys.argv))
+    if "--exact" not in sys.argv and "--debug-options" not in sys.argv:
+        print(build_torch_ext(force="--force" in sys.argv))

@@ -18,6 +18,32 @@ import torch
 
 from . import hip_lib
 
+# ------------------------------------------------------------------------------------------------------------------
+# The compiled torch extension (csrc/torch_ext.cpp -> lib/decompdiff_torch_ext.so: TORCH_LIBRARY(decompdiff_hip, ...),
+# HIP-key kernels that launch the same C-ABI entry points on torch's current stream).  When it is present the ops below
+# go through the dispatcher (torch.ops.decompdiff_hip.*); otherwise -- extension not built, or another library build
+# selected with DD_HIP_LIB (the extension is linked against the default one) -- through the ctypes binding of the same
+# entry points.  DD_TORCH_EXT=0 forces ctypes.  Either way the arithmetic is the HIP library's: no CPU path.
+# ------------------------------------------------------------------------------------------------------------------
+import os as _os
+
+_EXT_PATH = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "lib", "decompdiff_torch_ext.so")
+_ext_state = {"tried": False, "ops": None}
+
+
+def torch_ext():
+    """torch.ops.decompdiff_hip (compiled extension) or None."""
+    if not _ext_state["tried"]:
+        _ext_state["tried"] = True
+        if _os.environ.get("DD_TORCH_EXT", "1") != "0" and not _os.environ.get("DD_HIP_LIB") and _os.path.exists(_EXT_PATH):
+            try:
+                torch.ops.load_library(_EXT_PATH)
+                if int(torch.ops.decompdiff_hip.abi_version()) == hip_lib.ABI_VERSION:
+                    _ext_state["ops"] = torch.ops.decompdiff_hip
+            except (OSError, RuntimeError):                  # toolchain skew: the ctypes binding serves the same entry points
+                _ext_state["ops"] = None
+    return _ext_state["ops"]
+
 
 def knn_graph(x: torch.Tensor, k: int, batch: Optional[torch.Tensor] = None, loop: bool = False,
               flow: str = "source_to_target") -> torch.Tensor:
@@ -39,9 +65,13 @@ def knn_graph(x: torch.Tensor, k: int, batch: Optional[torch.Tensor] = None, loo
     kk = min(int(k), N - 1)
     if kk <= 0:
         return torch.empty(2, 0, dtype=torch.long, device=x.device)
-    nbr = torch.empty(B, N, kk, dtype=torch.int32, device=x.device)
     xc = x.detach().to(torch.float32).contiguous()
-    hip_lib.check(hip_lib.load().dd_knn(hip_lib.ptr(xc), B, N, kk, hip_lib.ptr(nbr), hip_lib.stream_ptr(x.device)), "dd_knn")
+    ext = torch_ext()
+    if ext is not None:
+        nbr = ext.knn(xc.view(B, N, 3), kk)
+    else:
+        nbr = torch.empty(B, N, kk, dtype=torch.int32, device=x.device)
+        hip_lib.check(hip_lib.load().dd_knn(hip_lib.ptr(xc), B, N, kk, hip_lib.ptr(nbr), hip_lib.stream_ptr(x.device)), "dd_knn")
     base = (torch.arange(B, device=x.device) * N).view(B, 1, 1)
     src = (nbr.long() + base).reshape(-1)
     dst = torch.arange(n, device=x.device).repeat_interleave(kk)
@@ -72,6 +102,9 @@ def scatter_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, index: 
     # converted copies are bound to locals that outlive the launch: a temporary freed before the kernel is enqueued
     # would hand its block to the next same-size allocation (k and v would alias)
     qf, kf, vf, seg = f(q), f(k), f(v), _seg_ptr(index, dim_size)
+    ext = torch_ext()
+    if ext is not None:
+        return ext.attn_aggregate_node(qf, bool(per_edge), kf, vf, ew, seg)
     hip_lib.check(hip_lib.load().dd_attn_aggregate_node(hip_lib.ptr(qf), int(per_edge), hip_lib.ptr(kf), hip_lib.ptr(vf),
                                                         hip_lib.ptr(ew), hip_lib.ptr(seg), dim_size,
                                                         hip_lib.ptr(out), hip_lib.stream_ptr(k.device)), "dd_attn_aggregate_node")
@@ -88,6 +121,9 @@ def scatter_attention_pos(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rel
     out = torch.empty(dim_size, 3, device=k.device)
     ew = None if e_w is None else e_w.detach().to(torch.float32).reshape(-1).contiguous()
     qf, kf, vf, rf, seg = f(q), f(k), f(v), f(rel_x), _seg_ptr(index, dim_size)      # (alive past the launch, see above)
+    ext = torch_ext()
+    if ext is not None:
+        return ext.attn_aggregate_pos(qf, kf, vf, ew, rf, seg)
     hip_lib.check(hip_lib.load().dd_attn_aggregate_pos(hip_lib.ptr(qf), hip_lib.ptr(kf), hip_lib.ptr(vf), hip_lib.ptr(ew),
                                                        hip_lib.ptr(rf), hip_lib.ptr(seg), dim_size,
                                                        hip_lib.ptr(out), hip_lib.stream_ptr(k.device)), "dd_attn_aggregate_pos")
@@ -135,9 +171,15 @@ def _prep_scatter(src: torch.Tensor, index: torch.Tensor, dim: int, dim_size: Op
 def _segment_reduce(src, index, dim, dim_size, op, out=None):
     x, ptr, n, perm = _prep_scatter(src, index, dim, dim_size)
     E, F = x.shape
-    res = torch.empty(n, F, device=src.device)
-    arg = torch.empty(n, F, dtype=torch.int64, device=src.device) if op in ("min", "max") else None
-    if n and F:
+    ext = torch_ext()
+    if ext is not None:
+        res, arg = ext.segment_reduce(x, ptr, _OPS[op])
+        if op not in ("min", "max"):
+            arg = None
+    else:
+        res = torch.empty(n, F, device=src.device)
+        arg = torch.empty(n, F, dtype=torch.int64, device=src.device) if op in ("min", "max") else None
+    if ext is None and n and F:
         hip_lib.check(hip_lib.load().dd_segment_reduce(hip_lib.ptr(x) if E else None, hip_lib.ptr(ptr), n, F, _OPS[op], E,
                                                        hip_lib.ptr(res), hip_lib.ptr(arg), hip_lib.stream_ptr(src.device)),
                       "dd_segment_reduce")
@@ -181,8 +223,9 @@ def scatter_softmax(src: torch.Tensor, index: torch.Tensor, dim: int = -1, dim_s
     scattered to it (max-shifted, no eps: torch_scatter >= 2.1)."""
     x, ptr, n, perm = _prep_scatter(src, index, dim if src.dim() > 1 or dim != -1 else 0, dim_size)
     E, F = x.shape
-    res = torch.empty_like(x)
-    if E and F:
+    ext = torch_ext()
+    res = ext.segment_softmax(x, ptr) if ext is not None else torch.empty_like(x)
+    if ext is None and E and F:
         hip_lib.check(hip_lib.load().dd_segment_softmax(hip_lib.ptr(x), hip_lib.ptr(ptr), n, F, hip_lib.ptr(res),
                                                         hip_lib.stream_ptr(src.device)), "dd_segment_softmax")
     if perm is not None:

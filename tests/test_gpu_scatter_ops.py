@@ -245,3 +245,34 @@ def test_torch_ops_backward_matches_autograd_of_the_oracle_ops():
                 (f_op(b, dst.to(dev), 0, n_seg) * w.to(dev)).sum().backward()
             err = float((b.grad.cpu().double() - a.grad).abs().max()) if E else 0.0
             assert b.grad.shape == src.shape and err < 2e-5, (name, n_seg, trail, err)
+
+
+def test_compiled_extension_ops_equal_the_ctypes_binding():
+    """The ops of the compiled torch extension (torch.ops.decompdiff_hip.*, csrc/torch_ext.cpp) launch the same C-ABI entry
+    points as the ctypes binding: functional.* through either route is bit-identical."""
+    from decompdiff_amd import functional as Fn
+    ops = Fn.torch_ext()
+    assert ops is not None, "compiled extension missing on the GPU box"
+    dev = torch.device("cuda:0")
+    ptr, dst, g = _segments(300, [0, 5, 32], 9)
+    E = int(ptr[-1])
+    src = (torch.randn(E, 16, generator=g) * 2).to(dev)
+    q, k, v = (torch.randn(n, 128, generator=g).to(dev) for n in (300, E, E))
+    v16, rel, ew = torch.randn(E, 16, generator=g).to(dev), torch.randn(E, 3, generator=g).to(dev), torch.rand(E, generator=g).to(dev)
+    x = torch.randn(3 * 70, 3, generator=g).to(dev)
+    batch = torch.arange(3, device=dev).repeat_interleave(70)
+    dstd = dst.to(dev)
+
+    def run():
+        return [Fn.knn_graph(x, 16, batch), Fn.scatter_sum(src, dstd, 0, dim_size=300), Fn.scatter_mean(src, dstd, 0, dim_size=300),
+                *Fn.scatter_min(src, dstd, 0, dim_size=300), Fn.scatter_softmax(src, dstd, 0, dim_size=300),
+                Fn.scatter_attention(q, k, v, dstd, 300, ew), Fn.scatter_attention_pos(q, k, v16, rel, dstd, 300, ew)]
+    via_ext = run()
+    saved = Fn._ext_state["ops"]
+    try:
+        Fn._ext_state["ops"] = None                          # force the ctypes route
+        via_ctypes = run()
+    finally:
+        Fn._ext_state["ops"] = saved
+    for a, b in zip(via_ext, via_ctypes):
+        assert a.shape == b.shape and a.dtype == b.dtype and torch.equal(a, b)

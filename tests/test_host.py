@@ -254,3 +254,18 @@ def test_sensitivity_fixture_and_class_tables():
                                                                         False, True, False]
     assert len(H.FULL_CLASSES) == 23 and H.atomic_numbers_from_index([0, 3, 12, 22], "full") == [1, 6, 9, 17]
     assert H.is_aromatic_from_index([3, 4], "full") == [True, False] and H.is_aromatic_from_index([1], "basic") is None
+
+
+def test_compiled_torch_extension_registers_the_op_level_boundary():
+    """csrc/torch_ext.cpp: TORCH_LIBRARY(decompdiff_hip) built by build(); every op has a HIP(=CUDA-key) kernel and no CPU one."""
+    import __graft_entry__
+    __graft_entry__.build()
+    from decompdiff_amd import functional as Fn
+    ops = Fn.torch_ext()
+    assert ops is not None, "lib/decompdiff_torch_ext.so did not load"
+    assert int(ops.abi_version()) == hip_lib.ABI_VERSION
+    for name in ("knn", "segment_reduce", "segment_softmax", "attn_aggregate_node", "attn_aggregate_pos"):
+        assert torch._C._dispatch_has_kernel_for_dispatch_key(f"decompdiff_hip::{name}", "CUDA"), name
+        assert not torch._C._dispatch_has_kernel_for_dispatch_key(f"decompdiff_hip::{name}", "CPU"), name
+    with pytest.raises(NotImplementedError):
+        ops.knn(torch.zeros(1, 4, 3), 2)                    # no CPU implementation: the dispatcher refuses

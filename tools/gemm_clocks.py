@@ -5,7 +5,7 @@ sys.path.insert(0, ".")
 from decompdiff_amd import hip_lib
 lib = hip_lib.load(); dev = torch.device("cuda:0"); st = torch.cuda.Stream()
 names = ["fetch0+commit+sync", "MFMA half 0", "sync+commit1+sync", "MFMA half 1", "stores"]
-for rows, ncols in [(6960, 640), (2640, 640), (64, 64), (65536, 640)]:
+for rows, ncols in [(6960, 640), (2640, 640), (64, 64), (2640, 128), (2640, 256), (6960, 256)]:
     X = torch.randn(rows, 128, device=dev); W = torch.randn(ncols, 128, device=dev); b = torch.randn(ncols, device=dev); Y = torch.zeros(rows, ncols, device=dev)
     nt = ((rows + 63) // 64) * ((ncols + 63) // 64)
     buf = torch.zeros(nt, 8, dtype=torch.int64, device=dev)
