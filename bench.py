@@ -69,8 +69,8 @@ def parse():
                                                                        "instead of failing (the job exchanges no data)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rooflines", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=20)
-    ap.add_argument("--cpu-warmup", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=5, help="steps of the CPU baseline's timed sample (~5.5 s each at B=8)")
+    ap.add_argument("--cpu-warmup", type=int, default=1)
     return ap.parse_args()
 
 
@@ -371,7 +371,7 @@ def cpu_baseline(torch, synth, cfg, batch_cpu, drift, B, n_cpu, n_warm):
     n_cpu, n_warm = max(1, n_cpu), max(1, n_warm)
     ncpu = os.cpu_count() or 1
     probe = {}
-    for nthreads in sorted({min(16, ncpu), min(64, ncpu), torch.get_num_threads()}):
+    for nthreads in sorted({min(16, ncpu), min(64, ncpu)}):     # (all 128-256 threads of such a host are slower still: dropped from the probe)
         torch.set_num_threads(nthreads)
         torch.manual_seed(7)
         OD.sample_diffusion(weights, cfg, num_steps=1, energy_drift_opt=drift, keep_traj=False, **batch_cpu)
