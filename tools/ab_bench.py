@@ -28,4 +28,11 @@ for rnd in range(5):
     for name, st in variants: res[name].append(run(st))
 for name, _ in variants:
     print(f"{name:20s} median {statistics.median(res[name]):.4f} ms/step   min {min(res[name]):.4f}   all {[round(x,3) for x in res[name]]}")
+import hashlib
+for name, st in variants:                       # bit-identity of the variants: hash of a seeded 10-step chain
+    for k, v in DEFAULTS.items(): lib.dd_debug_set_option(k, v)
+    for k, v in st: lib.dd_debug_set_option(k, v)
+    o = m.sample_diffusion(num_steps=10, center_pos_mode="protein", keep_traj=True, use_graph=True, seed=5, **b)
+    hsh = hashlib.sha256(o["pos"].cpu().numpy().tobytes() + o["v"].cpu().numpy().tobytes() + o["bond"].cpu().numpy().tobytes()).hexdigest()[:16]
+    print(f"{name:20s} sha256(pos|v|bond) after 10 steps: {hsh}")
 for k, v in DEFAULTS.items(): lib.dd_debug_set_option(k, v)
