@@ -563,6 +563,7 @@ class DecompScorePosNet3D(nn.Module):
     # 20-step bench is 27 ms of GPU work).  Chains with injected noise (parity mode) are not cached.
     _CACHE_MAX = int(os.environ.get("DD_CHAIN_CACHE_SIZE", "4"))
     _graph_counter = 0
+    _primed_devices: set = set()               # devices whose streamed-trajectory path has run once (_prime_streaming)
     _chain_cache: Dict[tuple, dict] = {}      # process-wide (keys carry device and weight arena): ONE destruction order for all graphs
 
     def _evict_chain_cache(self, keep=0):
@@ -1005,16 +1006,21 @@ class DecompScorePosNet3D(nn.Module):
         per_step = sum(bufs[k][0].numel() * bufs[k].element_size() for k in keys)
         # ~24 MB per chunk: the last chunk is the only one whose drain is not hidden (a few ms)
         chunk = int(os.environ.get("DD_TRAJ_CHUNK", "0")) or max(8, min(128, (24 << 20) // max(per_step, 1)))
-        sig = (str(dev), chunk, tuple((k, tuple(bufs[k].shape[1:]), bufs[k].dtype) for k in keys))
+        # staging: two flat pinned buffers per process and device, carved per shape (a pinned allocation costs tens of ms --
+        # a job over 100 pockets of different sizes must not repeat it per pocket); grown only if a chunk needs more
+        sizes = {k: chunk * bufs[k][0].numel() * bufs[k].element_size() for k in keys}
+        need = sum((n + 255) // 256 * 256 for n in sizes.values())
         cache = getattr(self, "_staging", None)
-        if cache is None or cache[0] != sig:
-            slots = [{k: torch.empty((chunk,) + tuple(bufs[k].shape[1:]), dtype=bufs[k].dtype).pin_memory() for k in keys}
-                     for _ in range(2)]
-            for sl in slots:                           # first device -> host transfer into every staging page happens here,
-                for k in keys:                         # not in the first chain long enough to reach it (~1 ms, measured)
-                    sl[k].copy_(torch.zeros(sl[k].shape, dtype=sl[k].dtype, device=dev))
-            cache = self._staging = (sig, slots)
-        slots = cache[1]
+        if cache is None or cache[0] != str(dev) or cache[1] < need:
+            cap = max(need, 32 << 20)
+            cache = self._staging = (str(dev), cap, [torch.empty(cap, dtype=torch.uint8).pin_memory() for _ in range(2)])
+        slots = []
+        for flat in cache[2]:
+            sl, off = {}, 0
+            for k in keys:
+                sl[k] = flat[off:off + sizes[k]].view(bufs[k].dtype).view((chunk,) + tuple(bufs[k].shape[1:]))
+                off += (sizes[k] + 255) // 256 * 256
+            slots.append(sl)
         widen = {"traj_v": torch.int64, "traj_bond": torch.int64}
         final = {k: torch.empty((num_steps,) + tuple(bufs[k].shape[1:]), dtype=widen.get(k, bufs[k].dtype)) for k in keys}
         side.wait_stream(cur)
@@ -1030,12 +1036,12 @@ class DecompScorePosNet3D(nn.Module):
             ent["graph"], ent["graph_sig"] = graph, gsig
             DecompScorePosNet3D._graph_counter += 1
             ent["graph_id"] = DecompScorePosNet3D._graph_counter
-            ent["primed"] = False
         graph = ent["graph"]
         cached = any(e is ent for e in DecompScorePosNet3D._chain_cache.values())
-        if prime and cached and not ent.get("primed") and os.environ.get("DD_PRIME", "1") != "0":
-            ent["primed"] = True
-            self._prime_streaming(chain)
+        if (prime and cached and str(dev) not in DecompScorePosNet3D._primed_devices
+                and os.environ.get("DD_PRIME", "1") != "0"):
+            if self._prime_streaming(chain):               # once per process and device (a 100-pocket job creates 100 graphs)
+                DecompScorePosNet3D._primed_devices.add(str(dev))
 
         dbg = int(os.environ.get("DD_TRAJ_DEBUG", "0"))
         final_np = {k: v.numpy() for k, v in final.items()}
@@ -1091,21 +1097,22 @@ class DecompScorePosNet3D(nn.Module):
         chain["traj_cpu"] = final
 
     def _prime_streaming(self, chain):
-        """One-off, when a cached chain's step graph is new: stream a short chain (3 pieces of 8 steps) through the same
-        launch / copy / drain code once and put the chain's state back.  The first streamed call of a process that is
-        three or more pieces long stalls the device for ~1 ms in its second or third piece (tools/first_call3.py: 10.6
-        instead of 9.7 ms for one 8-step piece); a 20-step chain after a 5-step warm-up would otherwise pay that inside
-        the caller's timed call."""
+        """One-off per process and device, with the first cached chain that is streamed: stream a short chain (3 pieces of
+        8 steps) through the same launch / copy / drain code once and put the chain's state back.  The first streamed
+        call of a process that is three or more pieces long stalls the device for ~1 ms in its second or third piece
+        (tools/first_call3.py: 10.6 instead of 9.7 ms for one 8-step piece); a 20-step chain after a 5-step warm-up would
+        otherwise pay that inside the caller's timed call.  Returns False if this chain cannot be used for it."""
         bufs, s = chain["bufs"], chain["s"]
         n = min(int(bufs["traj_pos"].shape[0]), 24, int(s.t_start) + 1)     # (never past t = 0)
         if n < 17:
-            return
+            return False
         state = {k: bufs[k].clone() for k in ("lig_pos", "lig_v", "lig_bond", "step_counter")}
         self._run_chain_streaming(chain, n, prime=False)
         chain.pop("traj_cpu", None)
         for k, v in state.items():
             bufs[k].copy_(v)
         torch.cuda.synchronize(chain["dev"])
+        return True
 
     def _collect_chain(self, chain, num_steps, keep_traj, rows_atoms=None, rows_bonds=None):
         """Result dict of a finished chain.  rows_atoms / rows_bonds (padded batches): the rows of the dense [B*NL] /
