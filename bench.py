@@ -307,7 +307,10 @@ def measure_step_rooflines(torch, model, hip_lib, lib, state, cfg, B, NP, NL, K,
                 "profiles/) / mean duration of the shipped fused launch from HIP events on its stream; VALU work (LayerNorm, "
                 "softmax, query fold, epilogue) is not counted.  algorithmic_tflops = SURVEY.md 8d factored FLOPs of the same "
                 "three sub-layers / the same time: work the exact restructurings of DESIGN.md 3 remove, not a utilisation.  "
-                "The kernel is fused: q / k / v never touch HBM, so it is priced against the fp32 MFMA peak, not HBM.",
+                "The kernel is fused: q / k / v never touch HBM, so it is priced against the fp32 MFMA peak, not HBM.  "
+                "On gfx950 fp32 MFMA and fp32 VALU instructions do not overlap on a SIMD, within a wave or across waves "
+                "(tools/bench_issue.hip, EXPERIMENTS.md R3-10): with this kernel's ~1:1 MFMA:VALU cycle mix the fraction is "
+                "capped near 0.45.",
         "ms_per_step_by_launch_class": {k: round(v, 4) for k, v in per_cat.items()},
     }
     g_flops, g_tiles = gemm_work_per_step(B, NP, NL, L, layer0_tables=bool(s2.l0_tables))
