@@ -462,8 +462,14 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
       load_row(Pf, a.ke + ((long)b * Eb + sj * NLm1 + (k - (k > sj ? 1 : 0))) * a.ld_ke, cg);
     }
   };
+  // bond-graph and triplet segments: the segment's own row is re-read per tile (L1 / L2) instead of held in 32 registers
+  // across the whole k pass -- the same sum (a + b = b + a).  The 4-tile node launch (ligands of 50-64 atoms) goes from 135
+  // spilled registers to none (C-large: 205 -> 222 steps/s), the 3-tile one from 56 to none, the 2-tile one from 252 to
+  // 229 registers (-0.4 % step time); results bit-identical (tools/lib_checksum.py).
+  constexpr bool REREAD = !KNN && !POS;
+  const float* rc_row = TRIP ? a.Rk + (long)seg * 128 : a.kd + drow * a.ld_kd;
   if (active && kside) {
-    load_row(Rc, TRIP ? a.Rk + (long)seg * 128 : a.kd + drow * a.ld_kd, cg);
+    if (!REREAD) load_row(Rc, rc_row, cg);
     fetch_k_rows(0);
     if (TRIP) {
 #pragma unroll
@@ -558,10 +564,19 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
     const float* tab_s = pass ? a.vs : a.ks;  const int ld_s = pass ? a.ld_vs : a.ld_ks;
     const float* tab_e = pass ? a.ve : a.ke;  const int ld_e = pass ? a.ld_ve : a.ld_ke;
     if (pass == 0) {
+      if (REREAD) {
 #pragma unroll
-      for (int k = 0; k < 32; ++k) {
-        P[k] = Rc[k] + Pf[k];
-        if (BOND) P[k] += Pf2[k];
+        for (int k = 0; k < 32; ++k) P[k] = Pf[k];
+        add_row(P, rc_row, cg);
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+          if (BOND) P[k] += Pf2[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+          P[k] = Rc[k] + Pf[k];
+          if (BOND) P[k] += Pf2[k];
+        }
       }
       if (t + 1 < MAXT && t + 1 < T) fetch_k_rows(t + 1);   // next tile's rows fly during this tile's arithmetic
     } else if (KNN) {
