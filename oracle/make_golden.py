@@ -384,6 +384,10 @@ def main():
         # configs[1] at its exact shape for the WHOLE chain: 300 + 30 atoms, B = 8, 1000 steps, checkpoints every 50 steps;
         # same pocket / seed as traj3_b8_plain, so the first three steps are that fixture's.  ~2 h of reference CPU time.
         gen_traj(ref, sd, cfg, "traj1000_b8_plain", synth.make_pocket_small(8), 8, 1000, None, 2041, every=50, check_oracle=False)
+    if args.only == "b8long_drift":
+        # configs[2] the same way: armsca + clash drift, the per-sample prior scales of traj3_b8_drift
+        gen_traj(ref, sd, cfg, "traj1000_b8_drift", synth.make_pocket_small(8), 8, 1000, DRIFT, 2042, every=50, check_oracle=False,
+                 std_scale=[1.0, 0.9, 0.8, 1.1, 1.0, 0.95, 1.05, 0.85])
     if want("traj1000_drift") and not args.skip_long:
         gen_traj(ref, sd, cfg, "traj1000_drift", synth.make_pocket_small(5), 1, 1000, DRIFT, 2025, every=50)
     if want("traj1000") and not args.skip_long:
