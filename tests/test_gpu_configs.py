@@ -94,13 +94,15 @@ def test_config1_full_chain_at_the_bench_shape_reference_golden():
 def test_config2_full_chain_at_the_bench_shape_reference_golden():
     """BASELINE configs[2] (armsca + clash drift) for the whole chain at the bench shape: 300 + 30 atoms, batch of 8, 1000
     reverse steps on the reference's injected noise against the reference's own trajectory (oracle/make_golden.py --only
-    b8long_drift, reference only).  The unscaled drift gradients make the free-running chain chaotic much earlier than the
-    plain one (tests/golden/sens_traj1000_drift.npz: the oracle's own +-1-ulp replays of ONE sample leave the reference by
-    1e-4 around step 300, by 1e-3 ... 2e-1 at the end, and one of eight flips bond types), so what is asserted for eight
-    samples is: types of every sample exact and coordinates within 1e-4 over the first 250 steps; at every later
-    checkpoint every sample within the largest self-divergence the oracle's replays show at that checkpoint or 1e-4,
-    whichever is larger ... for the samples whose discrete types still agree (a flipped type is a different molecule: its
-    coordinates are not compared); and at most 2 of the 8 samples with any type flip at all.  Everything is printed."""
+    b8long_drift: the reference alone, 1 h 30 min of CPU; checkpoints every 50 steps).
+
+    Asserted: atom and bond types of ALL 8 samples exact at ALL 20 checkpoints (the discrete part of the contract holds for
+    the whole guided chain); coordinates of all samples within 1e-4 for the first 600 steps (measured <= 5.1e-5; 7.9e-5 at
+    650).  The unscaled drift gradients make the free-running chain chaotic in its last third -- the ORACLE's own +-1-ulp
+    replays of one sample (tests/golden/sens_traj1000_drift.npz) leave the reference by up to 0.48 A and one of eight even
+    flips bond types -- so from step 650 on every sample is held to the largest self-divergence those replays show at the
+    checkpoint (measured here: three samples end at 2.9e-3 / 1.7e-2 / 4.8e-2, the other five at 2.6e-5 ... 7.3e-4).  The
+    step-for-step bound is test_chain_segments_from_reference_checkpoints."""
     if not os.path.exists(os.path.join(GU.GOLDEN, "traj1000_b8_drift.npz")):
         pytest.skip("traj1000_b8_drift.npz not generated (python -m oracle.make_golden --only b8long_drift)")
     scale = [1.0, 0.9, 0.8, 1.1, 1.0, 0.95, 1.05, 0.85]
@@ -113,20 +115,20 @@ def test_config2_full_chain_at_the_bench_shape_reference_golden():
     tb = torch.stack(r["bond_traj"]).numpy()[every - 1::every]
     n = len(tp)
     d = np.abs(tp.astype(np.float64) - g["traj_pos"]).reshape(n, 8, -1).max(2)                 # [checkpoint, sample]
-    mv = (tv != g["traj_v"]).reshape(n, 8, -1).sum(2)
-    mb = (tb != g["traj_bond"]).reshape(n, 8, -1).sum(2)
-    flipped = (mv + mb) > 0                                                                     # [checkpoint, sample]
+    mv = int((tv != g["traj_v"]).sum())
+    mb = int((tb != g["traj_bond"]).sum())
     print("configs[2] full chain (NP=300, NL=30, B=8, armsca + clash drift), checkpoints every 50 steps")
-    print("  max |pos - reference| over the samples whose types agree:", " ".join(f"{np.where(~flipped[i], d[i], 0).max():.2g}" for i in range(n)))
-    print("  samples with a type flip per checkpoint:", flipped.sum(1).tolist())
-    print("  per sample at step 1000:", " ".join(f"{e:.2g}" for e in d[-1]), " type flips:", (mv[-1] + mb[-1]).tolist())
-    assert not flipped[:5].any() and (d[:5] < POS_TOL).all()
+    print("  max |pos - reference| over the batch:", " ".join(f"{e:.2g}" for e in d.max(1)))
+    print("  per sample at step 1000:", " ".join(f"{e:.2g}" for e in d[-1]))
+    print(f"  type mismatches: atoms {mv}, bonds {mb}")
+    assert mv == 0 and mb == 0
+    assert np.array_equal(r["v"].cpu().numpy(), g["out_v"]) and np.array_equal(r["bond"].cpu().numpy(), g["out_bond"])
+    assert (d[:12] < POS_TOL).all()                       # steps 50 ... 600: the flat tolerance of BASELINE.json, all samples
     sens = GU.load("sens_traj1000_drift")
+    assert int(sens["every"]) == every and sens["pos_err"].shape == (8, n)
     bound = np.maximum(POS_TOL, sens["pos_err"].max(0))
-    ok = np.where(~flipped, d, 0.0)
-    worst = int(np.argmax(ok.max(1) / bound))
-    assert (ok.max(1) <= bound).all(), f"checkpoint {worst}: {ok.max(1)[worst]:.3g} > {bound[worst]:.3g}"
-    assert int(flipped.any(0).sum()) <= 2
+    worst = int(np.argmax(d.max(1) / bound))
+    assert (d.max(1) <= bound).all(), f"checkpoint {worst}: {d.max(1)[worst]:.3g} > {bound[worst]:.3g}"
 
 
 @pytest.mark.parametrize("name,nc", [("traj4_aromatic13", 13), ("traj4_full23", 23)])
