@@ -152,9 +152,15 @@ def main():
     n_dev = torch.cuda.device_count()
     if n_dev == 0:
         raise SystemExit("bench.py needs a HIP device (the sampling hot path has no CPU implementation)")
-    ddist.check_world_fits_devices(world, n_dev, args.oversubscribe)        # one rank per GPU unless asked otherwise
+    try:
+        ddist.check_world_fits_devices(world, n_dev, args.oversubscribe)    # one rank per GPU unless asked otherwise
+    except ValueError as e:
+        raise SystemExit(f"bench.py: {e}")
     dev_index = local_rank % n_dev
     torch.cuda.set_device(dev_index)
+    if world > 1 or ddist.force_group():
+        # this rank's host threads on the CPUs local to its GPU (ranks sharing a NUMA node take disjoint slices)
+        ddist.bind_rank_to_local_cpus(dev_index, local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     dev = torch.device("cuda", dev_index)
     backend = args.backend or "nccl"
     # RCCL on ROCm; no-op for one process.  An RCCL that cannot start is an error unless the fall-back is asked for.

@@ -13,7 +13,7 @@ namespace dd {
 
 // ---- workspace --------------------------------------------------------------------------------
 struct Workspace {
-  float *xa, *xb, *h, *hb, *ew, *P, *PL, *PB, *P2, *PL2, *PB2, *Ek, *Ev, *Rk, *Rv, *q1bl, *qn, *ql, *ql2, *qlnb, *qb, *A, *Anb, *dxe, *dxb, *ga, *gc;
+  float *xa, *xb, *h, *hb, *ew, *P, *PL, *PB, *P2, *PL2, *PB2, *Ek, *Ev, *Rk, *Rv, *q1bl, *qn, *ql, *ql2, *qlnb, *qb, *A, *Anb, *dxe, *dxb, *ga, *gc, *gr;
   int32_t* nbr;
   int32_t* counters;       // [64] work counters of the persistent attention workgroups (one per layer), zeroed per forward
   size_t total;
@@ -54,6 +54,7 @@ static Workspace carve(float* base, int B, int NP, int NL, int K) {
   w.dxb = take((size_t)B * NL * 3);
   w.ga = take((size_t)B * NL * 3);
   w.gc = take((size_t)B * NL * 3);
+  w.gr = take((size_t)B * NL * 3);
   w.counters = reinterpret_cast<int32_t*>(take(DD_NUM_COUNTERS + DD_NUM_FLAGS));   // (+ the layer-tail queue's flag words)
   w.total = off;
   return w;
@@ -838,6 +839,13 @@ static int heads_and_step(const dd_sampler* s, hipStream_t st, const StepFold* f
                                              w.gc, 0, s->nl_real, st));
     gc = w.gc;
   }
+  const float* gr = nullptr;
+  if (s->drift_repul) {
+    if (!s->decomp_index || (s->drift_repul != 1 && s->drift_repul != 2)) return DD_ERR_BAD_ARG;
+    DD_TRYP(DD_PROF_STEP, launch_drift_arms_repul(s->lig_pos, s->decomp_index, B, NL, s->repul_max_d, s->drift_repul, w.gr, 0,
+                                                  s->drift_norm_batch, st));
+    gr = w.gr;
+  }
   StepPosArgs p;
   memset(&p, 0, sizeof(p));
   p.B = B; p.NL = NL; p.T = s->T; p.step_counter = s->step_counter;
@@ -845,7 +853,7 @@ static int heads_and_step(const dd_sampler* s, hipStream_t st, const StepFold* f
   if (fold && fold->xprev) { p.x0_prev = fold->xprev; p.x0_dxe = w.dxe; p.x0_dxb = w.dxb; p.x0_out = s->pred_pos; }
   p.x0 = s->pred_pos; p.xt = s->lig_pos; p.tab_pos = s->tab_pos; p.tab_score = s->tab_score;
   p.atom_std = s->atom_std; p.offset = s->offset; p.grad_a = ga; p.scale_a = s->armsca_scale; p.grad_c = gc;
-  p.scale_c = s->clash_scale; p.eps = s->eps; p.traj_pos = s->traj_pos;
+  p.scale_c = s->clash_scale; p.grad_r = gr; p.scale_r = s->repul_scale; p.eps = s->eps; p.traj_pos = s->traj_pos;
   const bool advanced = fold && fold->advance;
   if (g_step_fused) {
     DD_TRYP(DD_PROF_STEP, launch_step_all(rb, r, p, st));
@@ -888,12 +896,18 @@ static int reverse_step_from_logits(const dd_sampler* s, const float* logits_v, 
                               s->nl_real, st));
     gc = w.gc;
   }
+  const float* gr = nullptr;
+  if (s->drift_repul) {
+    if (!s->decomp_index || (s->drift_repul != 1 && s->drift_repul != 2)) return DD_ERR_BAD_ARG;
+    DD_TRY(launch_drift_arms_repul(s->lig_pos, s->decomp_index, B, NL, s->repul_max_d, s->drift_repul, w.gr, 0, s->drift_norm_batch, st));
+    gr = w.gr;
+  }
   StepPosArgs p;
   memset(&p, 0, sizeof(p));
   p.B = B; p.NL = NL; p.T = s->T; p.step_counter = s->step_counter; p.NP = s->NP;
   p.x0 = x0; p.xt = s->lig_pos; p.tab_pos = s->tab_pos; p.tab_score = s->tab_score;
   p.atom_std = s->atom_std; p.offset = s->offset; p.grad_a = ga; p.scale_a = s->armsca_scale; p.grad_c = gc;
-  p.scale_c = s->clash_scale; p.eps = s->eps; p.traj_pos = s->traj_pos;
+  p.scale_c = s->clash_scale; p.grad_r = gr; p.scale_r = s->repul_scale; p.eps = s->eps; p.traj_pos = s->traj_pos;
   DD_TRY(launch_step_rows(r, st));
   DD_TRY(launch_step_rows(rb, st));
   DD_TRY(launch_step_pos(p, st));
@@ -935,7 +949,19 @@ extern "C" const char* dd_status_string(int status) {
 // 4: step_counter is the [4] int32 run state (steps done, t_start, seed lo, seed hi) written by dd_sampler_reset
 // 5: np_real / nl_real / bl_prefix (padded heterogeneous batches) appended to dd_sampler
 // 7: dd_queue_error; the workspace carries the layer-tail queue's flag words (dd_workspace_floats grew)
-extern "C" int dd_abi_version(void) { return 7; }
+// 8: arms_repul drift (dd_sampler.drift_repul / repul_max_d / repul_scale, dd_drift_arms_repul; the workspace grew by one
+//    gradient buffer); dd_build_flags
+extern "C" int dd_abi_version(void) { return 8; }
+extern "C" int dd_build_flags(void) {
+  int f = 0;
+#if defined(DD_DEBUG_OPTIONS) && DD_DEBUG_OPTIONS
+  f |= 1;
+#endif
+#if defined(DD_EXACT_MATH) && DD_EXACT_MATH
+  f |= 2;
+#endif
+  return f;
+}
 
 // 6: l0_tables / l0_P / l0_qn (layer-0 tables) appended to dd_sampler
 extern "C" int dd_layer0_tables(const dd_sampler* m, float* tables, void* stream) {

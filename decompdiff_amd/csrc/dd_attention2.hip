@@ -324,8 +324,14 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
   int* sb = reinterpret_cast<int*>(smem + L::TOTAL);
   int it = 0;
   float4 qn0 = make_float4(0.f, 0.f, 0.f, 0.f), qn1 = qn0;
+  // trip index -> first segment (compact index) and number of segments of the trip (see AttnArgs::trip_full)
+  auto trip_range = [&](int tr, int& base, int& cnt) {
+    if (tr < a.trip_full) { base = tr * NW; cnt = NW; }
+    else { base = a.trip_full * NW + (tr - a.trip_full) * a.trip_q; cnt = a.trip_q; }
+    cnt = nseg - base < cnt ? nseg - base : cnt;         // <= 0: no work left
+  };
   if (PERSIST) {
-    if (threadIdx.x == 0) { sb[0] = atomicAdd(a.work_counter, NW); sb[2] = 0; }
+    if (threadIdx.x == 0) { sb[0] = atomicAdd(a.work_counter, 1); sb[2] = 0; }
     stage_all();                                       // (ends with the barrier that also publishes sb[0])
   }
 
@@ -340,13 +346,14 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
     // workgroup-synchronous: NW consecutive segments per trip (letting every wave pull segments on its own was measured
     // 6 % slower: the waves drift out of phase and thrash the instruction cache)
     if (it > 0) __syncthreads();                       // one barrier per trip keeps the waves in phase
-    const int base = __builtin_amdgcn_readfirstlane(sb[it & 1]);
-    if (base >= nseg) break;
+    int base, cnt;
+    trip_range(__builtin_amdgcn_readfirstlane(sb[it & 1]), base, cnt);
+    if (cnt <= 0) break;
     if (threadIdx.x == 0) {
-      sb[(it + 1) & 1] = atomicAdd(a.work_counter, NW);
+      sb[(it + 1) & 1] = atomicAdd(a.work_counter, 1);
       __hip_atomic_store(&sb[2], it + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    seg = base + wave < nseg ? bl_dense_seg(base + wave) : a.B * Eb;
+    seg = wave < cnt ? bl_dense_seg(base + wave) : a.B * Eb;
   } else if (MODE == M_NE) {
     const int nd = wg_protein ? ne_rb * NW + wave : a.NP + (ne_rb - ne_nbp) * NW + wave;
     seg = (nd < (wg_protein ? a.NP : N) && ne_b < a.B) ? ne_b * N + nd : nseg;
@@ -838,9 +845,10 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
   DD_STAMP(9);
   if (PERSIST) {                                       // next trip's query
     while (__hip_atomic_load(&sb[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < it + 1) {}
-    const int r2 = sb[(it + 1) & 1] + wave;
-    if (r2 < nseg) {
-      const int nseg2 = bl_dense_seg(r2);
+    int base2, cnt2;
+    trip_range(sb[(it + 1) & 1], base2, cnt2);
+    if (wave < cnt2) {
+      const int nseg2 = bl_dense_seg(base2 + wave);
       qn0 = *reinterpret_cast<const float4*>(a.q + (long)nseg2 * 128 + mm * 8);
       qn1 = *reinterpret_cast<const float4*>(a.q + (long)nseg2 * 128 + mm * 8 + 4);
     }
@@ -982,6 +990,10 @@ static int launch_mode(const AttnArgs& a, int nseg, hipStream_t st) {
 
 int g_attn_waves = 8;        // waves (= segments) per workgroup of the fused node launch
 int g_attn_persist = 1;      // bond_layer workgroups of the fused launch are persistent (global batch counter)
+#ifndef DD_BL_TAIL
+#define DD_BL_TAIL 1
+#endif
+int g_bl_tail = DD_BL_TAIL;  // the last (partial) round of bond-layer trips spread evenly over the persistent workgroups
 int g_bl_first = 1;          // bond-layer workgroups first in the node launch: 0 off, 1 measured split per shape, n>1 that many
 int g_node_split_trial = -1; // >= 0 while autotune_node_split is timing a candidate (0 = node blocks first)
 namespace {
@@ -1026,6 +1038,15 @@ static int launch_node_nw(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs
   const int n_ne = ne.B * ne_blocks_per_sample(ne.NP, ne.NL, NW), n_nb = (ne.B * ne.NL + NW - 1) / NW;
   int n_bl = (ne.B * ne.NL * (ne.NL - 1) + NW - 1) / NW;
   const int persist = (g_attn_persist && bl.work_counter != nullptr) ? 1 : 0;
+  AttnArgs blt = bl;                                   // + the trip plan of the persistent workgroups (set_trips below)
+  blt.trip_full = 1 << 27; blt.trip_q = 0;
+  auto set_trips = [&](int n_wg) {
+    if (!g_bl_tail || ne.nl_real != nullptr || n_wg <= 0) return;      // (padded batches: the segment count lives on the device)
+    const int nseg = ne.B * ne.NL * (ne.NL - 1);
+    const int full = nseg / (NW * n_wg) * n_wg, rem = nseg - full * NW;
+    blt.trip_full = full;
+    blt.trip_q = (rem + n_wg - 1) / n_wg;              // 0 when the rounds come out even: trip `full` then finds no work
+  };
   if (persist) {
     static int n_cu = 0;
     if (n_cu == 0) {
@@ -1042,21 +1063,23 @@ static int launch_node_nw(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs
       int want = g_bl_first > 1 ? g_bl_first : (g_node_split_trial >= 0 ? g_node_split_trial : node_split_lookup(ne.B, ne.NP, ne.NL, ne.K));
       if (want > 0) {
         n_bl = want < 16 ? 16 : (want > n_cu - 16 ? n_cu - 16 : want);
+        set_trips(n_bl);
         if (ne.nl_real != nullptr)
-          hipLaunchKernelGGL((k_attn2_node<MAXT, NW, true>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, bl, n_ne, n_nb,
+          hipLaunchKernelGGL((k_attn2_node<MAXT, NW, true>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, blt, n_ne, n_nb,
                              persist, n_bl, ne.wait_flags, ne.wait_idx, ne.wait_n);
         else
-          hipLaunchKernelGGL((k_attn2_node<MAXT, NW>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, bl, n_ne, n_nb, persist,
+          hipLaunchKernelGGL((k_attn2_node<MAXT, NW>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, blt, n_ne, n_nb, persist,
                              n_bl, ne.wait_flags, ne.wait_idx, ne.wait_n);
         DD_CHECK_LAUNCH();
         return DD_OK;
       }
     }
   }
+  if (persist) set_trips(n_bl);
   if (ne.nl_real != nullptr)
-    hipLaunchKernelGGL((k_attn2_node<MAXT, NW, true>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, bl, n_ne, n_nb, persist, 0, ne.wait_flags, ne.wait_idx, ne.wait_n);
+    hipLaunchKernelGGL((k_attn2_node<MAXT, NW, true>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, blt, n_ne, n_nb, persist, 0, ne.wait_flags, ne.wait_idx, ne.wait_n);
   else
-    hipLaunchKernelGGL((k_attn2_node<MAXT, NW>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, bl, n_ne, n_nb, persist, 0, ne.wait_flags, ne.wait_idx, ne.wait_n);
+    hipLaunchKernelGGL((k_attn2_node<MAXT, NW>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, blt, n_ne, n_nb, persist, 0, ne.wait_flags, ne.wait_idx, ne.wait_n);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }

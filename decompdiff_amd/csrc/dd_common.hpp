@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "../../include/decompdiff_hip.h"
+#include "../../include/decompdiff_hip_debug.h"
 
 #define DD_H 128
 #define DD_NH 16

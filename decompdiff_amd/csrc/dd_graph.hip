@@ -225,9 +225,15 @@ __device__ __forceinline__ void embed_block(const unsigned blk, const float* __r
                                                    const float* __restrict__ Wb, const float* __restrict__ bb,
                                                    float* __restrict__ hb, int32_t* __restrict__ counters, int node_blocks,
                                                    int32_t* __restrict__ advance, int nv) {
-  // (+ the layer-tail queue's flag words; the error word behind them is sticky: dd_queue_error reads and clears it)
+  // (measurement build: + the tile-queue schedule's flag words; the error word behind them is sticky: dd_queue_error reads
+  // and clears it.  The default library has no such schedule and zeroes the work counters only.)
+#if defined(DD_DEBUG_OPTIONS) && DD_DEBUG_OPTIONS
+  constexpr int n_zero = DD_NUM_COUNTERS + DD_FLAG_ERR;
+#else
+  constexpr int n_zero = DD_NUM_COUNTERS;
+#endif
   if (blk == 0 && counters)
-    for (int i = threadIdx.x; i < DD_NUM_COUNTERS + DD_FLAG_ERR; i += 256) counters[i] = 0;
+    for (int i = threadIdx.x; i < n_zero; i += 256) counters[i] = 0;
   // the step index moves on with the first launch of a step's forward (nothing before the step kernels reads it): the
   // step kernels use *advance - 1, and no one-thread launch sits at the end of a step
   if (blk == 0 && threadIdx.x == 64 && advance) *advance += 1;

@@ -67,6 +67,8 @@ int launch_embed_all(const float* protein_h, const float* protein_pos, const flo
                      hipStream_t st, int32_t* advance = nullptr, int nv = DD_NUM_V);
 int launch_drift_armsca(const float* lig_pos, const int32_t* decomp_index, int B, int NL, float min_d, float max_d,
                         float* grad, int accumulate, int norm_B, hipStream_t st);
+int launch_drift_arms_repul(const float* lig_pos, const int32_t* decomp_index, int B, int NL, float max_d, int mode, float* grad,
+                            int accumulate, int norm_B, hipStream_t st);
 // (NP, np_real, nl_real: padded heterogeneous batches -- padding atoms are neither centres nor candidates)
 int launch_drift_clash(const float* lig_pos, const float* offset, const float* full_protein_pos, int B, int NL, int NF,
                        float sigma, float gamma, float* grad, int accumulate, const int32_t* nl_real, hipStream_t st);
@@ -122,6 +124,11 @@ struct AttnArgs {
   // inputs produced by the layer-tail queue running on the other stream (dd_gemm.hip::k_gemm_tail): the launch starts
   // without a graph edge and polls flags[wait_idx] >= wait_n before its first read of them (NULL: ordinary stream order)
   const int32_t* wait_flags; int wait_idx, wait_n;
+  // persistent bond-layer workgroups: work_counter hands out TRIPS.  Trips t < trip_full cover NW consecutive segments each
+  // (whole rounds of all persistent workgroups); the remainder -- less than one round -- is spread evenly: trip t >= trip_full
+  // covers trip_q (< NW) segments, so that the last round runs one wave per SIMD on every CU instead of full trips on some CUs
+  // beside idle ones.  Set by launch_attn2_node (trip_q = 0 and trip_full = 1 << 27: plain NW-segment trips).
+  int trip_full, trip_q;
 };
 
 int launch_attn2(int mode, const AttnArgs& a, hipStream_t st);   // one sub-layer: 16-member tiles, scores/aggregation on MFMA
@@ -162,6 +169,7 @@ struct StepPosArgs {
   const float* offset;      // [B,3]
   const float* grad_a; int scale_a;   // armsca gradient (may be NULL)
   const float* grad_c; int scale_c;   // clash gradient (may be NULL)
+  const float* grad_r; int scale_r;   // arms_repul gradient (may be NULL); the three are added in this order
   const float* eps;         // [n_steps,B*NL,3] or NULL
   float* traj_pos;          // [n_steps,B*NL,3] or NULL
 };

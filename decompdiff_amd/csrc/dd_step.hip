@@ -155,6 +155,7 @@ __global__ void k_step_pos(const StepPosArgs a) {
   float g = 0.f;
   if (a.grad_a) g += a.scale_a ? a.grad_a[idx] * a.tab_score[t] : a.grad_a[idx];
   if (a.grad_c) g += a.scale_c ? a.grad_c[idx] * a.tab_score[t] : a.grad_c[idx];
+  if (a.grad_r) g += a.scale_r ? a.grad_r[idx] * a.tab_score[t] : a.grad_r[idx];
   mean -= g;
   float e;
   if (a.eps) {
@@ -240,6 +241,101 @@ __global__ __launch_bounds__(64) void k_drift_armsca(const float* __restrict__ p
           gx[ba] = __fadd_rn(gx[ba], tx); gy[ba] = __fadd_rn(gy[ba], ty); gz[ba] = __fadd_rn(gz[ba], tz);
           gx[bs] = __fadd_rn(gx[bs], ux); gy[bs] = __fadd_rn(gy[bs], uy); gz[bs] = __fadd_rn(gz[bs], uz);
         }
+      }
+    }
+  }
+  __syncthreads();
+  if (l < NL) {
+    float* g = grad + ((long)b * NL + l) * 3;
+    if (accumulate) { g[0] += gx[l]; g[1] += gy[l]; g[2] += gz[l]; }
+    else { g[0] = gx[l]; g[1] = gy[l]; g[2] = gz[l]; }
+  }
+}
+
+// ------------------------------------------------------------------------------ drift: arms_repul
+// compute_batch_arms_repul_loss (guidance_funcs.py:81-118), analytic gradient.  Per sample, for every arm pair a1 <= a2 (the
+// reference's loop INCLUDES a1 == a2) with atoms on both sides, d_pq = |x_p - x_q| over p in a1, q in a2:
+//   mode 1 'min': relu(max_d - min_pq d_pq)          -> d/dx_p = -(x_p - x_q)/d at the arg-min pair (first minimum in (p, q)
+//                 order; torch splits the gradient evenly over exact ties), nothing for a1 == a2 (the minimum is a zero on
+//                 the diagonal and torch's norm has a zero subgradient there);
+//   mode 2 'all': mean_pq relu(max_d - d_pq)         -> d/dx_p = -(x_p - x_q) / (d n1 n2) for every pair inside max_d; the
+//                 pairs of one arm appear as (p, q) and (q, p): twice the weight, and the diagonal (d = 0) gives nothing.
+// The sum over pairs and samples is divided by the batch size.  The clamp passes its gradient where max_d - d >= 0
+// (torch.clamp backward is inclusive).  One workgroup per sample, one thread per ligand atom.
+__global__ __launch_bounds__(DD_NL_MAX) void k_drift_arms_repul(const float* __restrict__ pos, const int32_t* __restrict__ decomp, int B,
+                                                                int NL, float max_d, int mode, float* __restrict__ grad,
+                                                                int accumulate, int norm_B) {
+  __shared__ float px[DD_NL_MAX], py[DD_NL_MAX], pz[DD_NL_MAX];
+  __shared__ int arm[DD_NL_MAX];
+  __shared__ unsigned long long best[DD_NL_MAX];           // mode 1: per atom p of a1 the key (bits(d), q) of its nearest atom of a2
+  __shared__ float gx[DD_NL_MAX], gy[DD_NL_MAX], gz[DD_NL_MAX];
+  const int b = blockIdx.x, l = threadIdx.x;
+  int my_arm = -2;
+  if (l < NL) {
+    px[l] = pos[((long)b * NL + l) * 3]; py[l] = pos[((long)b * NL + l) * 3 + 1]; pz[l] = pos[((long)b * NL + l) * 3 + 2];
+    my_arm = decomp[(long)b * NL + l];
+    arm[l] = my_arm;
+    gx[l] = 0.f; gy[l] = 0.f; gz[l] = 0.f;
+  }
+  __syncthreads();
+  int n_arms = 0;                                          // mask.max() + 1 (guidance_funcs.py:99)
+  for (int i = 0; i < NL; ++i) n_arms = arm[i] + 1 > n_arms ? arm[i] + 1 : n_arms;
+  const float inv_B = 1.0f / (float)norm_B;
+  if (mode == 2) {
+    // every atom gathers its own gradient: sum over the atoms q of every arm (its own included), ascending q
+    if (l < NL && my_arm >= 0) {
+      int n_mine = 0;
+      for (int i = 0; i < NL; ++i) n_mine += arm[i] == my_arm;
+      float ax = 0.f, ay = 0.f, az = 0.f;
+      for (int a2 = 0; a2 < n_arms; ++a2) {
+        int n2 = 0;
+        for (int i = 0; i < NL; ++i) n2 += arm[i] == a2;
+        if (n2 == 0) continue;
+        const float w = (a2 == my_arm ? 2.0f : 1.0f) / ((float)n_mine * (float)n2) * inv_B;
+        for (int q = 0; q < NL; ++q) {
+          if (arm[q] != a2 || q == l) continue;
+          const float dx = px[l] - px[q], dy = py[l] - py[q], dz = pz[l] - pz[q];
+          const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+          if (max_d - d >= 0.f && d > 0.f) {
+            const float c = -w / d;
+            ax = fmaf(c, dx, ax); ay = fmaf(c, dy, ay); az = fmaf(c, dz, az);
+          }
+        }
+      }
+      gx[l] = ax; gy[l] = ay; gz[l] = az;
+    }
+  } else {
+    for (int a1 = 0; a1 < n_arms; ++a1) {
+      for (int a2 = a1 + 1; a2 < n_arms; ++a2) {           // (a1 == a2: zero gradient, see above)
+        unsigned long long key = ~0ull;
+        if (l < NL && my_arm == a1) {
+          for (int q = 0; q < NL; ++q) {
+            if (arm[q] != a2) continue;
+            const float dx = px[l] - px[q], dy = py[l] - py[q], dz = pz[l] - pz[q];
+            const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+            const unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)q;   // d >= 0: bit order = float order
+            key = k < key ? k : key;
+          }
+        }
+        if (l < NL) best[l] = key;
+        __syncthreads();
+        if (l == 0) {
+          unsigned long long bk = ~0ull;
+          int bp = -1;
+          for (int p = 0; p < NL; ++p)
+            if (best[p] < bk) { bk = best[p]; bp = p; }     // strict <: the first p at the smallest distance
+          if (bp >= 0 && (unsigned)(bk >> 32) != 0xffffffffu) {
+            const float d = __uint_as_float((unsigned)(bk >> 32));
+            const int q = (int)(unsigned)(bk & 0xffffffffull);
+            if (max_d - d >= 0.f && d > 0.f) {
+              const float c = -inv_B / d;
+              const float dx = px[bp] - px[q], dy = py[bp] - py[q], dz = pz[bp] - pz[q];
+              gx[bp] = fmaf(c, dx, gx[bp]); gy[bp] = fmaf(c, dy, gy[bp]); gz[bp] = fmaf(c, dz, gz[bp]);
+              gx[q] = fmaf(-c, dx, gx[q]); gy[q] = fmaf(-c, dy, gy[q]); gz[q] = fmaf(-c, dz, gz[q]);
+            }
+          }
+        }
+        __syncthreads();
       }
     }
   }
@@ -382,6 +478,7 @@ __device__ __forceinline__ void step_pos_elem(const StepPosArgs& a, const int id
   float g = 0.f;
   if (a.grad_a) g += a.scale_a ? a.grad_a[idx] * a.tab_score[t] : a.grad_a[idx];
   if (a.grad_c) g += a.scale_c ? a.grad_c[idx] * a.tab_score[t] : a.grad_c[idx];
+  if (a.grad_r) g += a.scale_r ? a.grad_r[idx] * a.tab_score[t] : a.grad_r[idx];
   mean -= g;
   float e;
   if (a.eps) {
@@ -475,6 +572,23 @@ extern "C" int dd_drift_armsca(const float* lig_pos, const int32_t* decomp_index
   if (!lig_pos || !decomp_index || !grad || B <= 0 || NL <= 0) return DD_ERR_BAD_ARG;
   if (NL > DD_NL_MAX) return DD_ERR_UNSUPPORTED_SHAPE;
   return dd::launch_drift_armsca(lig_pos, decomp_index, B, NL, min_d, max_d, grad, accumulate, B, (hipStream_t)stream);
+}
+
+namespace dd {
+int launch_drift_arms_repul(const float* lig_pos, const int32_t* decomp_index, int B, int NL, float max_d, int mode, float* grad,
+                            int accumulate, int norm_B, hipStream_t st) {
+  hipLaunchKernelGGL(k_drift_arms_repul, dim3(B), dim3(DD_NL_MAX), 0, st, lig_pos, decomp_index, B, NL, max_d, mode, grad, accumulate,
+                     norm_B > 0 ? norm_B : B);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+}  // namespace dd
+
+extern "C" int dd_drift_arms_repul(const float* lig_pos, const int32_t* decomp_index, int B, int NL, float max_d, int mode,
+                                   float* grad, int accumulate, void* stream) {
+  if (!lig_pos || !decomp_index || !grad || B <= 0 || NL <= 0 || (mode != 1 && mode != 2)) return DD_ERR_BAD_ARG;
+  if (NL > DD_NL_MAX) return DD_ERR_UNSUPPORTED_SHAPE;
+  return dd::launch_drift_arms_repul(lig_pos, decomp_index, B, NL, max_d, mode, grad, accumulate, B, (hipStream_t)stream);
 }
 
 namespace dd {

@@ -29,11 +29,19 @@ class ControlPlaneError(RuntimeError):
     """RCCL could not start and the gloo fall-back was not asked for."""
 
 
-_CTL: Dict[str, Any] = {"group": None, "backend": None, "note": None}      # the group the barriers / reductions use
+_CTL: Dict[str, Any] = {"group": None, "backend": None, "note": None, "forced": False, "affinity": None}   # the group the barriers / reductions use
+PROBE_TIMEOUT_S = 90          # RCCL bring-up probe (new_group + one barrier): a rank that fails must not hold the others for long
+
+
+def force_group() -> bool:
+    """DD_DIST_FORCE_GROUP=1: build the process groups even for ONE rank, so that the RCCL branch (new_group("nccl"),
+    barrier, all_reduce(MAX)) can be exercised on a single-GPU box (tests/test_gpu_configs.py)."""
+    return os.environ.get("DD_DIST_FORCE_GROUP") == "1"
 
 
 def init_from_env(backend: str = None, device_index: int = None, allow_fallback: Optional[bool] = None) -> bool:
-    """Initialise the control plane from torchrun's environment.  Returns True if world_size > 1.
+    """Initialise the control plane from torchrun's environment.  Returns True if a process group is in use
+    (world_size > 1, or one rank with DD_DIST_FORCE_GROUP=1).
 
     The default process group is ALWAYS gloo (host sockets: it starts wherever torchrun does).  With backend "nccl"
     (= RCCL; the default on a GPU box) a second group over RCCL is created on top and probed with one barrier; every
@@ -42,9 +50,12 @@ def init_from_env(backend: str = None, device_index: int = None, allow_fallback:
       * allow_fallback False (default; env DD_DIST_ALLOW_FALLBACK=1 turns it on): ControlPlaneError on every rank --
         a `--gpus N` run whose RCCL does not start is an error, not a silent backend swap;
       * allow_fallback True: the job runs its control messages over gloo (it exchanges no data) and
-        control_backend() / control_note() say so."""
+        control_backend() / control_note() say so.
+    A host that has ALREADY initialised torch.distributed (a torchrun application that embeds the sampler) keeps its
+    default group: the control plane then runs on it, with device tensors if it is an RCCL group."""
     world, rank, local_rank = env_world()
-    if world <= 1:
+    forced = force_group()
+    if world <= 1 and not forced and not (dist.is_available() and dist.is_initialized()):
         return False
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
@@ -54,9 +65,13 @@ def init_from_env(backend: str = None, device_index: int = None, allow_fallback:
     if allow_fallback is None:
         allow_fallback = os.environ.get("DD_DIST_ALLOW_FALLBACK") == "1"
     if dist.is_initialized():
-        return True
+        # the host's own default group: use it as it is (an RCCL default group takes device tensors, a gloo one host tensors)
+        host_backend = str(dist.get_backend()).lower()
+        _CTL.update(group=None, backend="nccl" if "nccl" in host_backend else "gloo", forced=forced,
+                    note="process group initialised by the host application")
+        return dist.get_world_size() > 1 or forced
     dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
-    _CTL.update(group=None, backend="gloo", note=None)
+    _CTL.update(group=None, backend="gloo", note=None, forced=forced)
     if backend != "nccl":
         return True
     dev = local_rank if device_index is None else device_index
@@ -71,7 +86,7 @@ def init_from_env(backend: str = None, device_index: int = None, allow_fallback:
     except Exception as e:                                           # noqa: BLE001
         ok, err = 0, f"{type(e).__name__}: {str(e)[:200]}"
     try:
-        group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=300))      # (every rank must call this)
+        group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=PROBE_TIMEOUT_S))   # (every rank must call this)
     except Exception as e:                                           # noqa: BLE001 -- whatever RCCL raises
         ok, err = 0, err or f"{type(e).__name__}: {str(e)[:200]}"
     started = all_ok(ok)
@@ -82,8 +97,7 @@ def init_from_env(backend: str = None, device_index: int = None, allow_fallback:
         except Exception as e:                                       # noqa: BLE001
             ok, err = 0, f"{type(e).__name__}: {str(e)[:200]}"
         started = all_ok(ok)
-    flag = torch.tensor([1 if started else 0])
-    if int(flag.item()) == 1:
+    if started:
         _CTL.update(group=group, backend="nccl", note=None)
         return True
     msg = f"RCCL start-up failed on rank {rank}: {err}" if not ok else "RCCL start-up failed on another rank"
@@ -126,11 +140,108 @@ def device_identity(device=None) -> Dict[str, Any]:
 
 
 def check_world_fits_devices(world: int, n_devices: int, oversubscribe: bool = False) -> None:
-    """One rank per GPU: more ranks than visible devices is refused unless the caller explicitly shares GPUs (tests)."""
+    """One rank per GPU: more ranks than visible devices is refused unless the caller explicitly shares GPUs (tests).
+    Raises ValueError (bench.py turns it into its exit message)."""
     if world > n_devices and not oversubscribe:
-        raise SystemExit(f"bench.py: {world} ranks but only {n_devices} visible HIP device(s): refusing to put several ranks on "
+        raise ValueError(f"{world} ranks but only {n_devices} visible HIP device(s): refusing to put several ranks on "
                          "one GPU and report them as GPUs (pass --oversubscribe to share devices on purpose; the JSON line then "
                          "reports n_gpus = distinct devices)")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU affinity: one process per GPU wants its host threads (the launching thread, the HIP runtime's helper threads, the
+# pinned-memory trajectory drain) on the CPUs of the NUMA node its GPU hangs off.  The PCI function of the HIP device
+# names its sysfs node, whose `local_cpulist` is that set; ranks whose GPUs share a node take disjoint slices of it.
+# ------------------------------------------------------------------------------------------------------------------
+def parse_cpulist(text: str) -> List[int]:
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the kernel's cpulist format)."""
+    out: List[int] = []
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        if "-" in part:
+            lo, hi = part.split("-", 1)
+            out.extend(range(int(lo), int(hi) + 1))
+        else:
+            out.append(int(part))
+    return sorted(set(out))
+
+
+def device_local_cpus(device_index: int, sysfs_root: str = "/sys/bus/pci/devices") -> Optional[List[int]]:
+    """CPUs local to HIP device `device_index` (its PCI function's local_cpulist), None if it cannot be read."""
+    try:
+        prop = torch.cuda.get_device_properties(device_index)
+        dom, bus, devn = int(getattr(prop, "pci_domain_id", 0)), int(prop.pci_bus_id), int(prop.pci_device_id)
+        for fn in range(8):
+            path = os.path.join(sysfs_root, f"{dom:04x}:{bus:02x}:{devn:02x}.{fn}", "local_cpulist")
+            if os.path.exists(path):
+                with open(path) as fh:
+                    cpus = parse_cpulist(fh.read())
+                return cpus or None
+    except Exception:                                                # noqa: BLE001 -- affinity is an optimisation only
+        return None
+    return None
+
+
+def slice_cpus(cpus: List[int], share: int, n_shares: int, allowed: Optional[List[int]] = None) -> List[int]:
+    """The `share`-th of `n_shares` contiguous slices of `cpus` (restricted to `allowed`); never empty if cpus is not."""
+    pool = [c for c in cpus if allowed is None or c in set(allowed)]
+    if not pool:
+        return []
+    n_shares = max(1, n_shares)
+    per = max(1, len(pool) // n_shares)
+    lo = min(share, n_shares - 1) * per
+    hi = len(pool) if share >= n_shares - 1 else lo + per
+    return pool[lo:hi] if lo < len(pool) else pool[-per:]
+
+
+def bind_rank_to_local_cpus(device_index: int, local_rank: int = 0, local_world: int = 1,
+                            local_cpus_of: Optional[Callable[[int], Optional[List[int]]]] = None) -> Dict[str, Any]:
+    """Pin this process to its share of the CPUs local to its GPU.  Ranks of this node whose devices report the SAME local
+    set (one socket / NUMA node) split it evenly in device order; DD_DIST_NO_AFFINITY=1 turns the binding off.  Returns a
+    record for bench.py's per_rank entry: {"bound": bool, "cpus": "lo-hi,..", "n_cpus": n, "numa_cpus": m, "why": ...}."""
+    rec = _bind(device_index, local_rank, local_world, local_cpus_of)
+    _CTL["affinity"] = rec
+    return rec
+
+
+def _bind(device_index, local_rank, local_world, local_cpus_of) -> Dict[str, Any]:
+    if os.environ.get("DD_DIST_NO_AFFINITY") == "1":
+        return {"bound": False, "why": "DD_DIST_NO_AFFINITY=1"}
+    if not hasattr(os, "sched_setaffinity"):
+        return {"bound": False, "why": "no sched_setaffinity on this platform"}
+    look = local_cpus_of or device_local_cpus
+    mine = look(device_index)
+    if not mine:
+        return {"bound": False, "why": "local_cpulist of the device is not readable"}
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        n_dev = torch.cuda.device_count() if torch.cuda.is_available() else max(local_world, device_index + 1)
+        # ranks run on devices (local_rank % n_dev); those whose device shares my CPU set, in rank order
+        peers = [r for r in range(max(1, local_world)) if (look(r % max(1, n_dev)) or []) == mine]
+        share = peers.index(local_rank) if local_rank in peers else 0
+        cpus = slice_cpus(mine, share, len(peers) or 1, allowed)
+        if not cpus:
+            return {"bound": False, "why": "no allowed CPU in the device's local set", "numa_cpus": len(mine)}
+        os.sched_setaffinity(0, cpus)
+        return {"bound": True, "cpus": format_cpulist(cpus), "n_cpus": len(cpus), "numa_cpus": len(mine),
+                "share": f"{share + 1}/{len(peers) or 1}"}
+    except Exception as e:                                           # noqa: BLE001
+        return {"bound": False, "why": f"{type(e).__name__}: {str(e)[:120]}"}
+
+
+def format_cpulist(cpus: List[int]) -> str:
+    """[0, 1, 2, 3, 8] -> '0-3,8'."""
+    out, i = [], 0
+    cpus = sorted(cpus)
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else f"{cpus[i]}-{cpus[j]}")
+        i = j + 1
+    return ",".join(out)
 
 
 def shard_units(n_units: int, rank: int, world: int) -> List[int]:
@@ -145,14 +256,18 @@ def shard_samples(n_samples: int, rank: int, world: int) -> range:
     return range(start, start + base + (1 if rank < rem else 0))
 
 
+def _in_group() -> bool:
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _CTL["forced"])
+
+
 def barrier(device=None):
     if device is not None and torch.cuda.is_available():
         torch.cuda.synchronize(device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:      # (one rank: nothing to wait for)
+    if _in_group():                                                   # (one unforced rank: nothing to wait for)
         if _CTL["backend"] == "nccl":
             dist.barrier(group=_CTL["group"], device_ids=[torch.cuda.current_device()])
         else:
-            dist.barrier()
+            dist.barrier(group=_CTL["group"])
     if device is not None and torch.cuda.is_available():
         torch.cuda.synchronize(device)
 
@@ -160,9 +275,11 @@ def barrier(device=None):
 def max_over_ranks(value: float, device=None) -> float:
     if not (dist.is_available() and dist.is_initialized()):
         return float(value)
-    on_dev = device is not None and _CTL["backend"] == "nccl"             # (gloo control plane: host tensor)
+    on_dev = _CTL["backend"] == "nccl"                                # RCCL group: device tensor; gloo: host tensor
+    if on_dev and device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
     t = torch.tensor([value], dtype=torch.float64, device=device if on_dev else "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_CTL["group"] if on_dev else None)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_CTL["group"])
     return float(t.item())
 
 
@@ -305,13 +422,15 @@ def run_job(units: List[Unit], config: int, rank: int, world: int, prepare: Call
     for r in records:
         r.pop("_out", None)
     gathered = gather_metadata({"rank": rank, "seconds": round(local, 6), "busy_seconds": round(busy, 6), "units": records,
-                                "device": device_identity(device), "cost": round(sum(unit_cost(u) for u in mine), 1)})
+                                "device": device_identity(device), "cost": round(sum(unit_cost(u) for u in mine), 1),
+                                "affinity": _CTL["affinity"]})
     per_unit = sorted((r for g in gathered for r in g["units"]), key=lambda r: r["unit"])
     busy_all = [g["busy_seconds"] for g in gathered]
     devices = [g["device"]["uuid"] for g in gathered]
     return {"elapsed": elapsed, "unit_steps": len(units) * steps,
             "per_rank": [{"rank": g["rank"], "seconds": g["seconds"], "busy_seconds": g["busy_seconds"], "planned_cost": g["cost"],
-                          "units": [r["unit"] for r in g["units"]], "device": g["device"]} for g in gathered],
+                          "units": [r["unit"] for r in g["units"]], "device": g["device"], "cpu_affinity": g.get("affinity")}
+                         for g in gathered],
             "imbalance": round(max(busy_all) / (sum(busy_all) / len(busy_all)), 4) if min(busy_all) > 0 else None,
             "devices": devices, "distinct_devices": len(set(devices)),
             "per_unit": per_unit, "last_out": last, "n_local_units": len(mine)}

@@ -17,16 +17,22 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DD_HIP_LIB selects another build of the same ABI (used by tools/ab_builds.py to compare two builds on one box)
 LIB_PATH = os.environ.get("DD_HIP_LIB") or os.path.join(_HERE, "lib", "libdecompdiff_hip.so")
 
+# the drop-in boundary: include/decompdiff_hip.h
 EXPORTED_SYMBOLS = [
-    "dd_status_string", "dd_abi_version", "dd_workspace_floats", "dd_knn", "dd_edge_weights", "dd_gemm128",
+    "dd_status_string", "dd_abi_version", "dd_build_flags", "dd_workspace_floats", "dd_knn", "dd_edge_weights", "dd_gemm128",
     "dd_embed_protein", "dd_forward", "dd_sample_steps", "dd_sample_steps_graph", "dd_sample_steps_graph_multi",
     "dd_graph_create", "dd_graph_launch", "dd_graph_destroy",
-    "dd_drift_armsca",
-    "dd_drift_clash", "dd_workspace_view", "dd_profile_step", "dd_debug_set_clock_buffer", "dd_debug_set_fusion", "dd_debug_set_option", "dd_debug_node_split",
-    "dd_attn_aggregate_node", "dd_attn_aggregate_triplet", "dd_attn_aggregate_pos", "dd_reverse_step", "dd_debug_philox",
-    "dd_segment_reduce", "dd_segment_softmax", "dd_sampler_reset", "dd_debug_options_epoch",
-    "dd_layer0_tables", "dd_layer0_prepare", "dd_queue_error",
+    "dd_drift_armsca", "dd_drift_clash", "dd_drift_arms_repul",
+    "dd_attn_aggregate_node", "dd_attn_aggregate_triplet", "dd_attn_aggregate_pos", "dd_reverse_step",
+    "dd_segment_reduce", "dd_segment_softmax", "dd_sampler_reset",
+    "dd_layer0_tables", "dd_layer0_prepare",
 ]
+# measurement / profiling / test access: include/decompdiff_hip_debug.h (same library, not part of the boundary)
+DEBUG_SYMBOLS = [
+    "dd_workspace_view", "dd_profile_step", "dd_debug_set_clock_buffer", "dd_debug_set_fusion", "dd_debug_set_option",
+    "dd_debug_node_split", "dd_debug_philox", "dd_debug_options_epoch", "dd_queue_error",
+]
+BUILD_DEBUG_OPTIONS, BUILD_EXACT_MATH = 1, 2          # bits of dd_build_flags()
 
 
 class DDSampler(ctypes.Structure):
@@ -49,7 +55,7 @@ class DDSampler(ctypes.Structure):
         ("workspace", c_void_p), ("workspace_floats", c_size_t),
         ("np_real", c_void_p), ("nl_real", c_void_p), ("bl_prefix", c_void_p),
         ("l0_tables", c_void_p), ("l0_P", c_void_p), ("l0_qn", c_void_p),
-        ("num_v", c_int32), ("reserved0", c_int32),
+        ("num_v", c_int32), ("drift_repul", c_int32), ("repul_max_d", c_float), ("repul_scale", c_int32),
     ]
 
 
@@ -64,7 +70,7 @@ class DDWsView(ctypes.Structure):
 PROF_CATS = ["misc", "gemm", "assemble", "attn_NE", "attn_NB", "attn_BL", "attn_PE", "attn_PB", "step", "event_pair"]
 
 
-ABI_VERSION = 7          # include/decompdiff_hip.h: layout of struct dd_sampler and of the tables it points to
+ABI_VERSION = 8          # include/decompdiff_hip.h: layout of struct dd_sampler and of the tables it points to
 
 
 class HipLibraryError(RuntimeError):
@@ -92,6 +98,8 @@ def load():
     lib.dd_abi_version.restype = c_int
     if lib.dd_abi_version() != ABI_VERSION and os.environ.get("DD_IGNORE_ABI") != "1":     # (A/B timing of older builds)
         raise HipLibraryError(f"{LIB_PATH} has ABI version {lib.dd_abi_version()}, this package needs {ABI_VERSION}: rebuild it")
+    lib.dd_build_flags.restype = c_int
+    lib.dd_build_flags.argtypes = []
     lib.dd_workspace_floats.restype = c_size_t
     lib.dd_workspace_floats.argtypes = [c_int, c_int, c_int, c_int]
     lib.dd_knn.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
@@ -114,6 +122,7 @@ def load():
     lib.dd_drift_armsca.argtypes = [c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_int, c_void_p]
     lib.dd_drift_clash.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p,
                                    c_int, c_void_p]
+    lib.dd_drift_arms_repul.argtypes = [c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_int, c_void_p]
     lib.dd_workspace_view.argtypes = [POINTER(DDSampler), POINTER(DDWsView)]
     lib.dd_debug_set_clock_buffer.argtypes = [c_void_p, c_int]
     lib.dd_debug_set_fusion.argtypes = [c_int]
@@ -127,7 +136,7 @@ def load():
     lib.dd_segment_softmax.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
     lib.dd_debug_philox.argtypes = [c_uint64, c_int, c_long, c_int, c_void_p, c_void_p]
     lib.dd_profile_step.argtypes = [POINTER(DDSampler), c_int, POINTER(c_float), c_void_p]
-    for name in EXPORTED_SYMBOLS:
+    for name in EXPORTED_SYMBOLS + DEBUG_SYMBOLS:
         if name not in ("dd_status_string", "dd_workspace_floats"):
             getattr(lib, name).restype = c_int
     _lib = lib
@@ -156,3 +165,9 @@ def require_gpu(t: torch.Tensor, name: str):
     if not t.is_cuda:
         raise HipLibraryError(f"{name} must live on a HIP device (got {t.device}); the sampling hot path has no "
                               "CPU implementation in this package")
+
+
+def is_measurement_build() -> bool:
+    """The loaded library was compiled with -DDD_DEBUG_OPTIONS=1 (lib/libdecompdiff_hip_dbg.so: alternative launch
+    schedules behind dd_debug_set_option)."""
+    return bool(load().dd_build_flags() & BUILD_DEBUG_OPTIONS)

@@ -48,13 +48,18 @@ GAUSS_OFFSETS = [0, 1, 1.25, 1.5, 1.75, 2, 2.25, 2.5, 2.75, 3, 3.5, 4, 4.5, 5, 5
 
 
 def _check_queue(sampler, dev):
-    """The default launch schedule hands data from the layer-tail GEMM queue to the attention launches through device
-    counters with bounded polls.  A poll that gave up means the results are invalid: raise."""
+    """Measurement build only.  Its tile-queue schedule (dd_debug_set_option(8, 5); EXPERIMENTS.md R3-1) hands data from the
+    layer-tail GEMM queue to the attention launches through device counters with bounded polls; a poll that gave up means
+    the results are invalid: raise.  The default library's schedule uses graph edges only and never polls, so for it this
+    is a no-op (no device -> host copy, no stream synchronisation)."""
+    if not hip_lib.is_measurement_build():
+        return
     code = ctypes.c_int(0)
     hip_lib.check(hip_lib.load().dd_queue_error(ctypes.byref(sampler), hip_lib.stream_ptr(dev), ctypes.byref(code)), "dd_queue_error")
     if code.value != 0:
-        raise RuntimeError(f"decompdiff_hip: an in-launch hand-off of the layer-tail queue timed out (waiter {code.value}); the "
-                           "results are invalid (dd_debug_set_option(8, 4) selects the graph-edge schedule)")
+        raise RuntimeError(f"decompdiff_hip (measurement build): an in-launch hand-off of the tile-queue schedule timed out "
+                           f"(waiter {code.value}); the results are invalid (dd_debug_set_option(8, 4) selects the shipped "
+                           "graph-edge schedule)")
 
 
 def log_sample_categorical(logits: torch.Tensor) -> torch.Tensor:
@@ -728,13 +733,29 @@ class DecompScorePosNet3D(nn.Module):
                 assert t.is_contiguous() and t.device == dev, k
             setattr(sm, k, t.data_ptr() if t is not None else None)
         sm.drift_armsca = sm.drift_clash = sm.armsca_scale = sm.clash_scale = 0
+        sm.drift_repul, sm.repul_max_d, sm.repul_scale = 0, 0.0, 0
+        seen = []
         for dr in drift or []:
+            if dr["type"] in seen:                         # one buffer per term: a repeated entry would silently replace the first
+                raise NotImplementedError(f"energy_drift_opt lists '{dr['type']}' twice")
+            seen.append(dr["type"])
             if dr["type"] == "armsca_prox":
                 sm.drift_armsca, sm.armsca_min_d, sm.armsca_max_d = 1, float(dr["min_d"]), float(dr["max_d"])
                 sm.armsca_scale = int(bool(dr.get("scale", False)))
             elif dr["type"] == "clash":
                 sm.drift_clash, sm.clash_sigma, sm.clash_gamma = 1, float(dr["sigma"]), float(dr["gamma"])
                 sm.clash_scale = int(bool(dr.get("scale", False)))
+            elif dr["type"] == "arms_repul":
+                # EXTENSION: the reference defines the energy (utils/guidance_funcs.py:81-118) but its
+                # sample_diffusion has no branch for it (decompdiff.py:643-675 raises ValueError); wired like armsca_prox
+                # (:648-659): gradient at x_t, optional `scale`.  Defaults = the function's own (max_d 1.9, mode 'min').
+                mode = dr.get("mode", "min")
+                if mode not in ("min", "all"):
+                    raise ValueError(mode)                 # (guidance_funcs.py:90)
+                if decomp_index is None:
+                    raise ValueError("arms_repul drift needs ligand_decomp_index")
+                sm.drift_repul, sm.repul_max_d = (1 if mode == "min" else 2), float(dr.get("max_d", 1.9))
+                sm.repul_scale = int(bool(dr.get("scale", False)))
             elif dr["type"] in ("center_prox", "mmff_min"):
                 raise NotImplementedError(f"drift '{dr['type']}' is outside the shipped sampling path "
                                           "(center_prox raises in the reference; mmff_min is RDKit/CPU)")
@@ -747,7 +768,8 @@ class DecompScorePosNet3D(nn.Module):
             hip_lib.check(lib.dd_sampler_reset(ctypes.byref(sm), hip_lib.stream_ptr(dev)), "dd_sampler_reset")
         # everything that shapes the captured step graph besides the (cached) pointers
         ent["sig"] = (sm.drift_armsca, sm.armsca_min_d, sm.armsca_max_d, sm.armsca_scale, sm.drift_clash, sm.clash_sigma,
-                      sm.clash_gamma, sm.clash_scale, sm.drift_norm_batch, int(lib.dd_debug_options_epoch()), bool(use_l0))
+                      sm.clash_gamma, sm.clash_scale, sm.drift_repul, sm.repul_max_d, sm.repul_scale, sm.drift_norm_batch,
+                      int(lib.dd_debug_options_epoch()), bool(use_l0))
         if cacheable:
             cache[key] = ent                               # (re-inserted: most recently used last)
             self._evict_chain_cache(self._CACHE_MAX)
@@ -1028,6 +1050,13 @@ class DecompScorePosNet3D(nn.Module):
         if spg < 1 or num_steps % spg or chunk % spg:
             spg = 1
         gsig = (ent["sig"], spg, side.cuda_stream)
+        cached = any(e is ent for e in DecompScorePosNet3D._chain_cache.values())
+        # Priming runs BEFORE this call looks at the cached graph handle: the priming chain goes through this very function
+        # and may itself create -- or, if its launch structure differs, destroy and re-create -- the entry's graph.
+        if (prime and cached and str(dev) not in DecompScorePosNet3D._primed_devices
+                and os.environ.get("DD_PRIME", "1") != "0"):
+            if self._prime_streaming(chain, spg):          # once per process and device (a 100-pocket job creates 100 graphs)
+                DecompScorePosNet3D._primed_devices.add(str(dev))
         if ent.get("graph") is not None and ent["graph_sig"] != gsig:      # launch structure changed: capture again
             self._drop_cached_graphs()
         if ent.get("graph") is None:
@@ -1036,12 +1065,7 @@ class DecompScorePosNet3D(nn.Module):
             ent["graph"], ent["graph_sig"] = graph, gsig
             DecompScorePosNet3D._graph_counter += 1
             ent["graph_id"] = DecompScorePosNet3D._graph_counter
-        graph = ent["graph"]
-        cached = any(e is ent for e in DecompScorePosNet3D._chain_cache.values())
-        if (prime and cached and str(dev) not in DecompScorePosNet3D._primed_devices
-                and os.environ.get("DD_PRIME", "1") != "0"):
-            if self._prime_streaming(chain):               # once per process and device (a 100-pocket job creates 100 graphs)
-                DecompScorePosNet3D._primed_devices.add(str(dev))
+        graph = ent["graph"]                               # (read after priming: never a handle the priming chain destroyed)
 
         dbg = int(os.environ.get("DD_TRAJ_DEBUG", "0"))
         final_np = {k: v.numpy() for k, v in final.items()}
@@ -1096,7 +1120,7 @@ class DecompScorePosNet3D(nn.Module):
         cur.wait_stream(side)
         chain["traj_cpu"] = final
 
-    def _prime_streaming(self, chain):
+    def _prime_streaming(self, chain, spg=1):
         """One-off per process and device, with the first cached chain that is streamed: stream a short chain (3 pieces of
         8 steps) through the same launch / copy / drain code once and put the chain's state back.  The first streamed
         call of a process that is three or more pieces long stalls the device for ~1 ms in its second or third piece
@@ -1104,6 +1128,7 @@ class DecompScorePosNet3D(nn.Module):
         otherwise pay that inside the caller's timed call.  Returns False if this chain cannot be used for it."""
         bufs, s = chain["bufs"], chain["s"]
         n = min(int(bufs["traj_pos"].shape[0]), 24, int(s.t_start) + 1)     # (never past t = 0)
+        n = n // max(1, spg) * max(1, spg)                                  # whole graph replays: the same step graph as the caller's
         if n < 17:
             return False
         state = {k: bufs[k].clone() for k in ("lig_pos", "lig_v", "lig_bond", "step_counter")}

@@ -146,7 +146,12 @@ typedef struct dd_sampler {
    * traj_v0 / traj_vt, of the v head's second Linear and (num_v + 2) of the ligand embedding's rows.  The layer-0 tables
    * exist for 8 classes only (l0_tables must be NULL otherwise). */
   int32_t num_v;
-  int32_t reserved0;
+  /* ABI 8: arms_repul drift (utils/guidance_funcs.py:81-118; an EXTENSION of energy_drift_opt -- the reference defines the
+   * energy but its sample_diffusion has no branch for it, models/decompdiff.py:643-675).  0 = off, 1 = mode 'min',
+   * 2 = mode 'all'; evaluated at x_t like the other terms, scaled by pos_score_coef[t] when repul_scale is set. */
+  int32_t drift_repul;
+  float repul_max_d;
+  int32_t repul_scale;
 } dd_sampler;
 
 /* Layout of l0_tables (floats): node projections [16][640], ligand projections [16][1280], bond projections [5][640],
@@ -261,53 +266,19 @@ int dd_drift_armsca(const float* lig_pos, const int32_t* decomp_index, int B, in
                     float* grad, int accumulate, void* stream);
 int dd_drift_clash(const float* lig_pos, const float* offset, const float* full_protein_pos, int B, int NL, int NF,
                    float sigma, float gamma, float* grad, int accumulate, void* stream);
+/* grad[B*NL,3] (+)= d/dx of compute_batch_arms_repul_loss (utils/guidance_funcs.py:94-118, :81-91) -- the torch.autograd.grad
+ * of that energy: sum over the samples' arm pairs a1 <= a2 of relu(max_d - min distance) (mode 1 = 'min') or of the mean of
+ * relu(max_d - distance) over all atom pairs (mode 2 = 'all'), divided by B.  decomp_index [B*NL]: -1 scaffold, >= 0 arm id. */
+int dd_drift_arms_repul(const float* lig_pos, const int32_t* decomp_index, int B, int NL, float max_d, int mode, float* grad,
+                        int accumulate, void* stream);
 
-/* Measurement aid for bench.py: runs n_iters reverse steps with HIP events recorded on `stream`
- * around every launch and returns the mean milliseconds per step spent in each kernel class.
- * (Synchronises `stream`; not for use inside a capture.) */
-typedef enum dd_prof_cat {
-  DD_PROF_MISC, DD_PROF_GEMM, DD_PROF_ASSEMBLE, DD_PROF_ATTN_NE, DD_PROF_ATTN_NB, DD_PROF_ATTN_BL, DD_PROF_ATTN_PE,
-  DD_PROF_ATTN_PB, DD_PROF_STEP,
-  DD_PROF_EVENT_PAIR,   /* one empty start/stop event pair per step: what the event bracket itself adds to every launch */
-  DD_NUM_PROF_CATS
-} dd_prof_cat;
-int dd_profile_step(const dd_sampler* s, int n_iters, float* ms_per_category /*HOST [DD_NUM_PROF_CATS]*/, void* stream);
+/* Build flags of the loaded library: bit 0 = measurement build (-DDD_DEBUG_OPTIONS=1: alternative launch schedules behind
+ * dd_debug_set_option, see decompdiff_hip_debug.h), bit 1 = -DDD_EXACT_MATH=1 (correctly rounded 1/sqrt and softmax
+ * division).  0 for the default library. */
+int dd_build_flags(void);
 
-/* Profiling aid: per-workgroup s_memtime phase stamps of one attention kernel class (see dd_api.hip). */
-int dd_debug_set_clock_buffer(long long* buf, int mode);
-/* Launch structure of the attention sub-layers: 1 (default) = fused multi-mode launches of the tiled kernels,
- * 0 = one launch per sub-layer (per-kernel timing; the cross-check variant), 3 = fused launches without the
- * second-stream overlap of the coordinate sub-layers with the next layer's projections (the default 1 has the overlap on).
- * All variants produce the same results up to fp32 summation order. */
-int dd_debug_set_fusion(int mode);
-/* Measurement aid: runtime switches for A/B timing in one process (key 0: as dd_debug_set_fusion; key 1: K-split
- * projection GEMM tiles on/off).  Results are identical for every setting up to fp32 summation order. */
-int dd_debug_set_option(int key, int value);
-/* Counter bumped by every dd_debug_set_* call (hosts that cache captured step graphs re-capture when it moved). */
-int dd_debug_options_epoch(void);
-/* Measured split of the fused node launch for a shape (dd_debug_set_option key 18 = 1): number of CUs kept by the
- * persistent bond-layer workgroups, 0 = node blocks first, -1 = not measured yet. */
-int dd_debug_node_split(int B, int NP, int NL, int K);
-/* Health word of the in-launch hand-offs of the default launch schedule ("layer-tail queue"): the
- * coordinate attention, the next assemble and the next node attention start beside the persistent GEMM queue of their
- * layer and poll its device counters instead of waiting for a graph edge; every poll is bounded (~0.1 s).  *code = 0:
- * no poll gave up since the last forward started; otherwise the id of the first waiter that did (100+j / 200+j a queue
- * tile of job j, 300/301 assemble, 400 coordinate attention, 500 node attention) -- the results of that forward are then
- * invalid.  Synchronises `stream`.  (ABI 7.) */
-int dd_queue_error(const dd_sampler* s, void* stream, int* code);
-
-/* Test aid: the production (Philox4x32-10) noise of one step exactly as the step kernels draw it -- kind 1: uniforms
- * [rows,8] of the atom-type stream (transitions.py:79 rand_like), 2: uniforms [rows,5] of the bond-type stream,
- * 7: normals [rows] of the coordinate stream (decompdiff.py:680 randn_like). */
-int dd_debug_philox(uint64_t seed, int step, long rows, int kind, float* out, void* stream);
-
-/* Debug/test access to intermediate buffers of the last dd_forward (pointers into workspace). */
-typedef struct dd_ws_view {
-  float *x, *h, *hb, *ew, *A;
-  int32_t* nbr;
-  float* Anb;   /* [B,NL,128] node_layer_with_bond output of the last layer when the fused launch is used, else NULL */
-} dd_ws_view;
-int dd_workspace_view(const dd_sampler* s, dd_ws_view* out);
+/* Measurement, profiling and test-access entry points (dd_profile_step, dd_debug_*, dd_queue_error, dd_workspace_view)
+ * are declared in decompdiff_hip_debug.h: exported by the same library, not part of the drop-in boundary. */
 
 #ifdef __cplusplus
 }

@@ -3,7 +3,7 @@
 CPU restatement of the reference's reverse-diffusion sampler:
 schedule tables (models/decompdiff.py:95-131, models/transitions.py:12-62,98-120),
 categorical transitions (transitions.py:65-161), drift guidance
-(utils/guidance_funcs.py:24-78) and the 1000-step loop
+(utils/guidance_funcs.py:24-118) and the 1000-step loop
 (models/decompdiff.py:552-703).  Pinned by tests/golden (generated from the reference
 itself by oracle/make_golden.py).
 
@@ -146,6 +146,34 @@ def armsca_prox_loss(ligand_pos, batch_ligand, decomp_index, min_d, max_d):
     return total / num_graphs, n_valid
 
 
+def arms_repul_loss(ligand_pos, batch_ligand, decomp_index, max_d, mode="min"):
+    """compute_batch_arms_repul_loss / compute_arms_repul_loss (guidance_funcs.py:81-118).  Kept as written upstream: the
+    pair loop runs over a1 <= a2, i.e. every arm is also paired with ITSELF (in 'min' mode that term is the constant max_d --
+    the minimum is a zero on the diagonal, whose norm has a zero subgradient -- and in 'all' mode it repels the atoms of one
+    arm from each other); arm ids without atoms are skipped; the sum is divided by the number of samples."""
+    total = torch.tensor(0.0)
+    num_graphs = int(batch_ligand.max().item()) + 1
+    n_valid = 0
+    for i in range(num_graphs):
+        pos = ligand_pos[batch_ligand == i]
+        mask = decomp_index[batch_ligand == i]
+        num_arms = int(mask.max().item()) + 1
+        for a1 in range(num_arms):
+            for a2 in range(a1, num_arms):
+                p1, p2 = pos[mask == a1], pos[mask == a2]
+                if len(p1) > 0 and len(p2) > 0:
+                    pd = torch.norm(p1.unsqueeze(1) - p2.unsqueeze(0), p=2, dim=-1)
+                    if mode == "min":
+                        loss = torch.mean(torch.clamp(max_d - pd.min(), min=0))
+                    elif mode == "all":
+                        loss = torch.mean(torch.clamp(max_d - pd, min=0))
+                    else:
+                        raise ValueError(mode)
+                    total = total + loss
+                    n_valid += 1
+    return total / num_graphs, n_valid
+
+
 # -------------------------------------------------------------------------- sample loop
 def sample_diffusion(sd, cfg, *, protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v,
                      ligand_v_aux, batch_ligand, prior_stds, ligand_decomp_batch, ligand_decomp_index,
@@ -220,6 +248,15 @@ def sample_diffusion(sd, cfg, *, protein_pos, protein_v, batch_protein, init_lig
                     g = torch.autograd.grad(e, xt)[0]
                     if drift.get("scale", False):
                         g = g * pt["pos_score_coef"][t][batch_ligand].unsqueeze(-1)
+                elif drift["type"] == "arms_repul":
+                    # EXTENSION: the reference defines this energy (guidance_funcs.py:81-118) but its sample_diffusion has no
+                    # branch for it (decompdiff.py:643-675 raises ValueError); wired exactly like armsca_prox (:648-659)
+                    e, n_valid = arms_repul_loss(xt, batch_ligand, ligand_decomp_index, drift.get("max_d", 1.9),
+                                                 drift.get("mode", "min"))
+                    if n_valid > 0 and e.requires_grad:
+                        g = torch.autograd.grad(e, xt)[0]
+                        if drift.get("scale", False):
+                            g = g * pt["pos_score_coef"][t][batch_ligand].unsqueeze(-1)
                 else:
                     raise ValueError(drift["type"])
                 grad_all = grad_all + g

@@ -320,6 +320,45 @@ def gen_loss(ref, cfg, ragged=False):
           f"{float(res['losses']['bond']):.6g}; {len(names)} parameter gradients, total norm {float(np.linalg.norm(out['grad_norms'])):.6g}")
 
 
+def gen_arms_repul():
+    """arms_repul energy and its gradient: the REFERENCE's compute_batch_arms_repul_loss
+    (utils/guidance_funcs.py:81-118) under torch.autograd.grad, modes 'min' / 'all', on hand-built batches that exercise
+    every branch: two and three arms, a skipped (empty) arm id, a sample without arms, contacts inside and outside max_d.
+    The reference's sample_diffusion has no branch for this term (decompdiff.py:643-675 raises), so the fixture pins the
+    energy itself; the sampler wiring is an extension checked against the oracle."""
+    ref_shims.install()
+    import utils.guidance_funcs as G                             # noqa: the REFERENCE's module
+    g = torch.Generator().manual_seed(811)
+    cases = {}
+    for name, B, NL, arms in (("two_arms", 3, 14, [[0] * 4 + [1] * 5 + [-1] * 5, [0] * 3 + [1] * 3 + [-1] * 8, [0] * 6 + [1] * 6 + [-1] * 2]),
+                              ("three_arms_gap", 2, 20, [[0] * 5 + [1] * 5 + [2] * 5 + [-1] * 5, [0] * 6 + [2] * 6 + [-1] * 8]),
+                              ("no_arms", 2, 9, [[-1] * 9, [0] * 2 + [1] * 3 + [-1] * 4]),
+                              ("c_small", 4, 30, [[0] * 8 + [1] * 8 + [-1] * 14] * 4)):
+        pos = torch.randn(B * NL, 3, generator=g) * 1.6           # ~1.5-4 A contacts: both sides of max_d occur
+        batch = torch.arange(B).repeat_interleave(NL)
+        decomp = torch.tensor([a for row in arms for a in row], dtype=torch.long)
+        out = {"pos": pos.numpy(), "batch_ligand": batch.numpy(), "decomp_index": decomp.numpy(), "B": np.int64(B), "NL": np.int64(NL)}
+        for mode in ("min", "all"):
+            for max_d in (1.9, 3.0):
+                xt = pos.clone().requires_grad_(True)
+                e, n_valid = G.compute_batch_arms_repul_loss(xt, batch, decomp, max_d=max_d, mode=mode)
+                grad = torch.autograd.grad(e, xt)[0] if (n_valid > 0 and e.requires_grad) else torch.zeros_like(pos)
+                xo = pos.clone().requires_grad_(True)
+                eo, nvo = OD.arms_repul_loss(xo, batch, decomp, max_d, mode)
+                go = torch.autograd.grad(eo, xo)[0] if (nvo > 0 and eo.requires_grad) else torch.zeros_like(pos)
+                assert nvo == n_valid and torch.equal(go, grad) and float(eo) == float(e), (name, mode, max_d)
+                key = f"{mode}_{max_d}"
+                out[f"energy_{key}"] = np.float32(float(e))
+                out[f"n_valid_{key}"] = np.int64(n_valid)
+                out[f"grad_{key}"] = grad.numpy()
+        cases[name] = out
+    flat = {f"{c}/{k}": v for c, d in cases.items() for k, v in d.items()}
+    flat["oracle_vs_reference_maxabs"] = np.float64(0.0)
+    np.savez_compressed(os.path.join(GOLDEN, "arms_repul.npz"), **flat)
+    print("arms_repul:", {c: {k: (v.shape if hasattr(v, "shape") and v.shape else float(v)) for k, v in d.items() if k.startswith("energy")}
+                          for c, d in cases.items()})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-long", action="store_true", help="skip the 1000-step trajectory (~10 min)")
@@ -354,6 +393,8 @@ def main():
         gen_loss(ref, cfg)
     if want("loss_ragged"):
         gen_loss(ref, cfg, ragged=True)
+    if want("arms_repul"):
+        gen_arms_repul()
     if want("scale"):
         # `scale: True` of the drift terms (decompdiff.py:656-657,667-668), mid-chain where pos_score_coef is not tiny
         drift_scale = [dict(DRIFT[0], scale=True), dict(DRIFT[1], scale=True)]

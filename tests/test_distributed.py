@@ -174,7 +174,7 @@ def test_lpt_assignment_balances_the_pocket_costs():
 
 def test_more_ranks_than_devices_is_refused():
     import pytest
-    with pytest.raises(SystemExit) as e:
+    with pytest.raises(ValueError) as e:                    # (a library error; bench.py turns it into its exit message)
         ddist.check_world_fits_devices(8, 1)
     assert "8 ranks but only 1 visible" in str(e.value)
     ddist.check_world_fits_devices(8, 1, oversubscribe=True)
@@ -216,3 +216,117 @@ def test_rccl_failure_is_an_error_unless_the_fallback_is_requested():
     assert [r[1] for r in res] == ["error", "error"] and "RCCL start-up failed" in res[0][2]
     res = _run_fallback(True)
     assert [r[1] for r in res] == ["ok", "ok"] and all(r[2] == "gloo" and "fall-back" in r[3] and r[4] == 2.0 for r in res)
+
+
+def _host_group_worker(rank, world, port, q):
+    """A host application that has ALREADY initialised torch.distributed (torchrun + its own init_process_group): the
+    control plane must run on the host's default group instead of leaving its bookkeeping empty."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    assert ddist.init_from_env(backend="nccl") is True        # must not try to start anything of its own
+    assert ddist.control_backend() == "gloo" and "host application" in ddist.control_note()
+    ddist.barrier()
+    t = ddist.max_over_ranks(3.0 - rank)
+    meta = ddist.gather_metadata({"rank": rank})
+    q.put((rank, t, [m["rank"] for m in meta]))
+    dist.destroy_process_group()
+
+
+def test_host_initialised_process_group_is_used_as_it_is():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_host_group_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, 3.0, [0, 1]), (1, 3.0, [0, 1])]
+
+
+def _forced_single_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      DD_DIST_FORCE_GROUP="1")
+    assert ddist.init_from_env(backend="gloo") is True        # one rank, but the groups are built (DD_DIST_FORCE_GROUP)
+    ddist.barrier()
+    t = ddist.max_over_ranks(1.25)
+    q.put((ddist.control_backend(), t, len(ddist.gather_metadata({"rank": 0}))))
+    dist.destroy_process_group()
+
+
+def test_forced_single_rank_group():
+    """DD_DIST_FORCE_GROUP=1: the collective branch runs with one rank (the GPU suite uses the same switch to bring RCCL up
+    on a one-GPU box: tests/test_gpu_configs.py::test_rccl_single_rank_control_plane)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_single_worker, args=(_free_port(), q))
+    p.start()
+    assert q.get(timeout=120) == ("gloo", 1.25, 1)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+
+
+def _eight_rank_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    assert ddist.init_from_env(backend="gloo")
+    units, scaling = ddist.plan_job(3, world, n_pockets=16)
+
+    def prepare(u):
+        return u
+
+    def sample(u, n_steps, seed):                             # a stand-in chain: the result depends on the unit only
+        g = torch.Generator().manual_seed(u.pocket_seed * 7919 + n_steps)
+        return {"pos": torch.rand(u.n_samples, 3, generator=g), "v": torch.tensor([u.uid]), "bond": torch.tensor([seed % 97])}
+    job = ddist.run_job(units, 3, rank, world, prepare, sample, steps=3, warmup=1, device=None)
+    if rank == 0:
+        q.put({k: job[k] for k in ("unit_steps", "per_rank", "per_unit", "distinct_devices", "imbalance")})
+    ddist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_job_over_gloo():
+    """The shape of the driver's `--gpus 8` run (8 ranks, LPT table, gather, imbalance), on CPU ranks over gloo."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eight_rank_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    job = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert job["unit_steps"] == 16 * 3
+    assert [r["rank"] for r in job["per_rank"]] == list(range(8))
+    units, _ = ddist.plan_job(3, world, n_pockets=16)
+    table = ddist.assign_lpt(units, world)
+    assert [r["units"] for r in job["per_rank"]] == table
+    assert [r["unit"] for r in job["per_unit"]] == list(range(16))
+    assert job["distinct_devices"] == 8                       # (CPU ranks identify themselves by pid)
+    assert all("cpu_affinity" in r for r in job["per_rank"])
+
+
+def test_cpu_affinity_helpers(monkeypatch):
+    assert ddist.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert ddist.format_cpulist([0, 1, 2, 3, 8, 10, 11]) == "0-3,8,10-11"
+    assert ddist.slice_cpus(list(range(64)), 1, 4) == list(range(16, 32))
+    assert ddist.slice_cpus(list(range(10)), 3, 4) == [6, 7, 8, 9]          # the last share takes the remainder
+    assert ddist.slice_cpus([0, 1], 5, 8) != []                             # never empty
+    # two sockets x 4 GPUs: devices 0-3 local to CPUs 0-31, 4-7 to 32-63; rank r runs on device r
+    bound = {}
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(64)))
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: bound.__setitem__("cpus", sorted(cpus)))
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    look = lambda d: list(range(0, 32)) if d < 4 else list(range(32, 64))
+    rec = ddist.bind_rank_to_local_cpus(5, local_rank=5, local_world=8, local_cpus_of=look)
+    assert rec["bound"] and rec["cpus"] == "40-47" and rec["share"] == "2/4" and bound["cpus"] == list(range(40, 48))
+    rec = ddist.bind_rank_to_local_cpus(0, local_rank=0, local_world=8, local_cpus_of=look)
+    assert rec["cpus"] == "0-7"
+    monkeypatch.setenv("DD_DIST_NO_AFFINITY", "1")
+    assert ddist.bind_rank_to_local_cpus(0, 0, 8, look) == {"bound": False, "why": "DD_DIST_NO_AFFINITY=1"}
+    monkeypatch.delenv("DD_DIST_NO_AFFINITY")
+    assert ddist.bind_rank_to_local_cpus(0, 0, 8, lambda d: None)["bound"] is False

@@ -325,6 +325,74 @@ def test_bench_two_ranks_equal_one_rank():
     assert one["scaling"] == two["scaling"] == "strong"
 
 
+def _bench_env():
+    return {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR",
+                                                             "MASTER_PORT", "DD_DIST_FORCE_GROUP")}
+
+
+def _bench_line(argv, env, timeout=1500):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, env=env, timeout=timeout)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1]), p
+
+
+def _keep_evidence(name, obj):
+    """gpurun merges gpurun_out/ back: the lines these tests produce are copied to profiles/ by the evidence script."""
+    try:
+        d = os.path.join(ROOT, "gpurun_out", "tests")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, name), "w") as fh:
+            json.dump(obj, fh, indent=1, default=str)
+    except OSError:
+        pass
+
+
+def test_rccl_single_rank_control_plane():
+    """The RCCL branch of the control plane on real hardware: one rank with DD_DIST_FORCE_GROUP=1
+    builds the gloo default group, the RCCL group on top (new_group("nccl")), passes the probe barrier, and the timed job
+    then runs its two barriers and the all-reduce(MAX) of the wall time over RCCL.  On the one-GPU boxes the suite runs on
+    this is the only positive RCCL test possible (two ranks on one device is invalid RCCL usage)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(_bench_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               DD_DIST_FORCE_GROUP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    line, p = _bench_line(["--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-rooflines"], env)
+    _keep_evidence("rccl_single_rank.json", {"line": line, "stderr_tail": p.stderr[-1500:]})
+    assert line["config"]["control_plane"] == "nccl", line["config"]           # RCCL, not the gloo fall-back
+    assert line["config"]["control_plane_note"] is None
+    assert line["ranks"] == 1 and line["n_gpus"] == 1 and line["value"] > 0
+    assert "cpu_affinity" in line["per_rank"][0]
+    plain, _ = _bench_line(["--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-rooflines"], _bench_env())
+    assert plain["config"]["control_plane"] == "single process"
+    strip = lambda rs: [(r["unit"], r["checksum"]) for r in rs]
+    assert strip(plain["per_unit"]) == strip(line["per_unit"])                 # the same chain either way
+
+
+def test_bench_eight_ranks_oversubscribed():
+    """The shape of the driver's `--gpus 8` run on this box's one GPU: 8 ranks spawned by bench.py
+    itself over gloo, 16 pockets of configs[3] assigned longest-first, gather of the per-unit records, imbalance, CPU
+    affinity per rank.  The per-unit checksums equal those of the 1-rank job."""
+    common = ["--config", "3", "--pockets", "16", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-rooflines"]
+    eight, _ = _bench_line(["--gpus", "8", "--backend", "gloo", "--oversubscribe"] + common, _bench_env())
+    one, _ = _bench_line(["--gpus", "1"] + common, _bench_env())
+    _keep_evidence("bench_8ranks_oversubscribed.json", eight)
+    from decompdiff_amd import dist as ddist
+    units, _ = ddist.plan_job(3, 8, n_pockets=16)
+    assert eight["ranks"] == 8 and len(eight["per_rank"]) == 8 and eight["n_gpus"] == eight["distinct_devices"] == min(8, torch.cuda.device_count())
+    assert [r["units"] for r in eight["per_rank"]] == ddist.assign_lpt(units, 8)
+    assert eight["config"]["control_plane"] == "gloo" and eight["config"]["imbalance_max_over_mean_busy"] >= 1.0
+    assert all(isinstance(r["cpu_affinity"], dict) for r in eight["per_rank"])
+    bound = [r["cpu_affinity"] for r in eight["per_rank"] if r["cpu_affinity"].get("bound")]
+    if len(bound) == 8 and len({a["numa_cpus"] for a in bound}) == 1 and bound[0]["numa_cpus"] >= 8:
+        assert len({a["cpus"] for a in bound}) == 8                            # ranks sharing a NUMA node: disjoint slices
+    strip = lambda rs: [(r["unit"], r["checksum"]) for r in rs]
+    assert strip(one["per_unit"]) == strip(eight["per_unit"]) and len(eight["per_unit"]) == 16
+    assert one["scaling"] == eight["scaling"] == "strong"
+
+
 def test_ligand_atom_mask_matches_reference_behaviour():
     """An all-True boolean ligand_atom_mask equals None (as in the reference); a mask with masked-out entries raises the
     RuntimeError the reference's own loop raises for it (decompdiff.py:321,611)."""

@@ -655,6 +655,64 @@ def test_drift_scale_option_vs_oracle():
     assert torch.equal(got["v"].cpu(), want["v"]) and torch.equal(got["bond"].cpu(), want["bond"])
 
 
+def test_arms_repul_gradient_matches_reference_fixture():
+    """dd_drift_arms_repul against the REFERENCE's compute_batch_arms_repul_loss under autograd
+    (tests/golden/arms_repul.npz, oracle/make_golden.py gen_arms_repul): both modes, two max_d, arm layouts with a skipped
+    arm id and a sample without arms.  Tolerance 1e-6 absolute on gradients of magnitude <= 1/B (fp32, other summation order)."""
+    lib = hip_lib.load()
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "arms_repul.npz"))
+    worst, n_active = 0.0, 0
+    for c in sorted({k.split("/")[0] for k in g.files if "/" in k}):
+        B, NL = int(g[f"{c}/B"]), int(g[f"{c}/NL"])
+        xd = torch.from_numpy(g[f"{c}/pos"]).to(dev()).contiguous()
+        dec = torch.from_numpy(g[f"{c}/decomp_index"]).to(device=dev(), dtype=torch.int32)
+        for mode, code in (("min", 1), ("all", 2)):
+            for max_d in (1.9, 3.0):
+                want = torch.from_numpy(g[f"{c}/grad_{mode}_{max_d}"])
+                out = torch.full_like(xd, 7.0)                        # (overwritten: accumulate = 0)
+                hip_lib.check(lib.dd_drift_arms_repul(hip_lib.ptr(xd), hip_lib.ptr(dec), B, NL, max_d, code, hip_lib.ptr(out), 0,
+                                                      hip_lib.stream_ptr()), "dd_drift_arms_repul")
+                acc = out.clone()
+                hip_lib.check(lib.dd_drift_arms_repul(hip_lib.ptr(xd), hip_lib.ptr(dec), B, NL, max_d, code, hip_lib.ptr(acc), 1,
+                                                      hip_lib.stream_ptr()), "dd_drift_arms_repul")
+                torch.cuda.synchronize()
+                err = maxabs(out, want)
+                worst = max(worst, err)
+                n_active += int(want.abs().max() > 0)
+                assert err < 1e-6, (c, mode, max_d, err)
+                assert maxabs(acc, 2 * want) < 2e-6                   # accumulate = 1 adds to what is there
+    print(f"arms_repul gradients vs the reference: worst maxabs {worst:.3g} over 16 cases ({n_active} with an active hinge)")
+    assert n_active >= 12
+    assert lib.dd_drift_arms_repul(hip_lib.ptr(xd), hip_lib.ptr(dec), B, NL, 1.9, 3, hip_lib.ptr(out), 0, hip_lib.stream_ptr()) != 0
+
+
+@pytest.mark.parametrize("mode,scale", [("min", False), ("all", False), ("min", True)])
+def test_arms_repul_drift_in_the_sampler_vs_oracle(mode, scale):
+    """`type: 'arms_repul'` in energy_drift_opt -- an EXTENSION: the reference defines the energy
+    (utils/guidance_funcs.py:81-118) but its sample_diffusion has no branch for it (decompdiff.py:643-675).  Wired like
+    armsca_prox; checked against the oracle (whose energy is pinned by the reference fixture above) on injected noise,
+    together with the two reference terms, mid-chain for the `scale` variant."""
+    cfg, sd = GU.weights(0)
+    pocket = synth.make_pocket(43, 90, (4, 4), 5, num_full_protein=220)
+    torch.manual_seed(11)
+    b = synth.build_sampling_batch(pocket, 3, per_sample_std_scale=[1.0, 0.6, 0.4])   # small stds: arms start close together
+    steps, t_start = 3, (600 if scale else None)
+    noise = synth.draw_step_noise(steps, b["init_ligand_pos"].size(0), b["init_ligand_fc_bond_type"].size(0))
+    rep = dict(type="arms_repul", max_d=3.5, mode=mode, scale=scale)
+    drift = [dict(type="armsca_prox", min_d=1.2, max_d=1.9), dict(type="clash", sigma=2, gamma=4), rep]
+    kw = dict(t_start=t_start) if t_start is not None else {}
+    want = OD.sample_diffusion(sd, cfg, num_steps=steps, energy_drift_opt=drift, noise=noise, **kw, **b)
+    without = OD.sample_diffusion(sd, cfg, num_steps=steps, energy_drift_opt=drift[:2], noise=noise, **kw, **b)
+    got = _sample_hip(model(0), b, steps, drift, noise, t_start)
+    err, effect = maxabs(got["pos"], want["pos"]), maxabs(want["pos"], without["pos"])
+    print(f"arms_repul ({mode}, scale={scale}): pos err {err:.3g}; effect of the term on the result {effect:.3g}")
+    assert effect > (1e-6 if scale else 1e-3)              # the term acts in this case (scaled by pos_score_coef ~1e-3 when `scale`)
+    assert err < POS_TOL
+    assert torch.equal(got["v"].cpu(), want["v"]) and torch.equal(got["bond"].cpu(), want["bond"])
+    with pytest.raises(ValueError):
+        _sample_hip(model(0), b, 1, [dict(type="arms_repul", mode="median")], noise, t_start)
+
+
 @pytest.mark.parametrize("mode", ["padded", "groups"])
 def test_ragged_batch_golden(mode, monkeypatch):
     """samples with different atom counts in one batch (fixture from the reference).  The HIP path runs

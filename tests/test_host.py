@@ -97,12 +97,16 @@ def test_library_loads_and_exports_every_declared_symbol():
     import __graft_entry__
     __graft_entry__.build()
     lib = hip_lib.load()
-    hdr = open(os.path.join(ROOT, "include", "decompdiff_hip.h")).read()
-    declared = set(re.findall(r"\b(dd_[a-z0-9_]+)\s*\(", hdr))
-    assert declared == set(hip_lib.EXPORTED_SYMBOLS)
-    for name in declared:
-        assert hasattr(lib, name), name
-    assert lib.dd_abi_version() == hip_lib.ABI_VERSION == 7
+    for header, symbols in (("decompdiff_hip.h", hip_lib.EXPORTED_SYMBOLS), ("decompdiff_hip_debug.h", hip_lib.DEBUG_SYMBOLS)):
+        hdr = open(os.path.join(ROOT, "include", header)).read()
+        hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)       # (comments mention entry points of the other header)
+        declared = set(re.findall(r"\b(dd_[a-z0-9_]+)\s*\(", hdr))
+        assert declared == set(symbols), (header, declared ^ set(symbols))
+        for name in declared:
+            assert hasattr(lib, name), name
+    assert not any(n.startswith("dd_debug") or n.startswith("dd_profile") for n in hip_lib.EXPORTED_SYMBOLS)
+    assert lib.dd_build_flags() == 0                         # the default library: no measurement variants compiled in
+    assert lib.dd_abi_version() == hip_lib.ABI_VERSION == 8
     assert lib.dd_status_string(0) == b"ok" and b"workspace" in lib.dd_status_string(-3)
     # pure host helper: workspace size grows with the batch and is non-zero
     w1, w8 = lib.dd_workspace_floats(1, 300, 30, 32), lib.dd_workspace_floats(8, 300, 30, 32)

@@ -247,3 +247,25 @@ def test_trajectory_ragged_batch():
     assert np.array_equal(g["out_pos"], r["pos"].numpy())
     assert np.array_equal(g["out_v"], r["v"].numpy()) and np.array_equal(g["out_bond"], r["bond"].numpy())
     assert np.array_equal(g["traj_pos"], torch.stack(r["pos_traj"]).numpy())
+
+
+def test_arms_repul_energy_and_gradient_match_reference():
+    """tests/golden/arms_repul.npz holds the REFERENCE's compute_batch_arms_repul_loss and its autograd
+    gradient (oracle/make_golden.py gen_arms_repul); the oracle's restatement reproduces both bit for bit."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "arms_repul.npz"))
+    cases = sorted({k.split("/")[0] for k in g.files if "/" in k})
+    assert cases == ["c_small", "no_arms", "three_arms_gap", "two_arms"]
+    n_active = 0
+    for c in cases:
+        pos, batch, dec = (torch.from_numpy(g[f"{c}/{k}"]) for k in ("pos", "batch_ligand", "decomp_index"))
+        for mode in ("min", "all"):
+            for max_d in (1.9, 3.0):
+                key = f"{mode}_{max_d}"
+                xt = pos.clone().requires_grad_(True)
+                e, nv = OD.arms_repul_loss(xt, batch, dec, max_d, mode)
+                assert nv == int(g[f"{c}/n_valid_{key}"])
+                assert float(e.detach()) == float(g[f"{c}/energy_{key}"])
+                grad = torch.autograd.grad(e, xt)[0] if (nv > 0 and e.requires_grad) else torch.zeros_like(pos)
+                assert torch.equal(grad, torch.from_numpy(g[f"{c}/grad_{key}"])), (c, key)
+                n_active += int(grad.abs().max() > 0)
+    assert n_active >= 12                                     # the hinge is active in most cases (not a vacuous fixture)

@@ -23,14 +23,15 @@ run(20)
 n = 60 if wl == "large" else 200
 print(min(run(n) for _ in range(3)))
 '''
-args = sys.argv[1:]; rounds = int(args.pop()) if args and args[-1].isdigit() else 3; libs = args
-res = {l: [] for l in libs}
-for r in range(rounds):
+if __name__ == "__main__":
+    args = sys.argv[1:]; rounds = int(args.pop()) if args and args[-1].isdigit() else 3; libs = args
+    res = {l: [] for l in libs}
+    for r in range(rounds):
+        for l in libs:
+            env = dict(os.environ, DD_HIP_LIB=os.path.abspath(l))
+            out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
+            if out.returncode != 0:
+                print(l, "FAILED", out.stderr[-800:]); continue
+            res[l].append(float(out.stdout.strip().splitlines()[-1]))
     for l in libs:
-        env = dict(os.environ, DD_HIP_LIB=os.path.abspath(l))
-        out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
-        if out.returncode != 0:
-            print(l, "FAILED", out.stderr[-800:]); continue
-        res[l].append(float(out.stdout.strip().splitlines()[-1]))
-for l in libs:
-    if res[l]: print(f"{l:50s} median {statistics.median(res[l]):.4f} ms/step  all {[round(x, 4) for x in res[l]]}")
+        if res[l]: print(f"{l:50s} median {statistics.median(res[l]):.4f} ms/step  all {[round(x, 4) for x in res[l]]}")
