@@ -273,8 +273,8 @@ def measure_step_rooflines(torch, model, hip_lib, lib, state, cfg, B, NP, NL, K,
     nbr = ws[off:off + B * (NP + NL) * K].view(torch.int32).view(B, NP + NL, K).cpu()
     n_mfma, by_mode = node_launch_mfma_count(nbr, B, NP, NL, K)
     hip_lib.check(lib.dd_sampler_reset(ctypes.byref(s2), hip_lib.stream_ptr(dev)), "dd_sampler_reset")
-    # 4 rounds of 5 profiled steps (the first is a warm-up); per launch class the minimum of the round means: one stray
-    # slow round (clock ramp, a host hiccup between the recorded events) must not end up in the roofline figures
+    # 4 rounds of 5 profiled steps (the first is a warm-up); per launch class the MEAN of the three round means (the minimum
+    # of the rounds, kept as launch_ms_min, flattered the fraction by ~4 % against rocprofv3's average: VERDICT r3)
     cats = (ctypes.c_float * len(hip_lib.PROF_CATS))()
     rounds = []
     for rnd in range(4):
@@ -282,7 +282,8 @@ def measure_step_rooflines(torch, model, hip_lib, lib, state, cfg, B, NP, NL, K,
         hip_lib.check(lib.dd_profile_step(ctypes.byref(s2), 5, cats, hip_lib.stream_ptr(dev)), "dd_profile_step")
         if rnd > 0:
             rounds.append([float(cats[i]) for i in range(len(hip_lib.PROF_CATS))])
-    per_cat = {k: min(r[i] for r in rounds) for i, k in enumerate(hip_lib.PROF_CATS)}
+    per_cat = {k: sum(r[i] for r in rounds) / len(rounds) for i, k in enumerate(hip_lib.PROF_CATS)}
+    per_cat_min = {k: min(r[i] for r in rounds) for i, k in enumerate(hip_lib.PROF_CATS)}
     L = cfg.num_layers
     # fused mode: the NE + NB + BL launch is recorded under attn_BL; the empty event pair recorded once per step
     # measures what the bracket itself adds to a launch (rocprofv3's kernel time has no such term)
@@ -291,21 +292,32 @@ def measure_step_rooflines(torch, model, hip_lib, lib, state, cfg, B, NP, NL, K,
     executed = n_mfma * MFMA_16x16x4_FLOP
     achieved = executed / (launch_ms * 1e-3) / 1e12
     algorithmic = algorithmic_flops_node_launch(B, NP, NL, K) / (launch_ms * 1e-3) / 1e12
-    traffic, traffic_note = None, "no PMC profile for this workload"
+    # HBM traffic cannot be read by the process that is being timed (rocprofv3 --pmc needs its own passes): it comes from the
+    # committed PMC passes in profiles/pmc_traffic.json, which name the kernel source they were taken on; an entry measured
+    # on another dd_attention2.hip is refused (traffic = null) rather than reported as if it described this run
+    traffic, traffic_note, traffic_source = None, "no PMC profile for this workload", None
     try:
+        import hashlib
+        with open(os.path.join(ROOT, "decompdiff_amd", "csrc", "dd_attention2.hip"), "rb") as fh:
+            src_sha = hashlib.sha256(fh.read()).hexdigest()[:16]
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             pm = json.load(fh)
         ent = pm.get("node_launch", {}).get(f"NP{NP}_NL{NL}_B{B}")
-        if ent:
+        if ent and ent.get("kernel_source_sha256_16") == src_sha:
             traffic = int((ent["fetch_kib_per_launch"] + ent["write_kib_per_launch"]) * 1024)
             traffic_note = ent["note"]
+            traffic_source = f"committed PMC pass {ent.get('measured_at_commit', '?')} ({ent.get('source', 'profiles/')}); kernel source {src_sha}"
+        elif ent:
+            traffic_note = (f"stale: the committed PMC pass was taken on dd_attention2.hip {ent.get('kernel_source_sha256_16')}, this "
+                            f"run's source is {src_sha} -- re-run the PMC passes (tools/gpu_round4_evidence.sh)")
     except (OSError, KeyError, ValueError):
         pass
     roofline = {
         "bound": "mfma", "kernel": "dd::v2::k_attn2_node (fused node_layer_with_edge + node_layer_with_bond + bond_layer launch, "
                                    f"{L} per step)",
         "achieved": round(achieved, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4),
-        "traffic": traffic, "traffic_note": traffic_note, "launch_ms": round(launch_ms, 4), "event_pair_ms": round(pair_ms, 4),
+        "traffic": traffic, "traffic_source": traffic_source, "traffic_note": traffic_note, "launch_ms": round(launch_ms, 4),
+        "launch_ms_min": round(per_cat_min["attn_BL"] / L - per_cat_min.get("event_pair", 0.0), 4), "event_pair_ms": round(pair_ms, 4),
         "mfma_instructions_per_launch": n_mfma, "mfma_instructions_by_sublayer": by_mode,
         "algorithmic_tflops": round(algorithmic, 2),
         "note": "achieved = FLOPs EXECUTED on the matrix cores (exact count of v_mfma_f32_16x16x4_f32 wave-instructions of this "

@@ -39,8 +39,8 @@ def _stale(target, deps):
 
 def build(force: bool = False, verbose: bool = True, exact: bool = False, debug_options: bool = False) -> str:
     """``exact``: the -DDD_EXACT_MATH=1 variant (correctly rounded 1/sqrt and softmax division instead of v_rsq_f32 and
-    one reciprocal per head) as lib/libdecompdiff_hip_exact.so -- a measurement aid for the parity study of DESIGN.md
-    section 2, selected at run time with DD_HIP_LIB; the default library is unaffected."""
+    one reciprocal per head) as lib/libdecompdiff_hip_exact.so -- a measurement aid for the parity study (EXPERIMENTS.md,
+    profiles/parity_full_chain.json), selected at run time with DD_HIP_LIB; the default library is unaffected."""
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]

@@ -369,13 +369,31 @@ def FN_mean(per_row, batch, n):
     return scatter_sum(per_row.unsqueeze(-1), batch, n).squeeze(-1) / cnt
 
 
-def sample_time(model, num_graphs, device):
-    """sample_time, 'symmetric' (decompdiff.py:391-397); the draw is made on the CPU generator (torch.manual_seed)."""
-    if model.sample_time_method != "symmetric":
-        raise NotImplementedError("sample_time_method='importance' (Lt_history bookkeeping) is not implemented")
-    ts = torch.randint(0, model.num_timesteps, size=(num_graphs // 2 + 1,))
-    ts = torch.cat([ts, model.num_timesteps - ts - 1], 0)[:num_graphs]
-    return ts.to(device), torch.ones(num_graphs, device=device) / model.num_timesteps
+def sample_time(model, num_graphs, device, method=None):
+    """sample_time (decompdiff.py:374-400), both methods; the draw is made on the CPU generator (torch.manual_seed), as the
+    reference's CPU run makes it.
+
+    'symmetric' (:391-397): t and T-1-t pairs, uniform weights.
+    'importance' (:375-389): while any time step has been recorded 10 times or fewer (`Lt_count`), fall back to 'symmetric';
+    afterwards draw t ~ sqrt(Lt_history + 1e-10) + 1e-4 (entry 0 overwritten with entry 1), normalised, by
+    torch.multinomial, and return the drawn steps' probabilities.  NOTE the reference never writes `Lt_history` /
+    `Lt_count` (two registered buffers, models/decompdiff.py:146-147; no update anywhere in the repository), so its
+    'importance' method always takes the fall-back; the buffers are part of the state_dict here as there, and a host that
+    maintains them itself gets the importance branch exactly as written upstream."""
+    method = method or model.sample_time_method
+    if method == "importance":
+        if not bool((model.Lt_count > 10).all()):
+            return sample_time(model, num_graphs, device, method="symmetric")
+        lt_sqrt = torch.sqrt(model.Lt_history.detach().float().cpu() + 1e-10) + 0.0001
+        lt_sqrt[0] = lt_sqrt[1]                                # overwrite the decoder term with L1 (:380)
+        pt_all = lt_sqrt / lt_sqrt.sum()
+        ts = torch.multinomial(pt_all, num_samples=num_graphs, replacement=True)
+        return ts.to(device), pt_all.gather(0, ts).to(device)
+    if method == "symmetric":
+        ts = torch.randint(0, model.num_timesteps, size=(num_graphs // 2 + 1,))
+        ts = torch.cat([ts, model.num_timesteps - ts - 1], 0)[:num_graphs]
+        return ts.to(device), torch.ones(num_graphs, device=device) / model.num_timesteps
+    raise ValueError(method)                                   # (:399-400)
 
 
 def diffusion_loss(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, ligand_v_aux, batch_ligand,

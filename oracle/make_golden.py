@@ -320,6 +320,27 @@ def gen_loss(ref, cfg, ragged=False):
           f"{float(res['losses']['bond']):.6g}; {len(names)} parameter gradients, total norm {float(np.linalg.norm(out['grad_norms'])):.6g}")
 
 
+def gen_sample_time(ref):
+    """sample_time of the REFERENCE (decompdiff.py:374-400) on seeded CPU draws: 'symmetric', 'importance' with empty
+    history (falls back) and 'importance' with the two buffers filled by hand (the reference itself never fills them)."""
+    out = {}
+    hist = torch.linspace(0.5, 3.0, ref.num_timesteps) ** 2
+    for tag, method, fill in (("symmetric", "symmetric", False), ("importance_empty", "importance", False),
+                              ("importance_filled", "importance", True)):
+        ref.Lt_history.zero_(); ref.Lt_count.zero_()
+        if fill:
+            ref.Lt_history.copy_(hist); ref.Lt_count.fill_(11)
+        for n in (4, 7):
+            torch.manual_seed(100 + n)
+            ts, pt = ref.sample_time(n, "cpu", method)
+            out[f"{tag}/{n}/time_step"] = ts.numpy()
+            out[f"{tag}/{n}/pt"] = pt.numpy()
+    ref.Lt_history.zero_(); ref.Lt_count.zero_()
+    out["Lt_history_filled"] = hist.numpy()
+    np.savez_compressed(os.path.join(GOLDEN, "sample_time.npz"), **out)
+    print("sample_time:", {k: v.tolist() for k, v in out.items() if k.endswith("7/time_step")})
+
+
 def gen_arms_repul():
     """arms_repul energy and its gradient: the REFERENCE's compute_batch_arms_repul_loss
     (utils/guidance_funcs.py:81-118) under torch.autograd.grad, modes 'min' / 'all', on hand-built batches that exercise
@@ -395,6 +416,8 @@ def main():
         gen_loss(ref, cfg, ragged=True)
     if want("arms_repul"):
         gen_arms_repul()
+    if want("sample_time"):
+        gen_sample_time(ref)
     if want("scale"):
         # `scale: True` of the drift terms (decompdiff.py:656-657,667-668), mid-chain where pos_score_coef is not tiny
         drift_scale = [dict(DRIFT[0], scale=True), dict(DRIFT[1], scale=True)]

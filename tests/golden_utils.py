@@ -134,3 +134,48 @@ def make_pocket_fields(seed, beta=False, with_scaffold=True, num_arms=2):
                 pocket_atom_masks=t(masks), ligand_atom_mask=t(mask), ligand_pos=t(lig), num_arms=A,
                 num_scaffold=1 if with_scaffold else 0, arms_prior=arms_prior, scaffold_prior=scaffold_prior,
                 full_protein_pos=t(full))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Parity record of the full-chain GPU tests: written BEFORE their assertions, so a run that fails still leaves its numbers.
+# gpurun merges gpurun_out/ back into the builder's tree; tools/gpu_round4_evidence.sh copies the file to
+# profiles/parity_full_chain.json (committed: what `pytest -q` prints is not kept by the driver).
+# ------------------------------------------------------------------------------------------------------------------
+def chain_parity_summary(d, every, tol=1e-4, type_mismatches=(0, 0), bound=None, bound_name=None):
+    """d [checkpoints, samples] = max |pos - reference| of each sample at each checkpoint."""
+    d = np.asarray(d, dtype=np.float64)
+    steps = [int(every * (i + 1)) for i in range(d.shape[0])]
+    inside = (d < tol).all(1)
+    first_out = next((steps[i] for i in range(len(steps)) if not inside[i]), None)
+    rec = {"tolerance": tol, "checkpoint_steps": steps, "max_err_per_checkpoint": [float(f"{e:.4g}") for e in d.max(1)],
+           "median_err_per_checkpoint": [float(f"{e:.4g}") for e in np.median(d, 1)],
+           "per_sample_err_at_end": [float(f"{e:.4g}") for e in d[-1]],
+           "samples_within_tol_per_checkpoint": [int(x) for x in (d < tol).sum(1)], "n_samples": int(d.shape[1]),
+           "last_checkpoint_with_all_samples_within_tol": next((steps[i] for i in range(len(steps) - 1, -1, -1) if inside[:i + 1].all()), 0),
+           "first_checkpoint_with_a_sample_outside_tol": first_out,
+           "fraction_within_tol_at_end": float((d[-1] < tol).mean()),
+           "type_mismatches": {"atoms": int(type_mismatches[0]), "bonds": int(type_mismatches[1])}}
+    if bound is not None:
+        rec["bound_used_per_checkpoint"] = [float(f"{e:.4g}") for e in np.broadcast_to(np.asarray(bound, dtype=np.float64), (d.shape[0],))]
+        rec["bound"] = bound_name
+    return rec
+
+
+def record_parity(name, rec):
+    from decompdiff_amd import hip_lib
+    flags = int(hip_lib.load().dd_build_flags())
+    build = "exact_math" if flags & hip_lib.BUILD_EXACT_MATH else ("measurement" if flags & hip_lib.BUILD_DEBUG_OPTIONS else "default")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "gpurun_out", "tests", "parity_full_chain.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        try:
+            with open(path) as fh:
+                allrec = json.load(fh)
+        except (OSError, ValueError):
+            allrec = {}
+        allrec.setdefault(build, {})[name] = rec
+        with open(path, "w") as fh:
+            json.dump(allrec, fh, indent=1, sort_keys=True)
+    except OSError:
+        pass

@@ -80,13 +80,16 @@ def test_config1_full_chain_at_the_bench_shape_reference_golden():
     print("  max |pos - reference| over the batch:", " ".join(f"{e:.2g}" for e in d.max(1)))
     print("  per sample at step 1000:", " ".join(f"{e:.2g}" for e in d[-1]))
     print(f"  type mismatches: atoms {mv}, bonds {mb}")
+    sens = GU.load("sens_traj1000_plain")
+    assert int(sens["every"]) == every and sens["pos_err"].shape == (8, len(tp))
+    cap = float(sens["pos_err"][:, -1].max())             # 1.1e-3: the oracle's own largest end-of-chain self-divergence
+    GU.record_parity("configs[1] 300+30 B=8 1000 steps (traj1000_b8_plain, reference)", GU.chain_parity_summary(
+        d, every, POS_TOL, (mv, mb), cap, "1e-4 through step 600 (all samples), >= 6 of 8 samples at step 1000, every sample <= the "
+        "oracle's largest end-of-chain self-divergence under +-1-ulp nudges (sens_traj1000_plain.npz)"))
     assert mv == 0 and mb == 0
     assert np.array_equal(r["v"].cpu().numpy(), g["out_v"]) and np.array_equal(r["bond"].cpu().numpy(), g["out_bond"])
     assert (d[:12] < POS_TOL).all()                       # steps 50 ... 600: the flat tolerance of BASELINE.json, all samples
     assert int((d[-1] < POS_TOL).sum()) >= 6              # ... and most samples to the very end
-    sens = GU.load("sens_traj1000_plain")
-    assert int(sens["every"]) == every and sens["pos_err"].shape == (8, len(tp))
-    cap = float(sens["pos_err"][:, -1].max())             # 1.1e-3: the oracle's own largest end-of-chain self-divergence
     print(f"  largest oracle self-divergence at the end of a plain chain: {cap:.2g}")
     assert d.max() <= cap
 
@@ -121,14 +124,20 @@ def test_config2_full_chain_at_the_bench_shape_reference_golden():
     print("  max |pos - reference| over the batch:", " ".join(f"{e:.2g}" for e in d.max(1)))
     print("  per sample at step 1000:", " ".join(f"{e:.2g}" for e in d[-1]))
     print(f"  type mismatches: atoms {mv}, bonds {mb}")
-    assert mv == 0 and mb == 0
-    assert np.array_equal(r["v"].cpu().numpy(), g["out_v"]) and np.array_equal(r["bond"].cpu().numpy(), g["out_bond"])
-    assert (d[:12] < POS_TOL).all()                       # steps 50 ... 600: the flat tolerance of BASELINE.json, all samples
     sens = GU.load("sens_traj1000_drift")
     assert int(sens["every"]) == every and sens["pos_err"].shape == (8, n)
     bound = np.maximum(POS_TOL, sens["pos_err"].max(0))
+    GU.record_parity("configs[2] 300+30 B=8 1000 steps armsca+clash drift (traj1000_b8_drift, reference)", GU.chain_parity_summary(
+        d, every, POS_TOL, (mv, mb), bound, "1e-4 through step 600 (all samples); then every sample <= max(1e-4, the largest "
+        "self-divergence of the oracle's +-1-ulp replays of a drift chain at that checkpoint, sens_traj1000_drift.npz) AND the median "
+        "sample <= 1e-3 at every checkpoint AND >= 5 of 8 samples <= 1e-3 at step 1000"))
+    assert mv == 0 and mb == 0
+    assert np.array_equal(r["v"].cpu().numpy(), g["out_v"]) and np.array_equal(r["bond"].cpu().numpy(), g["out_bond"])
+    assert (d[:12] < POS_TOL).all()                       # steps 50 ... 600: the flat tolerance of BASELINE.json, all samples
     worst = int(np.argmax(d.max(1) / bound))
     assert (d.max(1) <= bound).all(), f"checkpoint {worst}: {d.max(1)[worst]:.3g} > {bound[worst]:.3g}"
+    # the sensitivity bound comes from another pocket's chain and is loose in the last third (0.1-0.5 A): a hard cap beside it
+    assert (np.median(d, 1) <= 1e-3).all() and int((d[-1] <= 1e-3).sum()) >= 5
 
 
 @pytest.mark.parametrize("name,nc", [("traj4_aromatic13", 13), ("traj4_full23", 23)])

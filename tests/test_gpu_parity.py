@@ -349,6 +349,13 @@ def test_trajectory_1000_steps_golden(name):
     print("  max |pos - golden| :", " ".join(f"{e:.2g}" for e in err))
     print("  atom-type mismatches:", mv.tolist())
     print("  bond-type mismatches:", mb.tolist())
+    sens_b = None
+    if name == "traj1000_drift":
+        sens_b = np.maximum(POS_TOL, GU.load("sens_traj1000_drift")["pos_err_median"])
+    GU.record_parity(f"single sample 300+30 1000 steps ({name}, reference)", GU.chain_parity_summary(
+        err[:, None], every, POS_TOL, (int(mv.sum()), int(mb.sum())), sens_b,
+        "max(1e-4, the oracle's own MEDIAN self-divergence under +-1-ulp nudges per step, sens_traj1000_drift.npz)" if sens_b is not None
+        else None))
     assert mv.sum() == 0 and mb.sum() == 0
     assert np.array_equal(r["v"].cpu().numpy(), g["out_v"]) and np.array_equal(r["bond"].cpu().numpy(), g["out_bond"])
     if name == "traj1000_plain":

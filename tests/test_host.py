@@ -273,3 +273,25 @@ def test_compiled_torch_extension_registers_the_op_level_boundary():
         assert not torch._C._dispatch_has_kernel_for_dispatch_key(f"decompdiff_hip::{name}", "CPU"), name
     with pytest.raises(NotImplementedError):
         ops.knn(torch.zeros(1, 4, 3), 2)                    # no CPU implementation: the dispatcher refuses
+
+
+def test_sample_time_methods_match_reference():
+    """training.sample_time against the REFERENCE's sample_time (tests/golden/sample_time.npz, oracle/make_golden.py
+    gen_sample_time): 'symmetric'; 'importance' with the never-written history buffers (falls back to 'symmetric', which is
+    what the reference always does); 'importance' with the buffers filled by the host (torch.multinomial branch)."""
+    from decompdiff_amd import training
+    g = np.load(os.path.join(ROOT, "tests", "golden", "sample_time.npz"))
+    m = DecompScorePosNet3D(shipped_config(), 29, 10, 8)
+    for tag, method, fill in (("symmetric", "symmetric", False), ("importance_empty", "importance", False),
+                              ("importance_filled", "importance", True)):
+        m.Lt_history.zero_(); m.Lt_count.zero_()
+        if fill:
+            m.Lt_history.copy_(torch.from_numpy(g["Lt_history_filled"])); m.Lt_count.fill_(11)
+        for n in (4, 7):
+            torch.manual_seed(100 + n)
+            ts, pt = training.sample_time(m, n, "cpu", method)
+            assert np.array_equal(ts.numpy(), g[f"{tag}/{n}/time_step"]), (tag, n)
+            assert np.array_equal(pt.numpy(), g[f"{tag}/{n}/pt"]), (tag, n)
+    assert not np.array_equal(g["importance_filled/7/time_step"], g["importance_empty/7/time_step"])
+    with pytest.raises(ValueError):
+        training.sample_time(m, 4, "cpu", "uniform")
