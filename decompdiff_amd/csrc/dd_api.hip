@@ -156,7 +156,7 @@ DD_OPT g_sched = 4;                        // dd_debug_set_option(8, v): 5 = til
                                                // node attention
 DD_OPT g_xup_in_pos = 0;                   // dd_debug_set_option(11, v): x update inside the coordinate launch (last workgroup);
                                                // measured 1 % slower than the separate 3-block launch, off
-DD_OPT g_fused_max_nl = 64;                // dd_debug_set_option(13, v): largest ligand handled by the fused launches
+DD_OPT g_fused_max_nl = DD_NL_MAX;                // dd_debug_set_option(13, v): largest ligand handled by the fused launches
 DD_OPT g_defer_pos = 0;                    // dd_debug_set_option(14, v): record the coordinate launch after the next layer's GEMMs
                                                // (keeps the GEMM chain on the main queue; measured 1.3 % slower: the coordinate
                                                // launch then starves behind the projections' workgroups)
@@ -938,7 +938,7 @@ extern "C" const char* dd_status_string(int status) {
   switch (status) {
     case DD_OK: return "ok";
     case DD_ERR_BAD_ARG: return "bad argument (null pointer or non-positive size)";
-    case DD_ERR_UNSUPPORTED_SHAPE: return "unsupported shape (NL > 64, N > 1024, K > 32 or K > N-1)";
+    case DD_ERR_UNSUPPORTED_SHAPE: return "unsupported shape (NL > 128, N > 1024, K > 32 or K > N-1)";
     case DD_ERR_WORKSPACE_TOO_SMALL: return "workspace too small (see dd_workspace_floats)";
     case DD_ERR_HIP: return "HIP launch/runtime error";
   }

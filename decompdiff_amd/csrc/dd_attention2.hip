@@ -1018,13 +1018,18 @@ int launch_attn2(int mode, const AttnArgs& a, hipStream_t st) {
   using namespace v2;
   const int N = a.NP + a.NL;
   const bool small = a.NL <= 33;                     // NL-1 <= 32 members -> 2 tiles
+  const bool big = a.NL > 65;                        // up to 128 ligand atoms: 8 tiles (register spills accepted: rare sizes)
+  if (a.NL > 129) return DD_ERR_UNSUPPORTED_SHAPE;
   switch (mode) {
     case M_NE: return launch_mode<M_NE, 2, 8>(a, a.B * v2::ne_blocks_per_sample(a.NP, a.NL, 8) * 8, st);   // (blocks * NW)
     case M_PE: return launch_mode<M_PE, 2, 8>(a, a.B * a.NL, st);
-    case M_NB: return small ? launch_mode<M_NB, 2, 8>(a, a.B * a.NL, st) : launch_mode<M_NB, 4, 8>(a, a.B * a.NL, st);
-    case M_PB: return small ? launch_mode<M_PB, 2, 8>(a, a.B * a.NL, st) : launch_mode<M_PB, 4, 8>(a, a.B * a.NL, st);
+    case M_NB: return small ? launch_mode<M_NB, 2, 8>(a, a.B * a.NL, st)
+                            : (big ? launch_mode<M_NB, 8, 8>(a, a.B * a.NL, st) : launch_mode<M_NB, 4, 8>(a, a.B * a.NL, st));
+    case M_PB: return small ? launch_mode<M_PB, 2, 8>(a, a.B * a.NL, st)
+                            : (big ? launch_mode<M_PB, 8, 8>(a, a.B * a.NL, st) : launch_mode<M_PB, 4, 8>(a, a.B * a.NL, st));
     case M_BL: return small ? launch_mode<M_BL, 2, 8>(a, a.B * a.NL * (a.NL - 1), st)
-                            : launch_mode<M_BL, 4, 8>(a, a.B * a.NL * (a.NL - 1), st);
+                            : (big ? launch_mode<M_BL, 8, 8>(a, a.B * a.NL * (a.NL - 1), st)
+                                   : launch_mode<M_BL, 4, 8>(a, a.B * a.NL * (a.NL - 1), st));
   }
   return DD_ERR_BAD_ARG;
 }
@@ -1084,7 +1089,8 @@ static int launch_node_nw(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs
   return DD_OK;
 }
 int launch_attn2_node(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs& bl, hipStream_t st) {
-  if (ne.NL > 65) return DD_ERR_UNSUPPORTED_SHAPE;
+  if (ne.NL > 129) return DD_ERR_UNSUPPORTED_SHAPE;
+  if (ne.NL > 65) return launch_node_nw<8, 8>(ne, nb, bl, st);    // 65 .. 128 members per segment: 8 tiles (spills: rare sizes)
   if (ne.NL > 49) return launch_node_nw<8, 4>(ne, nb, bl, st);    // up to 64 members per segment: 4 tiles
   if (ne.NL > 33) return launch_node_nw<8, 3>(ne, nb, bl, st);    // up to 48 members: 3 tiles (fewer live registers than 4)
   return launch_node_nw<8, 2>(ne, nb, bl, st);             // (12- and 16-wave workgroups were tried: register spills)
@@ -1093,6 +1099,16 @@ template <int NW>
 static int launch_pos_nw(const AttnArgs& pe, const AttnArgs& pb, hipStream_t st) {
   using namespace v2;
   const int n = (pe.B * pe.NL + NW - 1) / NW;
+  if (pe.NL > 65) {                                    // 8 tiles: the weights' hand-over buffer fits the LDS for NW <= 4 only
+    if constexpr (NW <= 4) {
+      if (pe.nl_real != nullptr) hipLaunchKernelGGL((k_attn2_pos<8, NW, true>), dim3(2 * n), dim3(NW * 128), 0, st, pe, pb, n);
+      else hipLaunchKernelGGL((k_attn2_pos<8, NW>), dim3(2 * n), dim3(NW * 128), 0, st, pe, pb, n);
+      DD_CHECK_LAUNCH();
+      return DD_OK;
+    } else {
+      return DD_ERR_UNSUPPORTED_SHAPE;
+    }
+  }
   if (pe.nl_real != nullptr) {
     if (pe.NL > 49) hipLaunchKernelGGL((k_attn2_pos<4, NW, true>), dim3(2 * n), dim3(NW * 128), 0, st, pe, pb, n);
     else if (pe.NL > 33) hipLaunchKernelGGL((k_attn2_pos<3, NW, true>), dim3(2 * n), dim3(NW * 128), 0, st, pe, pb, n);
@@ -1105,7 +1121,8 @@ static int launch_pos_nw(const AttnArgs& pe, const AttnArgs& pb, hipStream_t st)
 }
 int g_pos_waves = 4;         // waves per workgroup of the fused coordinate launch: 2, 4 or 8
 int launch_attn2_pos(const AttnArgs& pe, const AttnArgs& pb, hipStream_t st) {
-  if (pe.NL > 65) return DD_ERR_UNSUPPORTED_SHAPE;
+  if (pe.NL > 129) return DD_ERR_UNSUPPORTED_SHAPE;
+  if (pe.NL > 65 && g_pos_waves > 4) return launch_pos_nw<4>(pe, pb, st);
   if (g_pos_waves == 2) return launch_pos_nw<2>(pe, pb, st);
   if (g_pos_waves == 4) return launch_pos_nw<4>(pe, pb, st);
   return launch_pos_nw<8>(pe, pb, st);

@@ -177,8 +177,9 @@ __global__ void k_reset_run_state(int32_t* rs, int t_start, uint32_t seed_lo, ui
 // ------------------------------------------------------------------------------ drift: armsca
 // Per sample: d_arm = min over (arm atom a in arm, scaffold atom s) |x_a - x_s|;
 // loss = sum_b mean_arms( relu(min_d - d) + relu(d - max_d) ) / B       (guidance_funcs.py:50-78)
-// One workgroup (64 threads) per sample; NL <= 64.
-__global__ __launch_bounds__(64) void k_drift_armsca(const float* __restrict__ pos, const int32_t* __restrict__ decomp,
+// One workgroup per sample: 64 threads (NL <= 64: one wave, the reduction stays in registers) or 128 (NL <= 128: the two
+// waves' winners meet in LDS).
+__global__ __launch_bounds__(DD_NL_MAX) void k_drift_armsca(const float* __restrict__ pos, const int32_t* __restrict__ decomp,
                                                      int B, int NL, float min_d, float max_d, float* __restrict__ grad,
                                                      int accumulate, int norm_B) {
   __shared__ float px[DD_NL_MAX], py[DD_NL_MAX], pz[DD_NL_MAX];
@@ -224,8 +225,18 @@ __global__ __launch_bounds__(64) void k_drift_armsca(const float* __restrict__ p
         const int w2 = __shfl_xor(who, off);
         if (k2 < key || (k2 == key && w2 < who)) { key = k2; who = w2; }
       }
+      int ba = __shfl(bca, who & 63);                      // this wave's winner and its arm atom
+      if (blockDim.x > 64) {                               // 65 .. 128 ligand atoms: second wave's winner through LDS
+        __shared__ unsigned wk[2];
+        __shared__ int ww[2], wa[2];
+        __syncthreads();                                   // (previous arm's readers are done)
+        if ((l & 63) == 0) { wk[l >> 6] = key; ww[l >> 6] = who; wa[l >> 6] = ba; }
+        __syncthreads();
+        const int pick = (wk[1] < wk[0] || (wk[1] == wk[0] && ww[1] < ww[0])) ? 1 : 0;
+        key = wk[pick]; who = ww[pick]; ba = wa[pick];
+      }
       const float best = __uint_as_float(key);
-      const int bs = who, ba = __shfl(bca, who);
+      const int bs = who;
       if (l == 0 && ba >= 0) {
         float coef = 0.f;
         if (min_d - best > 0.f) coef -= 1.f;
@@ -560,7 +571,7 @@ __global__ __launch_bounds__(256) void k_debug_philox(uint64_t seed, int step, l
 }
 int launch_drift_armsca(const float* lig_pos, const int32_t* decomp_index, int B, int NL, float min_d, float max_d,
                         float* grad, int accumulate, int norm_B, hipStream_t st) {
-  hipLaunchKernelGGL(k_drift_armsca, dim3(B), dim3(64), 0, st, lig_pos, decomp_index, B, NL, min_d, max_d, grad, accumulate,
+  hipLaunchKernelGGL(k_drift_armsca, dim3(B), dim3(NL > 64 ? 128 : 64), 0, st, lig_pos, decomp_index, B, NL, min_d, max_d, grad, accumulate,
                      norm_B > 0 ? norm_B : B);
   DD_CHECK_LAUNCH();
   return DD_OK;

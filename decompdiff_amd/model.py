@@ -294,7 +294,7 @@ class DecompScorePosNet3D(nn.Module):
             B = int(bp.max().item()) + 1
             n_p = torch.bincount(bp, minlength=B).cpu()
             n_l = torch.bincount(bl, minlength=B).cpu()
-            fits = int((n_p + n_l).min()) - 1 >= int(self.config.knn) and int(n_l.min()) >= 2 and int(n_l.max()) <= 64 \
+            fits = int((n_p + n_l).min()) - 1 >= int(self.config.knn) and int(n_l.min()) >= 2 and int(n_l.max()) <= 128 \
                 and int(n_p.max()) + int(n_l.max()) <= 1024
             if fits:
                 return self._sample_padded(kw, ligand_atom_mask, num_steps, center_pos_mode, energy_drift_opt, noise, seed,
@@ -529,8 +529,8 @@ class DecompScorePosNet3D(nn.Module):
             exp_p, exp_l, exp_fc = self._expected_layout(B, NP, NL, dev)
             if not (torch.equal(batch_protein, exp_p) and torch.equal(batch_ligand, exp_l)):
                 raise NotImplementedError("batch vectors must be sorted with equal counts per sample (PyG Batch order)")
-        if NL < 2 or NL > 64:
-            raise NotImplementedError(f"ligand size {NL} outside the supported range [2, 64]")
+        if NL < 2 or NL > 128:
+            raise NotImplementedError(f"ligand size {NL} outside the supported range [2, 128]")
         if NP + NL > 1024:
             raise NotImplementedError("more than 1024 atoms per sample")
         # the fused kernels use the closed-form fc layout of FeaturizeLigandBond('fc') (utils/transforms.py:331-337)

@@ -441,6 +441,11 @@ def main():
             ref_c = ref_shims.load_reference_model(cfg.to_dict(), sd_c, ligand_dim=nc + 2, num_classes=nc)
             gen_traj(ref_c, sd_c, cfg, "traj4_" + tag, synth.make_pocket_small(9), 2, 4, DRIFT, 2050 + nc, std_scale=[1.0, 0.9],
                      num_classes=nc)
+    if want("nl80"):
+        # a ligand beyond 64 atoms (num_atoms_mode ref_large / stat can produce them; the reference has no size limit,
+        # uni_transformer_edge.py:103-123,349-359): 120 + 80 atoms, batch of 2, 3 reverse steps with drift -- the 8-tile kernels
+        gen_traj(ref, sd, cfg, "traj3_nl80", synth.make_pocket(13, 120, (27, 27), 26, num_full_protein=300), 2, 3, DRIFT, 2061,
+                 std_scale=[1.0, 0.9])
     if want("large"):
         # configs[4] size (600 + 60 atoms) with drift guidance, batch of 2
         gen_traj(ref, sd, cfg, "traj3_large_drift", synth.make_pocket_large(6), 2, 3, DRIFT, 2032, std_scale=[1.0, 0.9])

@@ -188,6 +188,17 @@ def test_config4_large_pocket_drift_reference_golden():
     _check_chain("configs[4] size (NP=600, NL=60, B=2, drift)", r, g, 3)
 
 
+def test_ligand_beyond_64_atoms_reference_golden():
+    """A ligand of 80 atoms (num_atoms_mode ref_large / stat can exceed 64; the reference has no size limit,
+    uni_transformer_edge.py:103-123,349-359): 120 + 80 atoms, B = 2, armsca + clash drift, 3 reverse steps against the
+    reference's own output (oracle/make_golden.py --only nl80) -- the 8-tile variants of the segment kernels (79 bond members,
+    78 triplet members) and the two-wave arm-scaffold drift kernel."""
+    g, b, noise = _fixture_chain("traj3_nl80", synth.make_pocket(13, 120, (27, 27), 26, num_full_protein=300), 2, [1.0, 0.9])
+    assert b["init_ligand_pos"].shape[0] == 2 * 80
+    r = _sample_hip(model(0), b, 3, json.loads(str(g["drift"])), noise)
+    _check_chain("NL = 80 (NP=120, B=2, drift)", r, g, 3)
+
+
 def test_large_pocket_batch8_matches_batch2_rows():
     """C-large at the bench's batch size (B=8, where the persistent bond-layer split applies): rows of samples 0-1 equal the
     B=2 run bit for bit (sharding property at this size), everything finite."""

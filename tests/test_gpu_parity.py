@@ -221,11 +221,14 @@ def test_forward_intermediates_vs_dense_spec():
 
 @pytest.mark.parametrize("np_,arms,sca,B", [(600, (15, 15), 30, 1), (40, (2, 2), 2, 3), (20, (1, 1), 1, 2), (120, (5, 0), 3, 2),
                                             (60, (6, 5), 6, 2), (60, (6, 6), 6, 2), (100, (11, 11), 11, 2), (100, (11, 11), 12, 1),
-                                            (150, (15, 15), 15, 1), (80, (21, 21), 22, 1), (30, (1,), 1, 2), (1000, (8, 8), 8, 1)])
+                                            (150, (15, 15), 15, 1), (80, (21, 21), 22, 1), (30, (1,), 1, 2), (1000, (8, 8), 8, 1),
+                                            (60, (21, 21), 23, 1), (60, (22, 22), 22, 2), (50, (32, 32), 33, 1), (40, (42, 43), 43, 1)])
 def test_forward_vs_oracle_other_shapes(np_, arms, sca, B):
     """C-large, tiny graphs with fewer than 32 candidates (K = N-1), NL = 3, an empty arm, and the tile boundaries of the
     segment kernels: NL = 17 / 18 (15 / 16 triplet members: one tile), 33 / 34 (last size of the 2-tile kernels / first
-    of the 4-tile ones), 45 (3 of 4 tiles used), 64 (largest supported ligand), NL = 2 (bonds without any triplet), and the largest supported graph (1000 + 24 = 1024 atoms per sample)."""
+    of the 4-tile ones), 45 (3 of 4 tiles used), 64 (last size of the 4-tile kernels), NL = 2 (bonds without any triplet), the
+    largest supported graph (1000 + 24 = 1024 atoms per sample), and the 8-tile kernels for ligands beyond 64 atoms: NL = 65 / 66
+    (64 members = 4 full tiles / the first member of a fifth), 97 (tiles 6 -> 7) and 128 (largest supported ligand)."""
     cfg, sd = GU.weights(0)
     arms = tuple(a for a in arms)
     pocket = synth.make_pocket(11, np_, arms, sca, num_full_protein=np_ + 10)
@@ -812,6 +815,9 @@ def test_unsupported_inputs_fail_loudly():
     with pytest.raises(ValueError):
         _sample_hip(m, b, 1, [dict(type="nonsense")], None)
     big = synth.build_sampling_batch(synth.make_pocket(1, 1001, (8, 8), 8, num_full_protein=1100), 1)     # 1025 atoms
+    with pytest.raises(NotImplementedError):
+        _sample_hip(m, big, 1, None, None)
+    big = synth.build_sampling_batch(synth.make_pocket(1, 40, (43, 43), 43, num_full_protein=60), 1)        # 129 ligand atoms
     with pytest.raises(NotImplementedError):
         _sample_hip(m, big, 1, None, None)
     bad = dict(b)

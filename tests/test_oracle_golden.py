@@ -122,7 +122,8 @@ def _pocket_for(name):
             "traj3_b16": synth.make_pocket(7, 347, (9, 9), 19, num_full_protein=0),
             "traj3_b8_plain": synth.make_pocket_small(8), "traj3_b8_drift": synth.make_pocket_small(8),
             "traj4_aromatic13": synth.make_pocket_small(9), "traj4_full23": synth.make_pocket_small(9),
-            "traj3_large_drift": synth.make_pocket_large(6)}[name]
+            "traj3_large_drift": synth.make_pocket_large(6),
+            "traj3_nl80": synth.make_pocket(13, 120, (27, 27), 26, num_full_protein=300)}[name]
 
 
 def test_trajectory_20_steps_plain():
@@ -160,7 +161,7 @@ def test_trajectory_drift_scale_option():
 B8_STD = [1.0, 0.9, 0.8, 1.1, 1.0, 0.95, 1.05, 0.85]
 
 
-@pytest.mark.parametrize("name,std_scale", [("traj3_b16", None), ("traj3_large_drift", [1.0, 0.9]),
+@pytest.mark.parametrize("name,std_scale", [("traj3_b16", None), ("traj3_large_drift", [1.0, 0.9]), ("traj3_nl80", [1.0, 0.9]),
                                             ("traj3_b8_plain", None), ("traj3_b8_drift", B8_STD),
                                             ("traj4_aromatic13", [1.0, 0.9]), ("traj4_full23", [1.0, 0.9])])
 def test_trajectory_bench_config_shapes_first_step(name, std_scale):
