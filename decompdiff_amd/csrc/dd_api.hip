@@ -13,7 +13,7 @@ namespace dd {
 
 // ---- workspace --------------------------------------------------------------------------------
 struct Workspace {
-  float *xa, *xb, *h, *hb, *ew, *P, *PL, *PB, *P2, *PL2, *PB2, *Ek, *Ev, *Rk, *Rv, *q1bl, *qn, *ql, *ql2, *qlnb, *qb, *A, *Anb, *dxe, *dxb, *ga, *gc, *gr;
+  float *xa, *xb, *h, *hb, *ew, *P, *PL, *PB, *P2, *PL2, *PB2, *Ek, *Ev, *Rk, *Rv, *q1bl, *qn, *ql, *ql2, *qlnb, *qb, *A, *Anb, *dxe, *dxb, *ga, *gc, *gr, *h2, *hs;
   int32_t* nbr;
   int32_t* counters;       // [64] work counters of the persistent attention workgroups (one per layer), zeroed per forward
   size_t total;
@@ -55,6 +55,8 @@ static Workspace carve(float* base, int B, int NP, int NL, int K) {
   w.ga = take((size_t)B * NL * 3);
   w.gc = take((size_t)B * NL * 3);
   w.gr = take((size_t)B * NL * 3);
+  w.h2 = take(B * N * 128);                              // ping-pong partner of h / the side stream's own copy of the new h
+  w.hs = take(B * N * 128);                              // (launch schedule with one fork per layer, forward_impl)
   w.counters = reinterpret_cast<int32_t*>(take(DD_NUM_COUNTERS + DD_NUM_FLAGS));   // (+ the layer-tail queue's flag words)
   w.total = off;
   return w;
@@ -137,6 +139,9 @@ static DevCtx& dev_ctx() {
 // build (`python -m decompdiff_amd.build --debug-options` -> lib/libdecompdiff_hip_dbg.so, -DDD_DEBUG_OPTIONS=1, selected
 // with DD_HIP_LIB); in the default library the values below are compile-time constants, the alternative paths are not
 // compiled, and dd_debug_set_option only knows key 0 (one launch per sub-layer: the cross-check).
+#ifndef DD_SIDE_LIN_DEFAULT
+#define DD_SIDE_LIN_DEFAULT 0
+#endif
 #if defined(DD_DEBUG_OPTIONS) && DD_DEBUG_OPTIONS
 #define DD_OPT static int
 #else
@@ -165,6 +170,9 @@ DD_OPT g_pb_early = 1;                     // dd_debug_set_option(17, v): next l
 DD_OPT g_q1_in_gemm = 1;                   // dd_debug_set_option(12, v): bond-layer query hidden row summed inside the query GEMM
 DD_OPT g_l0_tables = 1;                    // dd_debug_set_option(22, v): first layer's projection / query rows gathered from tables
 DD_OPT g_head_fused = 1;                   // dd_debug_set_option(24, v): head of a forward in two launches (0 = four, the cross-check)
+DD_OPT g_side_lin = DD_SIDE_LIN_DEFAULT;   // dd_debug_set_option(27, v): ONE fork per layer -- the side stream forms the new h itself
+                                               // (a second, identical lin_node launch into its own buffer) instead of waiting for the
+                                               // main stream's lin_node, whose launch then has no cross-queue successor
 DD_OPT g_q_in_pos = 1;                     // dd_debug_set_option(9, v): coordinate query MLPs' second layer inside attn_pos
 // (ev_fork / ev_join: [0..7] per layer, [8] graph construction at the head of a forward)
 // DD_SIDE_PRIO: 1 (default) lowest priority for the side stream, 0 default priority, 2 highest
@@ -455,6 +463,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
 
   float* xcur = w.xa;
   float* xnext = w.xb;
+  float* hcur = w.h;                                     // (ping-pong with w.h2 under the one-fork schedule only)
   const long hN = (long)N * 128;
   const bool fused = g_fuse && NL <= g_fused_max_nl && g_dbg_clock == nullptr;
   const bool overlap = fused && g_overlap && g_prof == nullptr && s->num_layers <= 8;
@@ -535,17 +544,20 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     // ---- projections of the old h / h_bond: one launch (the q blocks are the last columns: skipped when fused above).
     //      With the projection-ahead schedule this launch was already issued on the side stream right after the
     //      previous layer's lin_node (it needs h and h_bond only) and is joined before its first consumer.
-    auto launch_batch1 = [&](int ll, hipStream_t sx) -> int { return launch_projections1(s, w, ll, w.h, w.P, sx); };
+    auto launch_batch1 = [&](int ll, hipStream_t sx) -> int { return launch_projections1(s, w, ll, hcur, w.P, sx); };
     // (schedule 2) the same projections in two launches: the bond part only needs h_bond, final once the node
     // attention is done; the node parts need h (lin_node)
-    auto launch_batch1_part = [&](int ll, int part, hipStream_t sx) -> int {
+    // (hsrc: the h the node parts read; lin_dup: the lin_node job that forms it first, one-fork schedule)
+    auto launch_batch1_part = [&](int ll, int part, hipStream_t sx, const float* hsrc, const GemmArgs* lin_dup) -> int {
       if (part == 0) {
-        GemmArgs j[1] = {gemm_args(w.hb, nE, 0, 128, nE, LW(ll, DD_W_b1), LW(ll, DD_b_b1), nullptr, w.PB, nE, 0, 640, 640, 0)};
-        return launch_gemm128_batch(j, 1, sx);
+        GemmArgs j[2] = {gemm_args(w.hb, nE, 0, 128, nE, LW(ll, DD_W_b1), LW(ll, DD_b_b1), nullptr, w.PB, nE, 0, 640, 640, 0),
+                         gemm_args(w.hb, nE, 0, 128, nE, LW(ll, DD_W_b1), LW(ll, DD_b_b1), nullptr, w.PB, nE, 0, 640, 640, 0)};
+        if (lin_dup) { j[1] = j[0]; j[0] = *lin_dup; }     // (the small job first: its consumers are the next launch)
+        return launch_gemm128_batch(j, lin_dup ? 2 : 1, sx);
       }
       GemmArgs j[2] = {
-          gemm_args(w.h, B * N, 0, 128, B * N, LW(ll, DD_W_n1), LW(ll, DD_b_n1), nullptr, w.P, B * N, 0, 640, 640, 0),
-          gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(ll, DD_W_l1), LW(ll, DD_b_l1), nullptr, w.PL, B * NL, 0, 1280, 1280, 0)};
+          gemm_args(hsrc, B * N, 0, 128, B * N, LW(ll, DD_W_n1), LW(ll, DD_b_n1), nullptr, w.P, B * N, 0, 640, 640, 0),
+          gemm_args(hsrc + (long)NP * 128, NL, hN, 128, B * NL, LW(ll, DD_W_l1), LW(ll, DD_b_l1), nullptr, w.PL, B * NL, 0, 1280, 1280, 0)};
       return launch_gemm128_batch(j, 2, sx);
     };
     const bool ahead = overlap && g_sched >= 1;
@@ -554,7 +566,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     const bool two_joins = ahead_b2 && g_sched >= 4;     // g_ev_qb_fork[l]: layer l's projections done (side stream)
     const bool pb_early = g_pb_early && g_lin_with_pb2 && !ahead;   // next layer's bond projections ride with lin_node
     const bool l0_here = l0 && l == 0;                  // this layer's projection / query rows came from the tables
-    if (pb_early && l > 0) DD_TRYP(DD_PROF_GEMM, launch_batch1_part(l, 1, st));
+    if (pb_early && l > 0) DD_TRYP(DD_PROF_GEMM, launch_batch1_part(l, 1, st, hcur, nullptr));
     else if (!(ahead && l > 0) && !l0_here) DD_TRYP(DD_PROF_GEMM, launch_batch1(l, st));
     // ---- queries (second Linear of the q MLPs, LayerNorm+ReLU prologue): one launch.  The bond-layer hidden row is
     //      q_hb[bond] + q_hi[dst atom], summed while the GEMM stages its rows, so this launch depends on the projections
@@ -624,9 +636,24 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     }
     if (ahead_split && l + 1 < s->num_layers && hipEventRecord(g_ev_qa_fork[l + 1], st) != hipSuccess) return DD_ERR_HIP;   // h_bond final
     // ---- h += lin_node(A + A_nb on ligand rows)
+    // One-fork schedule: the new h goes to the ping-pong partner (h_new = h_old + ...), because the side stream forms the same
+    // rows from h_old at the same time (side_lin job below: identical arithmetic, its own output buffer) -- the main stream's
+    // lin_node launch then has no successor on the other queue (every such edge costs the main chain ~5 us, EXPERIMENTS.md R3-2)
+    const bool side_lin = g_side_lin && ahead_split && ahead_b2 && l + 1 < s->num_layers;
+    float* const hold = hcur;
+    GemmArgs lin_dup;
     {
-      GemmArgs g = gemm_args(w.A, B * N, 0, 128, B * N, LW(l, DD_W_lin), LW(l, DD_b_lin), nullptr, w.h, B * N, 0, 128, 128, 1);
+      GemmArgs g = gemm_args(w.A, B * N, 0, 128, B * N, LW(l, DD_W_lin), LW(l, DD_b_lin), nullptr, hcur, B * N, 0, 128, 128, 1);
       g.X2 = w.Anb; g.x2_N = N; g.x2_NP = NP;
+      if (side_lin) {
+        float* hnew = (hcur == w.h) ? w.h2 : w.h;
+        g.Y = hnew; g.acc_src = hold;
+        lin_dup = g; lin_dup.Y = w.hs;
+        hcur = hnew;
+      } else if (hcur != w.h) {                            // last layer after an odd number of moves: the final h lands in w.h
+        g.Y = w.h; g.acc_src = hold;                       // (the side stream's last reader of w.h was joined before this layer's
+        hcur = w.h;                                        //  node attention)
+      }
       if (g_lin_with_pb2) {
         // the bond projections of the coordinate sub-layer only need the new h_bond: they share this launch, so that
         // the launch behind lin_node (projections of the new h) is a third of its former size
@@ -640,12 +667,12 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
         DD_TRYP(DD_PROF_GEMM, launch_gemm128(g, st));
       }
     }
-    if (ahead && l + 1 < s->num_layers && hipEventRecord(g_ev_fork[l + 1], st) != hipSuccess) return DD_ERR_HIP;   // h, h_bond final
+    if (ahead && !side_lin && l + 1 < s->num_layers && hipEventRecord(g_ev_fork[l + 1], st) != hipSuccess) return DD_ERR_HIP;   // h, h_bond final
     // ---- projections of the new h / h_bond: one launch
     {
       GemmArgs j[3] = {
-          gemm_args(w.h, B * N, 0, 128, B * N, LW(l, DD_W_n2), LW(l, DD_b_n2), nullptr, w.P2, B * N, 0, 256, 256, 0),
-          gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, LW(l, DD_W_l2), LW(l, DD_b_l2), nullptr, w.PL2, B * NL, 0, 1024, 1024, 0),
+          gemm_args(hcur, B * N, 0, 128, B * N, LW(l, DD_W_n2), LW(l, DD_b_n2), nullptr, w.P2, B * N, 0, 256, 256, 0),
+          gemm_args(hcur + (long)NP * 128, NL, hN, 128, B * NL, LW(l, DD_W_l2), LW(l, DD_b_l2), nullptr, w.PL2, B * NL, 0, 1024, 1024, 0),
           gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b2), LW(l, DD_b_b2), nullptr, w.PB2, nE, 0, 256, 256, 0)};
       DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, g_lin_with_pb2 ? 2 : 3, st));
     }
@@ -693,9 +720,9 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     if (ahead && l + 1 < s->num_layers) {                // (recorded after the main-stream nodes on purpose)
       if (ahead_split) {
         if (hipStreamWaitEvent(g_side, g_ev_qa_fork[l + 1], 0) != hipSuccess) return DD_ERR_HIP;
-        DD_TRY(launch_batch1_part(l + 1, 0, g_side));
-        if (hipStreamWaitEvent(g_side, g_ev_fork[l + 1], 0) != hipSuccess) return DD_ERR_HIP;
-        DD_TRY(launch_batch1_part(l + 1, 1, g_side));
+        DD_TRY(launch_batch1_part(l + 1, 0, g_side, nullptr, side_lin ? &lin_dup : nullptr));
+        if (!side_lin && hipStreamWaitEvent(g_side, g_ev_fork[l + 1], 0) != hipSuccess) return DD_ERR_HIP;
+        DD_TRY(launch_batch1_part(l + 1, 1, g_side, side_lin ? w.hs : hcur, nullptr));
         if (two_joins && hipEventRecord(g_ev_qb_fork[l + 1], g_side) != hipSuccess) return DD_ERR_HIP;
         if (ahead_b2) DD_TRY(launch_b2(l + 1, g_side));
       } else {
@@ -788,8 +815,10 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
   {
     GemmArgs j[2] = {
         gemm_args(w.hb, (int)(B * Eb), 0, 128, (int)(B * Eb), GW(DD_G_BH_W1), GW(DD_G_BH_b1), nullptr, w.qb, (int)(B * Eb), 0, 128, 128, 0),
-        gemm_args(w.h + (long)NP * 128, NL, hN, 128, B * NL, GW(DD_G_VH_W1), GW(DD_G_VH_b1), nullptr, w.qn, B * NL, 0, 128, 128, 0)};
+        gemm_args(hcur + (long)NP * 128, NL, hN, 128, B * NL, GW(DD_G_VH_W1), GW(DD_G_VH_b1), nullptr, w.qn, B * NL, 0, 128, 128, 0)};
     DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, 2, st));   // (v-head hidden -> qn: ql may still be read by the overlapped pos sub-layer)
+    if (hcur != w.h && hipMemcpyAsync(w.h, hcur, sizeof(float) * (size_t)B * N * 128, hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return DD_ERR_HIP;                                   // (odd number of ping-pong moves: the final h where dd_workspace_view reports it)
   }
   DD_TRY(flush_pos());                                   // last layer's coordinate launch (recorded after the head GEMMs)
   if (pending_join >= 0) {
@@ -1420,6 +1449,7 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 9) { dd::g_q_in_pos = value ? 1 : 0; return DD_OK; }
   if (key == 8) { if (value < 0 || value > 5) return DD_ERR_BAD_ARG; dd::g_sched = value; return DD_OK; }
   if (key == 25) { dd::g_tail_variant = value; return DD_OK; }
+  if (key == 27) { dd::g_side_lin = value ? 1 : 0; return DD_OK; }
   if (key == 7) { dd::g_step_fused = value ? 1 : 0; return DD_OK; }
   if (key == 5) { if (value != 2 && value != 4 && value != 8) return DD_ERR_BAD_ARG; dd::g_pos_waves = value; return DD_OK; }
   if (key == 2) { if (value != 8) return DD_ERR_BAD_ARG; dd::g_attn_waves = value; return DD_OK; }

@@ -69,7 +69,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, float* sm /*>= 
     if (vec_ok && gc + 3 < a.ncols) {
       if (a.bias) { const float4 bb = *reinterpret_cast<const float4*>(a.bias + gc); o[0] += bb.x; o[1] += bb.y; o[2] += bb.z; o[3] += bb.w; }
       if (a.accumulate) {
-        const float4 old = SC1 ? ld4_sc1(a.Y, yoff) : *reinterpret_cast<const float4*>(dst);
+        const float* ab = a.acc_src ? a.acc_src : a.Y;
+        const float4 old = SC1 ? ld4_sc1(ab, yoff) : *reinterpret_cast<const float4*>(ab + yoff);
         o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w;
       }
       if (SC1) st4_sc1(a.Y, yoff, make_float4(o[0], o[1], o[2], o[3]));
@@ -79,7 +80,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, float* sm /*>= 
       for (int e = 0; e < 4; ++e)
         if (gc + e < a.ncols) {
           float x = o[e] + (a.bias ? a.bias[gc + e] : 0.f);
-          if (a.accumulate) x += dst[e];
+          if (a.accumulate) x += (a.acc_src ? a.acc_src + yoff : dst)[e];
           dst[e] = x;
         }
     }

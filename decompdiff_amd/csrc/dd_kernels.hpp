@@ -17,12 +17,13 @@ struct GemmArgs {
   //   X[r] += X2[((r / x2_Eb) * x2_N + (r % x2_Eb) / x2_NLm1) * x2_ld]      (x2_N = ligand atoms per sample here)
   int x2_Eb, x2_NLm1, x2_ld;
   long long* dbg;          // profiling aid: s_memtime phase stamps, 8 per workgroup (single launches only)
+  const float* acc_src;    // accumulate = 1: the addend is read from acc_src (same layout as Y) instead of Y itself (NULL: Y)
 };
 inline GemmArgs gemm_args(const float* X, int x_rows_per_b, long x_stride_b, int ldx, int rows, const float* W,
                           const float* bias, const float* ln, float* Y, int y_rows_per_b, long y_stride_b, int ldy,
                           int ncols, int accumulate) {
   GemmArgs g{X, x_rows_per_b, x_stride_b, ldx, rows, W, bias, ln, Y, y_rows_per_b, y_stride_b, ldy, ncols, accumulate,
-             nullptr, 0, 0, 0, 0, 0, nullptr};
+             nullptr, 0, 0, 0, 0, 0, nullptr, nullptr};
   return g;
 }
 // Persistent layer-tail queue (dd_gemm.hip::k_gemm_tail): jobs in dependency order, counters in the workspace.
