@@ -521,6 +521,115 @@ int launch_gemm128(const GemmArgs& a, hipStream_t st) {
   return DD_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight-gradient GEMM of the training step (nn.Linear backward, dW = dY^T . X):
+//     C[o, i] = sum_r A[r, o] * X[r, i]        A = dY [rows, M] (M <= 128 output channels), X [rows, 128], C [M, 128]
+// The contraction runs over the ROWS (up to ~10^5 edges / triplets) and the output is one 128 x 128 block, the opposite
+// shape of the projection GEMM above: a workgroup takes a slab of `rch` rows, stages 32 rows of A and X per trip in LDS
+// (row-major, pitch 160: the two k halves of a v_mfma_f32_32x32x2_f32 operand fetch hit disjoint bank halves), wave w owns
+// columns 32 w .. 32 w + 31 of X and all MT 32-row tiles of the output, and writes its partial block; k_gemm_tn_reduce adds the
+// slabs in a fixed order (no atomics: bitwise reproducible).  Exact fp32 (k-ordered fmaf chains), like the forward GEMM.
+constexpr int TNP = 160;
+template <int MT>
+__global__ __launch_bounds__(256, 2) void k_gemm_tn(const float* __restrict__ A, int lda, int M, const float* __restrict__ X, int ldx,
+                                                    long rows, int rch, float* __restrict__ part /*[slabs][MT*32][128]*/) {
+  __shared__ __attribute__((aligned(16))) float As[32 * TNP];
+  __shared__ __attribute__((aligned(16))) float Bs[32 * TNP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, hh = lane >> 5;
+  const long r0 = (long)blockIdx.x * rch, r1 = (r0 + rch < rows) ? r0 + rch : rows;
+  f32x16 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+  const bool a_vec = ((lda & 3) == 0) && ((M & 3) == 0) && ((reinterpret_cast<size_t>(A) & 15) == 0);
+  float4 xv[4], av[MT];
+  // the rows of trip rb: requested one trip ahead (they fly while the previous 32 rows are multiplied)
+  auto fetch = [&](long rb) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + k * 256, r = i >> 5, c4 = (i & 31) * 4;
+      const long gr = rb + r;
+      xv[k] = gr < r1 ? *reinterpret_cast<const float4*>(X + gr * ldx + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < MT; ++k) {
+      const int i = tid + k * 256, r = i / (MT * 8), c4 = (i % (MT * 8)) * 4;
+      const long gr = rb + r;
+      av[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gr < r1) {
+        const float* src = A + gr * lda + c4;
+        if (a_vec && c4 + 3 < M) av[k] = *reinterpret_cast<const float4*>(src);
+        else {
+          if (c4 < M) av[k].x = src[0];
+          if (c4 + 1 < M) av[k].y = src[1];
+          if (c4 + 2 < M) av[k].z = src[2];
+          if (c4 + 3 < M) av[k].w = src[3];
+        }
+      }
+    }
+  };
+  fetch(r0);
+  for (long rb = r0; rb < r1; rb += 32) {
+    __syncthreads();                                     // the previous trip's operand reads are done
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + k * 256, r = i >> 5, c4 = (i & 31) * 4;
+      *reinterpret_cast<float4*>(&Bs[r * TNP + c4]) = xv[k];
+    }
+#pragma unroll
+    for (int k = 0; k < MT; ++k) {
+      const int i = tid + k * 256, r = i / (MT * 8), c4 = (i % (MT * 8)) * 4;
+      *reinterpret_cast<float4*>(&As[r * TNP + c4]) = av[k];
+    }
+    __syncthreads();
+    if (rb + 32 < r1) fetch(rb + 32);
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const float b = Bs[(2 * kk + hh) * TNP + 32 * wave + li];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float a = As[(2 * kk + hh) * TNP + 32 * mt + li];
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mt], 0, 0, 0);
+      }
+    }
+  }
+  float* dst = part + (long)blockIdx.x * (MT * 32) * 128;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;   // C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+      dst[(32 * mt + row) * 128 + 32 * wave + li] = acc[mt][r];
+    }
+}
+__global__ __launch_bounds__(256) void k_gemm_tn_reduce(const float* __restrict__ part, int slabs, int mpad, int M, float* __restrict__ out,
+                                                        int ldo, int accumulate) {
+  // 64 output elements per workgroup, the slabs dealt to 4 waves (slab w -> wave w mod 4, ascending), the four partial sums
+  // added in wave order: a fixed association, reproducible bit for bit
+  __shared__ float red[4][64];
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  float s = 0.f;
+  if (e < M * 128) {
+    const int o = e >> 7, i = e & 127;
+    for (int w = q; w < slabs; w += 4) s += part[((long)w * mpad + o) * 128 + i];
+  }
+  red[q][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (q == 0 && e < M * 128) {
+    const float t = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    float* d = out + (long)(e >> 7) * ldo + (e & 127);
+    *d = accumulate ? *d + t : t;
+  }
+}
+
+int gemm_tn_rows_per_slab(long rows) {
+  // ~512 slabs (two resident workgroups on each of the 256 CUs), at least 64 and at most 4096 rows each, whole 32-row trips
+  long rch = ((rows + 511) / 512 + 31) / 32 * 32;
+  if (rch < 64) rch = 64;
+  return (int)rch;
+}
 }  // namespace dd
 
 extern "C" int dd_gemm128(const float* X, int x_rows_per_b, long x_stride_b, int ldx, int rows, const float* W,
@@ -530,4 +639,31 @@ extern "C" int dd_gemm128(const float* X, int x_rows_per_b, long x_stride_b, int
   dd::GemmArgs a = dd::gemm_args(X, x_rows_per_b, x_stride_b, ldx, rows, W, bias, ln, Y, y_rows_per_b, y_stride_b, ldy, ncols, accumulate);
   a.dbg = dd::g_gemm_dbg;
   return dd::launch_gemm128(a, (hipStream_t)stream);
+}
+
+// nn.Linear backward, weight gradient (training step; ATen mm call sites of autograd behind models/common.py:85-105):
+// out[M,128] (+)= A[rows,M]^T . X[rows,128].  `scratch` holds dd_gemm128_tn_scratch_floats(rows, M) floats.
+extern "C" size_t dd_gemm128_tn_scratch_floats(long rows, int M) {
+  if (rows <= 0 || M <= 0 || M > 128) return 0;
+  const int rch = dd::gemm_tn_rows_per_slab(rows);
+  const long slabs = (rows + rch - 1) / rch;
+  const int mt = M <= 32 ? 1 : (M <= 64 ? 2 : 4);
+  return (size_t)slabs * mt * 32 * 128;
+}
+extern "C" int dd_gemm128_tn(const float* A, int lda, int M, const float* X, int ldx, long rows, float* scratch, float* out, int ldo,
+                             int accumulate, void* stream) {
+  if (!A || !X || !scratch || !out || M <= 0 || M > 128 || rows <= 0 || (ldx & 3) != 0 || lda < M || ldo < 128 ||
+      (reinterpret_cast<size_t>(X) & 15) != 0)
+    return DD_ERR_BAD_ARG;
+  const int rch = dd::gemm_tn_rows_per_slab(rows);
+  const int slabs = (int)((rows + rch - 1) / rch);
+  hipStream_t st = (hipStream_t)stream;
+  int mpad;
+  if (M <= 32) { mpad = 32; hipLaunchKernelGGL(dd::k_gemm_tn<1>, dim3(slabs), dim3(256), 0, st, A, lda, M, X, ldx, rows, rch, scratch); }
+  else if (M <= 64) { mpad = 64; hipLaunchKernelGGL(dd::k_gemm_tn<2>, dim3(slabs), dim3(256), 0, st, A, lda, M, X, ldx, rows, rch, scratch); }
+  else { mpad = 128; hipLaunchKernelGGL(dd::k_gemm_tn<4>, dim3(slabs), dim3(256), 0, st, A, lda, M, X, ldx, rows, rch, scratch); }
+  DD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(dd::k_gemm_tn_reduce, dim3((M * 128 + 63) / 64), dim3(256), 0, st, scratch, slabs, mpad, M, out, ldo, accumulate);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
 }

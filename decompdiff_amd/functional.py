@@ -168,8 +168,47 @@ def _prep_scatter(src: torch.Tensor, index: torch.Tensor, dim: int, dim_size: Op
     return x, ptr, n, perm
 
 
+class SegmentPlan:
+    """The checks and the segment pointer of one (index, dim_size) pair, made ONCE (three device -> host round trips and a
+    bincount) for callers that scatter over the same index many times -- a training step uses each of its five index
+    vectors 12-36 times (decompdiff_amd/training.py).  Pass it as `index` to scatter_sum / scatter_mean / scatter_softmax."""
+
+    def __init__(self, index: torch.Tensor, dim_size: Optional[int] = None):
+        hip_lib.require_gpu(index, "index")
+        if index.dim() != 1:
+            raise ValueError("SegmentPlan: 1-D index")
+        E = index.numel()
+        n = int(dim_size) if dim_size is not None else (int(index.max().item()) + 1 if E else 0)
+        if E and (int(index.min().item()) < 0 or int(index.max().item()) >= n):
+            raise IndexError("scatter index out of range")
+        self.perm = None
+        self.index = index
+        if E > 1 and bool((index[1:] < index[:-1]).any().item()):
+            self.index, self.perm = torch.sort(index, stable=True)
+        self.ptr = torch.zeros(n + 1, dtype=torch.int32, device=index.device)
+        if E:
+            self.ptr[1:] = torch.bincount(self.index, minlength=n).cumsum(0)
+        self.n, self.E = n, E
+        self.inv = None
+        if self.perm is not None:
+            self.inv = torch.empty_like(self.perm)
+            self.inv[self.perm] = torch.arange(E, device=index.device)
+
+
+def _prep(src, index, dim, dim_size):
+    """(rows [E,F] fp32 contiguous in segment order, ptr, n, perm) from an index vector or a SegmentPlan."""
+    if isinstance(index, SegmentPlan):
+        hip_lib.require_gpu(src, "src")
+        if src.size(0) != index.E or (dim_size is not None and int(dim_size) != index.n):
+            raise ValueError("SegmentPlan does not match src / dim_size")
+        x = src.detach().to(torch.float32).reshape(index.E, -1)
+        x = (x[index.perm] if index.perm is not None else x).contiguous()
+        return x, index.ptr, index.n, index.perm
+    return _prep_scatter(src, index, dim, dim_size)
+
+
 def _segment_reduce(src, index, dim, dim_size, op, out=None):
-    x, ptr, n, perm = _prep_scatter(src, index, dim, dim_size)
+    x, ptr, n, perm = _prep(src, index, dim, dim_size)
     E, F = x.shape
     ext = torch_ext()
     if ext is not None:
@@ -221,7 +260,7 @@ def scatter_max(src: torch.Tensor, index: torch.Tensor, dim: int = -1, out: Opti
 def scatter_softmax(src: torch.Tensor, index: torch.Tensor, dim: int = -1, dim_size: Optional[int] = None) -> torch.Tensor:
     """``torch_scatter.composite.scatter_softmax`` over dim 0: per destination and trailing element, softmax over the rows
     scattered to it (max-shifted, no eps: torch_scatter >= 2.1)."""
-    x, ptr, n, perm = _prep_scatter(src, index, dim if src.dim() > 1 or dim != -1 else 0, dim_size)
+    x, ptr, n, perm = _prep(src, index, dim if src.dim() > 1 or dim != -1 else 0, dim_size)
     E, F = x.shape
     ext = torch_ext()
     res = ext.segment_softmax(x, ptr) if ext is not None else torch.empty_like(x)
@@ -229,7 +268,10 @@ def scatter_softmax(src: torch.Tensor, index: torch.Tensor, dim: int = -1, dim_s
         hip_lib.check(hip_lib.load().dd_segment_softmax(hip_lib.ptr(x), hip_lib.ptr(ptr), n, F, hip_lib.ptr(res),
                                                         hip_lib.stream_ptr(src.device)), "dd_segment_softmax")
     if perm is not None:
-        inv = torch.empty_like(perm)
-        inv[perm] = torch.arange(E, device=perm.device)
+        if isinstance(index, SegmentPlan):
+            inv = index.inv
+        else:
+            inv = torch.empty_like(perm)
+            inv[perm] = torch.arange(E, device=perm.device)
         res = res[inv]
     return res.view(src.shape).to(src.dtype)

@@ -20,6 +20,7 @@ LIB_PATH = os.environ.get("DD_HIP_LIB") or os.path.join(_HERE, "lib", "libdecomp
 # the drop-in boundary: include/decompdiff_hip.h
 EXPORTED_SYMBOLS = [
     "dd_status_string", "dd_abi_version", "dd_build_flags", "dd_workspace_floats", "dd_knn", "dd_edge_weights", "dd_gemm128",
+    "dd_gemm128_tn", "dd_gemm128_tn_scratch_floats",
     "dd_embed_protein", "dd_forward", "dd_sample_steps", "dd_sample_steps_graph", "dd_sample_steps_graph_multi",
     "dd_graph_create", "dd_graph_launch", "dd_graph_destroy",
     "dd_drift_armsca", "dd_drift_clash", "dd_drift_arms_repul",
@@ -106,6 +107,9 @@ def load():
     lib.dd_edge_weights.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 7
     lib.dd_gemm128.argtypes = [c_void_p, c_int, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                c_long, c_int, c_int, c_int, c_void_p]
+    lib.dd_gemm128_tn_scratch_floats.restype = c_size_t
+    lib.dd_gemm128_tn_scratch_floats.argtypes = [c_long, c_int]
+    lib.dd_gemm128_tn.argtypes = [c_void_p, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_void_p, c_int, c_int, c_void_p]
     lib.dd_embed_protein.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.dd_forward.argtypes = [POINTER(DDSampler), c_void_p]
     lib.dd_sampler_reset.argtypes = [POINTER(DDSampler), c_void_p]

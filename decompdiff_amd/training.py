@@ -37,46 +37,178 @@ H, NH = 128, 16
 # --------------------------------------------------------------------------------------------------------------------
 class _ScatterSum(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, src, index, dim_size):
-        ctx.save_for_backward(index)
-        return FN.scatter_sum(src, index, dim=0, dim_size=dim_size)
+    def forward(ctx, src, plan):
+        ctx.plan = plan
+        return FN.scatter_sum(src, plan, dim=0, dim_size=plan.n)
 
     @staticmethod
     def backward(ctx, g):
-        (index,) = ctx.saved_tensors
-        return g.index_select(0, index), None, None
+        return g.index_select(0, ctx.plan.raw), None
 
 
 class _ScatterSoftmax(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, src, index, dim_size):
-        y = FN.scatter_softmax(src, index, dim=0, dim_size=dim_size)
-        ctx.save_for_backward(y, index)
-        ctx.dim_size = dim_size
+    def forward(ctx, src, plan):
+        y = FN.scatter_softmax(src, plan, dim=0, dim_size=plan.n)
+        ctx.save_for_backward(y)
+        ctx.plan = plan
         return y
 
     @staticmethod
     def backward(ctx, g):
-        y, index = ctx.saved_tensors
+        (y,) = ctx.saved_tensors
         yg = y * g
-        return yg - y * FN.scatter_sum(yg, index, dim=0, dim_size=ctx.dim_size).index_select(0, index), None, None
+        return yg - y * FN.scatter_sum(yg, ctx.plan, dim=0, dim_size=ctx.plan.n).index_select(0, ctx.plan.raw), None
 
 
-def scatter_sum(src, index, dim_size):
-    return _ScatterSum.apply(src, index, dim_size)
+class _Gather(torch.autograd.Function):
+    """rows = table[plan.raw]; the backward is a segment sum on the HIP kernel (ATen's index_select backward is an atomic
+    index_add_, advanced indexing a sort-based index_put: 17 + 10 ms of a 105 ms step before)."""
+
+    @staticmethod
+    def forward(ctx, table, plan):
+        ctx.plan = plan
+        ctx.rows = table.size(0)
+        return table.index_select(0, plan.raw)
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.rows != ctx.plan.n:
+            raise RuntimeError("gather plan built for another table height")
+        return FN.scatter_sum(g.contiguous(), ctx.plan, dim=0, dim_size=ctx.plan.n), None
 
 
-def scatter_softmax(src, index, dim_size):
-    return _ScatterSoftmax.apply(src, index, dim_size)
+def seg_plan(index, dim_size):
+    """One SegmentPlan per (index vector, table height) and network call: checks, sort (if needed) and segment pointers once."""
+    plan = FN.SegmentPlan(index, dim_size)
+    plan.raw = index
+    return plan
+
+
+def scatter_sum(src, plan, dim_size=None):
+    return _ScatterSum.apply(src, plan)
+
+
+def scatter_softmax(src, plan, dim_size=None):
+    return _ScatterSoftmax.apply(src, plan)
+
+
+def gather(table, plan):
+    return _Gather.apply(table, plan)
+
+
+class _Linear128(torch.autograd.Function):
+    """y = x W^T + b for K = 128 inputs on the library's own fp32 MFMA GEMMs, forward and backward: dd_gemm128 for y and for
+    dX = dY W (the transposed weight as its W operand; 128 outputs), dd_gemm128_tn for dW = dY^T X (row slabs reduced in a fixed
+    order).  No ATen GEMM behind the hidden-width layers of the training step (models/common.py:85-105)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        lib = hip_lib.load()
+        xc = x.contiguous()
+        Wc = W.contiguous()
+        rows, out = xc.size(0), Wc.size(0)
+        y = torch.empty(rows, out, device=x.device, dtype=torch.float32)
+        bc = b.contiguous() if b is not None else None
+        hip_lib.check(lib.dd_gemm128(hip_lib.ptr(xc), rows, 0, 128, rows, hip_lib.ptr(Wc), hip_lib.ptr(bc), None, hip_lib.ptr(y), rows, 0,
+                                     out, out, 0, hip_lib.stream_ptr(x.device)), "dd_gemm128")
+        ctx.save_for_backward(xc, Wc)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, Wc = ctx.saved_tensors
+        lib = hip_lib.load()
+        dy = dy.contiguous()
+        rows, out = dy.shape
+        st = hip_lib.stream_ptr(dy.device)
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            if out == 128:
+                Wt = Wc.t().contiguous()                                   # [in = 128 "columns", K = out = 128]
+                dx = torch.empty(rows, 128, device=dy.device, dtype=torch.float32)
+                hip_lib.check(lib.dd_gemm128(hip_lib.ptr(dy), rows, 0, 128, rows, hip_lib.ptr(Wt), None, None, hip_lib.ptr(dx), rows, 0,
+                                             128, 128, 0, st), "dd_gemm128")
+            else:                                                          # narrow heads (16 / 8 / 5 outputs): K is not 128
+                dx = dy @ Wc
+        if ctx.needs_input_grad[1]:
+            dW = torch.empty(out, 128, device=dy.device, dtype=torch.float32)
+            scratch = torch.empty(int(lib.dd_gemm128_tn_scratch_floats(rows, out)), device=dy.device, dtype=torch.float32)
+            hip_lib.check(lib.dd_gemm128_tn(hip_lib.ptr(dy), out, out, hip_lib.ptr(xc), 128, rows, hip_lib.ptr(scratch), hip_lib.ptr(dW),
+                                            128, 0, st), "dd_gemm128_tn")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(0)
+        return dx, dW, db
+
+
+class _LinearFeat(torch.autograd.Function):
+    """y = f W^T for a narrow feature block f [rows, Kf] (Kf = 84 type x Gaussian columns, 20 Gaussians, 13 angle codes) into the
+    128 hidden channels.  The forward is a thin ATen product (K = Kf); the backward -- where the contraction runs over 10^4-10^5
+    rows -- is on the library's kernels: df = dY W through dd_gemm128 (K = 128, Kf columns), dW^T = f^T dY through dd_gemm128_tn."""
+
+    @staticmethod
+    def forward(ctx, f, W):
+        fc, Wc = f.contiguous(), W.contiguous()
+        ctx.save_for_backward(fc, Wc)
+        return fc @ Wc.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        fc, Wc = ctx.saved_tensors
+        lib = hip_lib.load()
+        dy = dy.contiguous()
+        rows, kf = fc.shape
+        st = hip_lib.stream_ptr(dy.device)
+        df = dW = None
+        if ctx.needs_input_grad[0]:
+            Wt = Wc.t().contiguous()                                       # [Kf "columns", K = 128]
+            df = torch.empty(rows, kf, device=dy.device, dtype=torch.float32)
+            hip_lib.check(lib.dd_gemm128(hip_lib.ptr(dy), rows, 0, 128, rows, hip_lib.ptr(Wt), None, None, hip_lib.ptr(df), rows, 0,
+                                         kf, kf, 0, st), "dd_gemm128")
+        if ctx.needs_input_grad[1]:
+            dWt = torch.empty(kf, 128, device=dy.device, dtype=torch.float32)
+            scratch = torch.empty(int(lib.dd_gemm128_tn_scratch_floats(rows, kf)), device=dy.device, dtype=torch.float32)
+            hip_lib.check(lib.dd_gemm128_tn(hip_lib.ptr(fc), kf, kf, hip_lib.ptr(dy), 128, rows, hip_lib.ptr(scratch), hip_lib.ptr(dWt),
+                                            128, 0, st), "dd_gemm128_tn")
+            dW = dWt.t()
+        return df, dW
+
+
+def linear_feat(f, W):
+    """F.linear(f, W) without bias for narrow feature blocks feeding the 128 hidden channels."""
+    if f.dim() != 2 or W.size(0) != 128 or f.size(1) > 128 or f.dtype != torch.float32 or f.size(0) == 0:
+        return F.linear(f, W)
+    return _LinearFeat.apply(f, W)
+
+
+def linear128(x, W, b=None):
+    """F.linear for [rows, 128] inputs through the library's GEMMs (other widths: ATen)."""
+    if x.dim() != 2 or x.size(1) != 128 or W.size(1) != 128 or x.dtype != torch.float32 or W.size(0) > 128 or x.size(0) == 0:
+        return F.linear(x, W, b)
+    return _Linear128.apply(x, W, b)
+
+
+_CONST = {}
+
+
+def _const(values, device, dtype=torch.float32):
+    """Small constant vectors live on the device once per process (a torch.tensor(list, device=...) per call is a blocking
+    host -> device copy: 20 of them per training step before)."""
+    key = (tuple(values), str(device), dtype)
+    t = _CONST.get(key)
+    if t is None:
+        t = _CONST[key] = torch.tensor(list(values), dtype=dtype, device=device)
+    return t
 
 
 def _gauss(d):
-    off = torch.tensor(GAUSS_OFFSETS, dtype=d.dtype, device=d.device)
+    off = _const(GAUSS_OFFSETS, d.device, d.dtype)
     return torch.exp(-0.5 * (d.reshape(-1, 1) - off) ** 2)                # GaussianSmearing, coeff -0.5 (common.py:23)
 
 
 def _angle_code(theta):
-    f = torch.tensor([1.0, 2.0, 3.0, 1.0, 0.5, 1.0 / 3.0], dtype=theta.dtype, device=theta.device)
+    f = _const([1.0, 2.0, 3.0, 1.0, 0.5, 1.0 / 3.0], theta.device, theta.dtype)
     a = theta.unsqueeze(-1)
     return torch.cat([a, torch.sin(a * f), torch.cos(a * f)], -1)           # AngularEncoding (common.py:46-54), 13 wide
 
@@ -88,7 +220,7 @@ class _P:
         self.p = dict(model.named_parameters())
 
     def lin(self, name, x):
-        return F.linear(x, self.p[name + ".weight"], self.p[name + ".bias"])
+        return linear128(x, self.p[name + ".weight"], self.p[name + ".bias"])
 
     def w(self, name):
         return self.p[name + ".weight"]
@@ -105,17 +237,18 @@ class _P:
         return self.mlp_tail(name, self.lin(name + ".net.0", x))
 
 
-def _attention(q_e, k, v, seg, n_seg):
-    """alpha = scatter_softmax((q k / sqrt(d)).sum(-1)); out = scatter_sum(alpha v)  (uni_transformer_edge.py:63-68)."""
+def _attention(q_e, k, v, seg, n_seg=None):
+    """alpha = scatter_softmax((q k / sqrt(d)).sum(-1)); out = scatter_sum(alpha v)  (uni_transformer_edge.py:63-68).
+    `seg`: the SegmentPlan of the destination index."""
     hd = k.shape[1] // NH
     score = (q_e.view(-1, NH, hd) * k.view(-1, NH, hd)).sum(-1) / math.sqrt(hd)
-    alpha = scatter_softmax(score, seg, n_seg)
+    alpha = scatter_softmax(score, seg)
     return alpha
 
 
 def _edge_mlp_pre(P, name, W_off, dst_tab, src_tab, dst, src, extra):
     """first Linear of an edge MLP, factorised: W[:, a:b] applied per node once, gathered per edge."""
-    return dst_tab.index_select(0, dst) + src_tab.index_select(0, src) + extra + P.b(name + ".net.0")
+    return gather(dst_tab, dst) + src_tab.index_select(0, src) + extra + P.b(name + ".net.0")
 
 
 def check_batch_layout(batch_protein, batch_ligand, ligand_fc_bond_index, batch_ligand_bond=None):
@@ -190,6 +323,62 @@ def network_grouped(net, model, protein_pos, protein_v, batch_protein, ligand_po
             "pred_bond": cat("pred_bond", inv_b)}
 
 
+_STRUCT: Dict = {}
+
+
+def _structure(B, NP, NL, K, dev):
+    """Index structure of a dense batch of B samples with NP protein + NL ligand atoms each (static across steps)."""
+    key = (B, NP, NL, K, str(dev))
+    S = _STRUCT.get(key)
+    if S is not None:
+        return S
+    N = NP + NL
+    is_lig = torch.cat([torch.zeros(NP, dtype=torch.bool), torch.ones(NL, dtype=torch.bool)]).repeat(B).to(dev)
+    lig_rows = is_lig.nonzero().squeeze(1)
+    # dst-major fully connected bond list of FeaturizeLigandBond('fc') (utils/transforms.py:331-337), per-sample offsets
+    d = torch.arange(NL, device=dev).repeat_interleave(NL - 1)
+    sp = torch.arange(NL - 1, device=dev).repeat(NL)
+    fc1 = torch.stack([sp + (sp >= d).long(), d], 0)
+    fc = torch.cat([fc1 + b * NL for b in range(B)], 1)
+    bond_src, bond_dst = lig_rows[fc[0]], lig_rows[fc[1]]
+    dst = torch.arange(B * N, device=dev).repeat_interleave(K)
+    S = dict(is_lig=is_lig, lig_rows=lig_rows, fc=fc, bond_src=bond_src, bond_dst=bond_dst, dst=dst,
+             dst_is_prot=(~is_lig.index_select(0, dst)).long(), base=(torch.arange(B, device=dev) * N).view(B, 1, 1),
+             p_dst=seg_plan(dst, B * N), p_bdst=seg_plan(bond_dst, B * N), trip=None, p_ji=None)
+    # ---- triplets k -> j -> i over the fully connected ligand bond graph (BondUpdateLayer.triplets, :103-123)
+    NLm1, Ebs = NL - 1, NL * (NL - 1)
+    if NL > 2:
+        e_ji = torch.arange(Ebs, device=dev).repeat_interleave(NL - 2)                  # segment = bond (j -> i), dst-major
+        i_loc, jp = e_ji // NLm1, e_ji % NLm1
+        j_loc = jp + (jp >= i_loc).long()
+        mc = torch.arange(NL - 2, device=dev).repeat(Ebs)
+        lo, hi = torch.minimum(i_loc, j_loc), torch.maximum(i_loc, j_loc)
+        k_loc = mc + (mc >= lo).long()
+        k_loc = k_loc + (k_loc >= hi).long()
+        e_kj = j_loc * NLm1 + (k_loc - (k_loc > j_loc).long())                          # bond (k -> j)
+        boff = (torch.arange(B, device=dev) * Ebs).repeat_interleave(Ebs * (NL - 2))
+        aoff = (torch.arange(B, device=dev) * N + NP).repeat_interleave(Ebs * (NL - 2))
+        rep = lambda t: t.repeat(B)
+        S["trip"] = dict(ji=rep(e_ji) + boff, kj=rep(e_kj) + boff, i=rep(i_loc) + aoff, j=rep(j_loc) + aoff, k=rep(k_loc) + aoff)
+        S["p_ji"] = seg_plan(S["trip"]["ji"], B * Ebs)
+    if len(_STRUCT) >= 8:
+        _STRUCT.pop(next(iter(_STRUCT)))
+    _STRUCT[key] = S
+    return S
+
+
+def _knn_src(x, B, N, K, base):
+    """Sources of the kNN edges (dd_knn; edges grouped by centre in ascending order, neighbours by ascending distance)."""
+    xc = x.to(torch.float32).contiguous()
+    ext = FN.torch_ext()
+    if ext is not None:
+        nbr = ext.knn(xc.view(B, N, 3), K)
+    else:
+        nbr = torch.empty(B, N, K, dtype=torch.int32, device=x.device)
+        hip_lib.check(hip_lib.load().dd_knn(hip_lib.ptr(xc), B, N, K, hip_lib.ptr(nbr), hip_lib.stream_ptr(x.device)), "dd_knn")
+    return (nbr.long() + base).reshape(-1)
+
+
 def network(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, ligand_v_aux, batch_ligand,
             ligand_fc_bond_index, ligand_bond_type) -> Dict[str, torch.Tensor]:
     """DecompScorePosNet3D.forward for the shipped configuration, differentiable w.r.t. the model's parameters.
@@ -209,39 +398,27 @@ def network(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, 
     h_l = torch.cat([P.lin("ligand_atom_emb", lig_feat), torch.ones(B * NL, 1, device=dev)], -1)
     h = torch.cat([h_p.view(B, NP, H), h_l.view(B, NL, H)], 1).reshape(B * N, H)
     x = torch.cat([protein_pos.view(B, NP, 3), ligand_pos.view(B, NL, 3)], 1).reshape(B * N, 3)
-    is_lig = torch.cat([torch.zeros(NP, dtype=torch.bool), torch.ones(NL, dtype=torch.bool)]).repeat(B).to(dev)
-    batch_all = torch.arange(B, device=dev).repeat_interleave(N)
-    lig_rows = is_lig.nonzero().squeeze(1)
-    bond_src, bond_dst = lig_rows[ligand_fc_bond_index[0]], lig_rows[ligand_fc_bond_index[1]]
+    # ---- static index structure of the dense batch shape (context order, bond endpoints, triplets, segment plans): built once
+    #      per (B, NP, NL, K, device) and reused by every step of that shape -- ~150 small index kernels and ~20 device -> host
+    #      round trips per step otherwise
+    S = _structure(B, NP, NL, K, dev)
+    if ligand_fc_bond_index.shape != S["fc"].shape or not torch.equal(ligand_fc_bond_index, S["fc"]):
+        raise NotImplementedError("ligand_fc_bond_index must be the dst-major fully connected graph ('fc' mode)")
+    is_lig, lig_rows, bond_src, bond_dst, dst = S["is_lig"], S["lig_rows"], S["bond_src"], S["bond_dst"], S["dst"]
+    p_dst, p_bdst, p_ji, trip = S["p_dst"], S["p_bdst"], S["p_ji"], S["trip"]
     h_bond = P.lin("ligand_bond_emb", F.one_hot(ligand_bond_type, model.num_bond_classes).float())
     Eb_tot = h_bond.shape[0]
     # ---- graph of the step (uni_transformer_edge.py:404-427): kNN among all atoms of a sample, fixed for all layers
-    edge_index = FN.knn_graph(x.detach(), K, batch_all)
-    src, dst = edge_index[0], edge_index[1]
-    etype = 2 * (~is_lig[src]).long() + (~is_lig[dst]).long()             # 0 ll, 1 l->p(dst p), 2 p->l, 3 pp
+    src = _knn_src(x.detach(), B, N, K, S["base"])
+    etype = 2 * (~is_lig.index_select(0, src)).long() + S["dst_is_prot"]  # 0 ll, 1 l->p(dst p), 2 p->l, 3 pp
     etype_1h = F.one_hot(etype, 4).float()
-    d0 = (x[dst] - x[src]).norm(dim=-1)
+    d0 = (x.index_select(0, dst) - x.index_select(0, src)).norm(dim=-1)
     e_w = torch.sigmoid(P.mlp("refine_net.edge_pred_layer", _gauss(d0)))
-    # ---- triplets k -> j -> i over the fully connected ligand bond graph (BondUpdateLayer.triplets, :103-123)
     NLm1, Ebs = NL - 1, NL * (NL - 1)
-    trip = None
-    if NL > 2:
-        e_ji = torch.arange(Ebs, device=dev).repeat_interleave(NL - 2)                  # segment = bond (j -> i), dst-major
-        i_loc, jp = e_ji // NLm1, e_ji % NLm1
-        j_loc = jp + (jp >= i_loc).long()
-        mc = torch.arange(NL - 2, device=dev).repeat(Ebs)
-        lo, hi = torch.minimum(i_loc, j_loc), torch.maximum(i_loc, j_loc)
-        k_loc = mc + (mc >= lo).long()
-        k_loc = k_loc + (k_loc >= hi).long()
-        e_kj = j_loc * NLm1 + (k_loc - (k_loc > j_loc).long())                          # bond (k -> j)
-        boff = (torch.arange(B, device=dev) * Ebs).repeat_interleave(Ebs * (NL - 2))
-        aoff = (torch.arange(B, device=dev) * N + NP).repeat_interleave(Ebs * (NL - 2))
-        rep = lambda t: t.repeat(B)
-        trip = dict(ji=rep(e_ji) + boff, kj=rep(e_kj) + boff, i=rep(i_loc) + aoff, j=rep(j_loc) + aoff, k=rep(k_loc) + aoff)
     mask_l = is_lig.float().unsqueeze(-1)
     for l in range(int(cfg.num_layers)):
         p = f"refine_net.base_block.{l}"
-        rel = x[dst] - x[src]
+        rel = gather(x, p_dst) - x.index_select(0, src)
         dist = rel.norm(dim=-1)
         g = _gauss(dist)
         ef_type = torch.cat([(etype_1h.unsqueeze(-1) * g.unsqueeze(1)).reshape(-1, 80), etype_1h], -1)      # [E, 84]
@@ -252,8 +429,8 @@ def network(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, 
             for f_ in ("k", "v"):
                 nm = f"{p}.{name}.{'h' if name.startswith('node') else 'x'}{f_}_func"
                 W = P.w(nm + ".net.0")
-                pre = _edge_mlp_pre(P, nm, None, F.linear(hh, W[:, 84:212]), F.linear(hh, W[:, 212:340]), dst, src,
-                                    F.linear(ef_type, W[:, 0:84]))
+                pre = _edge_mlp_pre(P, nm, None, linear128(hh, W[:, 84:212]), linear128(hh, W[:, 212:340]), p_dst, src,
+                                    linear_feat(ef_type, W[:, 0:84]))
                 outs.append(P.mlp_tail(nm, pre))
             return outs
 
@@ -263,42 +440,43 @@ def network(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, 
             for f_ in ("k", "v"):
                 nm = f"{p}.{name}.{'h' if name.startswith('node') else 'x'}{f_}_func"
                 W = P.w(nm + ".net.0")
-                pre = _edge_mlp_pre(P, nm, None, F.linear(hh, W[:, 128:256]), F.linear(hh, W[:, 256:384]), bond_dst, bond_src,
-                                    F.linear(hb, W[:, 0:128]))
+                pre = _edge_mlp_pre(P, nm, None, linear128(hh, W[:, 128:256]), linear128(hh, W[:, 256:384]), p_bdst, bond_src,
+                                    linear128(hb, W[:, 0:128]))
                 outs.append(P.mlp_tail(nm, pre))
             return outs
 
         # node_layer_with_edge (NodeUpdateLayer, :42-74)
         k_e, v_e = node_layer_edge("node_layer_with_edge", h, H)
         q_e = P.mlp(f"{p}.node_layer_with_edge.hq_func", h)
-        alpha = _attention(q_e.index_select(0, dst), k_e, v_e, dst, B * N)
-        a_edge = scatter_sum((alpha.unsqueeze(-1) * (v_e * e_w).view(-1, NH, H // NH)).reshape(-1, H), dst, B * N)
+        alpha = _attention(gather(q_e, p_dst), k_e, v_e, p_dst)
+        a_edge = scatter_sum((alpha.unsqueeze(-1) * (v_e * e_w).view(-1, NH, H // NH)).reshape(-1, H), p_dst)
         # node_layer_with_bond
         k_b, v_b = node_layer_bond("node_layer_with_bond", h, h_bond)
         q_b = P.mlp(f"{p}.node_layer_with_bond.hq_func", h)
-        alpha = _attention(q_b.index_select(0, bond_dst), k_b, v_b, bond_dst, B * N)
-        a_bond = scatter_sum((alpha.unsqueeze(-1) * v_b.view(-1, NH, H // NH)).reshape(-1, H), bond_dst, B * N)
+        alpha = _attention(gather(q_b, p_bdst), k_b, v_b, p_bdst)
+        a_bond = scatter_sum((alpha.unsqueeze(-1) * v_b.view(-1, NH, H // NH)).reshape(-1, H), p_bdst)
         # bond_layer (BondUpdateLayer, :125-167): kv = [h_bond[kj](128), G(d_kj)(20), G(d_ji)(20), angle(13), h[k], h[j]]
         if trip is not None:
             nm_b = f"{p}.bond_layer"
-            d_bond = (x[bond_dst] - x[bond_src]).norm(dim=-1)
+            d_bond = (gather(x, p_bdst) - x.index_select(0, bond_src)).norm(dim=-1)
             gb = _gauss(d_bond)
-            v_ji, v_ki = x[trip["j"]] - x[trip["i"]], x[trip["k"]] - x[trip["i"]]
+            x_i = x.index_select(0, trip["i"])
+            v_ji, v_ki = x.index_select(0, trip["j"]) - x_i, x.index_select(0, trip["k"]) - x_i
             theta = torch.atan2(torch.cross(v_ji, v_ki, dim=-1).norm(dim=-1), (v_ji * v_ki).sum(-1))
             code = _angle_code(theta)
             kv = []
             for f_ in ("hk_func", "hv_func"):
                 W = P.w(f"{nm_b}.{f_}.net.0")
-                per_kj = F.linear(torch.cat([h_bond, gb], -1), W[:, 0:148])                     # h_bond[kj], G(d_kj)
-                per_ji = F.linear(gb, W[:, 148:168])                                             # G(d_ji)
-                pre = per_kj.index_select(0, trip["kj"]) + per_ji.index_select(0, trip["ji"]) + F.linear(code, W[:, 168:181]) \
-                    + F.linear(h, W[:, 181:309]).index_select(0, trip["k"]) + F.linear(h, W[:, 309:437]).index_select(0, trip["j"]) \
+                per_kj = linear128(h_bond, W[:, 0:128]) + linear_feat(gb, W[:, 128:148])                     # h_bond[kj], G(d_kj)
+                per_ji = linear_feat(gb, W[:, 148:168])                                             # G(d_ji)
+                pre = per_kj.index_select(0, trip["kj"]) + gather(per_ji, p_ji) + linear_feat(code, W[:, 168:181]) \
+                    + linear128(h, W[:, 181:309]).index_select(0, trip["k"]) + linear128(h, W[:, 309:437]).index_select(0, trip["j"]) \
                     + P.b(f"{nm_b}.{f_}.net.0")
                 kv.append(P.mlp_tail(f"{nm_b}.{f_}", pre))
             # hq depends on the (j -> i) bond only: evaluated per bond, gathered per triplet (exact)
-            q_bond = P.mlp(f"{nm_b}.hq_func", torch.cat([h_bond, h.index_select(0, bond_dst)], -1))
-            alpha = _attention(q_bond.index_select(0, trip["ji"]), kv[0], kv[1], trip["ji"], Eb_tot)
-            d_hb = scatter_sum((alpha.unsqueeze(-1) * kv[1].view(-1, NH, H // NH)).reshape(-1, H), trip["ji"], Eb_tot)
+            q_bond = P.mlp(f"{nm_b}.hq_func", torch.cat([h_bond, gather(h, p_bdst)], -1))
+            alpha = _attention(gather(q_bond, p_ji), kv[0], kv[1], p_ji)
+            d_hb = scatter_sum((alpha.unsqueeze(-1) * kv[1].view(-1, NH, H // NH)).reshape(-1, H), p_ji)
         else:
             d_hb = torch.zeros_like(h_bond)
         new_h_bond = h_bond + d_hb
@@ -306,13 +484,13 @@ def network(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, 
         # pos_layer_with_edge / pos_layer_with_bond (PosUpdateLayer, :188-210), with the NEW h / h_bond
         k_pe, v_pe = node_layer_edge("pos_layer_with_edge", new_h, NH)
         q_pe = P.mlp(f"{p}.pos_layer_with_edge.xq_func", new_h)
-        alpha = _attention(q_pe.index_select(0, dst), k_pe, None, dst, B * N)
-        dx_e = scatter_sum((alpha * (v_pe * e_w)).unsqueeze(-1) * rel.unsqueeze(1), dst, B * N).mean(1)
+        alpha = _attention(gather(q_pe, p_dst), k_pe, None, p_dst)
+        dx_e = scatter_sum(((alpha * (v_pe * e_w)).unsqueeze(-1) * rel.unsqueeze(1)).reshape(-1, NH * 3), p_dst).view(-1, NH, 3).mean(1)
         k_pb, v_pb = node_layer_bond("pos_layer_with_bond", new_h, new_h_bond)
         q_pb = P.mlp(f"{p}.pos_layer_with_bond.xq_func", new_h)
-        alpha = _attention(q_pb.index_select(0, bond_dst), k_pb, None, bond_dst, B * N)
-        rel_b = x[bond_dst] - x[bond_src]
-        dx_b = scatter_sum((alpha * v_pb).unsqueeze(-1) * rel_b.unsqueeze(1), bond_dst, B * N).mean(1)
+        alpha = _attention(gather(q_pb, p_bdst), k_pb, None, p_bdst)
+        rel_b = gather(x, p_bdst) - x.index_select(0, bond_src)
+        dx_b = scatter_sum(((alpha * v_pb).unsqueeze(-1) * rel_b.unsqueeze(1)).reshape(-1, NH * 3), p_bdst).view(-1, NH, 3).mean(1)
         x = x + (dx_e + dx_b) * mask_l
         h, h_bond = new_h, new_h_bond
     softplus = lambda t: F.softplus(t) - math.log(2.0)                              # ShiftedSoftplus (common.py:66-72)
@@ -364,9 +542,11 @@ def _v_loss(log_model, log_v0, log_true, t, batch, n):
 
 
 def FN_mean(per_row, batch, n):
-    """scatter_mean over samples, differentiable (sum through the HIP scatter, count is constant)."""
-    cnt = torch.bincount(batch, minlength=n).clamp(min=1).to(per_row.dtype)
-    return scatter_sum(per_row.unsqueeze(-1), batch, n).squeeze(-1) / cnt
+    """scatter_mean over samples, differentiable (sum through the HIP scatter, count is constant).  `batch`: index vector
+    or its SegmentPlan."""
+    plan = batch if isinstance(batch, FN.SegmentPlan) else seg_plan(batch, n)
+    cnt = (plan.ptr[1:] - plan.ptr[:-1]).clamp(min=1).to(per_row.dtype)
+    return scatter_sum(per_row.unsqueeze(-1), plan).squeeze(-1) / cnt
 
 
 def sample_time(model, num_graphs, device, method=None):

@@ -193,6 +193,15 @@ int dd_gemm128(const float* X, int x_rows_per_b, long x_stride_b, int ldx, int r
                const float* bias, const float* ln, float* Y, int y_rows_per_b, long y_stride_b, int ldy,
                int ncols, int accumulate, void* stream);
 
+/* nn.Linear backward of the training step (scripts/train_diffusion_decomp.py; the ATen mm calls autograd makes behind
+ * models/common.py:85-105), weight gradient:  out[M,128] (+)= A[rows,M]^T * X[rows,128]  (A = dY, M <= 128 output channels,
+ * row r of A at A + r*lda, of X at X + r*ldx, of out at out + o*ldo).  The input gradient dX = dY * W is dd_gemm128 with the
+ * transposed weight.  fp32 MFMA, slabs of rows reduced in a fixed order (bitwise reproducible, no atomics);
+ * scratch: dd_gemm128_tn_scratch_floats(rows, M) floats. */
+size_t dd_gemm128_tn_scratch_floats(long rows, int M);
+int dd_gemm128_tn(const float* A, int lda, int M, const float* X, int ldx, long rows, float* scratch, float* out, int ldo,
+                  int accumulate, void* stream);
+
 /* Op-level message passing: the torch_scatter pairs of the reference's attention layers as stand-alone ops
  *     alpha = scatter_softmax((q[dst] * k / sqrt(8)).sum(-1), dst, dim=0);  out = scatter_sum(alpha[..., None] * v, dst, dim=0)
  * (uni_transformer_edge.py:63-68 NodeUpdateLayer, :158-164 BondUpdateLayer, :205-211 PosUpdateLayer).  16 heads x 8
