@@ -173,6 +173,7 @@ DD_OPT g_head_fused = 1;                   // dd_debug_set_option(24, v): head o
 DD_OPT g_side_lin = DD_SIDE_LIN_DEFAULT;   // dd_debug_set_option(27, v): ONE fork per layer -- the side stream forms the new h itself
                                                // (a second, identical lin_node launch into its own buffer) instead of waiting for the
                                                // main stream's lin_node, whose launch then has no cross-queue successor
+DD_OPT g_heads_early = 1;                  // dd_debug_set_option(28, v): heads' first Linear in the last layer's projection launch
 DD_OPT g_q_in_pos = 1;                     // dd_debug_set_option(9, v): coordinate query MLPs' second layer inside attn_pos
 // (ev_fork / ev_join: [0..7] per layer, [8] graph construction at the head of a forward)
 // DD_SIDE_PRIO: 1 (default) lowest priority for the side stream, 0 default priority, 2 highest
@@ -522,6 +523,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     }
   }
   int pending_join = -1;
+  bool heads_done = false;
   // (schedule 0) the coordinate launch of layer l is *recorded* after the next layer's projection / query GEMMs: the graph
   // runtime keeps the first-recorded successor of a node on the same hardware queue, and the branch that pays the
   // 10-12 us of cross-queue fork + join latency must be the short one (coordinates), not the GEMM chain
@@ -668,13 +670,23 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
       }
     }
     if (ahead && !side_lin && l + 1 < s->num_layers && hipEventRecord(g_ev_fork[l + 1], st) != hipSuccess) return DD_ERR_HIP;   // h, h_bond final
-    // ---- projections of the new h / h_bond: one launch
+    // ---- projections of the new h / h_bond: one launch.  In the LAST layer the heads' first Linear (decompdiff.py:194-211:
+    //      bond head on the final h_bond, v head on the ligand rows of the final h) rides along: it needs nothing the coordinate
+    //      sub-layers produce, and as a launch of its own behind them it sat on the step's critical chain (8 us per step)
     {
-      GemmArgs j[3] = {
+      GemmArgs j[4] = {
           gemm_args(hcur, B * N, 0, 128, B * N, LW(l, DD_W_n2), LW(l, DD_b_n2), nullptr, w.P2, B * N, 0, 256, 256, 0),
           gemm_args(hcur + (long)NP * 128, NL, hN, 128, B * NL, LW(l, DD_W_l2), LW(l, DD_b_l2), nullptr, w.PL2, B * NL, 0, 1024, 1024, 0),
+          gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b2), LW(l, DD_b_b2), nullptr, w.PB2, nE, 0, 256, 256, 0),
           gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b2), LW(l, DD_b_b2), nullptr, w.PB2, nE, 0, 256, 256, 0)};
-      DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, g_lin_with_pb2 ? 2 : 3, st));
+      int nj = g_lin_with_pb2 ? 2 : 3;
+      if (g_heads_early && g_lin_with_pb2 && l + 1 == s->num_layers) {
+        j[2] = gemm_args(w.hb, nE, 0, 128, nE, GW(DD_G_BH_W1), GW(DD_G_BH_b1), nullptr, w.qb, nE, 0, 128, 128, 0);
+        j[3] = gemm_args(hcur + (long)NP * 128, NL, hN, 128, B * NL, GW(DD_G_VH_W1), GW(DD_G_VH_b1), nullptr, w.qn, B * NL, 0, 128, 128, 0);
+        nj = 4;
+        heads_done = true;
+      }
+      DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, nj, st));
     }
     const bool q_in_pos = g_q_in_pos;           // second layer of the coordinate query MLPs inside attn_pos
     if (!q_in_pos) {
@@ -812,11 +824,13 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     head_join = false;
   }
   // heads, first Linear (decompdiff.py:194-211): v head on ligand rows of h, bond head on h_bond
-  {
+  if (!heads_done) {
     GemmArgs j[2] = {
         gemm_args(w.hb, (int)(B * Eb), 0, 128, (int)(B * Eb), GW(DD_G_BH_W1), GW(DD_G_BH_b1), nullptr, w.qb, (int)(B * Eb), 0, 128, 128, 0),
         gemm_args(hcur + (long)NP * 128, NL, hN, 128, B * NL, GW(DD_G_VH_W1), GW(DD_G_VH_b1), nullptr, w.qn, B * NL, 0, 128, 128, 0)};
     DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, 2, st));   // (v-head hidden -> qn: ql may still be read by the overlapped pos sub-layer)
+  }
+  {
     if (hcur != w.h && hipMemcpyAsync(w.h, hcur, sizeof(float) * (size_t)B * N * 128, hipMemcpyDeviceToDevice, st) != hipSuccess)
       return DD_ERR_HIP;                                   // (odd number of ping-pong moves: the final h where dd_workspace_view reports it)
   }
@@ -1450,6 +1464,7 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 8) { if (value < 0 || value > 5) return DD_ERR_BAD_ARG; dd::g_sched = value; return DD_OK; }
   if (key == 25) { dd::g_tail_variant = value; return DD_OK; }
   if (key == 27) { dd::g_side_lin = value ? 1 : 0; return DD_OK; }
+  if (key == 28) { dd::g_heads_early = value ? 1 : 0; return DD_OK; }
   if (key == 7) { dd::g_step_fused = value ? 1 : 0; return DD_OK; }
   if (key == 5) { if (value != 2 && value != 4 && value != 8) return DD_ERR_BAD_ARG; dd::g_pos_waves = value; return DD_OK; }
   if (key == 2) { if (value != 8) return DD_ERR_BAD_ARG; dd::g_attn_waves = value; return DD_OK; }
