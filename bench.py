@@ -65,8 +65,11 @@ def parse():
                                                     "ranks share one GPU for testing)")
     ap.add_argument("--oversubscribe", action="store_true", help="allow more ranks than visible devices (several ranks share a "
                                                                  "GPU; testing only: n_gpus then reports the DISTINCT devices)")
-    ap.add_argument("--allow-gloo-fallback", action="store_true", help="if RCCL cannot start, run the control plane over gloo "
-                                                                       "instead of failing (the job exchanges no data)")
+    ap.add_argument("--strict-rccl", action="store_true", help="an RCCL group that cannot start is an error (default: the control "
+                                                               "plane -- two barriers, one all-reduce, one gather; the job exchanges no "
+                                                               "data -- then runs over the gloo group and the JSON line says so in "
+                                                               "config.control_plane / control_plane_note)")
+    ap.add_argument("--allow-gloo-fallback", action="store_true", help="(the default since round 4; kept for old command lines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rooflines", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=5, help="steps of the CPU baseline's timed sample (~5.5 s each at B=8)")
@@ -163,9 +166,11 @@ def main():
         ddist.bind_rank_to_local_cpus(dev_index, local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     dev = torch.device("cuda", dev_index)
     backend = args.backend or "nccl"
-    # RCCL on ROCm; no-op for one process.  An RCCL that cannot start is an error unless the fall-back is asked for.
-    distributed = ddist.init_from_env(backend=backend, device_index=dev_index,
-                                      allow_fallback=True if args.allow_gloo_fallback else None)
+    # RCCL on ROCm; no-op for one process.  If RCCL cannot start the control plane stays on gloo, loudly (stderr + the JSON line's
+    # control_plane / control_plane_note) -- a measured line with a visible note is worth more than no line; --strict-rccl or
+    # DD_DIST_STRICT_RCCL=1 makes it an error instead.
+    strict = args.strict_rccl or os.environ.get("DD_DIST_STRICT_RCCL") == "1"
+    distributed = ddist.init_from_env(backend=backend, device_index=dev_index, allow_fallback=not strict)
 
     cfg = shipped_config()
     model = DecompScorePosNet3D(cfg, 29, 10, 8)

@@ -747,6 +747,26 @@ def test_ragged_batch_golden(mode, monkeypatch):
     assert np.array_equal(r["v"].cpu().numpy(), g["out_v"]) and np.array_equal(r["bond"].cpu().numpy(), g["out_bond"])
 
 
+@pytest.mark.parametrize("mode", ["padded", "groups"])
+def test_arms_repul_in_a_ragged_batch_vs_oracle(mode, monkeypatch):
+    """The arms_repul extension on samples of different sizes (padding atoms carry arm id -2 and take no part; the batch mean
+    runs over the whole batch in both launch modes), all three drift terms together, against the oracle."""
+    monkeypatch.setenv("DD_RAGGED_MODE", mode)
+    cfg, sd = GU.weights(0)
+    batch = synth.ragged_demo_batch(77)
+    steps = 3
+    noise = synth.draw_step_noise(steps, batch["init_ligand_pos"].size(0), batch["init_ligand_fc_bond_type"].size(0))
+    drift = [dict(type="armsca_prox", min_d=1.2, max_d=1.9), dict(type="clash", sigma=2, gamma=4),
+             dict(type="arms_repul", max_d=4.0, mode="all")]
+    want = OD.sample_diffusion(sd, cfg, num_steps=steps, energy_drift_opt=drift, noise=noise, **batch)
+    without = OD.sample_diffusion(sd, cfg, num_steps=steps, energy_drift_opt=drift[:2], noise=noise, **batch)
+    got = _sample_hip(model(0), batch, steps, drift, noise)
+    err, effect = maxabs(got["pos"], want["pos"]), maxabs(want["pos"], without["pos"])
+    print(f"arms_repul, ragged ({mode}): pos err {err:.3g}; effect of the term {effect:.3g}")
+    assert effect > 1e-3 and err < POS_TOL
+    assert torch.equal(got["v"].cpu(), want["v"]) and torch.equal(got["bond"].cpu(), want["bond"])
+
+
 def test_harness_ragged_mode_vs_oracle():
     """End to end through the PyG-free harness in a mode whose samples differ in size (beta_prior / 'old':
     sample_diffusion_decomp.py:233-260): the batch built by pocket_data.build_batch (pinned against the reference's

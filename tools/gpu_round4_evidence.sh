@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 O=gpurun_out/r4fin; mkdir -p $O
 sha256sum decompdiff_amd/csrc/dd_attention2.hip | cut -c1-16 > $O/kernel_source_sha256_16.txt
 if [ "$1" != "notests" ]; then
-  python -X faulthandler -m pytest tests -m gpu -q -s > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee $O/pytest.rc
+  python -X faulthandler -m pytest tests -m gpu -q -s --durations=15 > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee $O/pytest.rc
   grep -E "passed|failed|FAILED|Fatal|Error" $O/pytest.log | tail -5
   python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
   # the two B = 8 full chains (and the single-sample ones) on the exact-math build: does v_rsq_f32 / the shared reciprocal move
