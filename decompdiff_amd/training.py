@@ -361,7 +361,7 @@ def _structure(B, NP, NL, K, dev):
         rep = lambda t: t.repeat(B)
         S["trip"] = dict(ji=rep(e_ji) + boff, kj=rep(e_kj) + boff, i=rep(i_loc) + aoff, j=rep(j_loc) + aoff, k=rep(k_loc) + aoff)
         S["p_ji"] = seg_plan(S["trip"]["ji"], B * Ebs)
-    if len(_STRUCT) >= 8:
+    if len(_STRUCT) >= 4:
         _STRUCT.pop(next(iter(_STRUCT)))
     _STRUCT[key] = S
     return S

@@ -767,6 +767,51 @@ def test_arms_repul_in_a_ragged_batch_vs_oracle(mode, monkeypatch):
     assert torch.equal(got["v"].cpu(), want["v"]) and torch.equal(got["bond"].cpu(), want["bond"])
 
 
+@pytest.mark.parametrize("mode", ["padded", "groups"])
+def test_ragged_batch_with_ligands_beyond_64_atoms_vs_oracle(mode, monkeypatch):
+    """Samples of 66 and 72 ligand atoms (and one of 20) in one batch: the padded launch sequence runs the masked 8-tile kernels
+    (real member counts 65 / 71 / 19 inside 8 tiles), the size-group mode the dense 8-tile and 2-tile ones; 2 reverse steps with all
+    three drift terms against the oracle."""
+    monkeypatch.setenv("DD_RAGGED_MODE", mode)
+    cfg, sd = GU.weights(0)
+    pa = synth.make_pocket(51, 44, (22, 22), 22, num_full_protein=100)       # NL = 66
+    pb = synth.make_pocket(52, 40, (24, 24), 24, num_full_protein=100)       # NL = 72
+    pc = synth.make_pocket(53, 50, (6, 6), 8, num_full_protein=100)          # NL = 20
+    torch.manual_seed(5)
+    batch = synth.concat_sampling_batches([synth.build_sampling_batch(p, 1) for p in (pa, pc, pb)])
+    steps = 2
+    noise = synth.draw_step_noise(steps, batch["init_ligand_pos"].size(0), batch["init_ligand_fc_bond_type"].size(0))
+    drift = [dict(type="armsca_prox", min_d=1.2, max_d=1.9), dict(type="clash", sigma=2, gamma=4),
+             dict(type="arms_repul", max_d=2.5, mode="min")]
+    want = OD.sample_diffusion(sd, cfg, num_steps=steps, energy_drift_opt=drift, noise=noise, **batch)
+    got = _sample_hip(model(0), batch, steps, drift, noise)
+    err = maxabs(got["pos"], want["pos"])
+    print(f"ragged, NL = 66 / 20 / 72 ({mode}): pos err {err:.3g}")
+    assert err < POS_TOL
+    assert torch.equal(got["v"].cpu(), want["v"]) and torch.equal(got["bond"].cpu(), want["bond"])
+
+
+def test_arms_repul_gradient_for_a_100_atom_ligand_vs_autograd():
+    """dd_drift_arms_repul with the 128-thread workgroup (ligands beyond 64 atoms) against the oracle's energy under autograd
+    (pinned bit for bit by the reference fixture at smaller sizes)."""
+    lib = hip_lib.load()
+    g = torch.Generator().manual_seed(3)
+    B, NL = 2, 100
+    pos = torch.randn(B * NL, 3, generator=g) * 2.5
+    batch = torch.arange(B).repeat_interleave(NL)
+    dec = torch.tensor(([0] * 30 + [1] * 30 + [2] * 20 + [-1] * 20) * B)
+    xd, dd = pos.to(dev()).contiguous(), dec.to(device=dev(), dtype=torch.int32)
+    for mode, code in (("min", 1), ("all", 2)):
+        x = pos.clone().requires_grad_(True)
+        e, nv = OD.arms_repul_loss(x, batch, dec, 2.2, mode)
+        want = torch.autograd.grad(e, x)[0]
+        out = torch.empty_like(xd)
+        hip_lib.check(lib.dd_drift_arms_repul(hip_lib.ptr(xd), hip_lib.ptr(dd), B, NL, 2.2, code, hip_lib.ptr(out), 0, hip_lib.stream_ptr()),
+                      "dd_drift_arms_repul")
+        torch.cuda.synchronize()
+        assert float(want.abs().max()) > 0 and maxabs(out, want) < 1e-6, (mode, maxabs(out, want))
+
+
 def test_harness_ragged_mode_vs_oracle():
     """End to end through the PyG-free harness in a mode whose samples differ in size (beta_prior / 'old':
     sample_diffusion_decomp.py:233-260): the batch built by pocket_data.build_batch (pinned against the reference's
