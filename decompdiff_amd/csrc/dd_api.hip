@@ -173,6 +173,7 @@ DD_OPT g_head_fused = 1;                   // dd_debug_set_option(24, v): head o
 DD_OPT g_side_lin = DD_SIDE_LIN_DEFAULT;   // dd_debug_set_option(27, v): ONE fork per layer -- the side stream forms the new h itself
                                                // (a second, identical lin_node launch into its own buffer) instead of waiting for the
                                                // main stream's lin_node, whose launch then has no cross-queue successor
+DD_OPT g_head_rows_first = 0;              // dd_debug_set_option(29, v): see the head of forward_impl
 DD_OPT g_heads_early = 1;                  // dd_debug_set_option(28, v): heads' first Linear in the last layer's projection launch
 DD_OPT g_q_in_pos = 1;                     // dd_debug_set_option(9, v): coordinate query MLPs' second layer inside attn_pos
 // (ev_fork / ev_join: [0..7] per layer, [8] graph construction at the head of a forward)
@@ -495,10 +496,14 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
                              parts, num_v(s));
     };
     if (hipEventRecord(g_ev_fork[8], st) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_fork[8], 0) != hipSuccess) return DD_ERR_HIP;
+    // (option 29: the rows launch is RECORDED first -- same dependencies, the fork point is the event above -- so that the graph
+    // runtime, which keeps the first-recorded successor of a node on its hardware queue, leaves the main chain's launch on the
+    // previous step kernel's queue and moves the graph construction, which has slack, to the other one)
+    if (g_head_rows_first) DD_TRYP(DD_PROF_MISC, head(st, 2));
     DD_TRYP(DD_PROF_MISC, head(g_side, 1));
     if (hipEventRecord(g_ev_join[8], g_side) != hipSuccess) return DD_ERR_HIP;
     head_join = true;
-    DD_TRYP(DD_PROF_MISC, head(st, 2));
+    if (!g_head_rows_first) DD_TRYP(DD_PROF_MISC, head(st, 2));
   } else {
     // embeddings + context (decompdiff.py:219-297) and the zeroed work counters: one launch
     DD_TRYP(DD_PROF_MISC, launch_embed_all(s->protein_h, s->protein_pos, s->lig_pos, s->lig_v, s->lig_aux, GW(DD_G_W_lemb),
@@ -1465,6 +1470,7 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 25) { dd::g_tail_variant = value; return DD_OK; }
   if (key == 27) { dd::g_side_lin = value ? 1 : 0; return DD_OK; }
   if (key == 28) { dd::g_heads_early = value ? 1 : 0; return DD_OK; }
+  if (key == 29) { dd::g_head_rows_first = value ? 1 : 0; return DD_OK; }
   if (key == 7) { dd::g_step_fused = value ? 1 : 0; return DD_OK; }
   if (key == 5) { if (value != 2 && value != 4 && value != 8) return DD_ERR_BAD_ARG; dd::g_pos_waves = value; return DD_OK; }
   if (key == 2) { if (value != 8) return DD_ERR_BAD_ARG; dd::g_attn_waves = value; return DD_OK; }
