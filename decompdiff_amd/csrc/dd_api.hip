@@ -986,7 +986,7 @@ extern "C" const char* dd_status_string(int status) {
   switch (status) {
     case DD_OK: return "ok";
     case DD_ERR_BAD_ARG: return "bad argument (null pointer or non-positive size)";
-    case DD_ERR_UNSUPPORTED_SHAPE: return "unsupported shape (NL > 128, N > 1024, K > 32 or K > N-1)";
+    case DD_ERR_UNSUPPORTED_SHAPE: return "unsupported shape (NL > 128, N > 2048, K > 32 or K > N-1)";
     case DD_ERR_WORKSPACE_TOO_SMALL: return "workspace too small (see dd_workspace_floats)";
     case DD_ERR_HIP: return "HIP launch/runtime error";
   }

@@ -10,8 +10,8 @@
 namespace dd {
 
 // ------------------------------------------------------------------------------------ kNN
-// One wave per centre.  Each lane owns candidates c = lane, lane+64, ... (<= 16 per lane,
-// N <= 1024).  Key = (bits(d2) << 32) | index is monotone in (d2, index) because d2 >= 0: the K
+// One wave per centre.  Each lane owns candidates c = lane, lane+64, ... (<= 32 per lane,
+// N <= 2048).  Key = (bits(d2) << 32) | index is monotone in (d2, index) because d2 >= 0: the K
 // smallest keys in ascending order are the neighbours in ascending (distance, index) — the same
 // total order the oracle's stable sort uses.  d2 = (dx*dx + dy*dy) + dz*dz with no FMA contraction.
 // The per-lane candidate count is a template parameter (ceil(N / 64), not the maximum 16).
@@ -551,6 +551,7 @@ int launch_knn(const float* x, int B, int N, int K, int32_t* nbr, hipStream_t st
   else if (cand <= 4) hipLaunchKernelGGL(k_knn<4>, grid, block, 0, st, x, B, N, K, nbr, NP, np_real, nl_real);
   else if (cand <= 6) hipLaunchKernelGGL(k_knn<6>, grid, block, 0, st, x, B, N, K, nbr, NP, np_real, nl_real);
   else if (cand <= 11) hipLaunchKernelGGL(k_knn<11>, grid, block, 0, st, x, B, N, K, nbr, NP, np_real, nl_real);
+  else if (cand <= 16) hipLaunchKernelGGL(k_knn<16>, grid, block, 0, st, x, B, N, K, nbr, NP, np_real, nl_real);
   else hipLaunchKernelGGL(k_knn<DD_N_MAX / 64>, grid, block, 0, st, x, B, N, K, nbr, NP, np_real, nl_real);
   DD_CHECK_LAUNCH();
   return DD_OK;
@@ -607,6 +608,7 @@ int launch_head_all(const float* protein_h, const float* protein_pos, const floa
     else if (cand <= 4) hipLaunchKernelGGL(k_head_graph<4>, grid, block, 0, st, a);
     else if (cand <= 6) hipLaunchKernelGGL(k_head_graph<6>, grid, block, 0, st, a);
     else if (cand <= 11) hipLaunchKernelGGL(k_head_graph<11>, grid, block, 0, st, a);
+    else if (cand <= 16) hipLaunchKernelGGL(k_head_graph<16>, grid, block, 0, st, a);
     else hipLaunchKernelGGL(k_head_graph<DD_N_MAX / 64>, grid, block, 0, st, a);
   }
   DD_CHECK_LAUNCH();

@@ -295,7 +295,7 @@ class DecompScorePosNet3D(nn.Module):
             n_p = torch.bincount(bp, minlength=B).cpu()
             n_l = torch.bincount(bl, minlength=B).cpu()
             fits = int((n_p + n_l).min()) - 1 >= int(self.config.knn) and int(n_l.min()) >= 2 and int(n_l.max()) <= 128 \
-                and int(n_p.max()) + int(n_l.max()) <= 1024
+                and int(n_p.max()) + int(n_l.max()) <= 2048
             if fits:
                 return self._sample_padded(kw, ligand_atom_mask, num_steps, center_pos_mode, energy_drift_opt, noise, seed,
                                            keep_traj, use_graph, start_step, n_p.tolist(), n_l.tolist())
@@ -531,8 +531,8 @@ class DecompScorePosNet3D(nn.Module):
                 raise NotImplementedError("batch vectors must be sorted with equal counts per sample (PyG Batch order)")
         if NL < 2 or NL > 128:
             raise NotImplementedError(f"ligand size {NL} outside the supported range [2, 128]")
-        if NP + NL > 1024:
-            raise NotImplementedError("more than 1024 atoms per sample")
+        if NP + NL > 2048:
+            raise NotImplementedError("more than 2048 atoms per sample")
         # the fused kernels use the closed-form fc layout of FeaturizeLigandBond('fc') (utils/transforms.py:331-337)
         if layout is None and (ligand_fc_bond_index.shape != exp_fc.shape or not torch.equal(ligand_fc_bond_index, exp_fc)):
             raise NotImplementedError("ligand_fc_bond_index must be the dst-major fully connected graph ('fc' mode)")

@@ -32,7 +32,7 @@ extern "C" {
 #define DD_NGAUSS 20
 #define DD_KNN_MAX 32
 #define DD_NL_MAX 128     /* ligand atoms per sample supported by the fused kernels (tile counts 2 / 3 / 4 / 8 of 16 members) */
-#define DD_N_MAX 1024     /* atoms per sample supported by the kNN kernel */
+#define DD_N_MAX 2048     /* atoms per sample supported by the kNN kernel (candidates per lane: 2 / 4 / 6 / 11 / 16 / 32) */
 #define DD_NUM_V 8        /* atom classes of ligand_atom_mode 'basic' (scripts/sample_diffusion_decomp.py:540); dd_sampler.num_v
                              selects 13 ('add_aromatic') or 23 ('full') instead (utils/transforms.py:15-64,138-151) */
 #define DD_NUM_V_MAX 23

@@ -222,12 +222,14 @@ def test_forward_intermediates_vs_dense_spec():
 @pytest.mark.parametrize("np_,arms,sca,B", [(600, (15, 15), 30, 1), (40, (2, 2), 2, 3), (20, (1, 1), 1, 2), (120, (5, 0), 3, 2),
                                             (60, (6, 5), 6, 2), (60, (6, 6), 6, 2), (100, (11, 11), 11, 2), (100, (11, 11), 12, 1),
                                             (150, (15, 15), 15, 1), (80, (21, 21), 22, 1), (30, (1,), 1, 2), (1000, (8, 8), 8, 1),
-                                            (60, (21, 21), 23, 1), (60, (22, 22), 22, 2), (50, (32, 32), 33, 1), (40, (42, 43), 43, 1)])
+                                            (60, (21, 21), 23, 1), (60, (22, 22), 22, 2), (50, (32, 32), 33, 1), (40, (42, 43), 43, 1),
+                                            (1500, (6, 6), 6, 1), (2030, (6, 6), 6, 1)])
 def test_forward_vs_oracle_other_shapes(np_, arms, sca, B):
     """C-large, tiny graphs with fewer than 32 candidates (K = N-1), NL = 3, an empty arm, and the tile boundaries of the
     segment kernels: NL = 17 / 18 (15 / 16 triplet members: one tile), 33 / 34 (last size of the 2-tile kernels / first
     of the 4-tile ones), 45 (3 of 4 tiles used), 64 (last size of the 4-tile kernels), NL = 2 (bonds without any triplet), the
-    largest supported graph (1000 + 24 = 1024 atoms per sample), and the 8-tile kernels for ligands beyond 64 atoms: NL = 65 / 66
+    last graph of the 16-candidates-per-lane kNN kernel (1000 + 24 = 1024 atoms per sample), graphs beyond it (1518 and 2048 atoms:
+    32 candidates per lane), and the 8-tile kernels for ligands beyond 64 atoms: NL = 65 / 66
     (64 members = 4 full tiles / the first member of a fifth), 97 (tiles 6 -> 7) and 128 (largest supported ligand)."""
     cfg, sd = GU.weights(0)
     arms = tuple(a for a in arms)
@@ -879,7 +881,7 @@ def test_unsupported_inputs_fail_loudly():
           ligand_fc_bond_index=b["ligand_fc_bond_index"], init_ligand_fc_bond_type=b["init_ligand_fc_bond_type"])
     with pytest.raises(ValueError):
         _sample_hip(m, b, 1, [dict(type="nonsense")], None)
-    big = synth.build_sampling_batch(synth.make_pocket(1, 1001, (8, 8), 8, num_full_protein=1100), 1)     # 1025 atoms
+    big = synth.build_sampling_batch(synth.make_pocket(1, 2025, (8, 8), 8, num_full_protein=2100), 1)     # 2049 atoms
     with pytest.raises(NotImplementedError):
         _sample_hip(m, big, 1, None, None)
     big = synth.build_sampling_batch(synth.make_pocket(1, 40, (43, 43), 43, num_full_protein=60), 1)        # 129 ligand atoms
