@@ -569,6 +569,12 @@ class DecompScorePosNet3D(nn.Module):
     _CACHE_MAX = int(os.environ.get("DD_CHAIN_CACHE_SIZE", "4"))
     _graph_counter = 0
     _primed_devices: set = set()               # devices whose streamed-trajectory path has run once (_prime_streaming)
+    # Step graphs of finished UNCACHED chains (injected noise: the parity tests) are parked, not destroyed one by one: the HIP
+    # runtime of ROCm 7.2 crashed now and then (hipEventSynchronize / hipStreamBeginCapture, ~1 in 10 runs of the GPU suite) when a
+    # single executable graph was destroyed while others stayed alive and another one was captured right after -- graphs only ever
+    # go away all together, newest first (_drop_cached_graphs), here once _PARK_MAX of them have piled up.
+    _parked_graphs: list = []
+    _PARK_MAX = 12
     _chain_cache: Dict[tuple, dict] = {}      # process-wide (keys carry device and weight arena): ONE destruction order for all graphs
 
     def _evict_chain_cache(self, keep=0):
@@ -579,26 +585,23 @@ class DecompScorePosNet3D(nn.Module):
         cache = getattr(self, "_chain_cache", None)
         if not cache or len(cache) <= keep:
             return
-        lib = hip_lib.load()
-        live = sorted((e for e in cache.values() if e.get("graph") is not None), key=lambda e: -e.get("graph_id", 0))
-        if live:
-            torch.cuda.synchronize(live[0]["dev"])
-        for e in live:
-            lib.dd_graph_destroy(e["graph"])
-            e["graph"] = None
+        self._drop_cached_graphs()
         while len(cache) > keep:
             cache.pop(next(iter(cache)))                  # oldest first (dicts keep insertion order)
 
     def _drop_cached_graphs(self):
-        """Destroy every cached step graph, newest first (see _evict_chain_cache); buffers stay cached."""
+        """Destroy every live step graph -- the cached entries' and the parked ones of finished uncached chains -- newest
+        first and all together (see _evict_chain_cache); buffers stay cached."""
         cache = getattr(self, "_chain_cache", None) or {}
-        live = sorted((e for e in cache.values() if e.get("graph") is not None), key=lambda e: -e.get("graph_id", 0))
+        live = [e for e in cache.values() if e.get("graph") is not None] + DecompScorePosNet3D._parked_graphs
+        live = sorted(live, key=lambda e: -e.get("graph_id", 0))
         if live:
             torch.cuda.synchronize(live[0]["dev"])
         lib = hip_lib.load()
         for e in live:
             lib.dd_graph_destroy(e["graph"])
             e["graph"] = None
+        DecompScorePosNet3D._parked_graphs = []
 
     # Validation / centring of the inputs that do not change between the calls of one sampling job (the pocket, the
     # batch vectors, the bond list).  A call that passes the SAME tensor objects with unchanged version counters reuses
@@ -984,13 +987,35 @@ class DecompScorePosNet3D(nn.Module):
                 and os.environ.get("DD_TRAJ_STREAMING", "1") != "0"):
             return self._run_chain_streaming(chains[0], num_steps)
         if len(chains) == 1 or not use_graph:
-            fn = lib.dd_sample_steps_graph if use_graph else lib.dd_sample_steps
             side = self._side_stream(dev)
             side.wait_stream(cur)
-            with torch.cuda.stream(side):
+            if use_graph and num_steps > 0:
+                # (not dd_sample_steps_graph: that entry point creates AND destroys its graph per call -- see _parked_graphs)
                 for c in chains:
-                    hip_lib.check(fn(ctypes.byref(c["s"]), int(num_steps), hip_lib.stream_ptr(dev)),
-                                  "dd_sample_steps_graph" if use_graph else "dd_sample_steps")
+                    ent = c["ent"]
+                    cached = any(e is ent for e in DecompScorePosNet3D._chain_cache.values())
+                    gsig = (ent["sig"], 1, side.cuda_stream)
+                    if ent.get("graph") is not None and ent["graph_sig"] != gsig:
+                        self._drop_cached_graphs()
+                    if ent.get("graph") is None:
+                        if len(DecompScorePosNet3D._parked_graphs) >= DecompScorePosNet3D._PARK_MAX:
+                            self._drop_cached_graphs()
+                        graph = ctypes.c_void_p()
+                        hip_lib.check(lib.dd_graph_create(ctypes.byref(c["s"]), 1, side.cuda_stream, ctypes.byref(graph)), "dd_graph_create")
+                        ent["graph"], ent["graph_sig"] = graph, gsig
+                        DecompScorePosNet3D._graph_counter += 1
+                        ent["graph_id"] = DecompScorePosNet3D._graph_counter
+                    try:
+                        hip_lib.check(lib.dd_graph_launch(ent["graph"], int(num_steps), side.cuda_stream), "dd_graph_launch")
+                    finally:
+                        side.synchronize()
+                        if not cached:
+                            DecompScorePosNet3D._parked_graphs.append({"graph": ent["graph"], "graph_id": ent["graph_id"], "dev": dev})
+                            ent["graph"] = None
+            else:
+                with torch.cuda.stream(side):
+                    for c in chains:
+                        hip_lib.check(lib.dd_sample_steps(ctypes.byref(c["s"]), int(num_steps), hip_lib.stream_ptr(dev)), "dd_sample_steps")
             cur.wait_stream(side)
             return
         if len(chains) > 64:                            # dd_sample_steps_graph_multi takes at most 64 chains
@@ -1060,6 +1085,8 @@ class DecompScorePosNet3D(nn.Module):
         if ent.get("graph") is not None and ent["graph_sig"] != gsig:      # launch structure changed: capture again
             self._drop_cached_graphs()
         if ent.get("graph") is None:
+            if len(DecompScorePosNet3D._parked_graphs) >= DecompScorePosNet3D._PARK_MAX:
+                self._drop_cached_graphs()                 # (all live graphs, newest first; cached entries re-capture on next use)
             graph = ctypes.c_void_p()
             hip_lib.check(lib.dd_graph_create(ctypes.byref(s), spg, side.cuda_stream, ctypes.byref(graph)), "dd_graph_create")
             ent["graph"], ent["graph_sig"] = graph, gsig
@@ -1115,7 +1142,7 @@ class DecompScorePosNet3D(nn.Module):
             side.synchronize()
             copy_st.synchronize()
             if not cached:                                 # (a cached entry keeps its graph for the next chain)
-                lib.dd_graph_destroy(graph)
+                DecompScorePosNet3D._parked_graphs.append({"graph": graph, "graph_id": ent.get("graph_id", 0), "dev": dev})
                 ent["graph"] = None
         cur.wait_stream(side)
         chain["traj_cpu"] = final
