@@ -1028,6 +1028,9 @@ class DecompScorePosNet3D(nn.Module):
         n = len(chains)
         ss = (ctypes.POINTER(hip_lib.DDSampler) * n)(*[ctypes.pointer(c["s"]) for c in chains])
         sts = (ctypes.c_void_p * n)(*[st.cuda_stream for st in pool])
+        # (the C entry point captures one graph per chain and destroys them at the end: no other graph may be alive across
+        #  that, see _parked_graphs -- cached entries re-capture theirs on next use)
+        self._drop_cached_graphs()
         hip_lib.check(lib.dd_sample_steps_graph_multi(ss, n, int(num_steps), sts), "dd_sample_steps_graph_multi")
         for st in pool:
             cur.wait_stream(st)
