@@ -405,16 +405,24 @@ def run_job(units: List[Unit], config: int, rank: int, world: int, prepare: Call
         barrier(device)
         t0 = time.perf_counter()
         records = []
+        trace = os.environ.get("DD_BENCH_TRACE") == "1"
         for u, st in zip(mine, states):
             t1 = time.perf_counter()
             out = sample(st, steps, u.noise_seed)
+            t2 = time.perf_counter()
+            cs = checksum(out)
             records.append({"unit": u.uid, "rank": rank, "pocket_seed": u.pocket_seed, "n_samples": u.n_samples,
-                            "checksum": checksum(out), "seconds_enqueue": round(time.perf_counter() - t1, 6), "_out": out})
+                            "checksum": cs, "seconds_enqueue": round(time.perf_counter() - t1, 6), "_out": out})
+            if trace:
+                print(f"[trace] unit {u.uid}: since t0 {1e3 * (t1 - t0):.3f} ms, sample {1e3 * (t2 - t1):.3f} ms, checksum "
+                      f"{1e3 * (time.perf_counter() - t2):.3f} ms", file=sys.stderr, flush=True)
         if device is not None and torch.cuda.is_available():
             torch.cuda.synchronize(device)                     # this rank's own work, without the wait for the others
         busy = time.perf_counter() - t0
         barrier(device)
         local = time.perf_counter() - t0
+        if trace:
+            print(f"[trace] busy {1e3 * busy:.3f} ms, local {1e3 * local:.3f} ms", file=sys.stderr, flush=True)
     finally:
         gc.enable()
     elapsed = max_over_ranks(local, device)
