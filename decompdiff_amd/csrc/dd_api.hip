@@ -1433,6 +1433,7 @@ namespace dd { extern int g_gemm_ksplit; extern int g_attn_waves; extern int g_a
 // First bounded spin of the layer-tail hand-offs that gave up (0 = none) since the word was last read (sticky; the
 // workspace must be zero-initialised once): 100+j / 200+j a queue tile of job j, 300/301 assemble, 400 coordinate attention, 500 node attention.
 // Synchronises the stream.  A non-zero code means the launches did not overlap as the schedule assumes (results invalid).
+#if defined(DD_DEBUG_OPTIONS) && DD_DEBUG_OPTIONS          // (the default library has no polling schedule: not exported there)
 extern "C" int dd_queue_error(const dd_sampler* s, void* stream, int* code) {
   if (!s || !s->workspace || !code) return DD_ERR_BAD_ARG;
   dd::Workspace w = dd::carve(s->workspace, s->B, s->NP, s->NL, s->K);
@@ -1444,6 +1445,7 @@ extern "C" int dd_queue_error(const dd_sampler* s, void* stream, int* code) {
   if (v != 0 && hipMemsetAsync(w.counters + dd::DD_NUM_COUNTERS + dd::DD_FLAG_ERR, 0, sizeof(v), (hipStream_t)stream) != hipSuccess) return DD_ERR_HIP;
   return DD_OK;
 }
+#endif
 
 extern "C" int dd_debug_node_split(int B, int NP, int NL, int K) { return dd::node_split_lookup(B, NP, NL, K); }
 

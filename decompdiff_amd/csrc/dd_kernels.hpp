@@ -36,7 +36,11 @@ enum { DD_FLAG_TICKET = 0, DD_FLAG_LIN = 1, DD_FLAG_TICKET2 = 2, DD_FLAG_PL1 = 3
 constexpr int DD_FLAG_LAYERS = 8;
 constexpr int DD_FLAG_STRIDE = 32;
 constexpr int DD_FLAG_ERR = DD_FLAG_LAYERS * DD_FLAGS_PER_LAYER * DD_FLAG_STRIDE;   // first spin that timed out (0 = none); sticky
+#if defined(DD_DEBUG_OPTIONS) && DD_DEBUG_OPTIONS
 constexpr int DD_NUM_FLAGS = DD_FLAG_ERR + DD_FLAG_STRIDE;
+#else
+constexpr int DD_NUM_FLAGS = 0;                                         // the default library's workspace carries no flag words
+#endif
 constexpr int DD_NUM_COUNTERS = 64;                                     // work counters of the persistent attention workgroups
 constexpr int DD_TAIL_CHUNK = 2;                                        // consecutive tiles drawn per ticket
 constexpr int DD_TAIL_MAX_JOBS = 14;

@@ -33,6 +33,8 @@ DEBUG_SYMBOLS = [
     "dd_workspace_view", "dd_profile_step", "dd_debug_set_clock_buffer", "dd_debug_set_fusion", "dd_debug_set_option",
     "dd_debug_node_split", "dd_debug_philox", "dd_debug_options_epoch", "dd_queue_error",
 ]
+# exported by the measurement build only (-DDD_DEBUG_OPTIONS=1): the tile-queue schedule's sticky error word
+MEASUREMENT_ONLY_SYMBOLS = ("dd_queue_error",)
 BUILD_DEBUG_OPTIONS, BUILD_EXACT_MATH = 1, 2          # bits of dd_build_flags()
 
 
@@ -97,52 +99,63 @@ def load():
     lib.dd_status_string.restype = c_char_p
     lib.dd_status_string.argtypes = [c_int]
     lib.dd_abi_version.restype = c_int
-    if lib.dd_abi_version() != ABI_VERSION and os.environ.get("DD_IGNORE_ABI") != "1":     # (A/B timing of older builds)
+    ignore_abi = os.environ.get("DD_IGNORE_ABI") == "1"                                    # (A/B timing of older builds)
+    if lib.dd_abi_version() != ABI_VERSION and not ignore_abi:
         raise HipLibraryError(f"{LIB_PATH} has ABI version {lib.dd_abi_version()}, this package needs {ABI_VERSION}: rebuild it")
-    lib.dd_build_flags.restype = c_int
-    lib.dd_build_flags.argtypes = []
-    lib.dd_workspace_floats.restype = c_size_t
-    lib.dd_workspace_floats.argtypes = [c_int, c_int, c_int, c_int]
-    lib.dd_knn.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
-    lib.dd_edge_weights.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 7
-    lib.dd_gemm128.argtypes = [c_void_p, c_int, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                               c_long, c_int, c_int, c_int, c_void_p]
-    lib.dd_gemm128_tn_scratch_floats.restype = c_size_t
-    lib.dd_gemm128_tn_scratch_floats.argtypes = [c_long, c_int]
-    lib.dd_gemm128_tn.argtypes = [c_void_p, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_void_p, c_int, c_int, c_void_p]
-    lib.dd_embed_protein.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
-    lib.dd_forward.argtypes = [POINTER(DDSampler), c_void_p]
-    lib.dd_sampler_reset.argtypes = [POINTER(DDSampler), c_void_p]
-    lib.dd_layer0_tables.argtypes = [POINTER(DDSampler), c_void_p, c_void_p]
-    lib.dd_layer0_prepare.argtypes = [POINTER(DDSampler), c_void_p]
-    lib.dd_debug_options_epoch.argtypes = []
-    lib.dd_queue_error.argtypes = [POINTER(DDSampler), c_void_p, POINTER(c_int)]
-    lib.dd_sample_steps.argtypes = [POINTER(DDSampler), c_int, c_void_p]
-    lib.dd_sample_steps_graph.argtypes = [POINTER(DDSampler), c_int, c_void_p]
-    lib.dd_graph_create.argtypes = [POINTER(DDSampler), c_int, c_void_p, POINTER(c_void_p)]
-    lib.dd_graph_launch.argtypes = [c_void_p, c_int, c_void_p]
-    lib.dd_graph_destroy.argtypes = [c_void_p]
-    lib.dd_sample_steps_graph_multi.argtypes = [POINTER(POINTER(DDSampler)), c_int, c_int, POINTER(c_void_p)]
-    lib.dd_drift_armsca.argtypes = [c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_int, c_void_p]
-    lib.dd_drift_clash.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p,
-                                   c_int, c_void_p]
-    lib.dd_drift_arms_repul.argtypes = [c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_int, c_void_p]
-    lib.dd_workspace_view.argtypes = [POINTER(DDSampler), POINTER(DDWsView)]
-    lib.dd_debug_set_clock_buffer.argtypes = [c_void_p, c_int]
-    lib.dd_debug_set_fusion.argtypes = [c_int]
-    lib.dd_debug_set_option.argtypes = [c_int, c_int]
-    lib.dd_debug_node_split.argtypes = [c_int, c_int, c_int, c_int]
-    lib.dd_reverse_step.argtypes = [POINTER(DDSampler), c_void_p, c_void_p, c_void_p, c_void_p]
-    lib.dd_attn_aggregate_node.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
-    lib.dd_attn_aggregate_triplet.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
-    lib.dd_attn_aggregate_pos.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
-    lib.dd_segment_reduce.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p]
-    lib.dd_segment_softmax.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
-    lib.dd_debug_philox.argtypes = [c_uint64, c_int, c_long, c_int, c_void_p, c_void_p]
-    lib.dd_profile_step.argtypes = [POINTER(DDSampler), c_int, POINTER(c_float), c_void_p]
+    S = POINTER(DDSampler)
+    # name -> argtypes (restype c_int = status code unless listed in `restypes`)
+    protos = {
+        "dd_build_flags": [],
+        "dd_workspace_floats": [c_int, c_int, c_int, c_int],
+        "dd_knn": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+        "dd_edge_weights": [c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 7,
+        "dd_gemm128": [c_void_p, c_int, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int,
+                       c_int, c_void_p],
+        "dd_gemm128_tn_scratch_floats": [c_long, c_int],
+        "dd_gemm128_tn": [c_void_p, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_void_p, c_int, c_int, c_void_p],
+        "dd_embed_protein": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+        "dd_forward": [S, c_void_p],
+        "dd_sampler_reset": [S, c_void_p],
+        "dd_layer0_tables": [S, c_void_p, c_void_p],
+        "dd_layer0_prepare": [S, c_void_p],
+        "dd_debug_options_epoch": [],
+        "dd_queue_error": [S, c_void_p, POINTER(c_int)],
+        "dd_sample_steps": [S, c_int, c_void_p],
+        "dd_sample_steps_graph": [S, c_int, c_void_p],
+        "dd_graph_create": [S, c_int, c_void_p, POINTER(c_void_p)],
+        "dd_graph_launch": [c_void_p, c_int, c_void_p],
+        "dd_graph_destroy": [c_void_p],
+        "dd_sample_steps_graph_multi": [POINTER(S), c_int, c_int, POINTER(c_void_p)],
+        "dd_drift_armsca": [c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_int, c_void_p],
+        "dd_drift_clash": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_int, c_void_p],
+        "dd_drift_arms_repul": [c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_int, c_void_p],
+        "dd_workspace_view": [S, POINTER(DDWsView)],
+        "dd_debug_set_clock_buffer": [c_void_p, c_int],
+        "dd_debug_set_fusion": [c_int],
+        "dd_debug_set_option": [c_int, c_int],
+        "dd_debug_node_split": [c_int, c_int, c_int, c_int],
+        "dd_reverse_step": [S, c_void_p, c_void_p, c_void_p, c_void_p],
+        "dd_attn_aggregate_node": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
+        "dd_attn_aggregate_triplet": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
+        "dd_attn_aggregate_pos": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
+        "dd_segment_reduce": [c_void_p, c_void_p, c_int, c_int, c_int, c_long, c_void_p, c_void_p, c_void_p],
+        "dd_segment_softmax": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
+        "dd_debug_philox": [c_uint64, c_int, c_long, c_int, c_void_p, c_void_p],
+        "dd_profile_step": [S, c_int, POINTER(c_float), c_void_p],
+    }
+    restypes = {"dd_workspace_floats": c_size_t, "dd_gemm128_tn_scratch_floats": c_size_t}
     for name in EXPORTED_SYMBOLS + DEBUG_SYMBOLS:
-        if name not in ("dd_status_string", "dd_workspace_floats"):
-            getattr(lib, name).restype = c_int
+        if name in ("dd_status_string", "dd_abi_version"):
+            continue
+        if not hasattr(lib, name):
+            # DD_IGNORE_ABI=1 with an older build (tools/ab_builds.py): entry points it lacks raise when CALLED, not at load
+            if ignore_abi or name in MEASUREMENT_ONLY_SYMBOLS:
+                continue
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}: rebuild it")
+        fn = getattr(lib, name)
+        if name in protos:
+            fn.argtypes = protos[name]
+        fn.restype = restypes.get(name, c_int)
     _lib = lib
     return lib
 
@@ -174,4 +187,7 @@ def require_gpu(t: torch.Tensor, name: str):
 def is_measurement_build() -> bool:
     """The loaded library was compiled with -DDD_DEBUG_OPTIONS=1 (lib/libdecompdiff_hip_dbg.so: alternative launch
     schedules behind dd_debug_set_option)."""
-    return bool(load().dd_build_flags() & BUILD_DEBUG_OPTIONS)
+    lib = load()
+    if not hasattr(lib, "dd_build_flags"):               # (an older build loaded with DD_IGNORE_ABI=1)
+        return False
+    return bool(lib.dd_build_flags() & BUILD_DEBUG_OPTIONS)

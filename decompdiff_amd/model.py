@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import time
 from typing import Dict, Optional
 
 import numpy as np
@@ -1115,6 +1116,8 @@ class DecompScorePosNet3D(nn.Module):
                 np.copyto(final_np[k][lo:hi], slots_np[slot][k][:hi - lo], casting="same_kind")
 
         pending = []
+        tr = self.__dict__.get("_trace")                   # tools/bench_call_trace.py: wall-clock stamps, no extra syncs
+        mark = (lambda name: tr.append((name, time.perf_counter()))) if tr is not None else (lambda name: None)
         try:
             # a chain shorter than one chunk is still drained in ~3 pieces: only the last piece's copy is exposed
             piece = min(chunk, max(8, -(-num_steps // 3)))
@@ -1122,7 +1125,9 @@ class DecompScorePosNet3D(nn.Module):
                 piece = max(spg, piece // spg * spg)
             for c, lo in enumerate(range(0, num_steps, piece)):
                 hi = min(num_steps, lo + piece)
+                mark(f"launch{c}<")
                 hip_lib.check(lib.dd_graph_launch(graph, (hi - lo) // spg, side.cuda_stream), "dd_graph_launch")
+                mark(f"launch{c}>")
                 ev = torch.cuda.Event()
                 ev.record(side)
                 copy_st.wait_event(ev)
@@ -1137,13 +1142,17 @@ class DecompScorePosNet3D(nn.Module):
                     tail = ((num_steps - 1) // piece) * piece
                     for k in keys:                     # first touch of the pages the un-hidden last drain writes
                         final_np[k][tail:].fill(0)
+                mark(f"copies{c}>")
                 if len(pending) == 2:
                     drain(pending.pop(0))
+                    mark(f"drained{c - 1}>")
             while pending:
                 drain(pending.pop(0))
+                mark("drained_tail>")
         finally:
             side.synchronize()
             copy_st.synchronize()
+            mark("synced>")
             if not cached:                                 # (a cached entry keeps its graph for the next chain)
                 DecompScorePosNet3D._parked_graphs.append({"graph": graph, "graph_id": ent.get("graph_id", 0), "dev": dev})
                 ent["graph"] = None

@@ -46,8 +46,11 @@ int dd_debug_node_split(int B, int NP, int NL, int K);
  * counters instead of waiting for a graph edge; every poll is bounded (~0.1 s).  *code = 0:
  * no poll gave up since the last forward started; otherwise the id of the first waiter that did (100+j / 200+j a queue
  * tile of job j, 300/301 assemble, 400 coordinate attention, 500 node attention) -- the results of that forward are then
- * invalid.  Synchronises `stream`.  (ABI 7.) */
+ * invalid.  Synchronises `stream`.  (ABI 7.)  Exported by the measurement build ONLY (lib/libdecompdiff_hip_dbg.so,
+ * dd_build_flags() & 1): the default library has neither the schedule nor its flag words in the workspace. */
+#if defined(DD_DEBUG_OPTIONS) && DD_DEBUG_OPTIONS
 int dd_queue_error(const dd_sampler* s, void* stream, int* code);
+#endif
 
 /* Test aid: the production (Philox4x32-10) noise of one step exactly as the step kernels draw it -- kind 1: uniforms
  * [rows,8] of the atom-type stream (transitions.py:79 rand_like), 2: uniforms [rows,5] of the bond-type stream,

@@ -103,7 +103,14 @@ def test_library_loads_and_exports_every_declared_symbol():
         declared = set(re.findall(r"\b(dd_[a-z0-9_]+)\s*\(", hdr))
         assert declared == set(symbols), (header, declared ^ set(symbols))
         for name in declared:
-            assert hasattr(lib, name), name
+            if name in hip_lib.MEASUREMENT_ONLY_SYMBOLS:         # declared under #if DD_DEBUG_OPTIONS: not in the default library
+                assert not hasattr(lib, name), name
+            else:
+                assert hasattr(lib, name), name
+    dbg = ctypes.CDLL(os.path.join(ROOT, "decompdiff_amd", "lib", "libdecompdiff_hip_dbg.so"))
+    assert all(hasattr(dbg, n) for n in hip_lib.MEASUREMENT_ONLY_SYMBOLS) and dbg.dd_build_flags() & 1
+    # size_t results keep their width (a c_int restype would truncate them silently)
+    assert lib.dd_workspace_floats.restype is ctypes.c_size_t and lib.dd_gemm128_tn_scratch_floats.restype is ctypes.c_size_t
     assert not any(n.startswith("dd_debug") or n.startswith("dd_profile") for n in hip_lib.EXPORTED_SYMBOLS)
     assert lib.dd_build_flags() == 0                         # the default library: no measurement variants compiled in
     assert lib.dd_abi_version() == hip_lib.ABI_VERSION == 8

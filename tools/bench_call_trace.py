@@ -27,7 +27,18 @@ if len(sys.argv) < 2 or sys.argv[1] == "1":
     gc.collect(); gc.disable()
 for rep in range(4):
     T.clear()
+    m.__dict__["_trace"] = tr = []
     torch.cuda.synchronize(); t0 = time.perf_counter()
     out = sample(20, u.noise_seed + rep)
     t1 = time.perf_counter(); ddist.checksum(out); torch.cuda.synchronize(); t2 = time.perf_counter()
     print(f"call {rep}: sample {1e3*(t1-t0):.2f} ms + checksum {1e3*(t2-t1):.2f} | " + " | ".join(f"{k} {v:.2f}" for k, v in T))
+    print("    streaming stamps (ms since call start): " + "  ".join(f"{k} {1e3*(t-t0):.2f}" for k, t in tr))
+m.__dict__["_trace"] = None
+# the device's own view: events around the 20 graph replays of a steady call
+for rep in range(2):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    side = m._side_stream(dev)
+    torch.cuda.synchronize(); e0.record(side)
+    out = sample(20, u.noise_seed + 10 + rep)
+    e1.record(side); torch.cuda.synchronize()
+    print(f"side-stream events around the call: {e0.elapsed_time(e1):.2f} ms")
