@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--no-rooflines", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=5, help="steps of the CPU baseline's timed sample (~5.5 s each at B=8)")
     ap.add_argument("--cpu-warmup", type=int, default=1)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default 0: picked by a one-step probe of 16 / 64)")
     return ap.parse_args()
 
 
@@ -221,7 +222,8 @@ def main():
             op_roofline = measure_op_level_roofline(torch, hip_lib, lib, dev)
         cpu = None
         if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(torch, synth, cfg, cpu_batches[u0.uid], DRIFT if u0.drift else None, B, args.cpu_steps, args.cpu_warmup)
+            cpu = cpu_baseline(torch, synth, cfg, cpu_batches[u0.uid], DRIFT if u0.drift else None, B, args.cpu_steps, args.cpu_warmup,
+                               args.cpu_threads)
         wl = {1: "configs[1]: single pocket ref_prior",
               2: "configs[2]: single pocket + armsca_prox/clash drift guidance (batch assembled as ref_prior with unit std "
                  "scales; the beta_prior harness mode only changes the initial state and prior stds, not the per-step work)",
@@ -254,6 +256,9 @@ def main():
             import hashlib
             result["per_unit_digest"] = hashlib.sha256(json.dumps(job["per_unit"], sort_keys=True, default=str).encode()).hexdigest()[:16]
             result["per_unit_checksum_pos_sum"] = round(sum(r["checksum"]["pos"] for r in job["per_unit"]), 6)
+        if world > 1 and ddist.control_backend() != "nccl" and backend == "nccl":
+            result["warning"] = ("RCCL did not start: the control plane (two barriers, one all-reduce of the wall time) ran over gloo; "
+                                 "the data path has no collective, so `value` is unaffected (--strict-rccl makes this an error)")
         if cpu:
             result["config"]["speedup_vs_cpu_baseline"] = round(steps_per_s / cpu["value"], 1)
         print(json.dumps(result), flush=True)
@@ -388,7 +393,7 @@ def measure_op_level_roofline(torch, hip_lib, lib, dev):
         return {"error": str(exc)}
 
 
-def cpu_baseline(torch, synth, cfg, batch_cpu, drift, B, n_cpu, n_warm):
+def cpu_baseline(torch, synth, cfg, batch_cpu, drift, B, n_cpu, n_warm, threads=0):
     """The oracle (the checker; CPU restatement of the reference) timed as the CPU baseline on this host: `n_cpu` steps
     after `n_warm` warm-up steps of the same pocket batch.  Small-op torch CPU code does not scale to 100+ threads, so
     the thread count is picked by a one-step probe of 16 / 64 / all threads first."""
@@ -397,7 +402,7 @@ def cpu_baseline(torch, synth, cfg, batch_cpu, drift, B, n_cpu, n_warm):
     n_cpu, n_warm = max(1, n_cpu), max(1, n_warm)
     ncpu = os.cpu_count() or 1
     probe = {}
-    for nthreads in sorted({min(16, ncpu), min(64, ncpu)}):     # (all 128-256 threads of such a host are slower still: dropped from the probe)
+    for nthreads in ([min(threads, ncpu)] if threads > 0 else sorted({min(16, ncpu), min(64, ncpu)})):     # (all 128-256 threads of such a host are slower still: dropped from the probe)
         torch.set_num_threads(nthreads)
         torch.manual_seed(7)
         OD.sample_diffusion(weights, cfg, num_steps=1, energy_drift_opt=drift, keep_traj=False, **batch_cpu)
@@ -413,7 +418,7 @@ def cpu_baseline(torch, synth, cfg, batch_cpu, drift, B, n_cpu, n_warm):
     rate = n_cpu / (time.perf_counter() - t1)
     return {"value": round(rate, 4), "unit": "denoising steps/s", "cores": best, "kind": "port",
             "sample": f"{n_cpu} steps after {n_warm} warm-up steps of the same pocket batch (B={B}); oracle = CPU restatement of "
-                      f"the reference (torch fp32); threads chosen by a 1-step probe of {sorted(probe)} "
+                      f"the reference (torch fp32); threads {'given (--cpu-threads)' if threads > 0 else 'chosen'} by a 1-step probe of {sorted(probe)} "
                       f"({', '.join(f'{k}: {v:.2f} s/step' for k, v in sorted(probe.items()))}); host has {ncpu} logical CPUs"}
 
 

@@ -55,8 +55,12 @@ static Workspace carve(float* base, int B, int NP, int NL, int K) {
   w.ga = take((size_t)B * NL * 3);
   w.gc = take((size_t)B * NL * 3);
   w.gr = take((size_t)B * NL * 3);
+#if defined(DD_DEBUG_OPTIONS) && DD_DEBUG_OPTIONS          // (measurement build: the one-fork-per-layer schedule, option 27)
   w.h2 = take(B * N * 128);                              // ping-pong partner of h / the side stream's own copy of the new h
-  w.hs = take(B * N * 128);                              // (launch schedule with one fork per layer, forward_impl)
+  w.hs = take(B * N * 128);
+#else
+  w.h2 = w.hs = nullptr;                                 // the shipped schedule never reads them (g_side_lin is the constant 0)
+#endif
   w.counters = reinterpret_cast<int32_t*>(take(DD_NUM_COUNTERS + DD_NUM_FLAGS));   // (+ the layer-tail queue's flag words)
   w.total = off;
   return w;

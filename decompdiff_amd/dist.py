@@ -47,10 +47,12 @@ def init_from_env(backend: str = None, device_index: int = None, allow_fallback:
     (= RCCL; the default on a GPU box) a second group over RCCL is created on top and probed with one barrier; every
     rank then all-reduces (MIN) its success flag over gloo, so all ranks take the SAME decision -- a rank whose RCCL
     failed alone cannot leave the others waiting inside an RCCL collective.  If any rank failed:
-      * allow_fallback False (default; env DD_DIST_ALLOW_FALLBACK=1 turns it on): ControlPlaneError on every rank --
-        a `--gpus N` run whose RCCL does not start is an error, not a silent backend swap;
-      * allow_fallback True: the job runs its control messages over gloo (it exchanges no data) and
-        control_backend() / control_note() say so.
+      * allow_fallback False (THIS function's default; env DD_DIST_ALLOW_FALLBACK=1 turns it on): ControlPlaneError on
+        every rank -- a library caller whose RCCL does not start gets an error, not a silent backend swap;
+      * allow_fallback True (what bench.py passes unless --strict-rccl / DD_DIST_STRICT_RCCL=1 is given): the job runs
+        its control messages over gloo (it exchanges no data), says so on stderr, and control_backend() /
+        control_note() -- `config.control_plane` / `control_plane_note` of bench.py's JSON line, plus a top-level
+        `warning` there -- carry it.
     A host that has ALREADY initialised torch.distributed (a torchrun application that embeds the sampler) keeps its
     default group: the control plane then runs on it, with device tensors if it is an RCCL group."""
     world, rank, local_rank = env_world()
@@ -106,10 +108,11 @@ def init_from_env(backend: str = None, device_index: int = None, allow_fallback:
             dist.destroy_process_group()
         except Exception:                                            # noqa: BLE001
             pass
-        raise ControlPlaneError(msg + " (DD_DIST_ALLOW_FALLBACK=1 / bench.py --allow-gloo-fallback runs the control "
-                                      "plane over gloo instead; the job exchanges no data)")
+        raise ControlPlaneError(msg + " (strict mode: init_from_env(allow_fallback=False), bench.py --strict-rccl or "
+                                      "DD_DIST_STRICT_RCCL=1; without it -- bench.py's default, or DD_DIST_ALLOW_FALLBACK=1 -- the "
+                                      "control plane stays on gloo, loudly; the job exchanges no data)")
     print(f"[decompdiff_amd.dist] {msg}; control plane stays on gloo", file=sys.stderr, flush=True)
-    _CTL.update(group=None, backend="gloo", note="RCCL start-up failed; gloo fall-back requested by the caller")
+    _CTL.update(group=None, backend="gloo", note="RCCL start-up failed: control plane on gloo (fall-back allowed by the caller; bench.py --strict-rccl / DD_DIST_STRICT_RCCL=1 make this an error)")
     return True
 
 
@@ -294,8 +297,9 @@ def gather_metadata(local: Dict[str, Any]) -> List[Dict[str, Any]]:
 
 def checksum(result: Dict[str, torch.Tensor]) -> Dict[str, float]:
     """Order-independent fingerprint of one sampling result (for cross-rank / cross-run comparison)."""
-    return {"pos": float(result["pos"].double().sum().item()), "v": int(result["v"].sum().item()),
-            "bond": int(result["bond"].sum().item())}
+    # (one device -> host copy for the three sums, not three synchronisations)
+    sums = torch.stack([result["pos"].double().sum(), result["v"].sum().double(), result["bond"].sum().double()]).cpu()
+    return {"pos": float(sums[0]), "v": int(sums[1]), "bond": int(sums[2])}
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -396,12 +400,15 @@ def run_job(units: List[Unit], config: int, rank: int, world: int, prepare: Call
     per-unit records.  `prepare(unit)` -> opaque state; `sample(state, n_steps, seed)` -> result dict with pos / v / bond."""
     mine = units_of_rank(units, config, rank, world)
     states = [prepare(u) for u in mine]
-    if warmup > 0:
-        for u, st in zip(mine, states):
-            checksum(sample(st, warmup, u.noise_seed + 1))      # (also loads the reduction kernels the timed region uses)
+    # The collector runs BEFORE the warm-up, not between the warm-up and the timed region: a full collection of a torch process
+    # takes tens of ms during which host and device idle, and the first call after it ran ~1.3 ms slower than a steady call
+    # (profiles/round5_call_trace.txt: cold host caches in the call's set-up, +0.45 ms in its first 8 steps on the device).
     gc.collect()
     gc.disable()                                   # no collector pause inside the timed region (re-enabled below)
     try:
+        if warmup > 0:
+            for u, st in zip(mine, states):
+                checksum(sample(st, warmup, u.noise_seed + 1))  # (also loads the reduction kernels the timed region uses)
         barrier(device)
         t0 = time.perf_counter()
         records = []

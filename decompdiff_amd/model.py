@@ -596,8 +596,8 @@ class DecompScorePosNet3D(nn.Module):
         cache = getattr(self, "_chain_cache", None) or {}
         live = [e for e in cache.values() if e.get("graph") is not None] + DecompScorePosNet3D._parked_graphs
         live = sorted(live, key=lambda e: -e.get("graph_id", 0))
-        if live:
-            torch.cuda.synchronize(live[0]["dev"])
+        for d in {str(e["dev"]): e["dev"] for e in live}.values():     # the cache and the parked list are process-wide
+            torch.cuda.synchronize(d)
         lib = hip_lib.load()
         for e in live:
             lib.dd_graph_destroy(e["graph"])
@@ -693,20 +693,29 @@ class DecompScorePosNet3D(nn.Module):
             sm.workspace_floats = ws_floats
             ent = dict(s=sm, bufs=bufs, graph=None, graph_sig=None, dev=dev, pw=pw)
         sm, bufs = ent["s"], ent["bufs"]
-        # ---- this chain's inputs
+        # ---- this chain's inputs.  The pocket side (protein coordinates / embedded features, arm indicators, full protein,
+        # layer-0 protein rows) is uploaded once per cached entry and pocket: a later call that passes the SAME tensor objects
+        # with unchanged version counters (the next batch of the pocket, the sampling script's loop) finds them in place --
+        # five launches less in front of the first graph replay.
+        src = d.get("upload_src") if cacheable else None
+        pocket_in_place = (src is not None and ent.get("uploaded") is not None and ent.get("uploaded_pw") is pw
+                           and ent.get("uploaded_mode") == d.get("upload_mode") and len(src) == len(ent["uploaded"])
+                           and all(t is u and (t is None or t._version == ver) for t, (u, ver) in zip(src, ent["uploaded"])))
+        ent["uploaded"] = None                             # (set again below, once everything is enqueued)
         goff = self._global_offsets(pw)
-        bufs["protein_pos"].copy_(d["protein_pos_centered"])
-        hip_lib.check(lib.dd_embed_protein(hip_lib.ptr(d["protein_v"].view(B * NP, -1)), B * NP,
-                                           ctypes.c_void_p(arena[goff["W_pemb"]:].data_ptr()),
-                                           ctypes.c_void_p(arena[goff["b_pemb"]:].data_ptr()),
-                                           hip_lib.ptr(bufs["protein_h"]), hip_lib.stream_ptr(dev)), "dd_embed_protein")
-        bufs["lig_aux"].copy_(d["ligand_aux"])
+        if not pocket_in_place:
+            bufs["protein_pos"].copy_(d["protein_pos_centered"])
+            hip_lib.check(lib.dd_embed_protein(hip_lib.ptr(d["protein_v"].view(B * NP, -1)), B * NP,
+                                               ctypes.c_void_p(arena[goff["W_pemb"]:].data_ptr()),
+                                               ctypes.c_void_p(arena[goff["b_pemb"]:].data_ptr()),
+                                               hip_lib.ptr(bufs["protein_h"]), hip_lib.stream_ptr(dev)), "dd_embed_protein")
+            bufs["lig_aux"].copy_(d["ligand_aux"])
+            if NF:
+                bufs["full_protein_pos"].copy_(full_protein_pos)
         bufs["atom_std"].copy_(atom_std.reshape(B * NL, 3))
         bufs["offset"].copy_(offset)
         if decomp_index is not None:
             bufs["decomp_index"].copy_(decomp_index.reshape(-1))
-        if NF:
-            bufs["full_protein_pos"].copy_(full_protein_pos)
         bufs["lig_pos"].copy_(d["ligand_pos_centered"])
         bufs["lig_v"].copy_(d["ligand_v"])
         bufs["lig_bond"].copy_(d["bond"])
@@ -766,8 +775,11 @@ class DecompScorePosNet3D(nn.Module):
             else:
                 raise ValueError(dr["type"])
         sm.drift_norm_batch = int(drift_norm_batch)
-        if use_l0:                                         # protein rows of the layer-0 tables (this chain's pocket)
+        if use_l0 and not (pocket_in_place and ent.get("uploaded_l0")):     # protein rows of the layer-0 tables (this chain's pocket)
             hip_lib.check(lib.dd_layer0_prepare(ctypes.byref(sm), hip_lib.stream_ptr(dev)), "dd_layer0_prepare")
+        if src is not None:
+            ent["uploaded"] = [(t, None if t is None else t._version) for t in src]
+            ent["uploaded_pw"], ent["uploaded_l0"], ent["uploaded_mode"] = pw, bool(use_l0), d.get("upload_mode")
         if n_steps > 0:
             hip_lib.check(lib.dd_sampler_reset(ctypes.byref(sm), hip_lib.stream_ptr(dev)), "dd_sampler_reset")
         # everything that shapes the captured step graph besides the (cached) pointers
@@ -971,6 +983,11 @@ class DecompScorePosNet3D(nn.Module):
         if start_step < 0 or num_steps + start_step > self.num_timesteps:
             raise ValueError("num_steps (+ start_step) exceeds num_timesteps")
         pw = self._packed_weights()
+        # (what the pocket-side device buffers of a cached entry were filled from: _make_sampler skips the upload if these very
+        #  tensors come again unchanged; the centring mode shapes protein_pos_centered / offset)
+        d["upload_src"] = (protein_pos, protein_v, ligand_v_aux, full_protein_pos, full_batch_protein) \
+            if center_pos_mode in ("protein", "none") else None
+        d["upload_mode"] = center_pos_mode
         s, bufs, ent = self._make_sampler(d, pw, num_steps, t_start, noise, keep_traj, energy_drift_opt, atom_std,
                                           offset.contiguous(), decomp, fpp, seed, drift_norm_batch, cache_slot=cache_slot)
         return dict(s=s, bufs=bufs, offset=offset, B=B, NL=NL, dev=dev, ent=ent,
@@ -1057,23 +1074,6 @@ class DecompScorePosNet3D(nn.Module):
         per_step = sum(bufs[k][0].numel() * bufs[k].element_size() for k in keys)
         # ~24 MB per chunk: the last chunk is the only one whose drain is not hidden (a few ms)
         chunk = int(os.environ.get("DD_TRAJ_CHUNK", "0")) or max(8, min(128, (24 << 20) // max(per_step, 1)))
-        # staging: two flat pinned buffers per process and device, carved per shape (a pinned allocation costs tens of ms --
-        # a job over 100 pockets of different sizes must not repeat it per pocket); grown only if a chunk needs more
-        sizes = {k: chunk * bufs[k][0].numel() * bufs[k].element_size() for k in keys}
-        need = sum((n + 255) // 256 * 256 for n in sizes.values())
-        cache = getattr(self, "_staging", None)
-        if cache is None or cache[0] != str(dev) or cache[1] < need:
-            cap = max(need, 32 << 20)
-            cache = self._staging = (str(dev), cap, [torch.empty(cap, dtype=torch.uint8).pin_memory() for _ in range(2)])
-        slots = []
-        for flat in cache[2]:
-            sl, off = {}, 0
-            for k in keys:
-                sl[k] = flat[off:off + sizes[k]].view(bufs[k].dtype).view((chunk,) + tuple(bufs[k].shape[1:]))
-                off += (sizes[k] + 255) // 256 * 256
-            slots.append(sl)
-        widen = {"traj_v": torch.int64, "traj_bond": torch.int64}
-        final = {k: torch.empty((num_steps,) + tuple(bufs[k].shape[1:]), dtype=widen.get(k, bufs[k].dtype)) for k in keys}
         side.wait_stream(cur)
         spg = int(os.environ.get("DD_STEPS_PER_GRAPH", "1"))
         if spg < 1 or num_steps % spg or chunk % spg:
@@ -1099,8 +1099,28 @@ class DecompScorePosNet3D(nn.Module):
         graph = ent["graph"]                               # (read after priming: never a handle the priming chain destroyed)
 
         dbg = int(os.environ.get("DD_TRAJ_DEBUG", "0"))
-        final_np = {k: v.numpy() for k, v in final.items()}
-        slots_np = [{k: v.numpy() for k, v in sl.items()} for sl in slots]
+        widen = {"traj_v": torch.int64, "traj_bond": torch.int64}
+        host = {}                                          # staging views and result tensors: set up AFTER the first launch
+
+        def setup_host_side():
+            # staging: two flat pinned buffers per process and device, carved per shape (a pinned allocation costs tens of ms --
+            # a job over 100 pockets of different sizes must not repeat it per pocket); grown only if a chunk needs more
+            sizes = {k: chunk * bufs[k][0].numel() * bufs[k].element_size() for k in keys}
+            need = sum((n + 255) // 256 * 256 for n in sizes.values())
+            cache = getattr(self, "_staging", None)
+            if cache is None or cache[0] != str(dev) or cache[1] < need:
+                cap = max(need, 32 << 20)
+                cache = self._staging = (str(dev), cap, [torch.empty(cap, dtype=torch.uint8).pin_memory() for _ in range(2)])
+            slots = []
+            for flat in cache[2]:
+                sl, off = {}, 0
+                for k in keys:
+                    sl[k] = flat[off:off + sizes[k]].view(bufs[k].dtype).view((chunk,) + tuple(bufs[k].shape[1:]))
+                    off += (sizes[k] + 255) // 256 * 256
+                slots.append(sl)
+            final = {k: torch.empty((num_steps,) + tuple(bufs[k].shape[1:]), dtype=widen.get(k, bufs[k].dtype)) for k in keys}
+            host.update(slots=slots, final=final, final_np={k: v.numpy() for k, v in final.items()},
+                        slots_np=[{k: v.numpy() for k, v in sl.items()} for sl in slots])
 
         def drain(item):
             lo, hi, slot, done = item
@@ -1110,10 +1130,10 @@ class DecompScorePosNet3D(nn.Module):
                 return
             if dbg & 16:
                 for k in keys:
-                    final[k][lo:hi].copy_(slots[slot][k][:hi - lo])
+                    host["final"][k][lo:hi].copy_(host["slots"][slot][k][:hi - lo])
                 return
             for k in keys:                             # single-threaded on purpose (see the docstring)
-                np.copyto(final_np[k][lo:hi], slots_np[slot][k][:hi - lo], casting="same_kind")
+                np.copyto(host["final_np"][k][lo:hi], host["slots_np"][slot][k][:hi - lo], casting="same_kind")
 
         pending = []
         tr = self.__dict__.get("_trace")                   # tools/bench_call_trace.py: wall-clock stamps, no extra syncs
@@ -1130,6 +1150,11 @@ class DecompScorePosNet3D(nn.Module):
                 mark(f"launch{c}>")
                 ev = torch.cuda.Event()
                 ev.record(side)
+                if c == 0:
+                    # everything the host needs for the drains is built while the device runs the first piece: the first
+                    # graph replay is enqueued ~0.1 ms earlier (20-step calls: what the driver's bench line times)
+                    setup_host_side()
+                slots = host["slots"]
                 copy_st.wait_event(ev)
                 with torch.cuda.stream(copy_st):
                     for k in keys:
@@ -1141,7 +1166,7 @@ class DecompScorePosNet3D(nn.Module):
                 if c == 0 and not dbg & 4:
                     tail = ((num_steps - 1) // piece) * piece
                     for k in keys:                     # first touch of the pages the un-hidden last drain writes
-                        final_np[k][tail:].fill(0)
+                        host["final_np"][k][tail:].fill(0)
                 mark(f"copies{c}>")
                 if len(pending) == 2:
                     drain(pending.pop(0))
@@ -1156,6 +1181,7 @@ class DecompScorePosNet3D(nn.Module):
             if not cached:                                 # (a cached entry keeps its graph for the next chain)
                 DecompScorePosNet3D._parked_graphs.append({"graph": graph, "graph_id": ent.get("graph_id", 0), "dev": dev})
                 ent["graph"] = None
+        final = host["final"]
         cur.wait_stream(side)
         chain["traj_cpu"] = final
 

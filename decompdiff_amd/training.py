@@ -22,6 +22,8 @@ from __future__ import annotations
 import math
 from typing import Dict, Optional
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -324,13 +326,28 @@ def network_grouped(net, model, protein_pos, protein_v, batch_protein, ligand_po
 
 
 _STRUCT: Dict = {}
+_STRUCT_MAX_BYTES = int(os.environ.get("DD_TRAIN_STRUCT_CACHE_MB", "512")) << 20     # device memory the cached index structures may hold
+_STRUCT_MAX_ENTRIES = 16
+
+
+def _tensor_bytes(obj) -> int:
+    if torch.is_tensor(obj):
+        return obj.numel() * obj.element_size()
+    if isinstance(obj, dict):
+        return sum(_tensor_bytes(v) for v in obj.values())
+    if isinstance(obj, (list, tuple)):
+        return sum(_tensor_bytes(v) for v in obj)
+    return sum(_tensor_bytes(v) for v in vars(obj).values()) if hasattr(obj, "__dict__") else 0
 
 
 def _structure(B, NP, NL, K, dev):
-    """Index structure of a dense batch of B samples with NP protein + NL ligand atoms each (static across steps)."""
+    """Index structure of a dense batch of B samples with NP protein + NL ligand atoms each (static across steps).
+    Cached per shape, least recently used first out, bounded by bytes (the triplet index vectors grow as B * NL^3: ~0.65 GB
+    at NL = 128, B = 8 -- a structure beyond the budget is built per call and not kept)."""
     key = (B, NP, NL, K, str(dev))
-    S = _STRUCT.get(key)
+    S = _STRUCT.pop(key, None)
     if S is not None:
+        _STRUCT[key] = S                                   # re-inserted: most recently used last
         return S
     N = NP + NL
     is_lig = torch.cat([torch.zeros(NP, dtype=torch.bool), torch.ones(NL, dtype=torch.bool)]).repeat(B).to(dev)
@@ -361,9 +378,11 @@ def _structure(B, NP, NL, K, dev):
         rep = lambda t: t.repeat(B)
         S["trip"] = dict(ji=rep(e_ji) + boff, kj=rep(e_kj) + boff, i=rep(i_loc) + aoff, j=rep(j_loc) + aoff, k=rep(k_loc) + aoff)
         S["p_ji"] = seg_plan(S["trip"]["ji"], B * Ebs)
-    if len(_STRUCT) >= 4:
-        _STRUCT.pop(next(iter(_STRUCT)))
-    _STRUCT[key] = S
+    S["_bytes"] = _tensor_bytes(S)
+    if S["_bytes"] <= _STRUCT_MAX_BYTES:
+        _STRUCT[key] = S
+        while len(_STRUCT) > _STRUCT_MAX_ENTRIES or sum(v["_bytes"] for v in _STRUCT.values()) > _STRUCT_MAX_BYTES:
+            _STRUCT.pop(next(iter(_STRUCT)))               # least recently used first
     return S
 
 

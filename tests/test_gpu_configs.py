@@ -547,7 +547,7 @@ def test_bench_json_line_contract():
     and the roofline / cpu_baseline objects."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--cpu-steps", "1",
-                        "--cpu-warmup", "1"], capture_output=True, text=True, env=env, timeout=900)
+                        "--cpu-warmup", "1", "--cpu-threads", "16"], capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -595,6 +595,40 @@ def test_static_input_memo_is_invalidated_by_in_place_changes():
     with pytest.raises((NotImplementedError, ValueError, RuntimeError, AssertionError)):
         bad = dict(b); bad["batch_ligand"] = b["batch_ligand"].clone(); bad["batch_ligand"][0] = 1
         m.sample_diffusion(**bad, **kw)
+
+
+@pytest.mark.gpu
+def test_pocket_side_uploads_are_skipped_only_for_unchanged_tensors():
+    """A cached chain entry keeps the pocket-side device buffers (protein coordinates / embedded features, arm indicators,
+    layer-0 protein rows) when the caller passes the very same tensors again (model._make_sampler: `pocket_in_place`); an
+    in-place change of any of them, another centring mode or a new tensor object must be uploaded again."""
+    m = model(0)
+    torch.manual_seed(6)
+    b = to_dev_local(synth.build_sampling_batch(synth.make_pocket(19, 60, (3, 3), 4, num_full_protein=0), 2))
+    kw = dict(num_steps=4, seed=78)
+    fresh = lambda bb, mode="protein": model(0).sample_diffusion(**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in bb.items()},
+                                                                 center_pos_mode=mode, **kw)
+    r0 = m.sample_diffusion(**b, center_pos_mode="protein", **kw)
+    ent = next(reversed(type(m)._chain_cache.values()))
+    assert ent.get("uploaded") is not None
+    r1 = m.sample_diffusion(**b, center_pos_mode="protein", **kw)            # uploads skipped
+    assert torch.equal(r0["pos"], r1["pos"]) and torch.equal(r0["v"], r1["v"]) and torch.equal(r0["bond"], r1["bond"])
+    # protein features changed in place (same object): the embedded rows must be rebuilt
+    b["protein_v"][:, :6] = b["protein_v"][:, :6].roll(1, dims=1)
+    r2 = m.sample_diffusion(**b, center_pos_mode="protein", **kw)
+    w2 = fresh(b)
+    assert torch.equal(r2["pos"], w2["pos"]) and torch.equal(r2["v"], w2["v"]) and not torch.equal(r2["pos"], r0["pos"])
+    # another centring mode with the same tensors
+    r3 = m.sample_diffusion(**b, center_pos_mode="none", **kw)
+    w3 = fresh(b, "none")
+    assert torch.equal(r3["pos"], w3["pos"]) and torch.equal(r3["v"], w3["v"])
+    r4 = m.sample_diffusion(**b, center_pos_mode="protein", **kw)
+    assert torch.equal(r4["pos"], r2["pos"])
+    # arm / scaffold indicators swapped in place
+    b["ligand_v_aux"].copy_(b["ligand_v_aux"].flip(1))
+    r5 = m.sample_diffusion(**b, center_pos_mode="protein", **kw)
+    w5 = fresh(b)
+    assert torch.equal(r5["pos"], w5["pos"]) and torch.equal(r5["v"], w5["v"]) and not torch.equal(r5["pos"], r2["pos"])
 
 
 def to_dev_local(batch):
