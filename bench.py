@@ -70,6 +70,8 @@ def parse():
                                                                "data -- then runs over the gloo group and the JSON line says so in "
                                                                "config.control_plane / control_plane_note)")
     ap.add_argument("--allow-gloo-fallback", action="store_true", help="(the default since round 4; kept for old command lines)")
+    ap.add_argument("--plan-only", action="store_true", help="print the job plan for --gpus N (units per rank, planned cost and imbalance, "
+                    "device and CPU slice per rank) as one JSON line and exit; needs no GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rooflines", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=5, help="steps of the CPU baseline's timed sample (~5.5 s each at B=8)")
@@ -141,6 +143,12 @@ def gemm_work_per_step(B, NP, NL, num_layers, layer0_tables=True):
 
 def main():
     args = parse()
+    if args.plan_only:
+        from decompdiff_amd import dist as ddist
+        print(json.dumps({"plan": ddist.describe_plan(args.config, args.gpus, batch=args.batch, n_pockets=args.pockets,
+                                                      num_samples=args.num_samples, drift=args.drift),
+                          "steps": args.steps, "warmup": args.warmup}), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(respawn_under_torchrun(args))
 
@@ -221,7 +229,7 @@ def main():
                                                              args.config, args.workload)
             op_roofline = measure_op_level_roofline(torch, hip_lib, lib, dev)
         cpu = None
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:                       # (rank 0 only, after the timed region and its closing barrier)
             cpu = cpu_baseline(torch, synth, cfg, cpu_batches[u0.uid], DRIFT if u0.drift else None, B, args.cpu_steps, args.cpu_warmup,
                                args.cpu_threads)
         wl = {1: "configs[1]: single pocket ref_prior",
@@ -400,7 +408,8 @@ def cpu_baseline(torch, synth, cfg, batch_cpu, drift, B, n_cpu, n_warm, threads=
     from oracle import diffusion as OD
     weights = synth.synthetic_state_dict(cfg, seed=0)
     n_cpu, n_warm = max(1, n_cpu), max(1, n_warm)
-    ncpu = os.cpu_count() or 1
+    # (a rank of a multi-GPU job is bound to its share of the CPUs local to its GPU: count those, not the whole host)
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     probe = {}
     for nthreads in ([min(threads, ncpu)] if threads > 0 else sorted({min(16, ncpu), min(64, ncpu)})):     # (all 128-256 threads of such a host are slower still: dropped from the probe)
         torch.set_num_threads(nthreads)
@@ -419,7 +428,7 @@ def cpu_baseline(torch, synth, cfg, batch_cpu, drift, B, n_cpu, n_warm, threads=
     return {"value": round(rate, 4), "unit": "denoising steps/s", "cores": best, "kind": "port",
             "sample": f"{n_cpu} steps after {n_warm} warm-up steps of the same pocket batch (B={B}); oracle = CPU restatement of "
                       f"the reference (torch fp32); threads {'given (--cpu-threads)' if threads > 0 else 'chosen'} by a 1-step probe of {sorted(probe)} "
-                      f"({', '.join(f'{k}: {v:.2f} s/step' for k, v in sorted(probe.items()))}); host has {ncpu} logical CPUs"}
+                      f"({', '.join(f'{k}: {v:.2f} s/step' for k, v in sorted(probe.items()))}); this process may use {ncpu} of the host's {os.cpu_count()} logical CPUs"}
 
 
 if __name__ == "__main__":

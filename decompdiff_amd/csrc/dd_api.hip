@@ -6,6 +6,10 @@
 #include <vector>
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
+#include <string>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "dd_kernels.hpp"
 
@@ -1110,6 +1114,67 @@ bool node_split_applies(int B, int NL, int n_cu);
 // keep (see launch_node_nw).  Times whole forward passes on `st` (eager, min of 2 after a warm-up pass) for a coarse and
 // then a fine set of splits around the work-proportional share; ~21 forward passes, before the first graph of a shape
 // is captured.  The passes only write the workspace and pred_*.
+// ---- measured splits kept ACROSS processes (per device model and build of this library): eight ranks of a node, or the next
+// run of the sampling script, read the file instead of each timing ~30 forward passes per shape while their neighbours do the same
+// on a shared host.  One text line per shape, "B NP NL K n_bl"; the file is replaced atomically (temp + rename), a lost update only
+// means that shape is measured again.  DD_NODE_SPLIT_CACHE=0 turns it off, DD_NODE_SPLIT_CACHE_DIR moves it (default
+// $XDG_CACHE_HOME or ~/.cache, /decompdiff_amd).  The split never changes results (it only decides WHICH CU computes a segment).
+static std::string node_split_cache_path(int n_cu) {
+  const char* off = getenv("DD_NODE_SPLIT_CACHE");
+  if (off && off[0] == '0') return std::string();
+  std::string dir;
+  if (const char* d = getenv("DD_NODE_SPLIT_CACHE_DIR")) dir = d;
+  else if (const char* x = getenv("XDG_CACHE_HOME")) dir = std::string(x) + "/decompdiff_amd";
+  else if (const char* h = getenv("HOME")) dir = std::string(h) + "/.cache/decompdiff_amd";
+  else return std::string();
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return std::string(); }
+  std::string name = std::string(prop.gcnArchName) + "_" + prop.name;
+  for (char& c : name) if (!((c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9'))) c = '_';
+  unsigned h = 2166136261u;                              // the build: a rebuilt kernel is measured again
+  for (const char* p = __DATE__ " " __TIME__; *p; ++p) h = (h ^ (unsigned char)*p) * 16777619u;
+  char tag[64];
+  snprintf(tag, sizeof(tag), "_cu%d_abi%d_%08x", n_cu, dd_abi_version(), h);
+  return dir + "/node_split_" + name + tag + ".txt";
+}
+static int node_split_cache_read(const std::string& path, int B, int NP, int NL, int K) {
+  if (path.empty()) return -1;
+  FILE* f = fopen(path.c_str(), "r");
+  if (!f) return -1;
+  int b, np, nl, k, n, found = -1;
+  while (fscanf(f, "%d %d %d %d %d", &b, &np, &nl, &k, &n) == 5)
+    if (b == B && np == NP && nl == NL && k == K) found = n;         // (the last line of a shape wins)
+  fclose(f);
+  return found;
+}
+static void node_split_cache_append(const std::string& path, int B, int NP, int NL, int K, int n_bl) {
+  if (path.empty()) return;
+  const size_t slash = path.rfind('/');
+  if (slash != std::string::npos) {
+    std::string dir = path.substr(0, slash);
+    for (size_t i = 1; i <= dir.size(); ++i)
+      if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0755);
+  }
+  std::string all;
+  if (FILE* f = fopen(path.c_str(), "r")) {
+    char buf[256];
+    while (fgets(buf, sizeof(buf), f)) all += buf;
+    fclose(f);
+  }
+  char line[96];
+  snprintf(line, sizeof(line), "%d %d %d %d %d\n", B, NP, NL, K, n_bl);
+  all += line;
+  char tmp[32];
+  snprintf(tmp, sizeof(tmp), ".tmp%d", (int)getpid());
+  const std::string t = path + tmp;
+  FILE* f = fopen(t.c_str(), "w");
+  if (!f) return;
+  const bool ok = fwrite(all.data(), 1, all.size(), f) == all.size();
+  fclose(f);
+  if (!ok || rename(t.c_str(), path.c_str()) != 0) (void)unlink(t.c_str());
+}
+
 static int autotune_node_split(const dd_sampler* s, hipStream_t st) {
   static int n_cu = 0;
   if (n_cu == 0) {
@@ -1123,6 +1188,14 @@ static int autotune_node_split(const dd_sampler* s, hipStream_t st) {
   static const bool enabled = [] { const char* e = getenv("DD_NODE_SPLIT_AUTOTUNE"); return !(e && e[0] == '0'); }();
   if (!enabled) return DD_OK;
   if (!fused || !dd::node_split_applies(s->B, s->NL, n_cu) || dd::node_split_lookup(s->B, s->NP, s->NL, s->K) >= 0) return DD_OK;
+  const std::string cache_path = node_split_cache_path(n_cu);
+  {
+    const int cached = node_split_cache_read(cache_path, s->B, s->NP, s->NL, s->K);
+    if (cached == 0 || (cached >= 16 && cached <= n_cu - 16 && cached % 8 == 0)) {       // (anything else: measure again)
+      dd::node_split_store(s->B, s->NP, s->NL, s->K, cached);
+      return DD_OK;
+    }
+  }
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return DD_ERR_HIP;
   int rc = DD_OK;
@@ -1188,8 +1261,22 @@ static int autotune_node_split(const dd_sampler* s, hipStream_t st) {
   dd::g_node_split_trial = -1;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
-  if (rc == DD_OK) dd::node_split_store(s->B, s->NP, s->NL, s->K, best_n);
+  if (rc == DD_OK) {
+    dd::node_split_store(s->B, s->NP, s->NL, s->K, best_n);
+    node_split_cache_append(cache_path, s->B, s->NP, s->NL, s->K, best_n);
+  }
   return rc;
+}
+
+extern "C" int dd_debug_node_split_cache_path(char* out, int cap) {
+  if (!out || cap <= 0) return DD_ERR_BAD_ARG;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return DD_ERR_HIP; }
+  const std::string p = node_split_cache_path(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+  if ((int)p.size() + 1 > cap) return DD_ERR_BAD_ARG;
+  memcpy(out, p.c_str(), p.size() + 1);                  // (empty string: the cache is turned off)
+  return DD_OK;
 }
 
 static int one_step(const dd_sampler* s, hipStream_t st) {

@@ -209,7 +209,13 @@ def bind_rank_to_local_cpus(device_index: int, local_rank: int = 0, local_world:
     return rec
 
 
-def _bind(device_index, local_rank, local_world, local_cpus_of) -> Dict[str, Any]:
+def plan_affinity(device_index: int, local_rank: int = 0, local_world: int = 1,
+                  local_cpus_of: Optional[Callable[[int], Optional[List[int]]]] = None) -> Dict[str, Any]:
+    """What bind_rank_to_local_cpus WOULD do for this rank, without touching the process's affinity (bench.py --plan-only)."""
+    return _bind(device_index, local_rank, local_world, local_cpus_of, dry_run=True)
+
+
+def _bind(device_index, local_rank, local_world, local_cpus_of, dry_run=False) -> Dict[str, Any]:
     if os.environ.get("DD_DIST_NO_AFFINITY") == "1":
         return {"bound": False, "why": "DD_DIST_NO_AFFINITY=1"}
     if not hasattr(os, "sched_setaffinity"):
@@ -227,8 +233,9 @@ def _bind(device_index, local_rank, local_world, local_cpus_of) -> Dict[str, Any
         cpus = slice_cpus(mine, share, len(peers) or 1, allowed)
         if not cpus:
             return {"bound": False, "why": "no allowed CPU in the device's local set", "numa_cpus": len(mine)}
-        os.sched_setaffinity(0, cpus)
-        return {"bound": True, "cpus": format_cpulist(cpus), "n_cpus": len(cpus), "numa_cpus": len(mine),
+        if not dry_run:
+            os.sched_setaffinity(0, cpus)
+        return {"bound": not dry_run, "planned": True, "cpus": format_cpulist(cpus), "n_cpus": len(cpus), "numa_cpus": len(mine),
                 "share": f"{share + 1}/{len(peers) or 1}"}
     except Exception as e:                                           # noqa: BLE001
         return {"bound": False, "why": f"{type(e).__name__}: {str(e)[:120]}"}
@@ -389,6 +396,38 @@ def units_of_rank(units: List[Unit], config: int, rank: int, world: int) -> List
     if config == 3:
         return [units[i] for i in assign_lpt(units, world)[rank]]
     return [units[i] for i in shard_units(len(units), rank, world)]
+
+
+def describe_plan(config: int, world: int, batch: Optional[int] = None, n_pockets: int = 100, num_samples: int = 64,
+                  drift: bool = False, local_cpus_of: Optional[Callable[[int], Optional[List[int]]]] = None,
+                  n_devices: Optional[int] = None) -> Dict[str, Any]:
+    """The job `bench.py --gpus world --config config` would run, without running it (bench.py --plan-only; no GPU needed):
+    the units, which rank takes which (LPT table for configs[3], contiguous shards for configs[4]), each rank's planned
+    cost and the imbalance of the plan, the device and the CPU slice every rank would bind to.  A function of the arguments
+    (and, for the affinity, of this host's PCI topology) only -- every rank computes the same table without talking."""
+    units, scaling = plan_job(config, world, batch=batch, n_pockets=n_pockets, num_samples=num_samples, drift=drift)
+    if n_devices is None:
+        n_devices = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    ranks = []
+    for r in range(world):
+        mine = units_of_rank(units, config, r, world)
+        rec = {"rank": r, "units": [u.uid for u in mine], "n_units": len(mine),
+               "planned_cost": round(sum(unit_cost(u) for u in mine), 1),
+               "device": (r % n_devices) if n_devices else None}
+        if n_devices or local_cpus_of is not None:
+            rec["cpu_affinity"] = plan_affinity(r % max(1, n_devices), r, world, local_cpus_of)
+        else:
+            rec["cpu_affinity"] = {"bound": False, "why": "no HIP device visible here: the PCI topology is read on the GPU host"}
+        ranks.append(rec)
+    costs = [x["planned_cost"] for x in ranks]
+    mean = sum(costs) / max(1, len(costs))
+    shapes = sorted({(u.num_protein, sum(u.arm_atoms) + u.scaffold_atoms, u.n_samples) for u in units})
+    return {"config": config, "world": world, "scaling": scaling, "n_units": len(units), "ranks": ranks,
+            "planned_imbalance_max_over_mean": round(max(costs) / mean, 4) if mean > 0 else None,
+            "distinct_shapes_NP_NL_B": len(shapes), "shapes_sample": shapes[:6],
+            "assignment": {3: "longest-processing-time first (assign_lpt)", 4: "contiguous sample shards (shard_samples)"}.get(
+                config, "unit u -> rank u (one identical pocket batch per rank)"),
+            "collectives": "none on the data path; control plane = 2 barriers + 1 all-reduce(MAX) of the wall time + 1 gather of records"}
 
 
 def run_job(units: List[Unit], config: int, rank: int, world: int, prepare: Callable[[Unit], Any],

@@ -40,6 +40,11 @@ int dd_debug_options_epoch(void);
 /* Measured split of the fused node launch for a shape (dd_debug_set_option key 18 = 1): number of CUs kept by the
  * persistent bond-layer workgroups, 0 = node blocks first, -1 = not measured yet. */
 int dd_debug_node_split(int B, int NP, int NL, int K);
+/* File that keeps the measured splits across processes (per device model, CU count and build of this library; one text line
+ * "B NP NL K n_bl" per shape; DD_NODE_SPLIT_CACHE=0 turns it off, DD_NODE_SPLIT_CACHE_DIR moves it from ~/.cache/decompdiff_amd):
+ * the ranks of a node and later runs read it instead of timing ~30 forward passes per shape each.  Writes the path (empty
+ * string: off) into out[cap]. */
+int dd_debug_node_split_cache_path(char* out, int cap);
 /* Health word of the in-launch hand-offs of the TILE-QUEUE schedule (dd_debug_set_option(8, 5); measurement build only --
  * the default library's schedule uses graph edges and never polls; EXPERIMENTS.md R3-1): the coordinate attention, the
  * next assemble and the next node attention start beside the persistent GEMM queue of their layer and poll its device

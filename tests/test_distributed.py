@@ -330,3 +330,30 @@ def test_cpu_affinity_helpers(monkeypatch):
     assert ddist.bind_rank_to_local_cpus(0, 0, 8, look) == {"bound": False, "why": "DD_DIST_NO_AFFINITY=1"}
     monkeypatch.delenv("DD_DIST_NO_AFFINITY")
     assert ddist.bind_rank_to_local_cpus(0, 0, 8, lambda d: None)["bound"] is False
+
+
+def test_plan_only_describes_the_eight_rank_job_without_a_gpu():
+    """bench.py --gpus 8 --plan-only: units per rank, planned cost / imbalance, device and CPU slice per rank -- a function of
+    the arguments only (every rank computes the same table), no GPU needed."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--config", "3", "--plan-only"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    plan = json.loads(p.stdout.strip().splitlines()[-1])["plan"]
+    assert plan["world"] == 8 and plan["n_units"] == 100 and plan["scaling"] == "strong"
+    assert sorted(u for r in plan["ranks"] for u in r["units"]) == list(range(100))          # every pocket exactly once
+    assert plan["planned_imbalance_max_over_mean"] < 1.03
+    units, _ = ddist.plan_job(3, 8)
+    assert [r["units"] for r in plan["ranks"]] == [[u.uid for u in ddist.units_of_rank(units, 3, r, 8)] for r in range(8)]
+    # affinity plan with an injected topology: two NUMA nodes of 4 GPUs each, 128 CPUs per node -> 32 CPUs per rank, disjoint
+    topo = lambda d: list(range(0, 128)) if d < 4 else list(range(128, 256))
+    allowed = sorted(os.sched_getaffinity(0))
+    plan = ddist.describe_plan(1, 8, local_cpus_of=topo, n_devices=8)
+    if len(allowed) >= 256:
+        cpus = [ddist.parse_cpulist(r["cpu_affinity"]["cpus"]) for r in plan["ranks"]]
+        assert all(len(c) == 32 for c in cpus) and len({x for c in cpus for x in c}) == 256
+    assert sorted(os.sched_getaffinity(0)) == allowed                                            # a plan binds nothing
+    assert all(r["cpu_affinity"].get("bound") is False for r in plan["ranks"])
+    cfg4 = ddist.describe_plan(4, 8, num_samples=64)
+    assert [r["n_units"] for r in cfg4["ranks"]] == [1] * 8 and cfg4["planned_imbalance_max_over_mean"] == 1.0

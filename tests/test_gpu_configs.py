@@ -631,6 +631,44 @@ def test_pocket_side_uploads_are_skipped_only_for_unchanged_tensors():
     assert torch.equal(r5["pos"], w5["pos"]) and torch.equal(r5["v"], w5["v"]) and not torch.equal(r5["pos"], r2["pos"])
 
 
+_SPLIT_PROBE = r"""
+import ctypes, json, sys, torch
+sys.path.insert(0, ".")
+from decompdiff_amd import DecompScorePosNet3D, hip_lib, shipped_config, synth
+from decompdiff_amd import dist as ddist
+dev = torch.device("cuda:0"); cfg = shipped_config()
+m = DecompScorePosNet3D(cfg, 29, 10, 8); sd = m.state_dict(); sd.update(synth.synthetic_state_dict(cfg, seed=0)); m.load_state_dict(sd); m = m.to(dev)
+torch.manual_seed(3)
+b = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synth.build_sampling_batch(synth.make_pocket_small(0), 8).items()}
+out = m.sample_diffusion(num_steps=3, center_pos_mode="protein", seed=5, **b)
+lib = hip_lib.load(); buf = ctypes.create_string_buffer(1024)
+hip_lib.check(lib.dd_debug_node_split_cache_path(buf, 1024))
+print(json.dumps({"split": int(lib.dd_debug_node_split(8, 300, 30, 32)), "path": buf.value.decode(), "cs": ddist.checksum(out)}))
+"""
+
+
+def test_measured_node_split_is_kept_across_processes(tmp_path):
+    """The CU split of the fused node launch is measured once per shape, device model and build, and kept in a file
+    (dd_api.hip::node_split_cache_*): a second process -- another rank of the node, the next run of the script -- reads it
+    instead of timing ~30 forward passes, and whatever split it reads the results are bit-identical."""
+    env = dict(_bench_env(), DD_NODE_SPLIT_CACHE_DIR=str(tmp_path))
+    run = lambda: json.loads(subprocess.run([sys.executable, "-c", _SPLIT_PROBE], cwd=ROOT, env=env, capture_output=True, text=True,
+                                            timeout=600, check=True).stdout.strip().splitlines()[-1])
+    first = run()
+    assert first["path"].startswith(str(tmp_path)) and os.path.exists(first["path"])
+    lines = open(first["path"]).read().split("\n")
+    assert f"8 300 30 32 {first['split']}" in lines and first["split"] % 8 == 0
+    other = 96 if first["split"] != 96 else 104
+    with open(first["path"], "a") as fh:                       # (the last line of a shape wins)
+        fh.write(f"8 300 30 32 {other}\n")
+    second = run()
+    assert second["split"] == other                            # read, not measured again
+    assert second["cs"] == first["cs"]                         # the split only decides which CU computes a segment
+    off = json.loads(subprocess.run([sys.executable, "-c", _SPLIT_PROBE], cwd=ROOT, env=dict(env, DD_NODE_SPLIT_CACHE="0"),
+                                    capture_output=True, text=True, timeout=600, check=True).stdout.strip().splitlines()[-1])
+    assert off["path"] == "" and off["cs"] == first["cs"]
+
+
 def to_dev_local(batch):
     return {k: (v.to(dev()) if torch.is_tensor(v) else v) for k, v in batch.items()}
 
