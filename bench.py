@@ -207,6 +207,14 @@ def main():
 
     def sample(state, n_steps, seed):
         batch, drift = state
+        if os.environ.get("DD_BENCH_TRACE") == "1":        # wall-clock stamps of the call's phases on stderr (no extra syncs)
+            model.__dict__["_trace"] = tr = [("call<", time.perf_counter())]
+            out = model.sample_diffusion(num_steps=n_steps, center_pos_mode="protein", energy_drift_opt=drift, seed=seed,
+                                         keep_traj=True, use_graph=not args.eager, **batch)
+            tr.append(("call>", time.perf_counter()))
+            print(f"[trace] {n_steps} steps: " + "  ".join(f"{k} {1e3 * (t - tr[0][1]):.2f}" for k, t in tr), file=sys.stderr, flush=True)
+            model.__dict__["_trace"] = None
+            return out
         return model.sample_diffusion(num_steps=n_steps, center_pos_mode="protein", energy_drift_opt=drift, seed=seed,
                                       keep_traj=True, use_graph=not args.eager, **batch)
 

@@ -184,6 +184,10 @@ DD_OPT g_side_lin = DD_SIDE_LIN_DEFAULT;   // dd_debug_set_option(27, v): ONE fo
 DD_OPT g_head_rows_first = 0;              // dd_debug_set_option(29, v): see the head of forward_impl
 DD_OPT g_heads_early = 1;                  // dd_debug_set_option(28, v): heads' first Linear in the last layer's projection launch
 DD_OPT g_q_in_pos = 1;                     // dd_debug_set_option(9, v): coordinate query MLPs' second layer inside attn_pos
+extern int g_pos_waves;                     // dd_attention2.hip: waves per workgroup of the coordinate launch
+DD_OPT g_p2_in_pos = 1;                    // dd_debug_set_option(30, v): the projections of the new h ({P2, PL2}; in the last layer the
+                                               // heads' first Linear too) run in the leading / trailing workgroups of the coordinate
+                                               // launch instead of a launch of their own on the critical chain (round 5, bit-identical)
 // (ev_fork / ev_join: [0..7] per layer, [8] graph construction at the head of a forward)
 // DD_SIDE_PRIO: 1 (default) lowest priority for the side stream, 0 default priority, 2 highest
 static int g_side_low_priority = [] { const char* e = getenv("DD_SIDE_PRIO"); return (e && e[0] == '0') ? 0 : ((e && e[0] == '2') ? 2 : 1); }();
@@ -686,21 +690,23 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     // ---- projections of the new h / h_bond: one launch.  In the LAST layer the heads' first Linear (decompdiff.py:194-211:
     //      bond head on the final h_bond, v head on the ligand rows of the final h) rides along: it needs nothing the coordinate
     //      sub-layers produce, and as a launch of its own behind them it sat on the step's critical chain (8 us per step)
-    {
-      GemmArgs j[4] = {
-          gemm_args(hcur, B * N, 0, 128, B * N, LW(l, DD_W_n2), LW(l, DD_b_n2), nullptr, w.P2, B * N, 0, 256, 256, 0),
-          gemm_args(hcur + (long)NP * 128, NL, hN, 128, B * NL, LW(l, DD_W_l2), LW(l, DD_b_l2), nullptr, w.PL2, B * NL, 0, 1024, 1024, 0),
-          gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b2), LW(l, DD_b_b2), nullptr, w.PB2, nE, 0, 256, 256, 0),
-          gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b2), LW(l, DD_b_b2), nullptr, w.PB2, nE, 0, 256, 256, 0)};
-      int nj = g_lin_with_pb2 ? 2 : 3;
-      if (g_heads_early && g_lin_with_pb2 && l + 1 == s->num_layers) {
-        j[2] = gemm_args(w.hb, nE, 0, 128, nE, GW(DD_G_BH_W1), GW(DD_G_BH_b1), nullptr, w.qb, nE, 0, 128, 128, 0);
-        j[3] = gemm_args(hcur + (long)NP * 128, NL, hN, 128, B * NL, GW(DD_G_VH_W1), GW(DD_G_VH_b1), nullptr, w.qn, B * NL, 0, 128, 128, 0);
-        nj = 4;
-        heads_done = true;
-      }
-      DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, nj, st));
+    GemmArgs p2j[4] = {
+        gemm_args(hcur, B * N, 0, 128, B * N, LW(l, DD_W_n2), LW(l, DD_b_n2), nullptr, w.P2, B * N, 0, 256, 256, 0),
+        gemm_args(hcur + (long)NP * 128, NL, hN, 128, B * NL, LW(l, DD_W_l2), LW(l, DD_b_l2), nullptr, w.PL2, B * NL, 0, 1024, 1024, 0),
+        gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b2), LW(l, DD_b_b2), nullptr, w.PB2, nE, 0, 256, 256, 0),
+        gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b2), LW(l, DD_b_b2), nullptr, w.PB2, nE, 0, 256, 256, 0)};
+    int p2n = g_lin_with_pb2 ? 2 : 3;
+    if (g_heads_early && g_lin_with_pb2 && l + 1 == s->num_layers) {
+      p2j[2] = gemm_args(w.hb, nE, 0, 128, nE, GW(DD_G_BH_W1), GW(DD_G_BH_b1), nullptr, w.qb, nE, 0, 128, 128, 0);
+      p2j[3] = gemm_args(hcur + (long)NP * 128, NL, hN, 128, B * NL, GW(DD_G_VH_W1), GW(DD_G_VH_b1), nullptr, w.qn, B * NL, 0, 128, 128, 0);
+      p2n = 4;
+      heads_done = true;
     }
+    // (round 5) these jobs ride INSIDE the coordinate launch below when it can take them (launch_attn2_pos_g): the attention
+    // workgroups wait for the first two, the heads' tiles trail behind them
+    bool p2_in_pos = g_p2_in_pos && g_lin_with_pb2 && g_q_in_pos && !g_xup_in_pos && g_pos_waves == 4 && NL <= 65 && l < 64 &&
+                     !(overlap && !ahead);
+    if (!p2_in_pos) DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(p2j, p2n, st));
     const bool q_in_pos = g_q_in_pos;           // second layer of the coordinate query MLPs inside attn_pos
     if (!q_in_pos) {
       GemmArgs j[2] = {
@@ -737,7 +743,17 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
         dpos.armed = true; dpos.pe = pe; dpos.pb = pb; dpos.xcur = xcur; dpos.xnext = xnext; dpos.layer = l; dpos.xup = xup_in_pos || xup_in_asm;
         if (!g_defer_pos) DD_TRY(flush_pos());
       } else {
-        DD_TRYP(DD_PROF_ATTN_PE, launch_attn2_pos(pe, pb, st));
+        if (p2_in_pos) {
+          int rc_g;
+          { ProfScope prof_scope__(DD_PROF_ATTN_PE, st); rc_g = launch_attn2_pos_g(pe, pb, p2j, p2n, 2, w.counters + 64 + l, st); }
+          if (rc_g == DD_ERR_UNSUPPORTED_SHAPE) {          // (e.g. padded output rows): the two launches
+            p2_in_pos = false;
+            DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(p2j, p2n, st));
+          } else if (rc_g != DD_OK) {
+            return rc_g;
+          }
+        }
+        if (!p2_in_pos) DD_TRYP(DD_PROF_ATTN_PE, launch_attn2_pos(pe, pb, st));
         if (!xup_in_pos && !xup_in_asm) DD_TRYP(DD_PROF_MISC, launch_xupdate(xcur, w.dxe, w.dxb, B, NP, NL, xnext, st));
       }
       if (xup_in_asm) xup_prev = xcur;
@@ -1562,6 +1578,7 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 8) { if (value < 0 || value > 5) return DD_ERR_BAD_ARG; dd::g_sched = value; return DD_OK; }
   if (key == 25) { dd::g_tail_variant = value; return DD_OK; }
   if (key == 27) { dd::g_side_lin = value ? 1 : 0; return DD_OK; }
+  if (key == 30) { dd::g_p2_in_pos = value ? 1 : 0; return DD_OK; }
   if (key == 28) { dd::g_heads_early = value ? 1 : 0; return DD_OK; }
   if (key == 29) { dd::g_head_rows_first = value ? 1 : 0; return DD_OK; }
   if (key == 7) { dd::g_step_fused = value ? 1 : 0; return DD_OK; }

@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "dd_kernels.hpp"
+#include "dd_gemm_tile.hpp"
 
 namespace dd {
 
@@ -222,6 +223,23 @@ struct Lds {
   static constexpr int TOTAL = WAO + (TRIP ? 2 * 12 * 128 : 0);
 };
 
+// consumer side of the in-launch hand-off of k_attn2_pos_g (see there)
+__device__ __forceinline__ void pos_wait_tiles(const int32_t* counter, int target) {
+  if (threadIdx.x == 0) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (spins == 0) __builtin_amdgcn_s_sleep(8);                  // 0.2, 0.4, 0.8 us, ... capped at 3.3 us between polls
+      else if (spins == 1) __builtin_amdgcn_s_sleep(16);
+      else if (spins == 2) __builtin_amdgcn_s_sleep(32);
+      else if (spins == 3) __builtin_amdgcn_s_sleep(64);
+      else __builtin_amdgcn_s_sleep(127);
+      if (++spins > (1u << 20)) __builtin_trap();                   // > 3 s: the producers of this launch never ran -- fail loudly
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+
 // node_layer_with_edge workgroups never mix protein and ligand centres (the Gaussian tables of only two edge types
 // are then needed): per sample ceil(NP/NW) protein blocks followed by ceil(NL/NW) ligand blocks.
 __host__ __device__ inline int ne_blocks_per_sample(int NP, int NL, int NW) { return (NP + NW - 1) / NW + (NL + NW - 1) / NW; }
@@ -409,6 +427,11 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
   }
 
   if (!PERSIST) stage_all();
+  if (POS && a.wait_flags != nullptr) {
+    // the projections of the new h (k / v source rows, destination rows, query hidden rows) are formed by the LEADING workgroups
+    // of this very launch (k_attn2_pos_g): staged the weight images first, now wait for their tile counter (see pos_wait_tiles)
+    pos_wait_tiles(a.wait_flags + a.wait_idx, a.wait_n);
+  }
   DD_STAMP(1);
 
   // query first: the Q~ fold must not queue behind the prefetched gathers (loads return in order)
@@ -977,6 +1000,60 @@ __global__ __launch_bounds__(NW * 128) void k_attn2_pos(const AttnArgs pe, const
   }
 }
 
+// ---- coordinate launch with the projections of the new h inside (k_attn2_pos_g) -------------------------------------------
+// The {P2, PL2} projection launch used to sit between lin_node and the coordinate attention on the step's critical chain
+// (11 us + the launch boundary, per layer).  Its 64 x 64 tiles now run in the LEADING workgroups of the coordinate launch (two
+// tiles per 512-thread workgroup, the GEMM launch's own tile code: bit-identical), while the attention workgroups -- dispatched
+// behind them, one per CU either way -- stage their 127 KB of weight images; then one lane per attention workgroup polls the tile
+// counter.  Producers never wait and are dispatched first, so the hand-off cannot deadlock.  Visibility (guide section 6,
+// Guideline 16, form R1): tiles store write-through (sc1) and bump the counter after their stores have drained; the consumer
+// does ONE agent-scope acquire after its poll, the workgroup barrier releases the other waves, plain loads follow.
+// Jobs listed after the first `n_lead` ones (the heads' first Linear in the last layer: nobody in this launch reads them) run
+// in TRAILING workgroups, behind the attention workgroups in dispatch order.
+struct PosGemm { GemmArgs job[4]; int end[4]; int nbx[4]; int njobs; };
+
+// tiles `first`, `first + 1` (< limit) of the job list: one per group of 256 threads, each in its own 33 KB LDS image
+__device__ __forceinline__ void pos_gemm_tiles(const PosGemm& pg, int first, int limit, float* smem) {
+  const int half = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+  int tile = first + half;
+  const bool valid = tile < limit;
+  if (!valid) tile = first;                              // (its rows are moved out of range below: barriers only)
+  int j = 0, base = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    if (j == i && tile >= pg.end[i] && i + 1 < pg.njobs) { base = pg.end[i]; j = i + 1; }
+  j = __builtin_amdgcn_readfirstlane(j);
+  const GemmArgs a = pg.job[j];                          // wave-uniform index into the kernel arguments: scalar loads
+  const int lb = tile - base, nbx = pg.nbx[j];
+  const int bx = valid ? lb % nbx : (1 << 20), by = lb / nbx;
+  gemm_tile_ksplit<false, true>(a, bx, by, smem + half * (2 * GT * GPH));
+}
+
+template <int MAXT, int NW, bool RAG = false>
+__global__ __launch_bounds__(NW * 128) void k_attn2_pos_g(const AttnArgs pe, const AttnArgs pb, int n_pe, const PosGemm pg, int n_g0,
+                                                          int n_tiles0, int n_att, int n_tiles_all, int32_t* counter) {
+  static_assert(NW == 4, "two 256-thread tile groups per workgroup");
+  constexpr int SZ = imax(Lds<M_PE>::TOTAL, Lds<M_PB>::TOTAL) + NW * 256 + NW * MAXT * 256;
+  static_assert(SZ >= 2 * 2 * GT * GPH, "two K-half tile images fit the attention workgroup's LDS");
+  __shared__ __attribute__((aligned(16))) float smem[SZ];
+  int blk = blockIdx.x;
+  if (blk < n_g0 || blk >= n_g0 + n_att) {
+    const bool lead = blk < n_g0;
+    const int first = lead ? 2 * blk : n_tiles0 + 2 * (blk - n_g0 - n_att);
+    pos_gemm_tiles(pg, first, lead ? n_tiles0 : n_tiles_all, smem);
+    if (lead) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's write-through stores have left
+      __syncthreads();                                              // ... and every other wave's of the workgroup
+      if (threadIdx.x == 0)
+        __hip_atomic_fetch_add(counter, n_tiles0 - first < 2 ? n_tiles0 - first : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  blk -= n_g0;
+  if (blk < n_pe) attn2_body<M_PE, 2, NW, false, RAG, true, false>(pe, blk, smem);
+  else attn2_body<M_PB, MAXT, NW, false, RAG, true, false>(pb, blk - n_pe, smem);
+}
+
 template <int MODE, int MAXT, int NW>
 static int launch_mode(const AttnArgs& a, int nseg, hipStream_t st) {
   if (nseg <= 0) return DD_OK;
@@ -1119,6 +1196,45 @@ static int launch_pos_nw(const AttnArgs& pe, const AttnArgs& pb, hipStream_t st)
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
+// Coordinate launch with up to 4 projection jobs inside: jobs[0 .. n_lead) are what the attention workgroups wait for (their tiles
+// run in the leading workgroups), the rest runs behind them.  `counter`: an int32 that is zero when the launch starts (one per
+// layer: the forward's first launch zeroes the workspace counters).  DD_ERR_UNSUPPORTED_SHAPE: use the two launches instead.
+int launch_attn2_pos_g(const AttnArgs& pe_in, const AttnArgs& pb_in, const GemmArgs* jobs, int njobs, int n_lead, int32_t* counter,
+                       hipStream_t st) {
+  using namespace v2;
+  if (njobs <= 0 || njobs > 4 || n_lead <= 0 || n_lead > njobs || counter == nullptr) return DD_ERR_BAD_ARG;
+  if (pe_in.NL > 65 || pe_in.work_counter != nullptr) return DD_ERR_UNSUPPORTED_SHAPE;
+  for (int i = 0; i < njobs; ++i)
+    if (jobs[i].ln != nullptr || (jobs[i].ldy & 3) || (jobs[i].ncols & 3) || (reinterpret_cast<size_t>(jobs[i].Y) & 15))
+      return DD_ERR_UNSUPPORTED_SHAPE;                   // (the write-through epilogue is the 16-byte path)
+  PosGemm pg;
+  pg.njobs = njobs;
+  int total = 0, tiles0 = 0;
+  for (int i = 0; i < 4; ++i) {
+    const GemmArgs& g = jobs[i < njobs ? i : 0];
+    pg.job[i] = g;
+    pg.nbx[i] = i < njobs ? (g.rows + GT - 1) / GT : 1;
+    if (i < njobs) total += pg.nbx[i] * ((g.ncols + GT - 1) / GT);
+    pg.end[i] = total;
+    if (i + 1 == n_lead) tiles0 = total;
+  }
+  constexpr int NW = 4;
+  const int n = (pe_in.B * pe_in.NL + NW - 1) / NW, n_att = 2 * n;
+  const int n_g0 = (tiles0 + 1) / 2, n_g1 = (total - tiles0 + 1) / 2;
+  AttnArgs pe = pe_in, pb = pb_in;
+  pe.wait_flags = pb.wait_flags = counter; pe.wait_idx = pb.wait_idx = 0; pe.wait_n = pb.wait_n = tiles0;
+  const dim3 grid(n_g0 + n_att + n_g1), block(NW * 128);
+  if (pe.nl_real != nullptr) {
+    if (pe.NL > 49) hipLaunchKernelGGL((k_attn2_pos_g<4, NW, true>), grid, block, 0, st, pe, pb, n, pg, n_g0, tiles0, n_att, total, counter);
+    else if (pe.NL > 33) hipLaunchKernelGGL((k_attn2_pos_g<3, NW, true>), grid, block, 0, st, pe, pb, n, pg, n_g0, tiles0, n_att, total, counter);
+    else hipLaunchKernelGGL((k_attn2_pos_g<2, NW, true>), grid, block, 0, st, pe, pb, n, pg, n_g0, tiles0, n_att, total, counter);
+  } else if (pe.NL > 49) hipLaunchKernelGGL((k_attn2_pos_g<4, NW>), grid, block, 0, st, pe, pb, n, pg, n_g0, tiles0, n_att, total, counter);
+  else if (pe.NL > 33) hipLaunchKernelGGL((k_attn2_pos_g<3, NW>), grid, block, 0, st, pe, pb, n, pg, n_g0, tiles0, n_att, total, counter);
+  else hipLaunchKernelGGL((k_attn2_pos_g<2, NW>), grid, block, 0, st, pe, pb, n, pg, n_g0, tiles0, n_att, total, counter);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
+
 int g_pos_waves = 4;         // waves per workgroup of the fused coordinate launch: 2, 4 or 8
 int launch_attn2_pos(const AttnArgs& pe, const AttnArgs& pb, hipStream_t st) {
   if (pe.NL > 129) return DD_ERR_UNSUPPORTED_SHAPE;

@@ -41,7 +41,8 @@ constexpr int DD_NUM_FLAGS = DD_FLAG_ERR + DD_FLAG_STRIDE;
 #else
 constexpr int DD_NUM_FLAGS = 0;                                         // the default library's workspace carries no flag words
 #endif
-constexpr int DD_NUM_COUNTERS = 64;                                     // work counters of the persistent attention workgroups
+constexpr int DD_NUM_COUNTERS = 128;                                    // [0, 64): work counters of the persistent attention workgroups (per
+                                                                        // layer), [64, 128): tile counters of the coordinate launches (k_attn2_pos_g)
 constexpr int DD_TAIL_CHUNK = 2;                                        // consecutive tiles drawn per ticket
 constexpr int DD_TAIL_MAX_JOBS = 14;
 struct TailJob {
@@ -139,6 +140,9 @@ struct AttnArgs {
 int launch_attn2(int mode, const AttnArgs& a, hipStream_t st);   // one sub-layer: 16-member tiles, scores/aggregation on MFMA
 int launch_attn2_node(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs& bl, hipStream_t st);   // NE+NB+BL, one launch (ne.wait_*)
 int launch_attn2_pos(const AttnArgs& pe, const AttnArgs& pb, hipStream_t st);                        // PE+PB, one launch
+// ... with the projections that feed it computed by its leading workgroups (dd_attention2.hip::k_attn2_pos_g)
+int launch_attn2_pos_g(const AttnArgs& pe, const AttnArgs& pb, const GemmArgs* jobs, int njobs, int n_lead, int32_t* counter,
+                       hipStream_t st);
 int launch_xupdate(const float* x, const float* dxe, const float* dxb, int B, int NP, int NL, float* x_next, hipStream_t st);
 
 struct StepRowsArgs {

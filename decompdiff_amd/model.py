@@ -933,8 +933,13 @@ class DecompScorePosNet3D(nn.Module):
                                     _drift_norm_batch, start_step, static=static)
         if static is None and "static" in chain:
             self._static_memo_put(key_t, center_pos_mode, chain["static"])
+        tr = self.__dict__.get("_trace")
+        if tr is not None:
+            tr.append(("prepared>", time.perf_counter()))
         self._run_chains([chain], num_steps, use_graph)
         out = self._collect_chain(chain, num_steps, keep_traj)
+        if tr is not None:
+            tr.append(("collected>", time.perf_counter()))
         self._last = (chain["s"], chain["bufs"])
         return out
 
@@ -1151,20 +1156,35 @@ class DecompScorePosNet3D(nn.Module):
             for c, lo in enumerate(range(0, num_steps, piece)):
                 hi = min(num_steps, lo + piece)
                 mark(f"launch{c}<")
+                if tr is not None and c == 0:              # (trace mode: the device's own clock around every piece)
+                    gpu_ev = [torch.cuda.Event(enable_timing=True)]
+                    gpu_ev[0].record(side)
                 hip_lib.check(lib.dd_graph_launch(graph, (hi - lo) // spg, side.cuda_stream), "dd_graph_launch")
                 mark(f"launch{c}>")
-                ev = torch.cuda.Event()
+                ev = torch.cuda.Event(enable_timing=tr is not None)
                 ev.record(side)
+                if tr is not None:
+                    gpu_ev.append(ev)
                 if c == 0:
                     # everything the host needs for the drains is built while the device runs the first piece: the first
                     # graph replay is enqueued ~0.1 ms earlier (20-step calls: what the driver's bench line times)
                     setup_host_side()
                 slots = host["slots"]
+                # The previous piece is drained BEFORE this piece's copies are enqueued (the device has this piece's replays
+                # queued, so it never waits for the host): at most one piece's copies -- 6 copies, torch's 6 pinned-block
+                # events, 2 of ours -- are ever outstanding on the copy stream.  With two pieces outstanding the HIP runtime
+                # blocked the host for 5.5 ms inside the 15th enqueue of a process's first three-piece call (an async copy of
+                # 111 KB) and the device lost 0.85 ms in the piece that was running (profiles/round5_call_trace.txt).
+                if pending:
+                    drain(pending.pop(0))
+                    mark(f"drained{c - 1}>")
                 copy_st.wait_event(ev)
+                mark(f"waitev{c}>")
                 with torch.cuda.stream(copy_st):
                     for k in keys:
                         if not dbg & 1:
                             slots[c % 2][k][:hi - lo].copy_(bufs[k][lo:hi], non_blocking=True)
+                            mark(f"cp{c}.{k[5:]}>")
                 done = torch.cuda.Event()
                 done.record(copy_st)
                 pending.append((lo, hi, c % 2, done))
@@ -1173,9 +1193,6 @@ class DecompScorePosNet3D(nn.Module):
                     for k in keys:                     # first touch of the pages the un-hidden last drain writes
                         host["final_np"][k][tail:].fill(0)
                 mark(f"copies{c}>")
-                if len(pending) == 2:
-                    drain(pending.pop(0))
-                    mark(f"drained{c - 1}>")
             while pending:
                 drain(pending.pop(0))
                 mark("drained_tail>")
@@ -1183,6 +1200,9 @@ class DecompScorePosNet3D(nn.Module):
             side.synchronize()
             copy_st.synchronize()
             mark("synced>")
+            if tr is not None:
+                tr.extend((f"[device ms piece {i}: {gpu_ev[i].elapsed_time(gpu_ev[i + 1]):.3f}]", time.perf_counter())
+                          for i in range(len(gpu_ev) - 1))
             if not cached:                                 # (a cached entry keeps its graph for the next chain)
                 DecompScorePosNet3D._parked_graphs.append({"graph": graph, "graph_id": ent.get("graph_id", 0), "dev": dev})
                 ent["graph"] = None

@@ -709,6 +709,41 @@ def test_layer0_tables_are_bit_identical_to_the_gemms(debug_options):
     assert not torch.equal(r["pred_ligand_v"], on["pred_ligand_v"])
 
 
+@pytest.mark.parametrize("shape", ["small", "mid", "ragged", "large_drift"])
+def test_projections_inside_the_coordinate_launch_are_bit_identical(debug_options, shape):
+    """Round 5: the {P2, PL2} projections of the new h (and, in the last layer, the heads' first Linear) run in the leading /
+    trailing workgroups of the coordinate launch (k_attn2_pos_g, in-launch hand-off through a tile counter) instead of a
+    launch of their own.  Same tile code, same operands: forward and chains must be bit-identical with option 30 off (the
+    two launches), graph replay and eager, dense / long-ligand / padded batches, with drift."""
+    if not debug_options:
+        return
+    lib = hip_lib.load()
+    m = model(0)
+    torch.manual_seed(11)
+    drift = None
+    if shape == "small":
+        b = to_dev_local(synth.build_sampling_batch(synth.make_pocket_small(3), 8))
+    elif shape == "mid":                                   # 37 ligand atoms: the 3-tile kernels
+        b = to_dev_local(synth.build_sampling_batch(synth.make_pocket(5, 347, (10, 9), 18, num_full_protein=0), 4))
+    elif shape == "ragged":
+        b = to_dev_local(_hetero_batch([12, 20, 9, 16], [70, 90, 60, 80]))
+    else:
+        b = to_dev_local(synth.build_sampling_batch(synth.make_pocket_large(2), 2))
+        drift = GU.DRIFT
+    run = lambda graph: m.sample_diffusion(num_steps=6, center_pos_mode="protein", energy_drift_opt=drift, seed=21, use_graph=graph, **b)
+    try:
+        on_g, on_e = run(True), run(False)
+        assert lib.dd_debug_set_option(30, 0) == 0
+        off_g, off_e = run(True), run(False)
+    finally:
+        assert lib.dd_debug_set_option(30, 1) == 0
+    for a, c in ((on_g, off_g), (on_e, off_e), (on_g, on_e)):
+        for k in ("pos", "v", "bond"):
+            assert torch.equal(a[k], c[k]), (shape, k)
+        for k in ("pos_traj", "v0_traj", "bt_traj"):
+            assert all(torch.equal(x, y) for x, y in zip(a[k], c[k])), (shape, k)
+
+
 def test_two_launch_head_is_bit_identical_to_the_four_launches(debug_options):
     """Head of a forward: k_head_graph (kNN by radix select + edge weights in one wave per centre, x_t read from the
     sampler's position buffers) beside k_head_rows (embeddings / context / counters + layer-0 rows) against the four
