@@ -122,15 +122,20 @@ def algorithmic_flops_node_launch(B, NP, NL, K):
     return 2.0 * (e * 2 * (21 * 128 + 128 * 128) + eb * 2 * (128 * 128) + e3 * 2 * (13 * 128 + 128 * 128))
 
 
-def gemm_work_per_step(B, NP, NL, num_layers, layer0_tables=True):
+def gemm_work_per_step(B, NP, NL, num_layers, layer0_tables=True, p2_in_pos=False):
     """(useful FLOPs, 64x64 output tiles) of the dense GEMM launches of one step (dd_api.hip forward_impl).  With the
-    layer-0 tables (dd_sampler.l0_tables) the first layer's projection and query launches do not run."""
+    layer-0 tables (dd_sampler.l0_tables) the first layer's projection and query launches do not run; with `p2_in_pos`
+    (dd_debug_schedule() & 1) the projections of the new h and the heads' first Linear run inside the coordinate launch and are
+    not GEMM launches any more (their time is then part of the coordinate launch's)."""
     N, Eb = NP + NL, NL * (NL - 1)
     first = [(B * N, 640), (B * NL, 1280), (B * Eb, 640),                     # projections of the old h / h_bond
              (B * Eb, 128), (B * N, 128), (B * NL, 128)]                      # query MLPs, second Linear
-    rest = [(B * N, 128), (B * Eb, 256),                                      # lin_node, bond projections (coordinates)
-            (B * N, 256), (B * NL, 1024)]                                     # projections of the new h
+    rest = [(B * N, 128), (B * Eb, 256)]                                      # lin_node, bond projections (coordinates)
     heads = [(B * Eb, 128), (B * NL, 128)]
+    if not p2_in_pos:
+        rest += [(B * N, 256), (B * NL, 1024)]                                # projections of the new h
+    else:
+        heads = []
     jobs = (first + rest) * num_layers + heads
     if layer0_tables:
         jobs = jobs[len(first):]
@@ -335,7 +340,7 @@ def measure_step_rooflines(torch, model, hip_lib, lib, state, cfg, B, NP, NL, K,
             traffic_source = f"committed PMC pass {ent.get('measured_at_commit', '?')} ({ent.get('source', 'profiles/')}); kernel source {src_sha}"
         elif ent:
             traffic_note = (f"stale: the committed PMC pass was taken on dd_attention2.hip {ent.get('kernel_source_sha256_16')}, this "
-                            f"run's source is {src_sha} -- re-run the PMC passes (tools/gpu_round4_evidence.sh)")
+                            f"run's source is {src_sha} -- re-run the PMC passes (tools/gpu_round5_evidence.sh)")
     except (OSError, KeyError, ValueError):
         pass
     roofline = {
@@ -357,14 +362,17 @@ def measure_step_rooflines(torch, model, hip_lib, lib, state, cfg, B, NP, NL, K,
                 "capped near 0.45.",
         "ms_per_step_by_launch_class": {k: round(v, 4) for k, v in per_cat.items()},
     }
-    g_flops, g_tiles = gemm_work_per_step(B, NP, NL, L, layer0_tables=bool(s2.l0_tables))
+    p2_in_pos = bool(lib.dd_debug_schedule() & 1) and NL <= 65
+    g_flops, g_tiles = gemm_work_per_step(B, NP, NL, L, layer0_tables=bool(s2.l0_tables), p2_in_pos=p2_in_pos)
     g_ms = per_cat["gemm"]
     roofline_gemm = {"bound": "mfma", "kernel": "dd::k_gemm128_batch (projection / query / lin_node / head GEMMs, serialised)",
                      "flops_per_step": g_flops, "tiles_64x64_per_step": g_tiles, "ms_per_step": round(g_ms, 4),
                      "achieved": round(g_flops / (g_ms * 1e-3) / 1e12, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(g_flops / (g_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
                      "note": "useful FLOPs (2 x rows x 128 x cols) of every GEMM launch of a step / their summed HIP-event "
-                             "durations with the launches serialised (in the step graph half of them overlap on a second stream)"}
+                             "durations with the launches serialised (in the step graph half of them overlap on a second stream)"
+                             + ("; the projections of the new h and the heads' first Linear run inside the coordinate launch "
+                                "(k_attn2_pos_g) and are not counted here" if p2_in_pos else "")}
     return roofline, roofline_gemm
 
 

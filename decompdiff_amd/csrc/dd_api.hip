@@ -185,9 +185,10 @@ DD_OPT g_head_rows_first = 0;              // dd_debug_set_option(29, v): see th
 DD_OPT g_heads_early = 1;                  // dd_debug_set_option(28, v): heads' first Linear in the last layer's projection launch
 DD_OPT g_q_in_pos = 1;                     // dd_debug_set_option(9, v): coordinate query MLPs' second layer inside attn_pos
 extern int g_pos_waves;                     // dd_attention2.hip: waves per workgroup of the coordinate launch
-DD_OPT g_p2_in_pos = 1;                    // dd_debug_set_option(30, v): the projections of the new h ({P2, PL2}; in the last layer the
+DD_OPT g_p2_in_pos = 0;                    // dd_debug_set_option(30, v): the projections of the new h ({P2, PL2}; in the last layer the
                                                // heads' first Linear too) run in the leading / trailing workgroups of the coordinate
-                                               // launch instead of a launch of their own on the critical chain (round 5, bit-identical)
+                                               // launch instead of a launch of their own on the critical chain (round 5: bit-identical,
+                                               // measured 2.6 % SLOWER -- 40 us where the two launches take 11 + 23; EXPERIMENTS.md R5-2)
 // (ev_fork / ev_join: [0..7] per layer, [8] graph construction at the head of a forward)
 // DD_SIDE_PRIO: 1 (default) lowest priority for the side stream, 0 default priority, 2 highest
 static int g_side_low_priority = [] { const char* e = getenv("DD_SIDE_PRIO"); return (e && e[0] == '0') ? 0 : ((e && e[0] == '2') ? 2 : 1); }();
@@ -1534,7 +1535,7 @@ extern "C" int dd_debug_set_fusion(int mode) {
   return DD_OK;
 }
 
-namespace dd { extern int g_gemm_ksplit; extern int g_attn_waves; extern int g_attn_persist; extern int g_pos_waves; extern int g_bl_first; extern int g_gemm_xcd; }
+namespace dd { extern int g_pos_g_mode; extern int g_gemm_ksplit; extern int g_attn_waves; extern int g_attn_persist; extern int g_pos_waves; extern int g_bl_first; extern int g_gemm_xcd; }
 // Measurement aid: runtime switches for A/B timing inside one process.  key 0: attention launch structure (same
 // values as dd_debug_set_fusion), key 1: K-split projection GEMM tiles (1 = on).
 // First bounded spin of the layer-tail hand-offs that gave up (0 = none) since the word was last read (sticky; the
@@ -1555,6 +1556,9 @@ extern "C" int dd_queue_error(const dd_sampler* s, void* stream, int* code) {
 #endif
 
 extern "C" int dd_debug_node_split(int B, int NP, int NL, int K) { return dd::node_split_lookup(B, NP, NL, K); }
+
+// bit 0: the projections of the new h (and the heads' first Linear) run inside the coordinate launch (k_attn2_pos_g), not as a GEMM launch
+extern "C" int dd_debug_schedule(void) { return dd::g_p2_in_pos ? 1 : 0; }
 
 extern "C" int dd_debug_set_option(int key, int value) {
   ++g_options_epoch;
@@ -1579,6 +1583,7 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 25) { dd::g_tail_variant = value; return DD_OK; }
   if (key == 27) { dd::g_side_lin = value ? 1 : 0; return DD_OK; }
   if (key == 30) { dd::g_p2_in_pos = value ? 1 : 0; return DD_OK; }
+  if (key == 31) { dd::g_pos_g_mode = value & 3; return DD_OK; }
   if (key == 28) { dd::g_heads_early = value ? 1 : 0; return DD_OK; }
   if (key == 29) { dd::g_head_rows_first = value ? 1 : 0; return DD_OK; }
   if (key == 7) { dd::g_step_fused = value ? 1 : 0; return DD_OK; }

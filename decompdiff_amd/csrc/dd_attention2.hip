@@ -223,12 +223,14 @@ struct Lds {
   static constexpr int TOTAL = WAO + (TRIP ? 2 * 12 * 128 : 0);
 };
 
-// consumer side of the in-launch hand-off of k_attn2_pos_g (see there)
-__device__ __forceinline__ void pos_wait_tiles(const int32_t* counter, int target) {
+// consumer side of the in-launch hand-off of k_attn2_pos_g (see there; measurement build)
+__device__ __forceinline__ void pos_wait_tiles(const int32_t* counter, int target_in) {
+  const bool fast = target_in < 0;                        // (measurement: negative target = poll every 0.2 us, no back-off)
+  const int target = fast ? -target_in : target_in;
   if (threadIdx.x == 0) {
     unsigned spins = 0;
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      if (spins == 0) __builtin_amdgcn_s_sleep(8);                  // 0.2, 0.4, 0.8 us, ... capped at 3.3 us between polls
+      if (spins == 0 || fast) __builtin_amdgcn_s_sleep(8);                  // 0.2, 0.4, 0.8 us, ... capped at 3.3 us between polls
       else if (spins == 1) __builtin_amdgcn_s_sleep(16);
       else if (spins == 2) __builtin_amdgcn_s_sleep(32);
       else if (spins == 3) __builtin_amdgcn_s_sleep(64);
@@ -427,11 +429,13 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
   }
 
   if (!PERSIST) stage_all();
+#if defined(DD_DEBUG_OPTIONS) && DD_DEBUG_OPTIONS          // (measurement build only: EXPERIMENTS.md R5-2)
   if (POS && a.wait_flags != nullptr) {
     // the projections of the new h (k / v source rows, destination rows, query hidden rows) are formed by the LEADING workgroups
     // of this very launch (k_attn2_pos_g): staged the weight images first, now wait for their tile counter (see pos_wait_tiles)
     pos_wait_tiles(a.wait_flags + a.wait_idx, a.wait_n);
   }
+#endif
   DD_STAMP(1);
 
   // query first: the Q~ fold must not queue behind the prefetched gathers (loads return in order)
@@ -1000,8 +1004,12 @@ __global__ __launch_bounds__(NW * 128) void k_attn2_pos(const AttnArgs pe, const
   }
 }
 
+#if defined(DD_DEBUG_OPTIONS) && DD_DEBUG_OPTIONS
 // ---- coordinate launch with the projections of the new h inside (k_attn2_pos_g) -------------------------------------------
-// The {P2, PL2} projection launch used to sit between lin_node and the coordinate attention on the step's critical chain
+// MEASUREMENT BUILD ONLY (dd_debug_set_option(30, 1)): bit-identical, but the launch takes 40 us where the two launches it
+// replaces take 11 + 23 -- an in-launch hand-off (write-through stores, counter, poll, acquire, cold reads) costs more than the
+// kernel boundary it removes, whatever the poll rate or the store type (EXPERIMENTS.md R5-2).
+// The {P2, PL2} projection launch sits between lin_node and the coordinate attention on the step's critical chain
 // (11 us + the launch boundary, per layer).  Its 64 x 64 tiles now run in the LEADING workgroups of the coordinate launch (two
 // tiles per 512-thread workgroup, the GEMM launch's own tile code: bit-identical), while the attention workgroups -- dispatched
 // behind them, one per CU either way -- stage their 127 KB of weight images; then one lane per attention workgroup polls the tile
@@ -1010,7 +1018,7 @@ __global__ __launch_bounds__(NW * 128) void k_attn2_pos(const AttnArgs pe, const
 // does ONE agent-scope acquire after its poll, the workgroup barrier releases the other waves, plain loads follow.
 // Jobs listed after the first `n_lead` ones (the heads' first Linear in the last layer: nobody in this launch reads them) run
 // in TRAILING workgroups, behind the attention workgroups in dispatch order.
-struct PosGemm { GemmArgs job[4]; int end[4]; int nbx[4]; int njobs; };
+struct PosGemm { GemmArgs job[4]; int end[4]; int nbx[4]; int njobs; int mode; };   // mode: bit 0 plain stores + release fence (not sc1)
 
 // tiles `first`, `first + 1` (< limit) of the job list: one per group of 256 threads, each in its own 33 KB LDS image
 __device__ __forceinline__ void pos_gemm_tiles(const PosGemm& pg, int first, int limit, float* smem) {
@@ -1026,7 +1034,8 @@ __device__ __forceinline__ void pos_gemm_tiles(const PosGemm& pg, int first, int
   const GemmArgs a = pg.job[j];                          // wave-uniform index into the kernel arguments: scalar loads
   const int lb = tile - base, nbx = pg.nbx[j];
   const int bx = valid ? lb % nbx : (1 << 20), by = lb / nbx;
-  gemm_tile_ksplit<false, true>(a, bx, by, smem + half * (2 * GT * GPH));
+  if (pg.mode & 1) gemm_tile_ksplit<false, false>(a, bx, by, smem + half * (2 * GT * GPH));
+  else gemm_tile_ksplit<false, true>(a, bx, by, smem + half * (2 * GT * GPH));
 }
 
 template <int MAXT, int NW, bool RAG = false>
@@ -1044,8 +1053,11 @@ __global__ __launch_bounds__(NW * 128) void k_attn2_pos_g(const AttnArgs pe, con
     if (lead) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's write-through stores have left
       __syncthreads();                                              // ... and every other wave's of the workgroup
-      if (threadIdx.x == 0)
-        __hip_atomic_fetch_add(counter, n_tiles0 - first < 2 ? n_tiles0 - first : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x == 0) {
+        const int n_done = n_tiles0 - first < 2 ? n_tiles0 - first : 2;
+        if (pg.mode & 1) __hip_atomic_fetch_add(counter, n_done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // (L2 write-back first)
+        else __hip_atomic_fetch_add(counter, n_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     return;
   }
@@ -1053,6 +1065,8 @@ __global__ __launch_bounds__(NW * 128) void k_attn2_pos_g(const AttnArgs pe, con
   if (blk < n_pe) attn2_body<M_PE, 2, NW, false, RAG, true, false>(pe, blk, smem);
   else attn2_body<M_PB, MAXT, NW, false, RAG, true, false>(pb, blk - n_pe, smem);
 }
+
+#endif
 
 template <int MODE, int MAXT, int NW>
 static int launch_mode(const AttnArgs& a, int nseg, hipStream_t st) {
@@ -1199,8 +1213,13 @@ static int launch_pos_nw(const AttnArgs& pe, const AttnArgs& pb, hipStream_t st)
 // Coordinate launch with up to 4 projection jobs inside: jobs[0 .. n_lead) are what the attention workgroups wait for (their tiles
 // run in the leading workgroups), the rest runs behind them.  `counter`: an int32 that is zero when the launch starts (one per
 // layer: the forward's first launch zeroes the workspace counters).  DD_ERR_UNSUPPORTED_SHAPE: use the two launches instead.
+int g_pos_g_mode = 0;        // measurement: bit 0 plain stores + release instead of write-through stores, bit 1 fast polls
 int launch_attn2_pos_g(const AttnArgs& pe_in, const AttnArgs& pb_in, const GemmArgs* jobs, int njobs, int n_lead, int32_t* counter,
                        hipStream_t st) {
+#if !(defined(DD_DEBUG_OPTIONS) && DD_DEBUG_OPTIONS)
+  (void)pe_in; (void)pb_in; (void)jobs; (void)njobs; (void)n_lead; (void)counter; (void)st;
+  return DD_ERR_UNSUPPORTED_SHAPE;                       // the default library does not compile the variant: the two launches
+#else
   using namespace v2;
   if (njobs <= 0 || njobs > 4 || n_lead <= 0 || n_lead > njobs || counter == nullptr) return DD_ERR_BAD_ARG;
   if (pe_in.NL > 65 || pe_in.work_counter != nullptr) return DD_ERR_UNSUPPORTED_SHAPE;
@@ -1209,6 +1228,7 @@ int launch_attn2_pos_g(const AttnArgs& pe_in, const AttnArgs& pb_in, const GemmA
       return DD_ERR_UNSUPPORTED_SHAPE;                   // (the write-through epilogue is the 16-byte path)
   PosGemm pg;
   pg.njobs = njobs;
+  pg.mode = g_pos_g_mode & 1;
   int total = 0, tiles0 = 0;
   for (int i = 0; i < 4; ++i) {
     const GemmArgs& g = jobs[i < njobs ? i : 0];
@@ -1222,7 +1242,7 @@ int launch_attn2_pos_g(const AttnArgs& pe_in, const AttnArgs& pb_in, const GemmA
   const int n = (pe_in.B * pe_in.NL + NW - 1) / NW, n_att = 2 * n;
   const int n_g0 = (tiles0 + 1) / 2, n_g1 = (total - tiles0 + 1) / 2;
   AttnArgs pe = pe_in, pb = pb_in;
-  pe.wait_flags = pb.wait_flags = counter; pe.wait_idx = pb.wait_idx = 0; pe.wait_n = pb.wait_n = tiles0;
+  pe.wait_flags = pb.wait_flags = counter; pe.wait_idx = pb.wait_idx = 0; pe.wait_n = pb.wait_n = (g_pos_g_mode & 2) ? -tiles0 : tiles0;
   const dim3 grid(n_g0 + n_att + n_g1), block(NW * 128);
   if (pe.nl_real != nullptr) {
     if (pe.NL > 49) hipLaunchKernelGGL((k_attn2_pos_g<4, NW, true>), grid, block, 0, st, pe, pb, n, pg, n_g0, tiles0, n_att, total, counter);
@@ -1233,6 +1253,7 @@ int launch_attn2_pos_g(const AttnArgs& pe_in, const AttnArgs& pb_in, const GemmA
   else hipLaunchKernelGGL((k_attn2_pos_g<2, NW>), grid, block, 0, st, pe, pb, n, pg, n_g0, tiles0, n_att, total, counter);
   DD_CHECK_LAUNCH();
   return DD_OK;
+#endif
 }
 
 int g_pos_waves = 4;         // waves per workgroup of the fused coordinate launch: 2, 4 or 8

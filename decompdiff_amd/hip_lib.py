@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
 # measurement / profiling / test access: include/decompdiff_hip_debug.h (same library, not part of the boundary)
 DEBUG_SYMBOLS = [
     "dd_workspace_view", "dd_profile_step", "dd_debug_set_clock_buffer", "dd_debug_set_fusion", "dd_debug_set_option",
-    "dd_debug_node_split", "dd_debug_node_split_cache_path", "dd_debug_philox", "dd_debug_options_epoch", "dd_queue_error",
+    "dd_debug_node_split", "dd_debug_node_split_cache_path", "dd_debug_schedule", "dd_debug_philox", "dd_debug_options_epoch", "dd_queue_error",
 ]
 # exported by the measurement build only (-DDD_DEBUG_OPTIONS=1): the tile-queue schedule's sticky error word
 MEASUREMENT_ONLY_SYMBOLS = ("dd_queue_error",)
@@ -135,6 +135,7 @@ def load():
         "dd_debug_set_option": [c_int, c_int],
         "dd_debug_node_split": [c_int, c_int, c_int, c_int],
         "dd_debug_node_split_cache_path": [c_char_p, c_int],
+        "dd_debug_schedule": [],
         "dd_reverse_step": [S, c_void_p, c_void_p, c_void_p, c_void_p],
         "dd_attn_aggregate_node": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
         "dd_attn_aggregate_triplet": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],

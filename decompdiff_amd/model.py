@@ -1214,7 +1214,7 @@ class DecompScorePosNet3D(nn.Module):
         """One-off per process and device, with the first cached chain that is streamed: stream a short chain (3 pieces of
         8 steps) through the same launch / copy / drain code once and put the chain's state back.  The first streamed
         call of a process that is three or more pieces long stalls the device for ~1 ms in its second or third piece
-        (tools/first_call3.py: 10.6 instead of 9.7 ms for one 8-step piece); a 20-step chain after a 5-step warm-up would
+        (EXPERIMENTS.md R3-8: 10.6 instead of 9.7 ms for one 8-step piece); a 20-step chain after a 5-step warm-up would
         otherwise pay that inside the caller's timed call.  Returns False if this chain cannot be used for it."""
         bufs, s = chain["bufs"], chain["s"]
         n = min(int(bufs["traj_pos"].shape[0]), 24, int(s.t_start) + 1)     # (never past t = 0)

@@ -45,6 +45,9 @@ int dd_debug_node_split(int B, int NP, int NL, int K);
  * the ranks of a node and later runs read it instead of timing ~30 forward passes per shape each.  Writes the path (empty
  * string: off) into out[cap]. */
 int dd_debug_node_split_cache_path(char* out, int cap);
+/* Launch structure in effect, for the accounting of measurement tools (bench.py's per-class FLOP counts): bit 0 = the {P2, PL2}
+ * projections of the new h and the heads' first Linear run inside the coordinate launch (k_attn2_pos_g) instead of a GEMM launch. */
+int dd_debug_schedule(void);
 /* Health word of the in-launch hand-offs of the TILE-QUEUE schedule (dd_debug_set_option(8, 5); measurement build only --
  * the default library's schedule uses graph edges and never polls; EXPERIMENTS.md R3-1): the coordinate attention, the
  * next assemble and the next node attention start beside the persistent GEMM queue of their layer and poll its device

@@ -146,7 +146,7 @@ def make_pocket_fields(seed, beta=False, with_scaffold=True, num_arms=2):
 
 # ------------------------------------------------------------------------------------------------------------------
 # Parity record of the full-chain GPU tests: written BEFORE their assertions, so a run that fails still leaves its numbers.
-# gpurun merges gpurun_out/ back into the builder's tree; tools/gpu_round4_evidence.sh copies the file to
+# gpurun merges gpurun_out/ back into the builder's tree; tools/gpu_round5_evidence.sh copies the file to
 # profiles/parity_full_chain.json (committed: what `pytest -q` prints is not kept by the driver).
 # ------------------------------------------------------------------------------------------------------------------
 def chain_parity_summary(d, every, tol=1e-4, type_mismatches=(0, 0), bound=None, bound_name=None):

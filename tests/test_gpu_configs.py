@@ -714,7 +714,8 @@ def test_projections_inside_the_coordinate_launch_are_bit_identical(debug_option
     """Round 5: the {P2, PL2} projections of the new h (and, in the last layer, the heads' first Linear) run in the leading /
     trailing workgroups of the coordinate launch (k_attn2_pos_g, in-launch hand-off through a tile counter) instead of a
     launch of their own.  Same tile code, same operands: forward and chains must be bit-identical with option 30 off (the
-    two launches), graph replay and eager, dense / long-ligand / padded batches, with drift."""
+    two launches: what ships -- the variant is 2.6 % slower, EXPERIMENTS.md R5-2), graph replay and eager, dense / long-ligand /
+    padded batches, with drift."""
     if not debug_options:
         return
     lib = hip_lib.load()
@@ -732,11 +733,12 @@ def test_projections_inside_the_coordinate_launch_are_bit_identical(debug_option
         drift = GU.DRIFT
     run = lambda graph: m.sample_diffusion(num_steps=6, center_pos_mode="protein", energy_drift_opt=drift, seed=21, use_graph=graph, **b)
     try:
+        assert lib.dd_debug_set_option(30, 1) == 0 and lib.dd_debug_schedule() & 1
         on_g, on_e = run(True), run(False)
         assert lib.dd_debug_set_option(30, 0) == 0
         off_g, off_e = run(True), run(False)
     finally:
-        assert lib.dd_debug_set_option(30, 1) == 0
+        assert lib.dd_debug_set_option(30, 0) == 0
     for a, c in ((on_g, off_g), (on_e, off_e), (on_g, on_e)):
         for k in ("pos", "v", "bond"):
             assert torch.equal(a[k], c[k]), (shape, k)

@@ -15,7 +15,7 @@ import os
 b = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synth.build_sampling_batch(pocket, int(os.environ.get("DD_B", "8"))).items()}
 lib = hip_lib.load()
 variants = [("baseline", [])] + [(a, [tuple(int(x) for x in kv.split("=")) for kv in a.split(",")]) for a in sys.argv[1:]]
-DEFAULTS = {0: 1, 1: 1, 2: 8, 3: 1, 5: 4, 7: 1, 8: 4, 9: 1, 11: 0, 12: 1, 14: 0, 16: 1, 17: 1, 18: 1, 19: 1, 20: 1, 21: 1, 22: 1, 27: 0, 28: 1, 29: 0}
+DEFAULTS = {0: 1, 1: 1, 2: 8, 3: 1, 5: 4, 7: 1, 8: 4, 9: 1, 11: 0, 12: 1, 14: 0, 16: 1, 17: 1, 18: 1, 19: 1, 20: 1, 21: 1, 22: 1, 27: 0, 28: 1, 29: 0, 30: 0, 31: 0}
 def run(settings, steps=200):
     for k, v in DEFAULTS.items(): lib.dd_debug_set_option(k, v)
     for k, v in settings: lib.dd_debug_set_option(k, v)

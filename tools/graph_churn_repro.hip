@@ -6,8 +6,7 @@
 //   mode 1  "one by one"   : every finished graph is destroyed at once (others -- the cached ones -- stay alive)
 //   mode 2  "parked"       : finished graphs are parked and destroyed all together, newest first, once 12 have piled up
 //                            (what decompdiff_amd/model.py does since round 4)
-//   mode 3  "one by one + event churn": mode 1, and while a graph is being captured unrelated events are created, recorded on
-//                            the copy stream, queried and destroyed (what a host framework's allocator and garbage collector do
+//   mode 3  "one by one + event churn": mode 1, and while a graph is being captured unrelated events are created, queried and destroyed (what a host framework's allocator and garbage collector do
 //                            at arbitrary points: torch's pinned-memory allocator queries its events on every allocation)
 // Every mode runs in a forked child (a crash of the runtime is a signal in the child, not the end of the experiment).
 //   hipcc --offload-arch=gfx950 -O2 tools/graph_churn_repro.hip -o tools/_build/graph_churn_repro && tools/_build/graph_churn_repro [iterations] [repeats]
@@ -31,7 +30,9 @@ static hipStream_t g_churn_stream = nullptr;            // mode 3: event traffic
 static void event_churn() {
   if (!g_churn_stream) return;
   hipEvent_t e[4];
-  for (auto& x : e) { CK(hipEventCreateWithFlags(&x, hipEventDisableTiming)); CK(hipEventRecord(x, g_churn_stream)); }
+  // (created, queried and destroyed only: RECORDING on another stream from the capturing thread is an "unsafe call" that
+  //  invalidates a thread-local capture with error 901 -- the first version of this mode found that, not a crash)
+  for (auto& x : e) { CK(hipEventCreateWithFlags(&x, hipEventDisableTiming)); }
   for (auto& x : e) { (void)hipEventQuery(x); }
   for (auto& x : e) CK(hipEventDestroy(x));
 }

@@ -21,7 +21,7 @@ for mode, nm in enumerate(["NE", "NB", "BL", "PE", "PB"]):
     last = 10
     d = np.diff(c[:, :last + 1], axis=1).astype(np.float64)
     tot = (c[:, last] - c[:, 0]).astype(np.float64)
-    print(f"{nm}: {len(c)} workgroups x 6 layers, median total {np.median(tot):.0f} ticks of s_memtime (100 MHz -> {np.median(tot)/100:.1f} us)")
+    print(f"{nm}: {len(c)} workgroups x 6 layers, median total {np.median(tot):.0f} ticks of s_memtime (shader clock, ~2.4 GHz -> {np.median(tot)/2400:.1f} us)")
     print("   " + " | ".join(f"{n} {np.median(d[:, i]):.0f}" for i, n in enumerate(names[:d.shape[1]])))
     f = np.concatenate([c[:, 4:5], c[:, 11:15]], axis=1).astype(np.float64)
     print("   tile0/pass1: rows arrive %.0f | table MFMAs %.0f | LayerNorm %.0f | score MFMAs %.0f" % tuple(np.median(np.diff(f, axis=1), axis=0)))
