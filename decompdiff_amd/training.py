@@ -294,6 +294,9 @@ def network_grouped(net, model, protein_pos, protein_v, batch_protein, ligand_po
     n_p, n_l = sizes if sizes is not None else check_batch_layout(batch_protein, batch_ligand, ligand_fc_bond_index)
     B, dev = len(n_p), protein_pos.device
     if len(set(zip(n_p, n_l))) == 1:
+        if net is network and sizes is not None:            # (layout established by check_batch_layout: no re-check, no sync)
+            return net(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, ligand_v_aux, batch_ligand,
+                       ligand_fc_bond_index, ligand_bond_type, checked_B=B)
         return net(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, ligand_v_aux, batch_ligand,
                    ligand_fc_bond_index, ligand_bond_type)
     o_p = [0] + list(torch.tensor(n_p).cumsum(0).tolist())
@@ -399,15 +402,16 @@ def _knn_src(x, B, N, K, base):
 
 
 def network(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, ligand_v_aux, batch_ligand,
-            ligand_fc_bond_index, ligand_bond_type) -> Dict[str, torch.Tensor]:
+            ligand_fc_bond_index, ligand_bond_type, checked_B: Optional[int] = None) -> Dict[str, torch.Tensor]:
     """DecompScorePosNet3D.forward for the shipped configuration, differentiable w.r.t. the model's parameters.
     Dense batches (equal sizes per sample, sorted batch vectors, dst-major fc bond index -- `check_batch_layout`, run by
-    `diffusion_loss`; samples of different sizes go through `network_grouped`)."""
+    `diffusion_loss`; samples of different sizes go through `network_grouped`).  `checked_B`: the caller has established the
+    layout (number of samples given): no device -> host round trip in here -- what a captured training step needs."""
     cfg = model.config
     P = _P(model)
     dev = protein_pos.device
     hip_lib.require_gpu(protein_pos, "protein_pos")
-    B = int(batch_protein.max().item()) + 1
+    B = int(checked_B) if checked_B is not None else int(batch_protein.max().item()) + 1
     NP, NL = batch_protein.numel() // B, batch_ligand.numel() // B
     N = NP + NL
     K = min(int(cfg.knn), N - 1)
@@ -421,7 +425,7 @@ def network(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, 
     #      per (B, NP, NL, K, device) and reused by every step of that shape -- ~150 small index kernels and ~20 device -> host
     #      round trips per step otherwise
     S = _structure(B, NP, NL, K, dev)
-    if ligand_fc_bond_index.shape != S["fc"].shape or not torch.equal(ligand_fc_bond_index, S["fc"]):
+    if checked_B is None and (ligand_fc_bond_index.shape != S["fc"].shape or not torch.equal(ligand_fc_bond_index, S["fc"])):
         raise NotImplementedError("ligand_fc_bond_index must be the dst-major fully connected graph ('fc' mode)")
     is_lig, lig_rows, bond_src, bond_dst, dst = S["is_lig"], S["lig_rows"], S["bond_src"], S["bond_dst"], S["dst"]
     p_dst, p_bdst, p_ji, trip = S["p_dst"], S["p_bdst"], S["p_ji"], S["trip"]
@@ -552,12 +556,27 @@ class _Trans:
         return un - torch.logsumexp(un, dim=-1, keepdim=True)
 
 
-def _v_loss(log_model, log_v0, log_true, t, batch, n):
+def _v_loss(log_model, log_v0, log_true, t, batch, n, plan=None):
     kl = (log_true.exp() * (log_true - log_model)).sum(1)                  # categorical_kl (decompdiff.py:35-37)
     nll = -(log_v0.exp() * log_model).sum(1)                                # -log_categorical (decompdiff.py:40-41)
     mask = (t == 0).float()[batch]
     per = mask * nll + (1.0 - mask) * kl
-    return FN_mean(per, batch, n)
+    return FN_mean(per, plan if plan is not None else batch, n)
+
+
+_PLANS: Dict = {}
+
+
+def _static_plan(batch, B, n_l, bonds):
+    """SegmentPlan of a batch vector whose content follows from the per-sample sizes (checked by check_batch_layout): built
+    once per (sizes, device) -- a plan per call costs three device -> host round trips, which a captured step cannot have."""
+    key = (tuple(n_l), bool(bonds), str(batch.device))
+    plan = _PLANS.get(key)
+    if plan is None or plan.E != batch.numel():
+        if len(_PLANS) > 64:
+            _PLANS.clear()
+        plan = _PLANS[key] = seg_plan(batch.clone(), B)
+    return plan
 
 
 def FN_mean(per_row, batch, n):
@@ -595,35 +614,58 @@ def sample_time(model, num_graphs, device, method=None):
     raise ValueError(method)                                   # (:399-400)
 
 
-def diffusion_loss(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, ligand_v_aux, batch_ligand,
-                   prior_centers, prior_stds, prior_num_atoms, batch_prior, ligand_decomp_batch, ligand_fc_bond_index,
-                   ligand_fc_bond_type, batch_ligand_bond, time_step=None, network_fn=None) -> Dict:
-    """get_diffusion_loss (decompdiff.py:419-550).  Noise is drawn on the CPU generator in the reference's order
-    (time steps, position noise, atom-type Gumbel uniforms, bond-type Gumbel uniforms) and moved to the device, so a
-    seeded call reproduces the reference's CPU run."""
+def prepare_batch(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, ligand_v_aux, batch_ligand,
+                  prior_centers, prior_stds, prior_num_atoms, batch_prior, ligand_decomp_batch, ligand_fc_bond_index,
+                  ligand_fc_bond_type, batch_ligand_bond, time_step=None) -> Dict:
+    """Host side of get_diffusion_loss (decompdiff.py:419-480): layout checks, the time steps and the three noise draws on the
+    CPU generator in the reference's order (time steps, position noise, atom-type Gumbel uniforms, bond-type Gumbel uniforms),
+    moved to the device -- everything a step needs that involves the host.  The device side is `objective`."""
     dev = protein_pos.device
     sizes = check_batch_layout(batch_protein, batch_ligand, ligand_fc_bond_index, batch_ligand_bond)
     B = len(sizes[0])
     if time_step is None:
         time_step, _ = sample_time(model, B, dev)
     time_step = time_step.to(dev)
-    a = model.alphas_cumprod.index_select(0, time_step)
     assert len(ligand_decomp_batch) == int(prior_num_atoms.sum().item())
-    centers = prior_centers[ligand_decomp_batch]
-    stds = prior_stds[ligand_decomp_batch]
-    a_pos = a[batch_ligand].unsqueeze(-1)
     pos_noise = torch.zeros(ligand_pos.shape).normal_().to(dev)
-    pos_pert = a_pos.sqrt() * (ligand_pos - centers) + (1.0 - a_pos).sqrt() * pos_noise * stds + centers
+    u_v = torch.rand(ligand_v.shape[0], model.num_classes).to(dev)
+    u_b = torch.rand(ligand_fc_bond_type.shape[0], model.num_bond_classes).to(dev)
+    return dict(sizes=sizes, B=B, time_step=time_step, pos_noise=pos_noise, u_v=u_v, u_b=u_b,
+                protein_pos=protein_pos, protein_v=protein_v, batch_protein=batch_protein, ligand_pos=ligand_pos, ligand_v=ligand_v,
+                ligand_v_aux=ligand_v_aux, batch_ligand=batch_ligand, prior_centers=prior_centers, prior_stds=prior_stds,
+                ligand_decomp_batch=ligand_decomp_batch, ligand_fc_bond_index=ligand_fc_bond_index,
+                ligand_fc_bond_type=ligand_fc_bond_type, batch_ligand_bond=batch_ligand_bond)
+
+
+# tensors of a prepared batch that change from step to step (a captured step copies them into its static buffers)
+PREP_TENSORS = ("time_step", "pos_noise", "u_v", "u_b", "protein_pos", "protein_v", "batch_protein", "ligand_pos", "ligand_v",
+                "ligand_v_aux", "batch_ligand", "prior_centers", "prior_stds", "ligand_decomp_batch", "ligand_fc_bond_index",
+                "ligand_fc_bond_type", "batch_ligand_bond")
+
+
+def objective(model, prep: Dict, network_fn=None) -> Dict:
+    """Device side of get_diffusion_loss (decompdiff.py:455-550) on a prepared batch: forward diffusion of the state, the
+    score network, the three losses.  No device -> host round trip when the batch is dense (one size for all samples) and
+    `network_fn` is the differentiable network: this is what `GraphedTrainStep` captures."""
+    dev = prep["protein_pos"].device
+    sizes, B, time_step = prep["sizes"], prep["B"], prep["time_step"]
+    protein_pos, protein_v, batch_protein = prep["protein_pos"], prep["protein_v"], prep["batch_protein"]
+    ligand_pos, ligand_v, ligand_v_aux, batch_ligand = prep["ligand_pos"], prep["ligand_v"], prep["ligand_v_aux"], prep["batch_ligand"]
+    ligand_decomp_batch, ligand_fc_bond_index = prep["ligand_decomp_batch"], prep["ligand_fc_bond_index"]
+    ligand_fc_bond_type, batch_ligand_bond = prep["ligand_fc_bond_type"], prep["batch_ligand_bond"]
+    a = model.alphas_cumprod.index_select(0, time_step)
+    centers = prep["prior_centers"][ligand_decomp_batch]
+    stds = prep["prior_stds"][ligand_decomp_batch]
+    a_pos = a[batch_ligand].unsqueeze(-1)
+    pos_pert = a_pos.sqrt() * (ligand_pos - centers) + (1.0 - a_pos).sqrt() * prep["pos_noise"] * stds + centers
     tv, tb = _Trans(model.atom_type_trans), _Trans(model.bond_type_trans)
     log_v0 = _log_onehot(ligand_v, model.num_classes)
     log_qv = tv.pred(log_v0, time_step, batch_ligand)
-    u = torch.rand(log_qv.shape).to(dev)
-    v_pert = (-torch.log(-torch.log(u + 1e-30) + 1e-30) + log_qv).argmax(-1)
+    v_pert = (-torch.log(-torch.log(prep["u_v"] + 1e-30) + 1e-30) + log_qv).argmax(-1)
     log_vt = _log_onehot(v_pert, model.num_classes)
     log_b0 = _log_onehot(ligand_fc_bond_type, model.num_bond_classes)
     log_qb = tb.pred(log_b0, time_step, batch_ligand_bond)
-    u = torch.rand(log_qb.shape).to(dev)
-    b_pert = (-torch.log(-torch.log(u + 1e-30) + 1e-30) + log_qb).argmax(-1)
+    b_pert = (-torch.log(-torch.log(prep["u_b"] + 1e-30) + 1e-30) + log_qb).argmax(-1)
     log_bt = _log_onehot(b_pert, model.num_bond_classes)
     # center_pos (decompdiff.py:20-32)
     if model.center_pos_mode == "protein":
@@ -644,15 +686,120 @@ def diffusion_loss(model, protein_pos, protein_v, batch_protein, ligand_pos, lig
                             ligand_fc_bond_index, b_pert, sizes=sizes)
     pred_pos, pred_v = preds["pred_ligand_pos"], preds["pred_ligand_v"]
     log_v_recon = F.log_softmax(pred_v, dim=-1)
+    plan_l, plan_b = _static_plan(batch_ligand, B, sizes[1], False), _static_plan(batch_ligand_bond, B, sizes[1], True)
     kl_v = _v_loss(tv.posterior(log_v_recon, log_vt, time_step, batch_ligand), log_v0,
-                   tv.posterior(log_v0, log_vt, time_step, batch_ligand), time_step, batch_ligand, B)
+                   tv.posterior(log_v0, log_vt, time_step, batch_ligand), time_step, batch_ligand, B, plan_l)
     log_b_recon = F.log_softmax(preds["pred_bond"], dim=-1)
     kl_b = _v_loss(tb.posterior(log_b_recon, log_bt, time_step, batch_ligand_bond), log_b0,
-                   tb.posterior(log_b0, log_bt, time_step, batch_ligand_bond), time_step, batch_ligand_bond, B)
+                   tb.posterior(log_b0, log_bt, time_step, batch_ligand_bond), time_step, batch_ligand_bond, B, plan_b)
     if model.loss_pos_type != "mse":
         raise ValueError(model.loss_pos_type)
-    loss_pos = FN_mean((((pred_pos - x_0) ** 2) / (stds ** 2)).sum(-1), batch_ligand, B).mean()
+    loss_pos = FN_mean((((pred_pos - x_0) ** 2) / (stds ** 2)).sum(-1), plan_l, B).mean()
     return {"losses": {"pos": loss_pos, "v": kl_v.mean(), "bond": kl_b.mean()},
             "x0": x_0, "pred_ligand_pos": pred_pos, "pred_ligand_v": pred_v, "pred_pos_noise": pred_pos - x_t,
             "ligand_v_recon": F.softmax(pred_v, dim=-1), "ligand_b_recon": F.softmax(preds["pred_bond"], dim=-1),
             "time_step": time_step}
+
+
+def diffusion_loss(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, ligand_v_aux, batch_ligand,
+                   prior_centers, prior_stds, prior_num_atoms, batch_prior, ligand_decomp_batch, ligand_fc_bond_index,
+                   ligand_fc_bond_type, batch_ligand_bond, time_step=None, network_fn=None) -> Dict:
+    """get_diffusion_loss (decompdiff.py:419-550) = `prepare_batch` (host: checks, time steps, noise on the CPU generator in the
+    reference's order, so a seeded call reproduces the reference's CPU run) + `objective` (device)."""
+    prep = prepare_batch(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, ligand_v_aux, batch_ligand,
+                         prior_centers, prior_stds, prior_num_atoms, batch_prior, ligand_decomp_batch, ligand_fc_bond_index,
+                         ligand_fc_bond_type, batch_ligand_bond, time_step=time_step)
+    return objective(model, prep, network_fn=network_fn)
+
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# One training iteration as ONE captured graph (dense batches of a fixed shape)
+# --------------------------------------------------------------------------------------------------------------------
+class GraphedTrainStep:
+    """loss + backward + optimizer step of scripts/train_diffusion_decomp.py's inner loop (get_diffusion_loss, the weighted sum of
+    its three losses, backward, optimizer.step) replayed as one hipGraph per batch shape.
+
+    The eager step is bound by the host: ~6 000 launches of 5-15 us kernels (`profiles/round4_train_step.txt`).  Everything of
+    a step that needs the host -- layout checks, the time-step and noise draws on the CPU generator (the reference's order, so
+    seeded runs stay comparable) -- is `prepare_batch`; the rest (`objective`, backward, the optimizer's update) touches the
+    device only and is captured with torch.cuda.graph after `warmup` eager iterations of that shape (on a side stream, as
+    torch's capture rules ask).  Later iterations copy the prepared tensors into the graph's static inputs and replay it.
+    Batches whose samples differ in size (they run as one sub-batch per size, with host-side index bookkeeping) stay eager.
+
+    The optimizer must be built with ``capturable=True`` (torch.optim.Adam / AdamW): its step counter then lives on the device.
+    ``step(**kw)`` takes get_diffusion_loss's keyword arguments and returns {"loss", "losses": {pos, v, bond}} (detached)."""
+
+    def __init__(self, model, optimizer, loss_weights=(1.0, 100.0, 100.0), warmup: int = 3, max_graphs: int = 4):
+        if not optimizer.defaults.get("capturable", False):
+            raise ValueError("GraphedTrainStep needs an optimizer built with capturable=True (its state must live on the device)")
+        self.model, self.opt, self.w = model, optimizer, tuple(float(x) for x in loss_weights)
+        self.warmup, self.max_graphs = int(warmup), int(max_graphs)
+        self._seen: Dict = {}
+        self._graphs: Dict = {}
+        self._side = None
+        self.replays = self.eager_steps = 0
+
+    def _total(self, res):
+        lo = res["losses"]
+        return self.w[0] * lo["pos"] + self.w[1] * lo["v"] + self.w[2] * lo["bond"]
+
+    def _eager(self, prep):
+        self.opt.zero_grad(set_to_none=True)
+        res = objective(self.model, prep)
+        loss = self._total(res)
+        loss.backward()
+        self.opt.step()
+        self.eager_steps += 1
+        return {"loss": loss.detach(), "losses": {k: v.detach() for k, v in res["losses"].items()}}
+
+    def step(self, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, ligand_v_aux, batch_ligand, prior_centers, prior_stds,
+             prior_num_atoms, batch_prior, ligand_decomp_batch, ligand_fc_bond_index, ligand_fc_bond_type, batch_ligand_bond,
+             time_step=None, **unused):
+        model = self.model
+        model.__dict__["_packed"] = None                   # parameters are about to change: never reuse a packed copy
+        prep = prepare_batch(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, ligand_v_aux, batch_ligand,
+                             prior_centers, prior_stds, prior_num_atoms, batch_prior, ligand_decomp_batch, ligand_fc_bond_index,
+                             ligand_fc_bond_type, batch_ligand_bond, time_step=time_step)
+        n_p, n_l = prep["sizes"]
+        dense = len(set(zip(n_p, n_l))) == 1
+        dev = protein_pos.device
+        key = (tuple(n_p), tuple(n_l), int(prior_centers.shape[0]), str(dev))
+        if not dense or os.environ.get("DD_TRAIN_GRAPH", "1") == "0":
+            return self._eager(prep)
+        ent = self._graphs.get(key)
+        if ent is None:
+            n = self._seen.get(key, 0)
+            self._seen[key] = n + 1
+            if self._side is None or self._side.device != dev:
+                self._side = torch.cuda.Stream(device=dev)
+            cur = torch.cuda.current_stream(dev)
+            self._side.wait_stream(cur)
+            if n < self.warmup:                            # eager iterations of this shape first (real steps, on the side stream)
+                with torch.cuda.stream(self._side):
+                    out = self._eager(prep)
+                cur.wait_stream(self._side)
+                return out
+            if len(self._graphs) >= self.max_graphs:
+                self._graphs.pop(next(iter(self._graphs)))
+            static = dict(prep)
+            for k in PREP_TENSORS:
+                static[k] = prep[k].clone()
+            self.opt.zero_grad(set_to_none=True)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=self._side):
+                res = objective(model, static)
+                loss = self._total(res)
+                loss.backward()
+                self.opt.step()
+            cur.wait_stream(self._side)
+            ent = self._graphs[key] = dict(graph=graph, static=static, loss=loss.detach(),
+                                           losses={k: v.detach() for k, v in res["losses"].items()})
+            # (the capture itself computed nothing: this iteration's update happens in the replay below)
+        else:
+            self._graphs[key] = self._graphs.pop(key)      # most recently used last
+        for k in PREP_TENSORS:
+            ent["static"][k].copy_(prep[k], non_blocking=True)
+        ent["graph"].replay()
+        self.replays += 1
+        return {"loss": ent["loss"].clone(), "losses": {k: v.clone() for k, v in ent["losses"].items()}}

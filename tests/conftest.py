@@ -17,6 +17,19 @@ def pytest_configure(config):
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 16)))
 
 
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """The measured parity numbers of the chain / step tests, printed at every verbosity (golden_utils.note_parity)."""
+    try:
+        import golden_utils as GU
+    except Exception:                                              # noqa: BLE001
+        return
+    if GU.PARITY_LINES:
+        terminalreporter.write_line("")
+        terminalreporter.write_line("parity against the reference's fixtures, as measured in this run:")
+        for line in GU.PARITY_LINES:
+            terminalreporter.write_line("  " + line)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")

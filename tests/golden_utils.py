@@ -169,8 +169,24 @@ def chain_parity_summary(d, every, tol=1e-4, type_mismatches=(0, 0), bound=None,
     return rec
 
 
+PARITY_LINES = []          # compact lines of this session's parity records: tests/conftest.py prints them in the terminal summary
+
+
+def note_parity(line):
+    """A measured parity number for the terminal summary (shown at -q too: the driver's log keeps only what pytest prints)."""
+    PARITY_LINES.append(str(line))
+
+
 def record_parity(name, rec):
     from decompdiff_amd import hip_lib
+    try:
+        e = rec["max_err_per_checkpoint"]
+        mid = rec["checkpoint_steps"].index(600) if 600 in rec["checkpoint_steps"] else len(e) // 2
+        note_parity(f"{name}: types {rec['type_mismatches']['atoms']}+{rec['type_mismatches']['bonds']} mismatches; max |pos - ref| "
+                    f"{max(e[:mid + 1]):.2g} through step {rec['checkpoint_steps'][mid]}, {e[-1]:.2g} at step {rec['checkpoint_steps'][-1]}; "
+                    f"samples within {rec['tolerance']:g} at the end: {rec['samples_within_tol_per_checkpoint'][-1]}/{rec['n_samples']}")
+    except (KeyError, ValueError, IndexError):
+        pass
     flags = int(hip_lib.load().dd_build_flags())
     build = "exact_math" if flags & hip_lib.BUILD_EXACT_MATH else ("measurement" if flags & hip_lib.BUILD_DEBUG_OPTIONS else "default")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -256,6 +256,8 @@ def test_chain_segments_from_reference_checkpoints(name):
     print(f"{name}: 50-step segments restarted from the reference's checkpoints")
     print("  max |pos - golden| :", " ".join(f"{e:.2g}" for e in errs))
     print("  type mismatches    : atoms", sum(mv), "bonds", sum(mb))
+    GU.note_parity(f"{name}: {n_ck} segments of {every} steps restarted from the reference's checkpoints: worst segment end "
+                   f"{max(errs):.2g} (tolerance {POS_TOL:g}), type mismatches {sum(mv)}+{sum(mb)}")
     assert sum(mv) == 0 and sum(mb) == 0
     assert max(errs) < POS_TOL, f"segment error {max(errs):.3g}"
 

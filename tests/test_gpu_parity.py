@@ -284,6 +284,7 @@ def test_single_steps_golden():
             print(f"step t={t_start} {tag}: pos {e_pos:.3g} log_v_prob {e_vp:.3g} log_b_prob {e_bp:.3g} "
                   f"log_v0 {e_v0:.3g} v-mismatch {nv} bond-mismatch {nb}")
             worst = max(worst, e_pos)
+            GU.note_parity(f"single step t={t_start} {tag}: pos {e_pos:.2g} (tol {POS_TOL:g}), log-probs {max(e_vp, e_bp, e_v0):.2g} (tol {LOGIT_TOL:g})")
             assert e_pos < POS_TOL and e_vp < LOGIT_TOL and e_bp < LOGIT_TOL and e_v0 < LOGIT_TOL
             assert nv == 0 and nb == 0
 

@@ -200,3 +200,51 @@ def test_linear_feat_backward_on_own_gemms(rows, kf):
     errs = dict(df=rel(f.grad, want_df), dW=rel(W.grad, want_dW))
     print(f"linear_feat rows={rows} kf={kf}:", {k: f"{v:.2g}" for k, v in errs.items()})
     assert max(errs.values()) < 2e-6
+
+
+def test_graphed_train_step_follows_the_eager_steps():
+    """training.GraphedTrainStep: get_diffusion_loss + backward + Adam as one captured graph per batch shape.  Same seeds, same
+    batches: the captured iterations must follow the eager ones (same losses step by step, same parameters at the end up to the
+    re-association of atomic gradient sums), and a batch of another shape gets its own graph."""
+    from decompdiff_amd import training
+    torch.manual_seed(3)
+    b1 = synth.build_sampling_batch(synth.make_pocket(31, 80, (4, 4), 6, num_full_protein=0), 3)
+    b2 = synth.build_sampling_batch(synth.make_pocket(32, 64, (3, 3), 5, num_full_protein=0), 2)
+    d = lambda t: t.to(dev()) if torch.is_tensor(t) else t
+    to_kw = lambda b: dict(
+        protein_pos=d(b["protein_pos"]), protein_v=d(b["protein_v"]), batch_protein=d(b["batch_protein"]),
+        protein_group_idx=d(b["protein_group_idx"]), ligand_pos=d(b["init_ligand_pos"]), ligand_v=d(b["init_ligand_v"]),
+        ligand_v_aux=d(b["ligand_v_aux"]), batch_ligand=d(b["batch_ligand"]), ligand_group_idx=d(b["ligand_group_idx"]),
+        prior_centers=d(b["prior_centers"]), prior_stds=d(b["prior_stds"]), prior_num_atoms=d(b["prior_num_atoms"]),
+        batch_prior=d(b["batch_prior"]), prior_group_idx=d(b["prior_group_idx"]), ligand_decomp_batch=d(b["ligand_decomp_batch"]),
+        ligand_decomp_index=d(b["ligand_decomp_index"]), ligand_fc_bond_index=d(b["ligand_fc_bond_index"]),
+        ligand_fc_bond_type=d(b["init_ligand_fc_bond_type"]), batch_ligand_bond=d(b["batch_ligand_bond"]))
+    kws = [to_kw(b1), to_kw(b2)]
+
+    def fresh(capturable):
+        m = DecompScorePosNet3D(shipped_config(), 29, 10, 8)
+        sd = m.state_dict(); sd.update(synth.synthetic_state_dict(shipped_config(), 1)); m.load_state_dict(sd)
+        m = m.to(dev()).train()
+        return m, torch.optim.Adam(m.parameters(), lr=1e-4, capturable=capturable)
+
+    order = [0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 0, 1, 0]
+    m_e, opt_e = fresh(False)
+    torch.manual_seed(11)
+    eager = []
+    for i in order:
+        opt_e.zero_grad(set_to_none=True)
+        r = m_e.get_diffusion_loss(**kws[i])
+        loss = r["losses"]["pos"] + 100.0 * r["losses"]["v"] + 100.0 * r["losses"]["bond"]
+        loss.backward(); opt_e.step()
+        eager.append(float(loss))
+    m_g, opt_g = fresh(True)
+    gs = training.GraphedTrainStep(m_g, opt_g, loss_weights=(1.0, 100.0, 100.0), warmup=2)
+    torch.manual_seed(11)
+    graphed = [float(gs.step(**kws[i])["loss"]) for i in order]
+    assert gs.replays == len(order) - 4 and gs.eager_steps == 4 and len(gs._graphs) == 2
+    for a, c in zip(eager, graphed):
+        assert abs(a - c) <= 2e-4 * max(1.0, abs(a)), (eager, graphed)
+    worst = max(float((p - q).abs().max()) for p, q in zip(m_e.parameters(), m_g.parameters()))
+    assert worst < 2e-4, worst
+    with pytest.raises(ValueError):
+        training.GraphedTrainStep(m_e, opt_e)

@@ -38,6 +38,18 @@ if torch.cuda.is_available():
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.steps
     print(f"GPU training step (B = {args.batch}, 300 + 30 atoms): {1e3 * dt:.1f} ms/step = {1 / dt:.2f} steps/s  (loss {l:.4f}, "
           f"peak memory {torch.cuda.max_memory_allocated() / 2**20:.0f} MiB)")
+    # the same iteration as one captured graph per batch shape (training.GraphedTrainStep; Adam with capturable=True)
+    from decompdiff_amd import training
+    torch.manual_seed(0)
+    m2 = DecompScorePosNet3D(cfg, 29, 10, 8); sd = m2.state_dict(); sd.update(synth.synthetic_state_dict(cfg, 0)); m2.load_state_dict(sd); m2 = m2.to(dev).train()
+    opt2 = torch.optim.Adam(m2.parameters(), lr=5e-4, capturable=True)
+    gs = training.GraphedTrainStep(m2, opt2, loss_weights=(1.0, 100.0, 100.0))
+    for _ in range(5): out = gs.step(**kw)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(args.steps): out = gs.step(**kw)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.steps
+    print(f"GPU training step, captured graph (B = {args.batch}): {1e3 * dt:.1f} ms/step = {1 / dt:.2f} steps/s  (loss {float(out['loss']):.4f}, "
+          f"{gs.replays} replays, {gs.eager_steps} eager warm-up steps)")
     m.eval()
     with torch.no_grad():
         for _ in range(2): m.get_diffusion_loss(**kw)
