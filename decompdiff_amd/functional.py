@@ -173,11 +173,23 @@ class SegmentPlan:
     bincount) for callers that scatter over the same index many times -- a training step uses each of its five index
     vectors 12-36 times (decompdiff_amd/training.py).  Pass it as `index` to scatter_sum / scatter_mean / scatter_softmax."""
 
-    def __init__(self, index: torch.Tensor, dim_size: Optional[int] = None):
+    def __init__(self, index: torch.Tensor, dim_size: Optional[int] = None, check: bool = True):
         hip_lib.require_gpu(index, "index")
         if index.dim() != 1:
             raise ValueError("SegmentPlan: 1-D index")
         E = index.numel()
+        if not check:
+            # No device -> host round trip (usable while a stream is being captured): the caller vouches for 0 <= index < dim_size
+            # (e.g. the sources of a kNN graph); the index is sorted unconditionally, the segment pointer comes from a search.
+            if dim_size is None:
+                raise ValueError("SegmentPlan(check=False) needs dim_size")
+            n = int(dim_size)
+            self.index, self.perm = torch.sort(index, stable=True)
+            self.ptr = torch.searchsorted(self.index, torch.arange(n + 1, device=index.device, dtype=index.dtype)).to(torch.int32)
+            self.n, self.E = n, E
+            self.inv = torch.empty_like(self.perm)
+            self.inv[self.perm] = torch.arange(E, device=index.device)
+            return
         n = int(dim_size) if dim_size is not None else (int(index.max().item()) + 1 if E else 0)
         if E and (int(index.min().item()) < 0 or int(index.max().item()) >= n):
             raise IndexError("scatter index out of range")

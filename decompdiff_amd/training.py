@@ -80,9 +80,10 @@ class _Gather(torch.autograd.Function):
         return FN.scatter_sum(g.contiguous(), ctx.plan, dim=0, dim_size=ctx.plan.n), None
 
 
-def seg_plan(index, dim_size):
-    """One SegmentPlan per (index vector, table height) and network call: checks, sort (if needed) and segment pointers once."""
-    plan = FN.SegmentPlan(index, dim_size)
+def seg_plan(index, dim_size, check=True):
+    """One SegmentPlan per (index vector, table height) and network call: checks, sort (if needed) and segment pointers once.
+    check=False: no host round trip (an index produced on the device inside a captured step, known to be in range)."""
+    plan = FN.SegmentPlan(index, dim_size, check=check)
     plan.raw = index
     return plan
 
@@ -250,7 +251,8 @@ def _attention(q_e, k, v, seg, n_seg=None):
 
 def _edge_mlp_pre(P, name, W_off, dst_tab, src_tab, dst, src, extra):
     """first Linear of an edge MLP, factorised: W[:, a:b] applied per node once, gathered per edge."""
-    return gather(dst_tab, dst) + src_tab.index_select(0, src) + extra + P.b(name + ".net.0")
+    by_src = gather(src_tab, src) if isinstance(src, FN.SegmentPlan) else src_tab.index_select(0, src)
+    return gather(dst_tab, dst) + by_src + extra + P.b(name + ".net.0")
 
 
 def check_batch_layout(batch_protein, batch_ligand, ligand_fc_bond_index, batch_ligand_bond=None):
@@ -364,7 +366,7 @@ def _structure(B, NP, NL, K, dev):
     dst = torch.arange(B * N, device=dev).repeat_interleave(K)
     S = dict(is_lig=is_lig, lig_rows=lig_rows, fc=fc, bond_src=bond_src, bond_dst=bond_dst, dst=dst,
              dst_is_prot=(~is_lig.index_select(0, dst)).long(), base=(torch.arange(B, device=dev) * N).view(B, 1, 1),
-             p_dst=seg_plan(dst, B * N), p_bdst=seg_plan(bond_dst, B * N), trip=None, p_ji=None)
+             p_dst=seg_plan(dst, B * N), p_bdst=seg_plan(bond_dst, B * N), p_bsrc=seg_plan(bond_src, B * N), trip=None, p_ji=None)
     # ---- triplets k -> j -> i over the fully connected ligand bond graph (BondUpdateLayer.triplets, :103-123)
     NLm1, Ebs = NL - 1, NL * (NL - 1)
     if NL > 2:
@@ -381,6 +383,10 @@ def _structure(B, NP, NL, K, dev):
         rep = lambda t: t.repeat(B)
         S["trip"] = dict(ji=rep(e_ji) + boff, kj=rep(e_kj) + boff, i=rep(i_loc) + aoff, j=rep(j_loc) + aoff, k=rep(k_loc) + aoff)
         S["p_ji"] = seg_plan(S["trip"]["ji"], B * Ebs)
+        # gathers of 128-wide rows by the (static, unsorted) triplet indices: their backward through a sorted segment sum instead of
+        # ATen's atomic index_add_ (every atom k receives (NL-1)(NL-2) rows: the atomics serialise)
+        S["p_tkj"] = seg_plan(S["trip"]["kj"], B * Ebs)
+        S["p_tk"], S["p_tj"] = seg_plan(S["trip"]["k"], B * N), seg_plan(S["trip"]["j"], B * N)
     S["_bytes"] = _tensor_bytes(S)
     if S["_bytes"] <= _STRUCT_MAX_BYTES:
         _STRUCT[key] = S
@@ -433,6 +439,7 @@ def network(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, 
     Eb_tot = h_bond.shape[0]
     # ---- graph of the step (uni_transformer_edge.py:404-427): kNN among all atoms of a sample, fixed for all layers
     src = _knn_src(x.detach(), B, N, K, S["base"])
+    p_src = seg_plan(src, B * N, check=False)              # rows gathered by source: backward = sorted segment sum, no atomics
     etype = 2 * (~is_lig.index_select(0, src)).long() + S["dst_is_prot"]  # 0 ll, 1 l->p(dst p), 2 p->l, 3 pp
     etype_1h = F.one_hot(etype, 4).float()
     d0 = (x.index_select(0, dst) - x.index_select(0, src)).norm(dim=-1)
@@ -452,7 +459,7 @@ def network(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, 
             for f_ in ("k", "v"):
                 nm = f"{p}.{name}.{'h' if name.startswith('node') else 'x'}{f_}_func"
                 W = P.w(nm + ".net.0")
-                pre = _edge_mlp_pre(P, nm, None, linear128(hh, W[:, 84:212]), linear128(hh, W[:, 212:340]), p_dst, src,
+                pre = _edge_mlp_pre(P, nm, None, linear128(hh, W[:, 84:212]), linear128(hh, W[:, 212:340]), p_dst, p_src,
                                     linear_feat(ef_type, W[:, 0:84]))
                 outs.append(P.mlp_tail(nm, pre))
             return outs
@@ -463,7 +470,7 @@ def network(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, 
             for f_ in ("k", "v"):
                 nm = f"{p}.{name}.{'h' if name.startswith('node') else 'x'}{f_}_func"
                 W = P.w(nm + ".net.0")
-                pre = _edge_mlp_pre(P, nm, None, linear128(hh, W[:, 128:256]), linear128(hh, W[:, 256:384]), p_bdst, bond_src,
+                pre = _edge_mlp_pre(P, nm, None, linear128(hh, W[:, 128:256]), linear128(hh, W[:, 256:384]), p_bdst, S["p_bsrc"],
                                     linear128(hb, W[:, 0:128]))
                 outs.append(P.mlp_tail(nm, pre))
             return outs
@@ -492,8 +499,8 @@ def network(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, 
                 W = P.w(f"{nm_b}.{f_}.net.0")
                 per_kj = linear128(h_bond, W[:, 0:128]) + linear_feat(gb, W[:, 128:148])                     # h_bond[kj], G(d_kj)
                 per_ji = linear_feat(gb, W[:, 148:168])                                             # G(d_ji)
-                pre = per_kj.index_select(0, trip["kj"]) + gather(per_ji, p_ji) + linear_feat(code, W[:, 168:181]) \
-                    + linear128(h, W[:, 181:309]).index_select(0, trip["k"]) + linear128(h, W[:, 309:437]).index_select(0, trip["j"]) \
+                pre = gather(per_kj, S["p_tkj"]) + gather(per_ji, p_ji) + linear_feat(code, W[:, 168:181]) \
+                    + gather(linear128(h, W[:, 181:309]), S["p_tk"]) + gather(linear128(h, W[:, 309:437]), S["p_tj"]) \
                     + P.b(f"{nm_b}.{f_}.net.0")
                 kv.append(P.mlp_tail(f"{nm_b}.{f_}", pre))
             # hq depends on the (j -> i) bond only: evaluated per bond, gathered per triplet (exact)
