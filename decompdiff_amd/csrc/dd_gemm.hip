@@ -306,7 +306,8 @@ int launch_gemm128(const GemmArgs& a, hipStream_t st) {
 constexpr int TNP = 160;
 template <int MT>
 __global__ __launch_bounds__(256, 2) void k_gemm_tn(const float* __restrict__ A, int lda, int M, const float* __restrict__ X, int ldx,
-                                                    long rows, int rch, float* __restrict__ part /*[slabs][MT*32][128]*/) {
+                                                    long rows, int rch, float* __restrict__ part /*[slabs][MT*32][128]*/,
+                                                    float* __restrict__ bpart /*[slabs][128] column sums of A (the bias gradient), or NULL*/) {
   __shared__ __attribute__((aligned(16))) float As[32 * TNP];
   __shared__ __attribute__((aligned(16))) float Bs[32 * TNP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, hh = lane >> 5;
@@ -318,6 +319,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const float* __restrict__ A,
     for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
   const bool a_vec = ((lda & 3) == 0) && ((M & 3) == 0) && ((reinterpret_cast<size_t>(A) & 15) == 0);
   float4 xv[4], av[MT];
+  float4 asum = make_float4(0.f, 0.f, 0.f, 0.f);       // this thread's share of the column sums of A (its MT rows per trip share a column group)
   // the rows of trip rb: requested one trip ahead (they fly while the previous 32 rows are multiplied)
   auto fetch = [&](long rb) {
 #pragma unroll
@@ -355,6 +357,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const float* __restrict__ A,
     for (int k = 0; k < MT; ++k) {
       const int i = tid + k * 256, r = i / (MT * 8), c4 = (i % (MT * 8)) * 4;
       *reinterpret_cast<float4*>(&As[r * TNP + c4]) = av[k];
+      asum.x += av[k].x; asum.y += av[k].y; asum.z += av[k].z; asum.w += av[k].w;
     }
     __syncthreads();
     if (rb + 32 < r1) fetch(rb + 32);
@@ -376,9 +379,39 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const float* __restrict__ A,
       const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;   // C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
       dst[(32 * mt + row) * 128 + 32 * wave + li] = acc[mt][r];
     }
+  if (bpart != nullptr) {
+    // column sums of this slab's rows of A: thread t owns column group t % (8 MT) in every trip; the 256 / (8 MT) threads of a
+    // group are added in ascending thread order (fixed association), through the operand buffer (dead by now)
+    constexpr int G = MT * 8;
+    __syncthreads();
+    reinterpret_cast<float4*>(As)[tid] = asum;
+    __syncthreads();
+    if (tid < G) {
+      float4 t = reinterpret_cast<const float4*>(As)[tid];
+#pragma unroll
+      for (int j = 1; j < 256 / G; ++j) {
+        const float4 u = reinterpret_cast<const float4*>(As)[tid + j * G];
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      }
+      float* d = bpart + (long)blockIdx.x * 128 + 4 * tid;
+      d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+    }
+  }
 }
 __global__ __launch_bounds__(256) void k_gemm_tn_reduce(const float* __restrict__ part, int slabs, int mpad, int M, float* __restrict__ out,
-                                                        int ldo, int accumulate) {
+                                                        int ldo, int accumulate, const float* __restrict__ bpart = nullptr,
+                                                        float* __restrict__ bias_out = nullptr, int n_main = 0) {
+  if (bpart != nullptr && (int)blockIdx.x >= n_main) {     // the bias gradient: M column sums, slabs dealt to the 4 waves as below
+    __shared__ float redb[4][64];
+    const int o = ((int)blockIdx.x - n_main) * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    float s = 0.f;
+    if (o < M)
+      for (int w = q; w < slabs; w += 4) s += bpart[(long)w * 128 + o];
+    redb[q][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (q == 0 && o < M) bias_out[o] = ((redb[0][threadIdx.x] + redb[1][threadIdx.x]) + redb[2][threadIdx.x]) + redb[3][threadIdx.x];
+    return;
+  }
   // 64 output elements per workgroup, the slabs dealt to 4 waves (slab w -> wave w mod 4, ascending), the four partial sums
   // added in wave order: a fixed association, reproducible bit for bit
   __shared__ float red[4][64];
@@ -421,22 +454,36 @@ extern "C" size_t dd_gemm128_tn_scratch_floats(long rows, int M) {
   const int rch = dd::gemm_tn_rows_per_slab(rows);
   const long slabs = (rows + rch - 1) / rch;
   const int mt = M <= 32 ? 1 : (M <= 64 ? 2 : 4);
-  return (size_t)slabs * mt * 32 * 128;
+  return (size_t)slabs * mt * 32 * 128 + (size_t)slabs * 128;      // (+ the slabs' column sums of A: dd_gemm128_tn_bias)
 }
-extern "C" int dd_gemm128_tn(const float* A, int lda, int M, const float* X, int ldx, long rows, float* scratch, float* out, int ldo,
-                             int accumulate, void* stream) {
+static int gemm128_tn_impl(const float* A, int lda, int M, const float* X, int ldx, long rows, float* scratch, float* out, int ldo,
+                           int accumulate, float* bias_out, void* stream) {
   if (!A || !X || !scratch || !out || M <= 0 || M > 128 || rows <= 0 || (ldx & 3) != 0 || lda < M || ldo < 128 ||
       (reinterpret_cast<size_t>(X) & 15) != 0)
     return DD_ERR_BAD_ARG;
   const int rch = dd::gemm_tn_rows_per_slab(rows);
   const int slabs = (int)((rows + rch - 1) / rch);
   hipStream_t st = (hipStream_t)stream;
-  int mpad;
-  if (M <= 32) { mpad = 32; hipLaunchKernelGGL(dd::k_gemm_tn<1>, dim3(slabs), dim3(256), 0, st, A, lda, M, X, ldx, rows, rch, scratch); }
-  else if (M <= 64) { mpad = 64; hipLaunchKernelGGL(dd::k_gemm_tn<2>, dim3(slabs), dim3(256), 0, st, A, lda, M, X, ldx, rows, rch, scratch); }
-  else { mpad = 128; hipLaunchKernelGGL(dd::k_gemm_tn<4>, dim3(slabs), dim3(256), 0, st, A, lda, M, X, ldx, rows, rch, scratch); }
+  const int mt = M <= 32 ? 1 : (M <= 64 ? 2 : 4), mpad = mt * 32;
+  float* bpart = bias_out ? scratch + (size_t)slabs * mpad * 128 : nullptr;
+  if (mt == 1) hipLaunchKernelGGL(dd::k_gemm_tn<1>, dim3(slabs), dim3(256), 0, st, A, lda, M, X, ldx, rows, rch, scratch, bpart);
+  else if (mt == 2) hipLaunchKernelGGL(dd::k_gemm_tn<2>, dim3(slabs), dim3(256), 0, st, A, lda, M, X, ldx, rows, rch, scratch, bpart);
+  else hipLaunchKernelGGL(dd::k_gemm_tn<4>, dim3(slabs), dim3(256), 0, st, A, lda, M, X, ldx, rows, rch, scratch, bpart);
   DD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(dd::k_gemm_tn_reduce, dim3((M * 128 + 63) / 64), dim3(256), 0, st, scratch, slabs, mpad, M, out, ldo, accumulate);
+  const int n_main = (M * 128 + 63) / 64, n_bias = bias_out ? (M + 63) / 64 : 0;
+  hipLaunchKernelGGL(dd::k_gemm_tn_reduce, dim3(n_main + n_bias), dim3(256), 0, st, scratch, slabs, mpad, M, out, ldo, accumulate,
+                     (const float*)bpart, bias_out, n_main);
   DD_CHECK_LAUNCH();
   return DD_OK;
+}
+extern "C" int dd_gemm128_tn(const float* A, int lda, int M, const float* X, int ldx, long rows, float* scratch, float* out, int ldo,
+                             int accumulate, void* stream) {
+  return gemm128_tn_impl(A, lda, M, X, ldx, rows, scratch, out, ldo, accumulate, nullptr, stream);
+}
+// ... and the bias gradient with it: bias_out[M] = column sums of A (= dY^T 1), formed from the rows the kernel stages anyway
+// (ATen's dy.sum(0) was 640 launches and 9.5 ms of a training step)
+extern "C" int dd_gemm128_tn_bias(const float* A, int lda, int M, const float* X, int ldx, long rows, float* scratch, float* out, int ldo,
+                                  int accumulate, float* bias_out, void* stream) {
+  if (!bias_out) return DD_ERR_BAD_ARG;
+  return gemm128_tn_impl(A, lda, M, X, ldx, rows, scratch, out, ldo, accumulate, bias_out, stream);
 }

@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("DD_HIP_LIB") or os.path.join(_HERE, "lib", "libdecomp
 # the drop-in boundary: include/decompdiff_hip.h
 EXPORTED_SYMBOLS = [
     "dd_status_string", "dd_abi_version", "dd_build_flags", "dd_workspace_floats", "dd_knn", "dd_edge_weights", "dd_gemm128",
-    "dd_gemm128_tn", "dd_gemm128_tn_scratch_floats",
+    "dd_gemm128_tn", "dd_gemm128_tn_bias", "dd_gemm128_tn_scratch_floats",
     "dd_embed_protein", "dd_forward", "dd_sample_steps", "dd_sample_steps_graph", "dd_sample_steps_graph_multi",
     "dd_graph_create", "dd_graph_launch", "dd_graph_destroy",
     "dd_drift_armsca", "dd_drift_clash", "dd_drift_arms_repul",
@@ -113,6 +113,7 @@ def load():
                        c_int, c_void_p],
         "dd_gemm128_tn_scratch_floats": [c_long, c_int],
         "dd_gemm128_tn": [c_void_p, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_void_p, c_int, c_int, c_void_p],
+        "dd_gemm128_tn_bias": [c_void_p, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
         "dd_embed_protein": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
         "dd_forward": [S, c_void_p],
         "dd_sampler_reset": [S, c_void_p],

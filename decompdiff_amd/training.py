@@ -135,12 +135,18 @@ class _Linear128(torch.autograd.Function):
                                              128, 128, 0, st), "dd_gemm128")
             else:                                                          # narrow heads (16 / 8 / 5 outputs): K is not 128
                 dx = dy @ Wc
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dW = torch.empty(out, 128, device=dy.device, dtype=torch.float32)
             scratch = torch.empty(int(lib.dd_gemm128_tn_scratch_floats(rows, out)), device=dy.device, dtype=torch.float32)
-            hip_lib.check(lib.dd_gemm128_tn(hip_lib.ptr(dy), out, out, hip_lib.ptr(xc), 128, rows, hip_lib.ptr(scratch), hip_lib.ptr(dW),
-                                            128, 0, st), "dd_gemm128_tn")
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            if want_db:                                    # the bias gradient (column sums of dY) from the same launch pair
+                db = torch.empty(out, device=dy.device, dtype=torch.float32)
+                hip_lib.check(lib.dd_gemm128_tn_bias(hip_lib.ptr(dy), out, out, hip_lib.ptr(xc), 128, rows, hip_lib.ptr(scratch),
+                                                     hip_lib.ptr(dW), 128, 0, hip_lib.ptr(db), st), "dd_gemm128_tn_bias")
+            else:
+                hip_lib.check(lib.dd_gemm128_tn(hip_lib.ptr(dy), out, out, hip_lib.ptr(xc), 128, rows, hip_lib.ptr(scratch),
+                                                hip_lib.ptr(dW), 128, 0, st), "dd_gemm128_tn")
+        if want_db and db is None:
             db = dy.sum(0)
         return dx, dW, db
 
@@ -252,7 +258,9 @@ def _attention(q_e, k, v, seg, n_seg=None):
 def _edge_mlp_pre(P, name, W_off, dst_tab, src_tab, dst, src, extra):
     """first Linear of an edge MLP, factorised: W[:, a:b] applied per node once, gathered per edge."""
     by_src = gather(src_tab, src) if isinstance(src, FN.SegmentPlan) else src_tab.index_select(0, src)
-    return gather(dst_tab, dst) + by_src + extra + P.b(name + ".net.0")
+    # (the bias joins the per-NODE table before the gather: its gradient is then a sum over N rows behind the gather's segment sum,
+    #  not a reduction over all E edge rows)
+    return gather(dst_tab + P.b(name + ".net.0"), dst) + by_src + extra
 
 
 def check_batch_layout(batch_protein, batch_ligand, ligand_fc_bond_index, batch_ligand_bond=None):
@@ -383,10 +391,10 @@ def _structure(B, NP, NL, K, dev):
         rep = lambda t: t.repeat(B)
         S["trip"] = dict(ji=rep(e_ji) + boff, kj=rep(e_kj) + boff, i=rep(i_loc) + aoff, j=rep(j_loc) + aoff, k=rep(k_loc) + aoff)
         S["p_ji"] = seg_plan(S["trip"]["ji"], B * Ebs)
-        # gathers of 128-wide rows by the (static, unsorted) triplet indices: their backward through a sorted segment sum instead of
-        # ATen's atomic index_add_ (every atom k receives (NL-1)(NL-2) rows: the atomics serialise)
+        # rows of bond (k -> j) gathered per triplet: the backward through a sorted segment sum (NL - 2 rows per bond) instead of
+        # ATen's atomic index_add_.  (The per-ATOM gathers of the triplets -- (NL-1)(NL-2) rows per atom -- stay on index_add_:
+        # a wave per segment is the wrong shape for 120 segments of 812 rows, measured 3 x slower than the atomics.)
         S["p_tkj"] = seg_plan(S["trip"]["kj"], B * Ebs)
-        S["p_tk"], S["p_tj"] = seg_plan(S["trip"]["k"], B * N), seg_plan(S["trip"]["j"], B * N)
     S["_bytes"] = _tensor_bytes(S)
     if S["_bytes"] <= _STRUCT_MAX_BYTES:
         _STRUCT[key] = S
@@ -499,9 +507,8 @@ def network(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, 
                 W = P.w(f"{nm_b}.{f_}.net.0")
                 per_kj = linear128(h_bond, W[:, 0:128]) + linear_feat(gb, W[:, 128:148])                     # h_bond[kj], G(d_kj)
                 per_ji = linear_feat(gb, W[:, 148:168])                                             # G(d_ji)
-                pre = gather(per_kj, S["p_tkj"]) + gather(per_ji, p_ji) + linear_feat(code, W[:, 168:181]) \
-                    + gather(linear128(h, W[:, 181:309]), S["p_tk"]) + gather(linear128(h, W[:, 309:437]), S["p_tj"]) \
-                    + P.b(f"{nm_b}.{f_}.net.0")
+                pre = gather(per_kj, S["p_tkj"]) + gather(per_ji + P.b(f"{nm_b}.{f_}.net.0"), p_ji) + linear_feat(code, W[:, 168:181]) \
+                    + linear128(h, W[:, 181:309]).index_select(0, trip["k"]) + linear128(h, W[:, 309:437]).index_select(0, trip["j"])
                 kv.append(P.mlp_tail(f"{nm_b}.{f_}", pre))
             # hq depends on the (j -> i) bond only: evaluated per bond, gathered per triplet (exact)
             q_bond = P.mlp(f"{nm_b}.hq_func", torch.cat([h_bond, gather(h, p_bdst)], -1))

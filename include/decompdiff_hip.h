@@ -201,6 +201,11 @@ int dd_gemm128(const float* X, int x_rows_per_b, long x_stride_b, int ldx, int r
 size_t dd_gemm128_tn_scratch_floats(long rows, int M);
 int dd_gemm128_tn(const float* A, int lda, int M, const float* X, int ldx, long rows, float* scratch, float* out, int ldo,
                   int accumulate, void* stream);
+/* ... with the bias gradient of the same Linear: bias_out[M] = column sums of A (dY^T 1; autograd's dy.sum(0)), formed from the
+ * rows the kernel stages anyway, slabs added in the same fixed order.  Same scratch size.  (Added in round 5; ABI unchanged:
+ * a new entry point, no struct layout touched.) */
+int dd_gemm128_tn_bias(const float* A, int lda, int M, const float* X, int ldx, long rows, float* scratch, float* out, int ldo,
+                       int accumulate, float* bias_out, void* stream);
 
 /* Op-level message passing: the torch_scatter pairs of the reference's attention layers as stand-alone ops
  *     alpha = scatter_softmax((q[dst] * k / sqrt(8)).sum(-1), dst, dim=0);  out = scatter_sum(alpha[..., None] * v, dst, dim=0)

@@ -250,3 +250,26 @@ def test_graphed_train_step_follows_the_eager_steps():
     assert worst < 0.5 * len(order) * 1e-4, worst
     with pytest.raises(ValueError):
         training.GraphedTrainStep(m_e, opt_e)
+
+
+def test_gemm128_tn_bias_matches_torch():
+    """dd_gemm128_tn_bias: dW = dY^T X and db = column sums of dY from one launch pair, against torch in float64, for the three
+    tile heights (M <= 32 / 64 / 128) and row counts that are not multiples of the 32-row trips."""
+    import ctypes
+    from decompdiff_amd import hip_lib
+    lib = hip_lib.load()
+    torch.manual_seed(2)
+    for rows, M in ((1000, 128), (4097, 128), (333, 16), (70000, 64), (129, 5)):
+        dy = torch.randn(rows, M, device=dev())
+        x = torch.randn(rows, 128, device=dev())
+        dW = torch.empty(M, 128, device=dev()); db = torch.empty(M, device=dev())
+        scratch = torch.empty(int(lib.dd_gemm128_tn_scratch_floats(rows, M)), device=dev())
+        hip_lib.check(lib.dd_gemm128_tn_bias(hip_lib.ptr(dy), M, M, hip_lib.ptr(x), 128, rows, hip_lib.ptr(scratch), hip_lib.ptr(dW), 128, 0,
+                                             hip_lib.ptr(db), hip_lib.stream_ptr(dev())), "dd_gemm128_tn_bias")
+        want_W = (dy.double().t() @ x.double()); want_b = dy.double().sum(0)
+        assert float((dW.double() - want_W).abs().max()) < 2e-4 * max(1.0, float(want_W.abs().max())), (rows, M)
+        assert float((db.double() - want_b).abs().max()) < 2e-4 * max(1.0, float(want_b.abs().max())), (rows, M)
+        dW2 = torch.empty_like(dW)
+        hip_lib.check(lib.dd_gemm128_tn(hip_lib.ptr(dy), M, M, hip_lib.ptr(x), 128, rows, hip_lib.ptr(scratch), hip_lib.ptr(dW2), 128, 0,
+                                        hip_lib.stream_ptr(dev())), "dd_gemm128_tn")
+        assert torch.equal(dW, dW2)                           # the weight gradient does not depend on the bias path
