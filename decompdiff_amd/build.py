@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdecompdiff_hip.so")
-SOURCES = ["dd_gemm.hip", "dd_graph.hip", "dd_attention2.hip", "dd_step.hip", "dd_scatter.hip", "dd_api.hip"]
+SOURCES = ["dd_gemm.hip", "dd_graph.hip", "dd_attention2.hip", "dd_step.hip", "dd_scatter.hip", "dd_train.hip", "dd_api.hip"]
 HEADERS = ["dd_common.hpp", "dd_kernels.hpp", "dd_gemm_tile.hpp", os.path.join("..", "..", "include", "decompdiff_hip.h"),
            os.path.join("..", "..", "include", "decompdiff_hip_debug.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on"]

@@ -21,6 +21,7 @@ LIB_PATH = os.environ.get("DD_HIP_LIB") or os.path.join(_HERE, "lib", "libdecomp
 EXPORTED_SYMBOLS = [
     "dd_status_string", "dd_abi_version", "dd_build_flags", "dd_workspace_floats", "dd_knn", "dd_edge_weights", "dd_gemm128",
     "dd_gemm128_tn", "dd_gemm128_tn_bias", "dd_gemm128_tn_scratch_floats",
+    "dd_ln_relu_scratch_floats", "dd_ln_relu_forward", "dd_ln_relu_backward",
     "dd_embed_protein", "dd_forward", "dd_sample_steps", "dd_sample_steps_graph", "dd_sample_steps_graph_multi",
     "dd_graph_create", "dd_graph_launch", "dd_graph_destroy",
     "dd_drift_armsca", "dd_drift_clash", "dd_drift_arms_repul",
@@ -114,6 +115,9 @@ def load():
         "dd_gemm128_tn_scratch_floats": [c_long, c_int],
         "dd_gemm128_tn": [c_void_p, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_void_p, c_int, c_int, c_void_p],
         "dd_gemm128_tn_bias": [c_void_p, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
+        "dd_ln_relu_scratch_floats": [c_long],
+        "dd_ln_relu_forward": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p],
+        "dd_ln_relu_backward": [c_void_p] * 9 + [c_long, c_void_p],
         "dd_embed_protein": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
         "dd_forward": [S, c_void_p],
         "dd_sampler_reset": [S, c_void_p],
@@ -146,7 +150,7 @@ def load():
         "dd_debug_philox": [c_uint64, c_int, c_long, c_int, c_void_p, c_void_p],
         "dd_profile_step": [S, c_int, POINTER(c_float), c_void_p],
     }
-    restypes = {"dd_workspace_floats": c_size_t, "dd_gemm128_tn_scratch_floats": c_size_t}
+    restypes = {"dd_workspace_floats": c_size_t, "dd_gemm128_tn_scratch_floats": c_size_t, "dd_ln_relu_scratch_floats": c_size_t}
     for name in EXPORTED_SYMBOLS + DEBUG_SYMBOLS:
         if name in ("dd_status_string", "dd_abi_version"):
             continue

@@ -184,6 +184,45 @@ class _LinearFeat(torch.autograd.Function):
         return df, dW
 
 
+class _LnRelu(torch.autograd.Function):
+    """relu(LayerNorm(x) * gamma + beta) over 128 channels (the middle of every MLP of the network, common.py:85-105) as one HIP
+    kernel each way (dd_train.hip): the backward forms dx, dgamma and dbeta in one pass over x and dy and recomputes the ReLU mask,
+    where autograd runs threshold_backward, native_layer_norm_backward (two passes) and a reduce."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        lib = hip_lib.load()
+        xc, g, b = x.contiguous(), gamma.contiguous(), beta.contiguous()
+        rows = xc.size(0)
+        y = torch.empty_like(xc)
+        stats = torch.empty(rows, 2, device=x.device, dtype=torch.float32)
+        hip_lib.check(lib.dd_ln_relu_forward(hip_lib.ptr(xc), hip_lib.ptr(g), hip_lib.ptr(b), hip_lib.ptr(y), hip_lib.ptr(stats), rows,
+                                             hip_lib.stream_ptr(x.device)), "dd_ln_relu_forward")
+        ctx.save_for_backward(xc, stats, g, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, stats, g, b = ctx.saved_tensors
+        lib = hip_lib.load()
+        dy = dy.contiguous()
+        rows = xc.size(0)
+        dx = torch.empty_like(xc)
+        dg, db = torch.empty(128, device=dy.device, dtype=torch.float32), torch.empty(128, device=dy.device, dtype=torch.float32)
+        scratch = torch.empty(int(lib.dd_ln_relu_scratch_floats(rows)), device=dy.device, dtype=torch.float32)
+        hip_lib.check(lib.dd_ln_relu_backward(hip_lib.ptr(xc), hip_lib.ptr(stats), hip_lib.ptr(g), hip_lib.ptr(b), hip_lib.ptr(dy),
+                                              hip_lib.ptr(dx), hip_lib.ptr(scratch), hip_lib.ptr(dg), hip_lib.ptr(db), rows,
+                                              hip_lib.stream_ptr(dy.device)), "dd_ln_relu_backward")
+        return dx, dg, db
+
+
+def ln_relu(x, gamma, beta):
+    """F.relu(F.layer_norm(x, (128,), gamma, beta, 1e-5)) for [rows, 128] fp32 device tensors on the fused kernels (others: ATen)."""
+    if x.dim() != 2 or x.size(1) != H or x.dtype != torch.float32 or not x.is_cuda or x.size(0) == 0:
+        return F.relu(F.layer_norm(x, (H,), gamma, beta, 1e-5))
+    return _LnRelu.apply(x, gamma, beta)
+
+
 def linear_feat(f, W):
     """F.linear(f, W) without bias for narrow feature blocks feeding the 128 hidden channels."""
     if f.dim() != 2 or W.size(0) != 128 or f.size(1) > 128 or f.dtype != torch.float32 or f.size(0) == 0:
@@ -239,8 +278,7 @@ class _P:
 
     def mlp_tail(self, name, pre):
         """LayerNorm -> ReLU -> second Linear of MLP(num_layer=2, norm=True) (common.py:85-105) on a pre-activation."""
-        y = F.layer_norm(pre, (H,), self.p[name + ".net.1.weight"], self.p[name + ".net.1.bias"], 1e-5)
-        return self.lin(name + ".net.3", F.relu(y))
+        return self.lin(name + ".net.3", ln_relu(pre, self.p[name + ".net.1.weight"], self.p[name + ".net.1.bias"]))
 
     def mlp(self, name, x):
         return self.mlp_tail(name, self.lin(name + ".net.0", x))

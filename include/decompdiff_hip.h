@@ -207,6 +207,16 @@ int dd_gemm128_tn(const float* A, int lda, int M, const float* X, int ldx, long 
 int dd_gemm128_tn_bias(const float* A, int lda, int M, const float* X, int ldx, long rows, float* scratch, float* out, int ldo,
                        int accumulate, float* bias_out, void* stream);
 
+/* LayerNorm(128) + ReLU of the reference's MLPs (models/common.py:85-105) for the training step, one kernel each way:
+ *   forward : y[r] = relu(LN(x[r]) * gamma + beta) (eps 1e-5), stats[r] = (mean, 1/std) kept for the backward;
+ *   backward: dx from dy (the ReLU mask is recomputed from x), dgamma[128] / dbeta[128] summed over the rows in a fixed order
+ *             (no atomics); scratch: dd_ln_relu_scratch_floats(rows) floats.
+ * Rows are contiguous ([rows,128] fp32, 8-byte aligned).  (Round 5; new entry points, ABI unchanged.) */
+size_t dd_ln_relu_scratch_floats(long rows);
+int dd_ln_relu_forward(const float* x, const float* gamma, const float* beta, float* y, float* stats, long rows, void* stream);
+int dd_ln_relu_backward(const float* x, const float* stats, const float* gamma, const float* beta, const float* dy, float* dx,
+                        float* scratch, float* dgamma, float* dbeta, long rows, void* stream);
+
 /* Op-level message passing: the torch_scatter pairs of the reference's attention layers as stand-alone ops
  *     alpha = scatter_softmax((q[dst] * k / sqrt(8)).sum(-1), dst, dim=0);  out = scatter_sum(alpha[..., None] * v, dst, dim=0)
  * (uni_transformer_edge.py:63-68 NodeUpdateLayer, :158-164 BondUpdateLayer, :205-211 PosUpdateLayer).  16 heads x 8

@@ -273,3 +273,27 @@ def test_gemm128_tn_bias_matches_torch():
         hip_lib.check(lib.dd_gemm128_tn(hip_lib.ptr(dy), M, M, hip_lib.ptr(x), 128, rows, hip_lib.ptr(scratch), hip_lib.ptr(dW2), 128, 0,
                                         hip_lib.stream_ptr(dev())), "dd_gemm128_tn")
         assert torch.equal(dW, dW2)                           # the weight gradient does not depend on the bias path
+
+
+def test_fused_layernorm_relu_matches_torch():
+    """training.ln_relu (dd_ln_relu_forward / _backward): y, dx, dgamma, dbeta against torch autograd in float64, row counts from
+    one row to more rows than the backward has partial-sum slabs."""
+    from decompdiff_amd import training
+    torch.manual_seed(4)
+    for rows in (1, 3, 130, 4099, 97440):
+        x = torch.randn(rows, 128, device=dev()) * 1.7 + 0.3
+        g = torch.randn(128, device=dev()) * 0.5 + 1.0
+        b = torch.randn(128, device=dev()) * 0.3
+        dy = torch.randn(rows, 128, device=dev())
+        xs, gs, bs = (t.clone().requires_grad_(True) for t in (x, g, b))
+        y = training.ln_relu(xs, gs, bs)
+        y.backward(dy)
+        xd, gd, bd = (t.double().clone().requires_grad_(True) for t in (x, g, b))
+        yd = torch.relu(torch.nn.functional.layer_norm(xd, (128,), gd, bd, 1e-5))
+        yd.backward(dy.double())
+        assert float((y.double() - yd).abs().max()) < 1e-5
+        assert float((xs.grad.double() - xd.grad).abs().max()) < 2e-5 * max(1.0, float(xd.grad.abs().max()))
+        for a, w in ((gs.grad, gd.grad), (bs.grad, bd.grad)):
+            assert float((a.double() - w).abs().max()) < 1e-4 * max(1.0, float(w.abs().max())), rows
+        y2 = training.ln_relu(xs, gs, bs)
+        assert torch.equal(y, y2)                              # run to run bit-identical (no atomics)
