@@ -15,56 +15,124 @@ namespace {
 
 constexpr int LN_WG = 1024;                              // partial-sum slabs of the backward (<= workgroups launched)
 
+// sum over the 16 lanes of a DPP row (the lanes of one input row)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  return v;
+}
+
+// 16 lanes per row (lane j of the group holds channels 8j .. 8j+7: two 16-byte loads, a row is one contiguous 512-byte access of
+// the group), four rows in flight per wave; mean / variance / the two backward sums are 4-step reductions inside a DPP row.
 __global__ __launch_bounds__(256) void k_ln_relu_fwd(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ stats,
                                                      long rows) {
-  const int lane = threadIdx.x & 63;
-  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (long)gridDim.x * 4;
-  const float2 g = *reinterpret_cast<const float2*>(gamma + 2 * lane), b = *reinterpret_cast<const float2*>(beta + 2 * lane);
-  for (long r = wave; r < rows; r += n_waves) {
-    const float2 v = *reinterpret_cast<const float2*>(x + r * 128 + 2 * lane);
-    const float mean = wave_sum(v.x + v.y) * (1.0f / 128.0f);
-    const float dx = v.x - mean, dy = v.y - mean;
-    const float var = wave_sum(fmaf(dx, dx, dy * dy)) * (1.0f / 128.0f);
-    const float rstd = 1.0f / sqrtf(var + 1e-5f);
-    float2 o;
-    o.x = fmaxf(fmaf(dx * rstd, g.x, b.x), 0.f);
-    o.y = fmaxf(fmaf(dy * rstd, g.y, b.y), 0.f);
-    *reinterpret_cast<float2*>(y + r * 128 + 2 * lane) = o;
-    if (lane == 0) *reinterpret_cast<float2*>(stats + 2 * r) = make_float2(mean, rstd);
+  const int j = threadIdx.x & 15;
+  const long grp = (long)blockIdx.x * 16 + (threadIdx.x >> 4), n_grp = (long)gridDim.x * 16;
+  float g[8], b[8];
+  {
+    const float4 g0 = *reinterpret_cast<const float4*>(gamma + 8 * j), g1 = *reinterpret_cast<const float4*>(gamma + 8 * j + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(beta + 8 * j), b1 = *reinterpret_cast<const float4*>(beta + 8 * j + 4);
+    g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+    b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
   }
+  // (every group of a wave runs the same number of trips: the DPP reductions need all lanes of the row active, and a wave's
+  //  groups differ only in whether their last row exists)
+  for (long r0 = (long)blockIdx.x * 16 + (threadIdx.x >> 6) * 4; r0 < rows; r0 += n_grp) {
+    const long r = r0 + ((threadIdx.x >> 4) & 3);
+    const bool live = r < rows;
+    float v[8];
+    if (live) {
+      const float4 a0 = *reinterpret_cast<const float4*>(x + r * 128 + 8 * j), a1 = *reinterpret_cast<const float4*>(x + r * 128 + 8 * j + 4);
+      v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[c] = 0.f;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s += v[c];
+    const float mean = row16_sum(s) * (1.0f / 128.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { v[c] -= mean; q = fmaf(v[c], v[c], q); }
+    const float rstd = 1.0f / sqrtf(row16_sum(q) * (1.0f / 128.0f) + 1e-5f);
+    if (live) {
+      float o[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) o[c] = fmaxf(fmaf(v[c] * rstd, g[c], b[c]), 0.f);
+      *reinterpret_cast<float4*>(y + r * 128 + 8 * j) = make_float4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<float4*>(y + r * 128 + 8 * j + 4) = make_float4(o[4], o[5], o[6], o[7]);
+      if (j == 0) *reinterpret_cast<float2*>(stats + 2 * r) = make_float2(mean, rstd);
+    }
+  }
+  (void)grp;
 }
 
 __global__ __launch_bounds__(256) void k_ln_relu_bwd(const float* __restrict__ x, const float* __restrict__ stats,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* __restrict__ dyp, float* __restrict__ dxp,
                                                      float* __restrict__ part /*[gridDim.x][2][128]*/, long rows) {
-  __shared__ float red[4][256];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const long wave = (long)blockIdx.x * 4 + w, n_waves = (long)gridDim.x * 4;
-  const float2 g = *reinterpret_cast<const float2*>(gamma + 2 * lane), b = *reinterpret_cast<const float2*>(beta + 2 * lane);
-  float2 sg = make_float2(0.f, 0.f), sb = make_float2(0.f, 0.f);
-  for (long r = wave; r < rows; r += n_waves) {
-    const float2 v = *reinterpret_cast<const float2*>(x + r * 128 + 2 * lane);
-    const float2 d = *reinterpret_cast<const float2*>(dyp + r * 128 + 2 * lane);
-    const float2 ms = *reinterpret_cast<const float2*>(stats + 2 * r);
-    const float hx = (v.x - ms.x) * ms.y, hy = (v.y - ms.x) * ms.y;             // normalised input
-    const float zx = fmaf(hx, g.x, b.x) > 0.f ? d.x : 0.f, zy = fmaf(hy, g.y, b.y) > 0.f ? d.y : 0.f;   // through the ReLU
-    sg.x = fmaf(zx, hx, sg.x); sg.y = fmaf(zy, hy, sg.y);
-    sb.x += zx; sb.y += zy;
-    const float ax = zx * g.x, ay = zy * g.y;                                    // gradient w.r.t. the normalised input
-    const float s1 = wave_sum(ax + ay) * (1.0f / 128.0f);
-    const float s2 = wave_sum(fmaf(ax, hx, ay * hy)) * (1.0f / 128.0f);
-    float2 o;
-    o.x = ms.y * (ax - s1 - hx * s2);
-    o.y = ms.y * (ay - s1 - hy * s2);
-    *reinterpret_cast<float2*>(dxp + r * 128 + 2 * lane) = o;
+  __shared__ float red[16][256];
+  const int j = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const long n_grp = (long)gridDim.x * 16;
+  float g[8], b[8], sg[8], sb[8];
+  {
+    const float4 g0 = *reinterpret_cast<const float4*>(gamma + 8 * j), g1 = *reinterpret_cast<const float4*>(gamma + 8 * j + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(beta + 8 * j), b1 = *reinterpret_cast<const float4*>(beta + 8 * j + 4);
+    g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+    b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
   }
-  red[w][2 * lane] = sg.x; red[w][2 * lane + 1] = sg.y;
-  red[w][128 + 2 * lane] = sb.x; red[w][128 + 2 * lane + 1] = sb.y;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { sg[c] = 0.f; sb[c] = 0.f; }
+  for (long r0 = (long)blockIdx.x * 16 + (threadIdx.x >> 6) * 4; r0 < rows; r0 += n_grp) {
+    const long r = r0 + (grp & 3);
+    const bool live = r < rows;
+    float h[8], a[8];
+    float mean = 0.f, rstd = 0.f;
+    if (live) {
+      const float4 a0 = *reinterpret_cast<const float4*>(x + r * 128 + 8 * j), a1 = *reinterpret_cast<const float4*>(x + r * 128 + 8 * j + 4);
+      const float4 d0 = *reinterpret_cast<const float4*>(dyp + r * 128 + 8 * j), d1 = *reinterpret_cast<const float4*>(dyp + r * 128 + 8 * j + 4);
+      const float2 ms = *reinterpret_cast<const float2*>(stats + 2 * r);
+      mean = ms.x; rstd = ms.y;
+      h[0] = a0.x; h[1] = a0.y; h[2] = a0.z; h[3] = a0.w; h[4] = a1.x; h[5] = a1.y; h[6] = a1.z; h[7] = a1.w;
+      a[0] = d0.x; a[1] = d0.y; a[2] = d0.z; a[3] = d0.w; a[4] = d1.x; a[5] = d1.y; a[6] = d1.z; a[7] = d1.w;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { h[c] = 0.f; a[c] = 0.f; }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      h[c] = (h[c] - mean) * rstd;                                            // normalised input
+      const float z = fmaf(h[c], g[c], b[c]) > 0.f ? a[c] : 0.f;              // gradient through the ReLU
+      sg[c] = fmaf(z, h[c], sg[c]);
+      sb[c] += z;
+      a[c] = z * g[c];                                                        // gradient w.r.t. the normalised input
+      s1 += a[c];
+      s2 = fmaf(a[c], h[c], s2);
+    }
+    s1 = row16_sum(s1) * (1.0f / 128.0f);
+    s2 = row16_sum(s2) * (1.0f / 128.0f);
+    if (live) {
+      float o[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) o[c] = rstd * (a[c] - s1 - h[c] * s2);
+      *reinterpret_cast<float4*>(dxp + r * 128 + 8 * j) = make_float4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<float4*>(dxp + r * 128 + 8 * j + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+  }
+  // the 16 row groups of the workgroup hold partial sums for the same 128 channels: added in group order
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { red[grp][8 * j + c] = sg[c]; red[grp][128 + 8 * j + c] = sb[c]; }
   __syncthreads();
-  const int t = threadIdx.x;                             // 256 threads = [gamma 128 | beta 128], the 4 waves added in order
-  part[(long)blockIdx.x * 256 + t] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+  const int t = threadIdx.x;                             // 256 threads = [gamma 128 | beta 128]
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += red[k][t];
+  part[(long)blockIdx.x * 256 + t] = s;
 }
 
 __global__ __launch_bounds__(256) void k_ln_relu_bwd_reduce(const float* __restrict__ part, int slabs, float* __restrict__ dgamma,
@@ -83,7 +151,7 @@ __global__ __launch_bounds__(256) void k_ln_relu_bwd_reduce(const float* __restr
 }
 
 inline int ln_grid(long rows) {
-  long g = (rows + 3) / 4;                               // one wave per row if the rows are few
+  long g = (rows + 15) / 16;                             // sixteen rows per workgroup and trip
   if (g > LN_WG) g = LN_WG;
   return (int)(g < 1 ? 1 : g);
 }
