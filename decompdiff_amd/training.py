@@ -543,10 +543,12 @@ def network(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, 
             kv = []
             for f_ in ("hk_func", "hv_func"):
                 W = P.w(f"{nm_b}.{f_}.net.0")
-                per_kj = linear128(h_bond, W[:, 0:128]) + linear_feat(gb, W[:, 128:148])                     # h_bond[kj], G(d_kj)
-                per_ji = linear_feat(gb, W[:, 148:168])                                             # G(d_ji)
-                pre = gather(per_kj, S["p_tkj"]) + gather(per_ji + P.b(f"{nm_b}.{f_}.net.0"), p_ji) + linear_feat(code, W[:, 168:181]) \
-                    + linear128(h, W[:, 181:309]).index_select(0, trip["k"]) + linear128(h, W[:, 309:437]).index_select(0, trip["j"])
+                # every triplet (k -> j -> i) term is a per-BOND row: h[k] rides with bond (k -> j) (its source atom), h[j] and the bias
+                # with bond (j -> i) -- two gathers of [Eb, 128] tables per MLP instead of four [E3, 128] ones, and no per-atom
+                # index_add_ of 812 rows per atom in the backward
+                per_kj = linear128(h_bond, W[:, 0:128]) + linear_feat(gb, W[:, 128:148]) + gather(linear128(h, W[:, 181:309]), S["p_bsrc"])
+                per_ji = linear_feat(gb, W[:, 148:168]) + P.b(f"{nm_b}.{f_}.net.0") + gather(linear128(h, W[:, 309:437]), S["p_bsrc"])
+                pre = gather(per_kj, S["p_tkj"]) + gather(per_ji, p_ji) + linear_feat(code, W[:, 168:181])
                 kv.append(P.mlp_tail(f"{nm_b}.{f_}", pre))
             # hq depends on the (j -> i) bond only: evaluated per bond, gathered per triplet (exact)
             q_bond = P.mlp(f"{nm_b}.hq_func", torch.cat([h_bond, gather(h, p_bdst)], -1))

@@ -292,8 +292,16 @@ def test_fused_layernorm_relu_matches_torch():
         yd = torch.relu(torch.nn.functional.layer_norm(xd, (128,), gd, bd, 1e-5))
         yd.backward(dy.double())
         assert float((y.double() - yd).abs().max()) < 1e-5
-        assert float((xs.grad.double() - xd.grad).abs().max()) < 2e-5 * max(1.0, float(xd.grad.abs().max()))
+        # a pre-activation within rounding of 0 may take the other side of the ReLU in fp32: rows with such an element are left
+        # out of the dx comparison (a row's dx depends on all of its masks), and each may move dgamma / dbeta by one |dy|
+        pre = torch.nn.functional.layer_norm(xd.detach(), (128,), gd.detach(), bd.detach(), 1e-5)
+        safe = (pre.abs() > 1e-5).all(1)
+        n_edge = int((~safe).sum())
+        assert n_edge <= 2 + rows // 4000
+        err = (xs.grad.double() - xd.grad).abs().max(1).values
+        assert float(err[safe].max()) < 2e-5 * max(1.0, float(xd.grad.abs().max())), rows
+        slack = n_edge * float(dy.abs().max()) * 4.0
         for a, w in ((gs.grad, gd.grad), (bs.grad, bd.grad)):
-            assert float((a.double() - w).abs().max()) < 1e-4 * max(1.0, float(w.abs().max())), rows
+            assert float((a.double() - w).abs().max()) < 1e-4 * max(1.0, float(w.abs().max())) + slack, rows
         y2 = training.ln_relu(xs, gs, bs)
         assert torch.equal(y, y2)                              # run to run bit-identical (no atomics)
