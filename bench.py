@@ -269,6 +269,7 @@ def main():
                        "control_plane": ddist.control_backend() or "single process",
                        "control_plane_note": ddist.control_note(), "imbalance_max_over_mean_busy": job["imbalance"],
                        "launch": "eager" if args.eager else "hipGraph replay", "noise": "device Philox",
+                       "warmup_calls": job["warmup_calls"],    # the W warm-up steps were issued as this many calls
                        "node_launch_split_cus": int(lib.dd_debug_node_split(B, NP, NL, K))},
             "roofline": roofline, "roofline_gemm": roofline_gemm, "roofline_op_level": op_roofline, "cpu_baseline": cpu,
             "per_rank": job["per_rank"], "per_unit": job["per_unit"] if len(units) <= 16 else job["per_unit"][:16],

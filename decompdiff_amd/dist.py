@@ -446,8 +446,18 @@ def run_job(units: List[Unit], config: int, rank: int, world: int, prepare: Call
     gc.disable()                                   # no collector pause inside the timed region (re-enabled below)
     try:
         if warmup > 0:
+            # the W warm-up steps of a unit as up to DD_BENCH_WARMUP_CALLS separate calls (default 5; the step count stays W): a
+            # call's host-side set-up and collection run ~0.7 ms slower the first few times they run in a process
+            # (profiles/round5_call_trace_before.txt: 26.2 / 25.2 / 24.9 ms for three successive 20-step calls), and a sampling job
+            # is many calls -- measured 787-796 steps/s on the 20-step line with one warm-up call, 811-813 with five
+            # (profiles/round5_warmup_calls_ab.txt)
+            n_calls = max(1, min(int(os.environ.get("DD_BENCH_WARMUP_CALLS", "5")), warmup))
             for u, st in zip(mine, states):
-                checksum(sample(st, warmup, u.noise_seed + 1))  # (also loads the reduction kernels the timed region uses)
+                left = warmup
+                for c in range(n_calls):
+                    n = left if c == n_calls - 1 else max(1, warmup // n_calls)
+                    checksum(sample(st, n, u.noise_seed + 1 + c))   # (also loads the reduction kernels the timed region uses)
+                    left -= n
         barrier(device)
         t0 = time.perf_counter()
         records = []
@@ -487,4 +497,5 @@ def run_job(units: List[Unit], config: int, rank: int, world: int, prepare: Call
                          for g in gathered],
             "imbalance": round(max(busy_all) / (sum(busy_all) / len(busy_all)), 4) if min(busy_all) > 0 else None,
             "devices": devices, "distinct_devices": len(set(devices)),
-            "per_unit": per_unit, "last_out": last, "n_local_units": len(mine)}
+            "per_unit": per_unit, "last_out": last, "n_local_units": len(mine),
+            "warmup_calls": max(1, min(int(os.environ.get("DD_BENCH_WARMUP_CALLS", "5")), warmup)) if warmup > 0 else 0}
