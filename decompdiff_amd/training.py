@@ -362,9 +362,10 @@ def network_grouped(net, model, protein_pos, protein_v, batch_protein, ligand_po
         rb = torch.cat([ar(o_b[b], nl_ * (nl_ - 1)) for b in members])
         g = len(members)
         _, _, fc = model._expected_layout(g, np_, nl_, dev)
+        extra = {"checked_B": g} if net is network else {}      # (batch vectors and bond list built right here: no re-check, no sync)
         outs.append(net(model, protein_pos[rp], protein_v[rp], torch.arange(g, device=dev).repeat_interleave(np_),
                         ligand_pos[rl], ligand_v[rl], ligand_v_aux[rl], torch.arange(g, device=dev).repeat_interleave(nl_),
-                        fc, ligand_bond_type[rb]))
+                        fc, ligand_bond_type[rb], **extra))
         rows_l.append(rl)
         rows_b.append(rb)
     inv_l = torch.empty(o_l[-1], dtype=torch.long, device=dev)

@@ -8,10 +8,15 @@ import argparse, sys, time, torch
 sys.path.insert(0, ".")
 from decompdiff_amd import DecompScorePosNet3D, shipped_config, synth
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=4); ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--ragged", action="store_true", help="four DIFFERENT complexes per batch (what the reference's loader yields): one dense sub-batch per size, eager")
 args = ap.parse_args()
 cfg = shipped_config()
 torch.manual_seed(0)
 bc = synth.build_sampling_batch(synth.make_pocket_small(0), args.batch)
+if args.ragged:
+    shapes = [(300, (8, 8), 14), (280, (7, 7), 12), (320, (9, 9), 16), (310, (8, 7), 13)][:max(2, args.batch)]
+    bc = synth.concat_sampling_batches([synth.build_sampling_batch(synth.make_pocket(40 + i, n_p, arms, sca, num_full_protein=0), 1)
+                                        for i, (n_p, arms, sca) in enumerate(shapes)])
 def loss_kwargs(b, dev):
     d = lambda t: t.to(dev) if torch.is_tensor(t) else t
     return dict(protein_pos=d(b["protein_pos"]), protein_v=d(b["protein_v"]), batch_protein=d(b["batch_protein"]),
