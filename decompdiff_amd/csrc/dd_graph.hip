@@ -643,6 +643,15 @@ extern "C" int dd_knn(const float* x, int B, int N, int K, int32_t* nbr, void* s
   return dd::launch_knn(x, B, N, K, nbr, (hipStream_t)stream);
 }
 
+// ... for a padded heterogeneous batch (the sampler's layout: NP + NL rows per sample, the real atoms are the first np_real[b]
+// protein rows and the first nl_real[b] ligand rows): padding atoms are neither centres nor candidates.
+extern "C" int dd_knn_masked(const float* x, int B, int NP, int NL, int K, const int32_t* np_real, const int32_t* nl_real, int32_t* nbr,
+                             void* stream) {
+  const int N = NP + NL;
+  if (!x || !nbr || !nl_real || B <= 0 || NP < 0 || NL <= 0 || K <= 0 || K > DD_KNN_MAX || K > N - 1 || N > DD_N_MAX) return DD_ERR_BAD_ARG;
+  return dd::launch_knn(x, B, N, K, nbr, (hipStream_t)stream, NP, np_real, nl_real);
+}
+
 extern "C" int dd_edge_weights(const float* x, const int32_t* nbr, int B, int N, int K, const float* W1T,
                                const float* b1, const float* ln, const float* w2, const float* b2, float* ew,
                                void* stream) {

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("DD_HIP_LIB") or os.path.join(_HERE, "lib", "libdecomp
 
 # the drop-in boundary: include/decompdiff_hip.h
 EXPORTED_SYMBOLS = [
-    "dd_status_string", "dd_abi_version", "dd_build_flags", "dd_workspace_floats", "dd_knn", "dd_edge_weights", "dd_gemm128",
+    "dd_status_string", "dd_abi_version", "dd_build_flags", "dd_workspace_floats", "dd_knn", "dd_knn_masked", "dd_edge_weights", "dd_gemm128",
     "dd_gemm128_tn", "dd_gemm128_tn_bias", "dd_gemm128_tn_scratch_floats",
     "dd_ln_relu_scratch_floats", "dd_ln_relu_forward", "dd_ln_relu_backward",
     "dd_embed_protein", "dd_forward", "dd_sample_steps", "dd_sample_steps_graph", "dd_sample_steps_graph_multi",
@@ -109,6 +109,7 @@ def load():
         "dd_build_flags": [],
         "dd_workspace_floats": [c_int, c_int, c_int, c_int],
         "dd_knn": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+        "dd_knn_masked": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
         "dd_edge_weights": [c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 7,
         "dd_gemm128": [c_void_p, c_int, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int,
                        c_int, c_void_p],

@@ -284,12 +284,18 @@ class _P:
         return self.mlp_tail(name, self.lin(name + ".net.0", x))
 
 
-def _attention(q_e, k, v, seg, n_seg=None):
+def _attention(q_e, k, v, seg, n_seg=None, member_real=None):
     """alpha = scatter_softmax((q k / sqrt(d)).sum(-1)); out = scatter_sum(alpha v)  (uni_transformer_edge.py:63-68).
-    `seg`: the SegmentPlan of the destination index."""
+    `seg`: the SegmentPlan of the destination index.  `member_real` (padded batches): bool per member -- padding members get a
+    score of -1e30 (their exponential is exactly 0: the softmax is the softmax over the real members, same sums) and a weight of
+    exactly 0 afterwards (a segment without any real member then contributes nothing)."""
     hd = k.shape[1] // NH
     score = (q_e.view(-1, NH, hd) * k.view(-1, NH, hd)).sum(-1) / math.sqrt(hd)
+    if member_real is not None:
+        score = torch.where(member_real.unsqueeze(-1), score, torch.full_like(score, -1e30))
     alpha = scatter_softmax(score, seg)
+    if member_real is not None:
+        alpha = alpha * member_real.unsqueeze(-1).to(alpha.dtype)
     return alpha
 
 
@@ -347,6 +353,10 @@ def network_grouped(net, model, protein_pos, protein_v, batch_protein, ligand_po
                        ligand_fc_bond_index, ligand_bond_type, checked_B=B)
         return net(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, ligand_v_aux, batch_ligand,
                    ligand_fc_bond_index, ligand_bond_type)
+    if net is network and os.environ.get("DD_TRAIN_PAD", "1") != "0":
+        out = network_padded(model, protein_pos, protein_v, ligand_pos, ligand_v, ligand_v_aux, ligand_bond_type, n_p, n_l)
+        if out is not None:
+            return out
     o_p = [0] + list(torch.tensor(n_p).cumsum(0).tolist())
     o_l = [0] + list(torch.tensor(n_l).cumsum(0).tolist())
     n_b = [n * (n - 1) for n in n_l]
@@ -375,6 +385,55 @@ def network_grouped(net, model, protein_pos, protein_v, batch_protein, ligand_po
     cat = lambda k, inv: torch.cat([o[k] for o in outs], 0).index_select(0, inv)
     return {"pred_ligand_pos": cat("pred_ligand_pos", inv_l), "pred_ligand_v": cat("pred_ligand_v", inv_l),
             "pred_bond": cat("pred_bond", inv_b)}
+
+
+def _pad_rows(n_p, n_l):
+    """Row maps of a heterogeneous batch into its padded dense layout (numpy, host): real protein / ligand rows and real bonds
+    (the caller's dst-major lists over n_l[b] atoms) -> rows of the [B*NPm] / [B*NLm] / [B*NLm(NLm-1)] padded arrays."""
+    import numpy as np
+    B, NPm, NLm = len(n_p), max(n_p), max(n_l)
+    Ebm = NLm * (NLm - 1)
+    rows_p = np.concatenate([b * NPm + np.arange(n) for b, n in enumerate(n_p)])
+    rows_l = np.concatenate([b * NLm + np.arange(n) for b, n in enumerate(n_l)])
+    rb = []
+    for b, n in enumerate(n_l):
+        dst = np.repeat(np.arange(n), n - 1)
+        sp = np.tile(np.arange(n - 1), n)
+        src = sp + (sp >= dst)
+        rb.append(b * Ebm + dst * (NLm - 1) + (src - (src > dst)))
+    return rows_p, rows_l, np.concatenate(rb)
+
+
+def network_padded(model, protein_pos, protein_v, ligand_pos, ligand_v, ligand_v_aux, ligand_bond_type, n_p, n_l):
+    """A batch whose samples differ in size -- what the reference's loader yields (batch_size 4 different complexes,
+    configs/training.yml:62) -- as ONE dense pass: every sample is padded to the batch's largest protein / ligand, padding atoms
+    sit far away at distinct non-collinear positions (finite features everywhere), are excluded from the kNN graph and masked as
+    members of the bond-graph and triplet attentions; the outputs' real rows are returned in the caller's order.  One network
+    pass instead of one per distinct size (4 x fewer launches of a host-bound step) for max-size padding waste in the NL^3
+    triplet count.  Returns None if a sample has fewer than K + 1 real atoms (the per-sample kNN degree would differ)."""
+    dev = protein_pos.device
+    B, NPm, NLm = len(n_p), max(n_p), max(n_l)
+    N = NPm + NLm
+    K = min(int(model.config.knn), N - 1)
+    if min(a + b for a, b in zip(n_p, n_l)) < K + 1:
+        return None
+    rows_p, rows_l, rows_b = (torch.from_numpy(r).to(dev) for r in _pad_rows(n_p, n_l))
+    # padding atoms: far from everything and from each other, never collinear (norms / cross products keep finite gradients)
+    i_p = torch.arange(B * NPm, device=dev, dtype=torch.float32)
+    far_p = torch.stack([1.0e3 + 3.0 * i_p, 5.0 * torch.sin(1.3 * i_p), 4.0 * torch.cos(2.1 * i_p)], -1)
+    i_l = torch.arange(B * NLm, device=dev, dtype=torch.float32)
+    far_l = torch.stack([-1.0e3 - 3.0 * i_l, 5.0 * torch.cos(1.7 * i_l), 4.0 * torch.sin(0.9 * i_l)], -1)
+    pp = far_p.index_copy(0, rows_p, protein_pos.to(torch.float32))
+    lp = far_l.index_copy(0, rows_l, ligand_pos.to(torch.float32))
+    pv = torch.zeros(B * NPm, protein_v.shape[1], device=dev, dtype=protein_v.dtype).index_copy(0, rows_p, protein_v)
+    lv = torch.zeros(B * NLm, device=dev, dtype=ligand_v.dtype).index_copy(0, rows_l, ligand_v)
+    la = torch.zeros(B * NLm, ligand_v_aux.shape[1], device=dev, dtype=ligand_v_aux.dtype).index_copy(0, rows_l, ligand_v_aux)
+    bt = torch.zeros(B * NLm * (NLm - 1), device=dev, dtype=ligand_bond_type.dtype).index_copy(0, rows_b, ligand_bond_type)
+    b_p, b_l, fc = model._expected_layout(B, NPm, NLm, dev)
+    pad = dict(np_real=torch.tensor(n_p, dtype=torch.int32, device=dev), nl_real=torch.tensor(n_l, dtype=torch.int32, device=dev))
+    out = network(model, pp, pv, b_p, lp, lv, la, b_l, fc, bt, checked_B=B, pad=pad)
+    return {"pred_ligand_pos": out["pred_ligand_pos"].index_select(0, rows_l), "pred_ligand_v": out["pred_ligand_v"].index_select(0, rows_l),
+            "pred_bond": out["pred_bond"].index_select(0, rows_b)}
 
 
 _STRUCT: Dict = {}
@@ -410,10 +469,12 @@ def _structure(B, NP, NL, K, dev):
     fc1 = torch.stack([sp + (sp >= d).long(), d], 0)
     fc = torch.cat([fc1 + b * NL for b in range(B)], 1)
     bond_src, bond_dst = lig_rows[fc[0]], lig_rows[fc[1]]
+    bsrc_loc, b_of_bond = fc[0] % NL, fc[0] // NL           # (padded batches: is the source atom of a bond real?)
     dst = torch.arange(B * N, device=dev).repeat_interleave(K)
     S = dict(is_lig=is_lig, lig_rows=lig_rows, fc=fc, bond_src=bond_src, bond_dst=bond_dst, dst=dst,
              dst_is_prot=(~is_lig.index_select(0, dst)).long(), base=(torch.arange(B, device=dev) * N).view(B, 1, 1),
-             p_dst=seg_plan(dst, B * N), p_bdst=seg_plan(bond_dst, B * N), p_bsrc=seg_plan(bond_src, B * N), trip=None, p_ji=None)
+             p_dst=seg_plan(dst, B * N), p_bdst=seg_plan(bond_dst, B * N), p_bsrc=seg_plan(bond_src, B * N), trip=None, p_ji=None,
+             bsrc_loc=bsrc_loc, b_of_bond=b_of_bond)
     # ---- triplets k -> j -> i over the fully connected ligand bond graph (BondUpdateLayer.triplets, :103-123)
     NLm1, Ebs = NL - 1, NL * (NL - 1)
     if NL > 2:
@@ -429,6 +490,7 @@ def _structure(B, NP, NL, K, dev):
         aoff = (torch.arange(B, device=dev) * N + NP).repeat_interleave(Ebs * (NL - 2))
         rep = lambda t: t.repeat(B)
         S["trip"] = dict(ji=rep(e_ji) + boff, kj=rep(e_kj) + boff, i=rep(i_loc) + aoff, j=rep(j_loc) + aoff, k=rep(k_loc) + aoff)
+        S["tk_loc"], S["b_of_trip"] = rep(k_loc), boff // Ebs
         S["p_ji"] = seg_plan(S["trip"]["ji"], B * Ebs)
         # rows of bond (k -> j) gathered per triplet: the backward through a sorted segment sum (NL - 2 rows per bond) instead of
         # ATen's atomic index_add_.  (The per-ATOM gathers of the triplets -- (NL-1)(NL-2) rows per atom -- stay on index_add_:
@@ -442,9 +504,15 @@ def _structure(B, NP, NL, K, dev):
     return S
 
 
-def _knn_src(x, B, N, K, base):
-    """Sources of the kNN edges (dd_knn; edges grouped by centre in ascending order, neighbours by ascending distance)."""
+def _knn_src(x, B, N, K, base, NP=None, pad=None):
+    """Sources of the kNN edges (dd_knn; edges grouped by centre in ascending order, neighbours by ascending distance).
+    `pad` (padded batches): real atom counts per sample -- padding atoms are neither centres nor candidates (dd_knn_masked)."""
     xc = x.to(torch.float32).contiguous()
+    if pad is not None:
+        nbr = torch.empty(B, N, K, dtype=torch.int32, device=x.device)
+        hip_lib.check(hip_lib.load().dd_knn_masked(hip_lib.ptr(xc), B, NP, N - NP, K, hip_lib.ptr(pad["np_real"]), hip_lib.ptr(pad["nl_real"]),
+                                                   hip_lib.ptr(nbr), hip_lib.stream_ptr(x.device)), "dd_knn_masked")
+        return (nbr.long() + base).reshape(-1)
     ext = FN.torch_ext()
     if ext is not None:
         nbr = ext.knn(xc.view(B, N, 3), K)
@@ -455,11 +523,14 @@ def _knn_src(x, B, N, K, base):
 
 
 def network(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, ligand_v_aux, batch_ligand,
-            ligand_fc_bond_index, ligand_bond_type, checked_B: Optional[int] = None) -> Dict[str, torch.Tensor]:
+            ligand_fc_bond_index, ligand_bond_type, checked_B: Optional[int] = None, pad: Optional[Dict] = None) -> Dict[str, torch.Tensor]:
     """DecompScorePosNet3D.forward for the shipped configuration, differentiable w.r.t. the model's parameters.
     Dense batches (equal sizes per sample, sorted batch vectors, dst-major fc bond index -- `check_batch_layout`, run by
     `diffusion_loss`; samples of different sizes go through `network_grouped`).  `checked_B`: the caller has established the
-    layout (number of samples given): no device -> host round trip in here -- what a captured training step needs."""
+    layout (number of samples given): no device -> host round trip in here -- what a captured training step needs.
+    `pad` = dict(np_real, nl_real: int32 [B] on the device): a PADDED heterogeneous batch (`network_padded`) -- every sample's
+    real atoms are the first rows of its protein / ligand block; padding atoms are excluded from the kNN graph and masked as
+    members of the bond-graph and triplet attentions, so the real rows of the outputs equal the unpadded network's."""
     cfg = model.config
     P = _P(model)
     dev = protein_pos.device
@@ -485,7 +556,13 @@ def network(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, 
     h_bond = P.lin("ligand_bond_emb", F.one_hot(ligand_bond_type, model.num_bond_classes).float())
     Eb_tot = h_bond.shape[0]
     # ---- graph of the step (uni_transformer_edge.py:404-427): kNN among all atoms of a sample, fixed for all layers
-    src = _knn_src(x.detach(), B, N, K, S["base"])
+    src = _knn_src(x.detach(), B, N, K, S["base"], NP=NP, pad=pad)
+    real_b = real_t = None
+    if pad is not None:                                    # members of the bond-graph / triplet segments that are real atoms
+        nl_r = pad["nl_real"].long()
+        real_b = S["bsrc_loc"] < nl_r.index_select(0, S["b_of_bond"])
+        if trip is not None:
+            real_t = S["tk_loc"] < nl_r.index_select(0, S["b_of_trip"])
     p_src = seg_plan(src, B * N, check=False)              # rows gathered by source: backward = sorted segment sum, no atomics
     etype = 2 * (~is_lig.index_select(0, src)).long() + S["dst_is_prot"]  # 0 ll, 1 l->p(dst p), 2 p->l, 3 pp
     etype_1h = F.one_hot(etype, 4).float()
@@ -530,7 +607,7 @@ def network(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, 
         # node_layer_with_bond
         k_b, v_b = node_layer_bond("node_layer_with_bond", h, h_bond)
         q_b = P.mlp(f"{p}.node_layer_with_bond.hq_func", h)
-        alpha = _attention(gather(q_b, p_bdst), k_b, v_b, p_bdst)
+        alpha = _attention(gather(q_b, p_bdst), k_b, v_b, p_bdst, member_real=real_b)
         a_bond = scatter_sum((alpha.unsqueeze(-1) * v_b.view(-1, NH, H // NH)).reshape(-1, H), p_bdst)
         # bond_layer (BondUpdateLayer, :125-167): kv = [h_bond[kj](128), G(d_kj)(20), G(d_ji)(20), angle(13), h[k], h[j]]
         if trip is not None:
@@ -553,7 +630,7 @@ def network(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, 
                 kv.append(P.mlp_tail(f"{nm_b}.{f_}", pre))
             # hq depends on the (j -> i) bond only: evaluated per bond, gathered per triplet (exact)
             q_bond = P.mlp(f"{nm_b}.hq_func", torch.cat([h_bond, gather(h, p_bdst)], -1))
-            alpha = _attention(gather(q_bond, p_ji), kv[0], kv[1], p_ji)
+            alpha = _attention(gather(q_bond, p_ji), kv[0], kv[1], p_ji, member_real=real_t)
             d_hb = scatter_sum((alpha.unsqueeze(-1) * kv[1].view(-1, NH, H // NH)).reshape(-1, H), p_ji)
         else:
             d_hb = torch.zeros_like(h_bond)
@@ -566,7 +643,7 @@ def network(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, 
         dx_e = scatter_sum(((alpha * (v_pe * e_w)).unsqueeze(-1) * rel.unsqueeze(1)).reshape(-1, NH * 3), p_dst).view(-1, NH, 3).mean(1)
         k_pb, v_pb = node_layer_bond("pos_layer_with_bond", new_h, new_h_bond)
         q_pb = P.mlp(f"{p}.pos_layer_with_bond.xq_func", new_h)
-        alpha = _attention(gather(q_pb, p_bdst), k_pb, None, p_bdst)
+        alpha = _attention(gather(q_pb, p_bdst), k_pb, None, p_bdst, member_real=real_b)
         rel_b = gather(x, p_bdst) - x.index_select(0, bond_src)
         dx_b = scatter_sum(((alpha * v_pb).unsqueeze(-1) * rel_b.unsqueeze(1)).reshape(-1, NH * 3), p_bdst).view(-1, NH, 3).mean(1)
         x = x + (dx_e + dx_b) * mask_l

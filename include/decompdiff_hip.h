@@ -178,6 +178,11 @@ size_t dd_workspace_floats(int B, int NP, int NL, int K);
 /* torch_geometric.nn.knn_graph -> torch_cluster.knn (call site uni_transformer_edge.py:353):
  * per-sample K nearest other atoms, ascending (d2, index); d2 = (dx*dx+dy*dy)+dz*dz in fp32. */
 int dd_knn(const float* x /*[B,N,3]*/, int B, int N, int K, int32_t* nbr /*[B,N,K]*/, void* stream);
+/* The same for a padded heterogeneous batch in the layout of dd_sampler.np_real / nl_real (NP + NL rows per sample, the real atoms
+ * first in each block; np_real may be NULL = all NP rows real): padding atoms are neither centres nor candidates; the list of a
+ * padding centre is zeros.  Every sample needs at least K + 1 real atoms.  (Round 5: the padded training network.) */
+int dd_knn_masked(const float* x /*[B,NP+NL,3]*/, int B, int NP, int NL, int K, const int32_t* np_real, const int32_t* nl_real,
+                  int32_t* nbr /*[B,NP+NL,K]*/, void* stream);
 
 /* e_w = sigmoid(MLP(GaussianSmearing(dist)))  (uni_transformer_edge.py:422-427). */
 int dd_edge_weights(const float* x, const int32_t* nbr, int B, int N, int K, const float* W1T /*[20,128]*/,

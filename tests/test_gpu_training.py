@@ -305,3 +305,29 @@ def test_fused_layernorm_relu_matches_torch():
             assert float((a.double() - w).abs().max()) < 1e-4 * max(1.0, float(w.abs().max())), rows
         y2 = training.ln_relu(xs, gs, bs)
         assert torch.equal(y, y2)                              # run to run bit-identical (no atomics)
+
+
+def test_padded_heterogeneous_training_batch_equals_size_groups(monkeypatch):
+    """training.network_padded: a batch of different complexes as ONE padded dense pass (padding atoms out of the kNN graph, masked
+    in the bond-graph / triplet attentions) against one dense pass per distinct size (DD_TRAIN_PAD=0): same losses, same gradients
+    up to the association of the row sums -- and both against the reference's own numbers (`loss_grad_ragged`)."""
+    g = GU.load("loss_grad_ragged")
+    kw = _loss_kwargs(g)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DD_TRAIN_PAD", mode)
+        m = _fresh_model(); m.train()
+        torch.manual_seed(int(g["noise_seed"]))
+        r = m.get_diffusion_loss(**kw)
+        loss = r["losses"]["pos"] + 100.0 * r["losses"]["v"] + 100.0 * r["losses"]["bond"]
+        loss.backward()
+        res[mode] = (r, {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+    (ra, ga), (rb, gb) = res["1"], res["0"]
+    for k in ("pos", "v", "bond"):
+        assert abs(float(ra["losses"][k]) - float(rb["losses"][k])) <= 2e-6 * max(1.0, abs(float(rb["losses"][k]))), k
+        assert abs(float(ra["losses"][k]) - float(g["loss_" + k])) <= 1e-4 * max(1.0, abs(float(g["loss_" + k])))
+    assert maxabs(ra["pred_ligand_pos"], rb["pred_ligand_pos"]) < 1e-5 and maxabs(ra["pred_ligand_v"], rb["pred_ligand_v"]) < 1e-5
+    assert set(ga) == set(gb)
+    worst = max(float((ga[n] - gb[n]).abs().max()) / max(1e-3, float(gb[n].abs().max())) for n in ga)
+    assert worst < 2e-4, worst
+    assert all(bool(torch.isfinite(v).all()) for v in ga.values())
