@@ -387,11 +387,12 @@ def network_grouped(net, model, protein_pos, protein_v, batch_protein, ligand_po
             "pred_bond": cat("pred_bond", inv_b)}
 
 
-def _pad_rows(n_p, n_l):
+def _pad_rows(n_p, n_l, NPm=None, NLm=None):
     """Row maps of a heterogeneous batch into its padded dense layout (numpy, host): real protein / ligand rows and real bonds
     (the caller's dst-major lists over n_l[b] atoms) -> rows of the [B*NPm] / [B*NLm] / [B*NLm(NLm-1)] padded arrays."""
     import numpy as np
-    B, NPm, NLm = len(n_p), max(n_p), max(n_l)
+    B = len(n_p)
+    NPm, NLm = NPm or max(n_p), NLm or max(n_l)
     Ebm = NLm * (NLm - 1)
     rows_p = np.concatenate([b * NPm + np.arange(n) for b, n in enumerate(n_p)])
     rows_l = np.concatenate([b * NLm + np.arange(n) for b, n in enumerate(n_l)])
@@ -402,6 +403,16 @@ def _pad_rows(n_p, n_l):
         src = sp + (sp >= dst)
         rb.append(b * Ebm + dst * (NLm - 1) + (src - (src > dst)))
     return rows_p, rows_l, np.concatenate(rb)
+
+
+def _far_positions(B, NPm, NLm, dev):
+    """Positions of padding atoms: far from everything and from each other, never collinear (norms / cross products keep finite
+    gradients): protein padding around x = +1000, ligand padding around x = -1000 (and beyond, 3 A apart)."""
+    i_p = torch.arange(B * NPm, device=dev, dtype=torch.float32)
+    far_p = torch.stack([1.0e3 + 3.0 * i_p, 5.0 * torch.sin(1.3 * i_p), 4.0 * torch.cos(2.1 * i_p)], -1)
+    i_l = torch.arange(B * NLm, device=dev, dtype=torch.float32)
+    far_l = torch.stack([-1.0e3 - 3.0 * i_l, 5.0 * torch.cos(1.7 * i_l), 4.0 * torch.sin(0.9 * i_l)], -1)
+    return far_p, far_l
 
 
 def network_padded(model, protein_pos, protein_v, ligand_pos, ligand_v, ligand_v_aux, ligand_bond_type, n_p, n_l):
@@ -418,11 +429,7 @@ def network_padded(model, protein_pos, protein_v, ligand_pos, ligand_v, ligand_v
     if min(a + b for a, b in zip(n_p, n_l)) < K + 1:
         return None
     rows_p, rows_l, rows_b = (torch.from_numpy(r).to(dev) for r in _pad_rows(n_p, n_l))
-    # padding atoms: far from everything and from each other, never collinear (norms / cross products keep finite gradients)
-    i_p = torch.arange(B * NPm, device=dev, dtype=torch.float32)
-    far_p = torch.stack([1.0e3 + 3.0 * i_p, 5.0 * torch.sin(1.3 * i_p), 4.0 * torch.cos(2.1 * i_p)], -1)
-    i_l = torch.arange(B * NLm, device=dev, dtype=torch.float32)
-    far_l = torch.stack([-1.0e3 - 3.0 * i_l, 5.0 * torch.cos(1.7 * i_l), 4.0 * torch.sin(0.9 * i_l)], -1)
+    far_p, far_l = _far_positions(B, NPm, NLm, dev)
     pp = far_p.index_copy(0, rows_p, protein_pos.to(torch.float32))
     lp = far_l.index_copy(0, rows_l, ligand_pos.to(torch.float32))
     pv = torch.zeros(B * NPm, protein_v.shape[1], device=dev, dtype=protein_v.dtype).index_copy(0, rows_p, protein_v)
@@ -833,6 +840,107 @@ def objective(model, prep: Dict, network_fn=None) -> Dict:
             "time_step": time_step}
 
 
+def pad_prepared(model, prep: Dict, bucket=(32, 4)) -> Optional[Dict]:
+    """A prepared heterogeneous batch in a FIXED-SHAPE padded layout (sizes rounded up to `bucket`): every per-atom / per-bond tensor
+    of `prep` scattered into [B*NPm] / [B*NLm] / [B*NLm(NLm-1)] arrays, the per-atom prior centres / stds gathered, row weights
+    (1 real, 0 padding) and the real counts.  Runs outside any capture (its index maps have batch-dependent lengths); the result
+    feeds `objective_padded`, whose tensors all have shapes that depend on (B, NPm, NLm) only.  None if a sample has fewer than
+    K + 1 real atoms."""
+    n_p, n_l = prep["sizes"]
+    B = len(n_p)
+    up = lambda n, q: -(-n // q) * q
+    NPm, NLm = up(max(n_p), int(bucket[0])), up(max(n_l), int(bucket[1]))
+    dev = prep["protein_pos"].device
+    K = min(int(model.config.knn), NPm + NLm - 1)
+    if min(a + b for a, b in zip(n_p, n_l)) < K + 1:
+        return None
+    rows_p, rows_l, rows_b = (torch.from_numpy(r).to(dev) for r in _pad_rows(n_p, n_l, NPm, NLm))
+    Ebm = NLm * (NLm - 1)
+    far_p, far_l = _far_positions(B, NPm, NLm, dev)
+    z = lambda n, like, fill=0: torch.full((n,) + tuple(like.shape[1:]), fill, device=dev, dtype=like.dtype)
+    dec = prep["ligand_decomp_batch"]
+    out = dict(B=B, NPm=NPm, NLm=NLm, time_step=prep["time_step"],
+               protein_pos=far_p.index_copy(0, rows_p, prep["protein_pos"].float()),
+               protein_v=z(B * NPm, prep["protein_v"]).index_copy(0, rows_p, prep["protein_v"]),
+               ligand_pos=far_l.index_copy(0, rows_l, prep["ligand_pos"].float()),
+               ligand_v=z(B * NLm, prep["ligand_v"]).index_copy(0, rows_l, prep["ligand_v"]),
+               ligand_v_aux=z(B * NLm, prep["ligand_v_aux"]).index_copy(0, rows_l, prep["ligand_v_aux"]),
+               bond_type=z(B * Ebm, prep["ligand_fc_bond_type"]).index_copy(0, rows_b, prep["ligand_fc_bond_type"]),
+               pos_noise=z(B * NLm, prep["pos_noise"]).index_copy(0, rows_l, prep["pos_noise"]),
+               u_v=z(B * NLm, prep["u_v"], 0.5).index_copy(0, rows_l, prep["u_v"]),
+               u_b=z(B * Ebm, prep["u_b"], 0.5).index_copy(0, rows_b, prep["u_b"]),
+               centers=torch.zeros(B * NLm, 3, device=dev).index_copy(0, rows_l, prep["prior_centers"][dec].float()),
+               stds=torch.ones(B * NLm, 3, device=dev).index_copy(0, rows_l, prep["prior_stds"][dec].float()),
+               w_p=torch.zeros(B * NPm, device=dev).index_fill(0, rows_p, 1.0),
+               w_l=torch.zeros(B * NLm, device=dev).index_fill(0, rows_l, 1.0),
+               w_b=torch.zeros(B * Ebm, device=dev).index_fill(0, rows_b, 1.0),
+               np_real=torch.tensor(n_p, dtype=torch.int32, device=dev), nl_real=torch.tensor(n_l, dtype=torch.int32, device=dev))
+    out["cnt_p"], out["cnt_l"] = out["np_real"].float(), out["nl_real"].float()
+    out["cnt_b"] = out["cnt_l"] * (out["cnt_l"] - 1.0)
+    out["rows_l"], out["rows_b"] = rows_l, rows_b           # (for callers that want the real rows back; not used by the objective)
+    return out
+
+
+PAD_TENSORS = ("time_step", "protein_pos", "protein_v", "ligand_pos", "ligand_v", "ligand_v_aux", "bond_type", "pos_noise", "u_v", "u_b",
+               "centers", "stds", "w_p", "w_l", "w_b", "np_real", "nl_real", "cnt_p", "cnt_l", "cnt_b")
+
+
+def objective_padded(model, pp: Dict) -> Dict:
+    """`objective` on a padded batch (`pad_prepared`): the same forward diffusion, network and losses with every per-sample mean
+    taken over the real rows (weights 0 / 1, real counts).  Shapes depend on (B, NPm, NLm) only and nothing touches the host, so
+    mixed-size batches of one shape bucket share ONE captured graph (`GraphedTrainStep`)."""
+    B, NPm, NLm = pp["B"], pp["NPm"], pp["NLm"]
+    dev = pp["protein_pos"].device
+    time_step = pp["time_step"]
+    b_p, b_l, fc = model._expected_layout(B, NPm, NLm, dev)
+    b_b = torch.arange(B, device=dev).repeat_interleave(NLm * (NLm - 1))
+    a = model.alphas_cumprod.index_select(0, time_step)
+    a_pos = a[b_l].unsqueeze(-1)
+    ligand_pos, centers, stds = pp["ligand_pos"], pp["centers"], pp["stds"]
+    pos_pert = a_pos.sqrt() * (ligand_pos - centers) + (1.0 - a_pos).sqrt() * pp["pos_noise"] * stds + centers
+    tv, tb = _Trans(model.atom_type_trans), _Trans(model.bond_type_trans)
+    log_v0 = _log_onehot(pp["ligand_v"], model.num_classes)
+    v_pert = (-torch.log(-torch.log(pp["u_v"] + 1e-30) + 1e-30) + tv.pred(log_v0, time_step, b_l)).argmax(-1)
+    log_vt = _log_onehot(v_pert, model.num_classes)
+    log_b0 = _log_onehot(pp["bond_type"], model.num_bond_classes)
+    b_pert = (-torch.log(-torch.log(pp["u_b"] + 1e-30) + 1e-30) + tb.pred(log_b0, time_step, b_b)).argmax(-1)
+    log_bt = _log_onehot(b_pert, model.num_bond_classes)
+    if model.center_pos_mode == "protein":                 # mean of the REAL protein rows of each sample
+        offset = (pp["protein_pos"] * pp["w_p"].unsqueeze(-1)).view(B, NPm, 3).sum(1) / pp["cnt_p"].unsqueeze(-1)
+    elif model.center_pos_mode == "none":
+        offset = torch.zeros(B, 3, device=dev)
+    else:
+        raise NotImplementedError(model.center_pos_mode)
+    p_pos = pp["protein_pos"] - offset[b_p]
+    x_t = pos_pert - offset[b_l]
+    x_0 = ligand_pos - offset[b_l]
+    preds = network(model, p_pos, pp["protein_v"], b_p, x_t, v_pert, pp["ligand_v_aux"], b_l, fc, b_pert, checked_B=B,
+                    pad=dict(np_real=pp["np_real"], nl_real=pp["nl_real"]))
+    pred_pos, pred_v = preds["pred_ligand_pos"], preds["pred_ligand_v"]
+    plan_l, plan_b = _static_plan(b_l, B, [NLm] * B, False), _static_plan(b_b, B, [NLm] * B, True)
+
+    def sample_mean(per_row, w, plan, cnt):                # scatter_mean over the real rows of every sample
+        return scatter_sum((per_row * w).unsqueeze(-1), plan).squeeze(-1) / cnt
+
+    def v_loss(log_model, log_v0_, log_true, batch, w, plan, cnt):
+        kl = (log_true.exp() * (log_true - log_model)).sum(1)
+        nll = -(log_v0_.exp() * log_model).sum(1)
+        mask = (time_step == 0).float()[batch]
+        return sample_mean(mask * nll + (1.0 - mask) * kl, w, plan, cnt)
+
+    log_v_recon = F.log_softmax(pred_v, dim=-1)
+    kl_v = v_loss(tv.posterior(log_v_recon, log_vt, time_step, b_l), log_v0, tv.posterior(log_v0, log_vt, time_step, b_l), b_l,
+                  pp["w_l"], plan_l, pp["cnt_l"])
+    log_b_recon = F.log_softmax(preds["pred_bond"], dim=-1)
+    kl_b = v_loss(tb.posterior(log_b_recon, log_bt, time_step, b_b), log_b0, tb.posterior(log_b0, log_bt, time_step, b_b), b_b,
+                  pp["w_b"], plan_b, pp["cnt_b"])
+    if model.loss_pos_type != "mse":
+        raise ValueError(model.loss_pos_type)
+    loss_pos = sample_mean((((pred_pos - x_0) ** 2) / (stds ** 2)).sum(-1), pp["w_l"], plan_l, pp["cnt_l"]).mean()
+    return {"losses": {"pos": loss_pos, "v": kl_v.mean(), "bond": kl_b.mean()}, "pred_ligand_pos": pred_pos, "pred_ligand_v": pred_v,
+            "pred_bond": preds["pred_bond"], "x0": x_0, "time_step": time_step}
+
+
 def diffusion_loss(model, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, ligand_v_aux, batch_ligand,
                    prior_centers, prior_stds, prior_num_atoms, batch_prior, ligand_decomp_batch, ligand_fc_bond_index,
                    ligand_fc_bond_type, batch_ligand_bond, time_step=None, network_fn=None) -> Dict:
@@ -857,16 +965,17 @@ class GraphedTrainStep:
     seeded runs stay comparable) -- is `prepare_batch`; the rest (`objective`, backward, the optimizer's update) touches the
     device only and is captured with torch.cuda.graph after `warmup` eager iterations of that shape (on a side stream, as
     torch's capture rules ask).  Later iterations copy the prepared tensors into the graph's static inputs and replay it.
-    Batches whose samples differ in size (they run as one sub-batch per size, with host-side index bookkeeping) stay eager.
+    Batches whose samples differ in size go through the padded layout of their shape bucket (`pad_prepared` / `objective_padded`:
+    sizes rounded up to `bucket`), so all batches of a bucket share one graph.
 
     The optimizer must be built with ``capturable=True`` (torch.optim.Adam / AdamW): its step counter then lives on the device.
     ``step(**kw)`` takes get_diffusion_loss's keyword arguments and returns {"loss", "losses": {pos, v, bond}} (detached)."""
 
-    def __init__(self, model, optimizer, loss_weights=(1.0, 100.0, 100.0), warmup: int = 3, max_graphs: int = 4):
+    def __init__(self, model, optimizer, loss_weights=(1.0, 100.0, 100.0), warmup: int = 3, max_graphs: int = 4, bucket=(32, 4)):
         if not optimizer.defaults.get("capturable", False):
             raise ValueError("GraphedTrainStep needs an optimizer built with capturable=True (its state must live on the device)")
         self.model, self.opt, self.w = model, optimizer, tuple(float(x) for x in loss_weights)
-        self.warmup, self.max_graphs = int(warmup), int(max_graphs)
+        self.warmup, self.max_graphs, self.bucket = int(warmup), int(max_graphs), (int(bucket[0]), int(bucket[1]))
         self._seen: Dict = {}
         self._graphs: Dict = {}
         self._side = None
@@ -876,9 +985,9 @@ class GraphedTrainStep:
         lo = res["losses"]
         return self.w[0] * lo["pos"] + self.w[1] * lo["v"] + self.w[2] * lo["bond"]
 
-    def _eager(self, prep):
+    def _eager(self, prep, fn=None):
         self.opt.zero_grad(set_to_none=True)
-        res = objective(self.model, prep)
+        res = (fn or objective)(self.model, prep)
         loss = self._total(res)
         loss.backward()
         self.opt.step()
@@ -896,9 +1005,19 @@ class GraphedTrainStep:
         n_p, n_l = prep["sizes"]
         dense = len(set(zip(n_p, n_l))) == 1
         dev = protein_pos.device
-        key = (tuple(n_p), tuple(n_l), int(prior_centers.shape[0]), str(dev))
-        if not dense or os.environ.get("DD_TRAIN_GRAPH", "1") == "0":
+        if os.environ.get("DD_TRAIN_GRAPH", "1") == "0":
             return self._eager(prep)
+        if dense:
+            key = (tuple(n_p), tuple(n_l), int(prior_centers.shape[0]), str(dev))
+            data, names, fn = prep, PREP_TENSORS, objective
+        else:
+            # samples of different sizes: the padded layout of their shape bucket (sizes rounded up to `bucket`) -- all batches
+            # whose largest protein / ligand fall into one bucket share a graph
+            data = pad_prepared(model, prep, self.bucket)
+            if data is None:
+                return self._eager(prep)
+            key = ("padded", data["B"], data["NPm"], data["NLm"], str(dev))
+            names, fn = PAD_TENSORS, objective_padded
         ent = self._graphs.get(key)
         if ent is None:
             n = self._seen.get(key, 0)
@@ -909,29 +1028,29 @@ class GraphedTrainStep:
             self._side.wait_stream(cur)
             if n < self.warmup:                            # eager iterations of this shape first (real steps, on the side stream)
                 with torch.cuda.stream(self._side):
-                    out = self._eager(prep)
+                    out = self._eager(data, fn)
                 cur.wait_stream(self._side)
                 return out
             if len(self._graphs) >= self.max_graphs:
                 self._graphs.pop(next(iter(self._graphs)))
-            static = dict(prep)
-            for k in PREP_TENSORS:
-                static[k] = prep[k].clone()
+            static = dict(data)
+            for k in names:
+                static[k] = data[k].clone()
             self.opt.zero_grad(set_to_none=True)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=self._side):
-                res = objective(model, static)
+                res = fn(model, static)
                 loss = self._total(res)
                 loss.backward()
                 self.opt.step()
             cur.wait_stream(self._side)
-            ent = self._graphs[key] = dict(graph=graph, static=static, loss=loss.detach(),
+            ent = self._graphs[key] = dict(graph=graph, static=static, names=names, loss=loss.detach(),
                                            losses={k: v.detach() for k, v in res["losses"].items()})
             # (the capture itself computed nothing: this iteration's update happens in the replay below)
         else:
             self._graphs[key] = self._graphs.pop(key)      # most recently used last
-        for k in PREP_TENSORS:
-            ent["static"][k].copy_(prep[k], non_blocking=True)
+        for k in ent["names"]:
+            ent["static"][k].copy_(data[k], non_blocking=True)
         ent["graph"].replay()
         self.replays += 1
         return {"loss": ent["loss"].clone(), "losses": {k: v.clone() for k, v in ent["losses"].items()}}

@@ -331,3 +331,83 @@ def test_padded_heterogeneous_training_batch_equals_size_groups(monkeypatch):
     worst = max(float((ga[n] - gb[n]).abs().max()) / max(1e-3, float(gb[n].abs().max())) for n in ga)
     assert worst < 2e-4, worst
     assert all(bool(torch.isfinite(v).all()) for v in ga.values())
+
+
+@pytest.mark.parametrize("bucket", [(1, 1), (32, 4)])
+def test_padded_objective_equals_the_ragged_objective(bucket):
+    """training.objective_padded on pad_prepared(...) -- fixed shapes, per-sample means over the real rows -- against
+    training.objective on the same prepared ragged batch: same losses, same gradients (also with sizes rounded up to a bucket,
+    i.e. whole padding atoms beyond the batch's largest sample), and the reference's own losses (`loss_grad_ragged`)."""
+    from decompdiff_amd import training
+    g = GU.load("loss_grad_ragged")
+    kw = _loss_kwargs(g)
+    names = ("protein_pos", "protein_v", "batch_protein", "ligand_pos", "ligand_v", "ligand_v_aux", "batch_ligand", "prior_centers",
+             "prior_stds", "prior_num_atoms", "batch_prior", "ligand_decomp_batch", "ligand_fc_bond_index", "ligand_fc_bond_type",
+             "batch_ligand_bond")
+    out = {}
+    for mode in ("ragged", "padded"):
+        m = _fresh_model(); m.train()
+        torch.manual_seed(int(g["noise_seed"]))
+        prep = training.prepare_batch(m, *[kw[n] for n in names], time_step=kw["time_step"])
+        if mode == "ragged":
+            r = training.objective(m, prep)
+        else:
+            pp = training.pad_prepared(m, prep, bucket)
+            assert pp is not None and pp["NPm"] % bucket[0] == 0 and pp["NLm"] % bucket[1] == 0
+            r = training.objective_padded(m, pp)
+        loss = r["losses"]["pos"] + 100.0 * r["losses"]["v"] + 100.0 * r["losses"]["bond"]
+        loss.backward()
+        out[mode] = (r, {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+    (ra, ga), (rb, gb) = out["padded"], out["ragged"]
+    for k in ("pos", "v", "bond"):
+        assert abs(float(ra["losses"][k]) - float(rb["losses"][k])) <= 2e-6 * max(1.0, abs(float(rb["losses"][k]))), k
+        assert abs(float(ra["losses"][k]) - float(g["loss_" + k])) <= 1e-4 * max(1.0, abs(float(g["loss_" + k])))
+    worst = max(float((ga[n] - gb[n]).abs().max()) / max(1e-3, float(gb[n].abs().max())) for n in gb)
+    assert set(ga) == set(gb) and worst < 2e-4, worst
+    assert all(bool(torch.isfinite(v).all()) for v in ga.values())
+
+
+def test_graphed_train_step_with_batches_of_different_complexes():
+    """GraphedTrainStep on mixed-size batches: batches whose largest protein / ligand fall into one shape bucket share ONE captured
+    graph (padded layout); the captured iterations follow the eager ones."""
+    from decompdiff_amd import training
+    torch.manual_seed(8)
+    mk = lambda seed, shapes: synth.concat_sampling_batches(
+        [synth.build_sampling_batch(synth.make_pocket(seed + i, n_p, arms, sca, num_full_protein=0), 1) for i, (n_p, arms, sca) in enumerate(shapes)])
+    batches = [mk(60, [(70, (3, 3), 4), (64, (2, 3), 3), (58, (3, 2), 5)]),          # largest: 70 + 10  -> bucket (96, 12)
+               mk(70, [(66, (3, 3), 5), (72, (3, 3), 3), (60, (2, 2), 4)]),          # largest: 72 + 11  -> the same bucket
+               mk(80, [(90, (4, 3), 4), (65, (2, 2), 5), (69, (3, 3), 6)])]          # largest: 90 + 12  -> the same bucket
+    d = lambda t: t.to(dev()) if torch.is_tensor(t) else t
+    to_kw = lambda b: dict(
+        protein_pos=d(b["protein_pos"]), protein_v=d(b["protein_v"]), batch_protein=d(b["batch_protein"]),
+        protein_group_idx=d(b["protein_group_idx"]), ligand_pos=d(b["init_ligand_pos"]), ligand_v=d(b["init_ligand_v"]),
+        ligand_v_aux=d(b["ligand_v_aux"]), batch_ligand=d(b["batch_ligand"]), ligand_group_idx=d(b["ligand_group_idx"]),
+        prior_centers=d(b["prior_centers"]), prior_stds=d(b["prior_stds"]), prior_num_atoms=d(b["prior_num_atoms"]),
+        batch_prior=d(b["batch_prior"]), prior_group_idx=d(b["prior_group_idx"]), ligand_decomp_batch=d(b["ligand_decomp_batch"]),
+        ligand_decomp_index=d(b["ligand_decomp_index"]), ligand_fc_bond_index=d(b["ligand_fc_bond_index"]),
+        ligand_fc_bond_type=d(b["init_ligand_fc_bond_type"]), batch_ligand_bond=d(b["batch_ligand_bond"]))
+    kws = [to_kw(b) for b in batches]
+
+    def fresh(capturable):
+        m = DecompScorePosNet3D(shipped_config(), 29, 10, 8)
+        sd = m.state_dict(); sd.update(synth.synthetic_state_dict(shipped_config(), 1)); m.load_state_dict(sd)
+        m = m.to(dev()).train()
+        return m, torch.optim.Adam(m.parameters(), lr=1e-4, capturable=capturable)
+
+    order = [0, 1, 2, 0, 1, 2, 1, 0]
+    m_e, opt_e = fresh(False)
+    torch.manual_seed(12)
+    eager = []
+    for i in order:
+        opt_e.zero_grad(set_to_none=True)
+        r = m_e.get_diffusion_loss(**kws[i])
+        loss = r["losses"]["pos"] + 100.0 * r["losses"]["v"] + 100.0 * r["losses"]["bond"]
+        loss.backward(); opt_e.step()
+        eager.append(float(loss))
+    m_g, opt_g = fresh(True)
+    gs = training.GraphedTrainStep(m_g, opt_g, loss_weights=(1.0, 100.0, 100.0), warmup=2, bucket=(32, 4))
+    torch.manual_seed(12)
+    graphed = [float(gs.step(**kws[i])["loss"]) for i in order]
+    assert len(gs._graphs) == 1 and gs.replays == len(order) - 2 and gs.eager_steps == 2      # one bucket, one graph
+    for a, c in zip(eager, graphed):
+        assert abs(a - c) <= 2e-4 * max(1.0, abs(a)), (eager, graphed)
