@@ -96,8 +96,9 @@ def respawn_under_torchrun(args):
 # ---------------------------------------------------------------------------------------------------------- FLOP counts
 def node_launch_mfma_count(nbr, B, NP, NL, K):
     """Exact number of v_mfma_f32_16x16x4_f32 wave-instructions of one fused node launch (dd_attention2.hip): per
-    16-member tile the scores and the aggregation take 32 each; the first-Linear table contraction takes 48 per pass and
-    source kind present in the tile (kNN modes; a tile mixing protein and ligand sources runs both tables) or 24 per pass
+    16-member tile the scores and the aggregation take 32 each; the first-Linear table contraction takes 40 per pass and
+    source kind present in the tile (kNN modes: 20 Gaussians = 5 k-steps x 8 channel tiles -- the per-type constant row is added
+    on the VALU since round 5, bit-identically; a tile mixing protein and ligand sources runs both tables) or 24 per pass
     (triplets: 12 merged angle codes); node_layer_with_bond has no table.  `nbr` [B,N,K] is the kNN graph of the step."""
     N = NP + NL
     tiles_e = (K + 15) // 16
@@ -107,7 +108,7 @@ def node_launch_mfma_count(nbr, B, NP, NL, K):
         has_p = (m < NP).any(-1)
         has_l = (m >= NP).any(-1)
         kinds += int(has_p.sum() + has_l.sum())
-    ne = 2 * 48 * kinds + 64 * B * N * tiles_e
+    ne = 2 * 40 * kinds + 64 * B * N * tiles_e
     nb = 64 * B * NL * ((NL - 1 + 15) // 16)
     bl = (2 * 24 + 64) * B * NL * (NL - 1) * ((NL - 2 + 15) // 16)
     return ne + nb + bl, {"NE": ne, "NB": nb, "BL": bl}

@@ -25,6 +25,10 @@
 #include "dd_kernels.hpp"
 #include "dd_gemm_tile.hpp"
 
+#ifndef DD_KNN_CONST_ADD
+#define DD_KNN_CONST_ADD 1
+#endif
+
 namespace dd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -568,6 +572,10 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
     if (KNN) {
       // Gaussian / type tables: F = 20 Gaussians + the per-type constant (24 rows = 6 k-steps).  A tile whose members
       // mix ligand and protein sources runs once per table with the other members' features zeroed.
+      // DD_KNN_CONST_ADD: the sixth k-step only adds table row 20 (feature 1, rows 21-23 are zero rows) -- fma(1, w, acc) is
+      // round(acc + w), and the steps of the OTHER table add exact zeros to a member, so the row of the member's own table added
+      // on the VALU after the Gaussian steps gives the same bits: 8 (16 in a mixed tile) MFMAs less per tile pass.
+      constexpr int KS = DD_KNN_CONST_ADD ? 5 : 6;
       float F[6];
 #pragma unroll
       for (int s = 0; s < 5; ++s) F[s] = gauss_feat(dm[t], 4 * s + cg);
@@ -579,7 +587,21 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
         const bool want = half ? hi : !hi;
         if (__builtin_amdgcn_ballot_w64(want) != 0ull) {
 #pragma unroll
-          for (int s = 0; s < 6; ++s) mfma_table_step<TR>(acc, tab + half * TABP + s * 512, want ? F[s] : 0.0f);
+          for (int s = 0; s < KS; ++s) mfma_table_step<TR>(acc, tab + half * TABP + s * 512, want ? F[s] : 0.0f);
+        }
+      }
+      if (DD_KNN_CONST_ADD) {
+        // row 20 in the operand layout: channel 16 nt + i sits at (nt / 4) * 64 + i * 4 + nt % 4
+        const float* row20 = smem + L::TAB + pass * 2 * TABP + 20 * 128;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // TR: acc[nt][r] = member 4cg + r, channel 16 nt + mm;  else: member mm, channel 16 nt + 4cg + r
+          const bool hi_r = TR ? (jT[t][r] < a.NP) : hi;
+          const float* p = row20 + (hi_r ? TABP : 0) + (TR ? mm : 4 * cg + r) * 4;
+          const float4 c0 = *reinterpret_cast<const float4*>(p);
+          const float4 c1 = *reinterpret_cast<const float4*>(p + 64);
+          acc[0][r] += c0.x; acc[1][r] += c0.y; acc[2][r] += c0.z; acc[3][r] += c0.w;
+          acc[4][r] += c1.x; acc[5][r] += c1.y; acc[6][r] += c1.z; acc[7][r] += c1.w;
         }
       }
     } else if (TRIP) {
