@@ -969,6 +969,10 @@ class GraphedTrainStep:
     sizes rounded up to `bucket`), so all batches of a bucket share one graph.
 
     The optimizer must be built with ``capturable=True`` (torch.optim.Adam / AdamW): its step counter then lives on the device.
+    A captured graph holds the ADDRESSES of the parameters, their gradients and the optimizer state: in-place updates
+    (optimizer steps, ``load_state_dict``) are seen by the next replay, but anything that gives the parameters new storage
+    (``model.to(...)``, re-creating the optimizer) needs a new ``GraphedTrainStep``.  At most ``max_graphs`` graphs are kept (least
+    recently used first out); each holds the activations of one iteration of its shape (~5 GB at B = 4, 300 + 30 atoms).
     ``step(**kw)`` takes get_diffusion_loss's keyword arguments and returns {"loss", "losses": {pos, v, bond}} (detached)."""
 
     def __init__(self, model, optimizer, loss_weights=(1.0, 100.0, 100.0), warmup: int = 3, max_graphs: int = 4, bucket=(32, 4)):
