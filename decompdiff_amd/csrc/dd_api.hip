@@ -817,6 +817,8 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     a.lnk = LW(l, DD_BL_lnk); a.lnv = LW(l, DD_BL_lnv);
     a.W2k = LW(l, DD_BL_W2k); a.W2v = LW(l, DD_BL_W2v); a.b2v = LW(l, DD_BL_b2v); a.out = w.hb;
     a.Rk = w.Rk; a.Rv = w.Rv;
+    a.work_counter = (l < 64) ? w.counters + l : nullptr;   // (small ligands: the fused launch's persistent cooperative workgroups)
+    a.bl_prefix = s->bl_prefix;
     DD_TRYP(DD_PROF_ATTN_BL, attn_dispatch(M_BL, a, st));
     // ---- h += lin_node(A)
     DD_TRYP(DD_PROF_GEMM, launch_gemm128({w.A, B * N, 0, 128, B * N, LW(l, DD_W_lin), LW(l, DD_b_lin), nullptr, w.h, B * N, 0, 128, 128, 1}, st));
@@ -1024,7 +1026,7 @@ extern "C" const char* dd_status_string(int status) {
 // 7: dd_queue_error; the workspace carries the layer-tail queue's flag words (dd_workspace_floats grew)
 // 8: arms_repul drift (dd_sampler.drift_repul / repul_max_d / repul_scale, dd_drift_arms_repul; the workspace grew by one
 //    gradient buffer); dd_build_flags
-extern "C" int dd_abi_version(void) { return 8; }
+extern "C" int dd_abi_version(void) { return 9; }
 extern "C" int dd_build_flags(void) {
   int f = 0;
 #if defined(DD_DEBUG_OPTIONS) && DD_DEBUG_OPTIONS

@@ -28,6 +28,33 @@
 #ifndef DD_KNN_CONST_ADD
 #define DD_KNN_CONST_ADD 1
 #endif
+// Round 6 (EXPERIMENTS.md R6-1): the VALU stream of a segment cut by a quarter.  Each switch builds the round-5 form when 0
+// (tools/build_variant.sh); DD_LN_FOLD also selects the weight form the library expects (dd_weights_form(), packing.py).
+#ifndef DD_LN_FOLD
+#define DD_LN_FOLD 1       // LayerNorm + ReLU of the key / value MLPs as max(fma(P, rstd, beta'), 0) on mean-free, sign-folded rows
+#endif
+#ifndef DD_FAST_ANGLE
+#define DD_FAST_ANGLE 1    // angle codes without library atan2f / IEEE sqrt / IEEE division
+#endif
+#ifndef DD_PEEL_FOLD
+#define DD_PEEL_FOLD 0     // first step of the query fold as products instead of zero-initialised accumulators (measured: +1 %, R6-1)
+#endif
+#ifndef DD_PEEL_Z
+#define DD_PEEL_Z 0        // the same for the aggregation chains (measured: +1.8 %, 48 more registers, R6-1)
+#endif
+#ifndef DD_COOP
+#define DD_COOP 0          // persistent bond-layer workgroups: query fold and epilogue split by head over the 8 waves of a trip (bl_coop_body);
+                           // measured equal to the per-wave fold / epilogue (EXPERIMENTS.md R6-2): built with -DDD_COOP=1 for the A/B only
+#endif
+#ifndef DD_COOP_WK_RELOAD
+#define DD_COOP_WK_RELOAD 0   // bl_coop_body: the wave's 16 W2k rows re-read (L2) with every trip's prologue instead of held in 32 registers
+#endif
+#ifndef DD_COOP_RC
+#define DD_COOP_RC 0          // bl_coop_body: the segment's own row (Rk) requested with the next trip's prologue instead of at its first tile
+#endif
+#ifndef DD_UNCOND_FETCH
+#define DD_UNCOND_FETCH 1  // next tile's rows requested unconditionally (clipped members): no register copies at the tile joins
+#endif
 
 namespace dd {
 
@@ -99,7 +126,23 @@ __device__ __forceinline__ void load_row(float (&P)[32], const float* __restrict
 }
 
 // LayerNorm(128)+ReLU of a member row spread over the 4 lanes {l, l^16, l^32, l^48}, 32 channels each.
+// DD_LN_FOLD (packing.py::kernel_form_layer): the rows arrive mean-free with the sign of gamma folded in, |gamma| sits in the
+// second Linear and beta' = beta / |gamma| in ln[128..]: the variance is E[P^2] and the activation one FMA + one max.
 __device__ __forceinline__ void ln_relu32(float (&P)[32], const float* __restrict__ ln /*LDS: gamma[128], beta[128]*/, int cg) {
+#if DD_LN_FOLD
+  float v0 = P[0] * P[0], v1 = P[1] * P[1];
+#pragma unroll
+  for (int k = 2; k < 32; k += 2) { v0 = fmaf(P[k], P[k], v0); v1 = fmaf(P[k + 1], P[k + 1], v1); }
+  const float rstd = dd_rsqrt(quad_sum(v0 + v1) * (1.0f / 128.0f) + 1e-5f);
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) {
+    const float4 b = *reinterpret_cast<const float4*>(ln + 128 + 16 * nt + 4 * cg);
+    P[4 * nt] = fmaxf(fmaf(P[4 * nt], rstd, b.x), 0.f);
+    P[4 * nt + 1] = fmaxf(fmaf(P[4 * nt + 1], rstd, b.y), 0.f);
+    P[4 * nt + 2] = fmaxf(fmaf(P[4 * nt + 2], rstd, b.z), 0.f);
+    P[4 * nt + 3] = fmaxf(fmaf(P[4 * nt + 3], rstd, b.w), 0.f);
+  }
+#else
   float s = 0.f;
 #pragma unroll
   for (int k = 0; k < 32; ++k) s += P[k];
@@ -117,6 +160,7 @@ __device__ __forceinline__ void ln_relu32(float (&P)[32], const float* __restric
     P[4 * nt + 2] = fmaxf(fmaf(P[4 * nt + 2] * rstd, g.z, b.z), 0.f);
     P[4 * nt + 3] = fmaxf(fmaf(P[4 * nt + 3] * rstd, g.w, b.w), 0.f);
   }
+#endif
 }
 
 // D[m][h] = sum_c z[m][c] * Bm[h][c] for one tile; two accumulators hide the 40-cycle dependent latency
@@ -141,6 +185,20 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 // LayerNorm(128)+ReLU in the member-major ("T") layout: Tz[4*nt + r] = row of member 4*cg + r, channel 16*nt + mm.
 __device__ __forceinline__ void ln_relu_T(float (&Tz)[32], const float* __restrict__ ln /*LDS*/, int mm) {
+#if DD_LN_FOLD
+  float be[8];
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) be[nt] = ln[128 + 16 * nt + mm];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float v0 = Tz[r] * Tz[r], v1 = Tz[4 + r] * Tz[4 + r];
+#pragma unroll
+    for (int nt = 2; nt < 8; nt += 2) { v0 = fmaf(Tz[4 * nt + r], Tz[4 * nt + r], v0); v1 = fmaf(Tz[4 * nt + 4 + r], Tz[4 * nt + 4 + r], v1); }
+    const float rstd = dd_rsqrt(row16_sum(v0 + v1) * (1.0f / 128.0f) + 1e-5f);
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) Tz[4 * nt + r] = fmaxf(fmaf(Tz[4 * nt + r], rstd, be[nt]), 0.f);
+  }
+#else
   float g[8], be[8];
 #pragma unroll
   for (int nt = 0; nt < 8; ++nt) { g[nt] = ln[16 * nt + mm]; be[nt] = ln[128 + 16 * nt + mm]; }
@@ -157,6 +215,7 @@ __device__ __forceinline__ void ln_relu_T(float (&Tz)[32], const float* __restri
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) Tz[4 * nt + r] = fmaxf(fmaf(Tz[4 * nt + r] * rstd, g[nt], be[nt]), 0.f);
   }
+#endif
 }
 
 // sin and cos of x for 0 <= x <= ~10 (angle codes: x <= 3*pi): three-term Cody-Waite reduction by pi/2 and the
@@ -182,7 +241,43 @@ __device__ __forceinline__ void sincos_small(float x, float& sn, float& cs) {
 // (AngularEncoding, models/common.py:38-53: freq 1,2,3 then 1,1/2,1/3; th = atan2(|a x b|, a.b)).
 // sin/cos of th come straight from the cross and dot products, the multiples from the addition formulas and the
 // half angle from sin th = 2 sin(th/2) cos(th/2) with the well-conditioned root; only th/3 needs a sincos.
-__device__ __forceinline__ void angle_codes(float n /*|a x b|*/, float dt /*a.b*/, int cg, float (&out)[3]) {
+__device__ __forceinline__ void angle_codes(float nn /*|a x b|^2*/, float dt /*a.b*/, int cg, float (&out)[3]) {
+#if DD_FAST_ANGLE
+  // No library atan2f, no IEEE sqrt / division (v_sqrt / v_rsq / v_rcp are 1 ulp): sin th and cos th from the products,
+  //   tan(phi) = sin th / (1 + |cos th|)  with phi = th/2 (cos th >= 0) or pi/2 - th/2, phi in [0, pi/4], atan as an odd
+  //   degree-15 minimax polynomial (2e-8 on [0, 1]);  sin / cos of th/3 by doubling from th/6 in [0, pi/6] (cephes kernels).
+  // All 11 codes within 5e-7 of the exact values (tools/angle_codes_check.py: no worse than atan2f + sinf / cosf of fp32 products).
+  const float n = __builtin_amdgcn_sqrtf(nn);
+  const float n2 = fmaf(dt, dt, nn);
+  const bool ok = n2 > 0.f;
+  const float r = ok ? dd_rsqrt(n2) : 0.f;
+  const float s1 = n * r, c1 = ok ? dt * r : 1.0f;
+  const float s2 = 2.0f * s1 * c1, c2 = fmaf(c1, c1, -s1 * s1);
+  const float s3 = fmaf(s2, c1, c2 * s1), c3 = fmaf(c2, c1, -s2 * s1);
+  const float den = 1.0f + fabsf(c1);
+  const float x = s1 * __builtin_amdgcn_rcpf(den);
+  const float u = x * x;
+  float p = -4.0544654832e-03f;
+  p = fmaf(p, u, 2.1862573855e-02f);
+  p = fmaf(p, u, -5.5911747027e-02f);
+  p = fmaf(p, u, 9.6421528094e-02f);
+  p = fmaf(p, u, -1.3908611309e-01f);
+  p = fmaf(p, u, 1.9946561855e-01f);
+  p = fmaf(p, u, -3.3329860447e-01f);
+  p = fmaf(p, u, 9.9999933550e-01f);
+  const float phi = p * x;
+  const bool acute = c1 >= 0.f;
+  const float th = acute ? 2.0f * phi : fmaf(-2.0f, phi, 3.14159265358979f);
+  const float big = __builtin_amdgcn_sqrtf(0.5f * den);            // the well-conditioned half-angle root
+  const float small = 0.5f * s1 * __builtin_amdgcn_rcpf(big);
+  const float sh = acute ? small : big, ch = acute ? big : small;
+  const float a6 = th * (1.0f / 6.0f), z = a6 * a6;
+  const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, a6, a6);
+  const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z,
+                        fmaf(-0.5f, z, 1.0f));
+  const float st = 2.0f * ps * pc, ct = fmaf(-2.0f * ps, ps, 1.0f);
+#else
+  const float n = sqrtf(nn);
   const float th = atan2f(n, dt);
   const float n2 = fmaf(n, n, dt * dt);
   const float r = n2 > 0.f ? dd_rsqrt(n2) : 0.f;
@@ -194,6 +289,7 @@ __device__ __forceinline__ void angle_codes(float n /*|a x b|*/, float dt /*a.b*
   else           { sh = sqrtf(0.5f * (1.0f - c1)); ch = 0.5f * s1 / sh; }
   float st, ct;
   sincos_small(th * (1.0f / 3.0f), st, ct);
+#endif
   // merged code order (packing.py _ANGLE_MERGE): [th, s1, s2, s3 | sin th/2, sin th/3, c1, c2 | c3, cos th/2, cos th/3, 0]
   out[0] = cg == 0 ? th : (cg == 1 ? s1 : (cg == 2 ? s2 : s3));      // g = 0..3
   out[1] = cg == 0 ? sh : (cg == 1 ? st : (cg == 2 ? c1 : c2));      // g = 4..7
@@ -527,16 +623,34 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
 
   // ---- Q~ as the MFMA B operand: lane (h = mm, cg) holds Q~[h][c(kk, cg)] ----------------------------------
   float Qb[32];
+#if !DD_PEEL_FOLD
 #pragma unroll
   for (int k = 0; k < 32; ++k) Qb[k] = 0.f;
+#endif
   if (active && kside) {
     // a real loop (8 LDS reads in flight per trip): fully unrolled, the scheduler hoists all 64 reads = 256 registers.
     // The 8 query values rotate through r0 so that no dynamic register indexing is needed.
     float r0 = q0.x, r1 = q0.y, r2 = q0.z, r3 = q0.w, r4 = q1.x, r5 = q1.y, r6 = q1.z, r7 = q1.w;
+#if DD_PEEL_FOLD
+    {                                                    // d = 0 peeled: products instead of 32 zeroing moves + 32 FMAs
+      const float* wr = WB + mm * WPITCH + 4 * cg;
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        const float4 w = *reinterpret_cast<const float4*>(wr + 16 * nt);
+        Qb[4 * nt] = r0 * w.x; Qb[4 * nt + 1] = r0 * w.y; Qb[4 * nt + 2] = r0 * w.z; Qb[4 * nt + 3] = r0 * w.w;
+      }
+      r0 = r1; r1 = r2; r2 = r3; r3 = r4; r4 = r5; r5 = r6; r6 = r7;
+    }
+#pragma nounroll
+    for (int d = 1; d < 8; ++d) {
+      const float qv = r0;
+      r0 = r1; r1 = r2; r2 = r3; r3 = r4; r4 = r5; r5 = r6; r6 = qv;
+#else
 #pragma nounroll
     for (int d = 0; d < 8; ++d) {                        // (unrolled by 2: fewer spills, but 2 % slower end to end)
       const float qv = r0;
       r0 = r1; r1 = r2; r2 = r3; r3 = r4; r4 = r5; r5 = r6; r6 = r7; r7 = qv;
+#endif
       const float* wr = WB + (d * 16 + mm) * WPITCH + 4 * cg;
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) {
@@ -547,8 +661,10 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
         Qb[4 * nt + 3] = fmaf(qv, w.w, Qb[4 * nt + 3]);
       }
     }
+#if !DD_LN_FOLD                                          // (the softmax scale 1 / sqrt(8) lives in the W2k image otherwise)
 #pragma unroll
     for (int k = 0; k < 32; ++k) Qb[k] *= 0.35355339059327373f;
+#endif
   }
   DD_STAMP(2);
 
@@ -561,7 +677,7 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
       const float bx = tri_k[t][0] - tri_i[0], by = tri_k[t][1] - tri_i[1], bz = tri_k[t][2] - tri_i[2];
       const float dot = ax * bx + ay * by + az * bz;
       const float cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
-      angle_codes(sqrtf(cx * cx + cy * cy + cz * cz), dot, cg, cod[t]);
+      angle_codes(cx * cx + cy * cy + cz * cz, dot, cg, cod[t]);
     }
   }
   DD_STAMP(3);
@@ -634,7 +750,8 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
           if (BOND) P[k] += Pf2[k];
         }
       }
-      if (t + 1 < MAXT && t + 1 < T) fetch_k_rows(t + 1);   // next tile's rows fly during this tile's arithmetic
+      if (t + 1 < MAXT && (DD_UNCOND_FETCH || t + 1 < T)) fetch_k_rows(t + 1);   // next tile's rows fly during this tile's arithmetic
+                                                              // (unconditional: members are clipped, a tile beyond T re-reads row M - 1)
     } else if (KNN) {
       load_row(P, tab_d + drow * ld_d, cg);
       add_row(P, tab_s + (src_base + jm[t]) * ld_s, cg);
@@ -708,7 +825,7 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
         if (BOND) v += Tr2[4 * nt + r];
         Tz[4 * nt + r] = v;
       }
-    if (t + 1 < MAXT && t + 1 < T) fetch_T(t + 1);       // next tile's rows fly during this tile's arithmetic
+    if (t + 1 < MAXT && (DD_UNCOND_FETCH || t + 1 < T)) fetch_T(t + 1);       // next tile's rows fly during this tile's arithmetic
     if (KNN || TRIP) {
       f32x4 acc[8];
 #pragma unroll
@@ -872,6 +989,37 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
   // member-major layout (row = channel 16nt + mm, k = member 16t + 4cg + ks), B = alpha*w of the same member as
   // produced by pass 1 (S[t][ks]) -- no transposes, no LDS
   f32x4 Z[8];
+#if DD_PEEL_Z
+  if (active && T > 0) {                                 // the first k-step of tile 0 starts the chains from an inline zero
+    {
+      float Tz[32];
+      finish_T(0, Tz);
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) Z[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Tz[4 * nt], S[0][0], zero4, 0, 0, 0);
+#pragma unroll
+      for (int ks = 1; ks < 4; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt)
+          Z[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Tz[4 * nt + ks], S[0][ks], Z[nt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 1; t < MAXT; ++t) {
+      if (t < T) {
+        float Tz[32];
+        finish_T(t, Tz);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int nt = 0; nt < 8; ++nt)
+            Z[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Tz[4 * nt + ks], S[t][ks], Z[nt], 0, 0, 0);
+      }
+    }
+  } else {                                               // (idle wave, or a bond pair without a third atom: NL = 2)
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) Z[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#else
 #pragma unroll
   for (int nt = 0; nt < 8; ++nt) Z[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (active) {
@@ -888,6 +1036,7 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
       }
     }
   }
+#endif
   DD_STAMP(8);
 
   // ---- epilogue: out[o] = W2v[o,:] . Z~[head(o),:] + b2v[o] * sum_m alpha*w ----------------------------------
@@ -944,6 +1093,409 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
 #undef DD_STAMP
 }
 
+// ---- persistent bond-layer workgroups with a COOPERATIVE query fold and epilogue (round 6, EXPERIMENTS.md R6-2) ------------------
+// In attn2_body every wave folds its own query (Q~ = q . blockdiag(W2k): each of the 16 K weights used once per segment) and runs
+// its own epilogue (W2v . Z~: the same), streaming the whole 64 KB W2k / W2v image through the LDS port shared by 8 in-phase waves:
+// 1 MiB of LDS reads per trip of 8 segments, ~8 k cycles at the port's 128 B/clk for ~3 k cycles of arithmetic.  Here the 8 waves
+// of a trip split both by HEAD instead: wave w owns heads 2w, 2w + 1 of all 8 segments.
+//   * fold: the 16 W2k rows of its heads live in 32 registers for the workgroup's lifetime (no W2k image in LDS at all); the 8
+//     queries of the trip are published in LDS (4 KB, broadcast reads); the 8 x 2 x 128 products go to an exchange buffer that
+//     takes the W2k image's place, and every wave reads the Q~ of ITS segment back in the MFMA B-operand layout (8 x 16 bytes).
+//   * epilogue: every wave writes its Z~ (16 heads x 128 channels) to the same buffer; wave w forms out[s][16w .. 16w + 15] for the 8
+//     segments as ONE 16 x 16 x 128 MFMA chain (rows = (segment, head of the pair), columns = the 16 outputs of its two heads;
+//     the two diagonal 8-column blocks are the results), W2v as the B operand from a natural-order LDS image (8 KB per wave).
+//   LDS traffic per trip: 64 (queries, broadcast) + 64 + 64 + 64 + 64 + 64 KB instead of 1 MiB.
+//   * the NEXT trip's prologue (segment indices, query, gather rows of its first k-pass tile, triplet geometry) is issued in front
+//     of the epilogue, so those loads fly during the epilogue, the trip barrier and the next fold.
+// Exchange buffer addressing: (s, h, c) -> s * XSTR + h * WPITCH + c with XSTR = 16 * WPITCH + 16: writers (lane = head, fixed
+// segment), the Q~ readers (the same) and the epilogue's A-operand readers (lane i = 2 * segment-in-pair... row i = 2s + h') all
+// hit 16-byte bank slots 2 * (lane & 15) + (lane >> 4) (mod 16), the conflict-free pattern of the weight images (see WPITCH).
+struct CoopLds {
+  static constexpr int XSTR = 16 * WPITCH + 16;
+  static constexpr int XB = 0;                          // exchange buffer [8 segments][16 heads][WPITCH] (+ 16 floats of skew per segment)
+  static constexpr int WV = 8 * XSTR;                   // W2v image, natural row order, pitch WPITCH
+  static constexpr int LNP = WV + WB_FLOATS;            // [4][128] LayerNorm parameters (k: gamma, beta; v: gamma, beta)
+  static constexpr int WAO = LNP + 512;                 // [2][12][128] angle tables (MFMA operand layout)
+  static constexpr int QS = WAO + 2 * 12 * 128;         // [8][128] queries of the trip
+  static constexpr int SS = QS + 8 * 128;               // [8][16] sum of the attention weights per (segment, head)
+  static constexpr int SG = SS + 8 * 16;                // ints: [8] dense segment ids of the trip, [8..10] trip indices (current, next)
+  static constexpr int TOTAL = SG + 16;
+};
+
+template <int MAXT, bool RAG, bool STAMPS, typename ARGS>
+__device__ __forceinline__ void bl_coop_body(const ARGS& a, float* smem) {
+  constexpr int NW = 8, NT = NW * 64;
+  using C = CoopLds;
+  constexpr int XSTR = C::XSTR;
+  const int wave = threadIdx.x >> 6, lane0 = threadIdx.x & 63;
+  const int NLm1 = a.NL - 1, Eb = a.NL * NLm1;
+  const int nseg = RAG ? a.bl_prefix[a.B] : a.B * Eb;
+  float* const XB = smem + C::XB;
+  float* const WV = smem + C::WV;
+  float* const QS = smem + C::QS;
+  float* const SS = smem + C::SS;
+  int* const sg = reinterpret_cast<int*>(smem + C::SG);
+  int* const sb = sg + 8;
+  long long* const dbg0 = STAMPS ? a.dbg_clock : nullptr;
+  long long* dbg = nullptr;
+#define DD_STAMP(i) do { if (STAMPS && dbg && threadIdx.x == 0) dbg[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+
+  // ---- once per workgroup: W2v image (natural order), LayerNorm parameters, angle tables; this wave's W2k rows in registers
+  {
+    constexpr int PER = 4096 / NT;
+    float4 tmp[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) tmp[k] = reinterpret_cast<const float4*>(a.W2v)[threadIdx.x + k * NT];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = threadIdx.x + k * NT;
+      *reinterpret_cast<float4*>(&WV[(i >> 5) * WPITCH + (i & 31) * 4]) = tmp[k];
+    }
+    if (threadIdx.x < 64) {
+      reinterpret_cast<float4*>(smem + C::LNP)[threadIdx.x] = reinterpret_cast<const float4*>(a.lnk)[threadIdx.x];
+      reinterpret_cast<float4*>(smem + C::LNP + 256)[threadIdx.x] = reinterpret_cast<const float4*>(a.lnv)[threadIdx.x];
+    }
+    for (int i = threadIdx.x; i < 12 * 32; i += NT) {
+      reinterpret_cast<float4*>(smem + C::WAO)[i] = reinterpret_cast<const float4*>(a.Wakp)[i];
+      reinterpret_cast<float4*>(smem + C::WAO + 12 * 128)[i] = reinterpret_cast<const float4*>(a.Wavp)[i];
+    }
+  }
+  float Wk[32];                                          // W2k[16 wave + r][2 lane + {0, 1}]  (rows 8 h + d of heads 2 wave, 2 wave + 1)
+  auto load_wk = [&](int lane) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float2 w = *reinterpret_cast<const float2*>(a.W2k + (16 * wave + r) * 128 + 2 * lane);
+#if DD_LN_FOLD
+      Wk[2 * r] = w.x; Wk[2 * r + 1] = w.y;
+#else
+      Wk[2 * r] = w.x * 0.35355339059327373f; Wk[2 * r + 1] = w.y * 0.35355339059327373f;
+#endif
+    }
+  };
+  load_wk(lane0);
+  // (loop-invariant, and loaded HERE: a global load inside the epilogue would queue behind the next trip's gathers)
+  const float ep_bias = a.b2v[(2 * wave + ((lane0 & 15) >> 3)) * 8 + (lane0 & 7)];
+  if (threadIdx.x == 0) sb[0] = atomicAdd(a.work_counter, 1);
+  __syncthreads();
+
+  auto trip_range = [&](int tr, int& base, int& cnt) {
+    if (tr < a.trip_full) { base = tr * NW; cnt = NW; }
+    else { base = a.trip_full * NW + (tr - a.trip_full) * a.trip_q; cnt = a.trip_q; }
+    cnt = nseg - base < cnt ? nseg - base : cnt;         // <= 0: no work left
+  };
+  auto bl_dense_seg = [&](int r) -> int {                // compact index of a real segment -> id in the dense (padded) enumeration
+    if (!RAG) return r;
+    int bb = 0;
+    while (a.bl_prefix[bb + 1] <= r) ++bb;
+    const int nm1 = a.nl_real[bb] - 1, e = r - a.bl_prefix[bb];
+    return bb * Eb + (e / nm1) * NLm1 + (e % nm1);
+  };
+
+  // ---- state of the NEXT trip's segment, filled one trip ahead (fetch) --------------------------------------------------------
+  int segN = 0, bN = 0, siN = 0, sjN = 0, MN = 0;
+  bool actN = false;
+  float2 q2 = make_float2(0.f, 0.f);
+  float Pf[32];
+#if DD_COOP_RC
+  float Rc[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) Rc[k] = 0.f;
+#endif
+  float tri_i[3] = {0.f, 0.f, 0.f}, tri_j[3] = {0.f, 0.f, 0.f}, tri_k[MAXT][3];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) Pf[k] = 0.f;
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) tri_k[t][0] = tri_k[t][1] = tri_k[t][2] = 0.f;
+  auto third_atom = [](int mc, int si, int sj) { const int lo = si < sj ? si : sj, hi = si < sj ? sj : si; int k = mc; if (k >= lo) ++k; if (k >= hi) ++k; return k; };
+  auto fetch = [&](int tr, int lane) {
+    int base, cnt;
+    trip_range(tr, base, cnt);
+    actN = wave < cnt;
+    if (!actN) return;
+    const int mm = lane & 15, cg = lane >> 4;
+    segN = bl_dense_seg(base + wave);
+    bN = segN / Eb;
+    const int e = segN % Eb;
+    siN = e / NLm1;
+    const int jp = e % NLm1;
+    sjN = jp + (jp >= siN ? 1 : 0);
+    MN = RAG ? a.nl_real[bN] - 2 : a.NL - 2;
+    q2 = *reinterpret_cast<const float2*>(a.q + (long)segN * 128 + 2 * lane);
+    {                                                    // k-pass rows of tile 0: bond (k -> j) of member mm
+      const int mc = mm < MN ? mm : (MN > 0 ? MN - 1 : 0);
+      const int k = third_atom(mc, siN, sjN);
+      load_row(Pf, a.ke + ((long)bN * Eb + sjN * NLm1 + (k - (k > sjN ? 1 : 0))) * a.ld_ke, cg);
+    }
+#if DD_COOP_RC
+    load_row(Rc, a.Rk + (long)segN * 128, cg);
+#endif
+    const float* xl = a.x + ((long)bN * (a.NP + a.NL) + a.NP) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { tri_i[c] = xl[3 * siN + c]; tri_j[c] = xl[3 * sjN + c]; }
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int m = 16 * t + mm;
+      const int k = third_atom(m < MN ? m : MN - 1, siN, sjN);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) tri_k[t][c] = xl[3 * k + c];
+    }
+  };
+  fetch(__builtin_amdgcn_readfirstlane(sb[0]), lane0);
+
+  for (int it = 0;; ++it) {
+    // (the lane id is laundered per iteration: loop-invariant per-lane address arithmetic stays inside the iteration)
+    int lane = lane0;
+    asm volatile("" : "+v"(lane) :: "memory");
+    const int mm = lane & 15, cg = lane >> 4;
+
+    // ---- 1. publish this wave's query and segment id; barrier A (also: the previous trip's epilogue reads of XB are done)
+    if (actN) *reinterpret_cast<float2*>(QS + wave * 128 + 2 * lane) = q2;
+    if (lane == 0) sg[wave] = segN;
+    __syncthreads();
+    int base, cnt;
+    trip_range(__builtin_amdgcn_readfirstlane(sb[it & 1]), base, cnt);
+    if (cnt <= 0) break;
+    if (threadIdx.x == 0) sb[(it + 1) & 1] = atomicAdd(a.work_counter, 1);
+    if (STAMPS && dbg0) dbg = dbg0 + (long)__builtin_amdgcn_readfirstlane(sb[it & 1]) * 16;
+    DD_STAMP(0);
+
+    const int seg = segN, b = bN, si = siN, sj = sjN;
+    const bool active = actN;
+    const int M = MN, T = (M + 15) >> 4;
+
+    // old values of the rows this wave will update in the epilogue (out[s][8 (2 wave + h) + j] for s = 2 (lane >> 4) + {0, 1}):
+    // requested now, ahead of every gather of the trip (loads return in order)
+    const int eh = mm >> 3, ej = mm & 7;                 // epilogue: column = output 8 eh + ej of head 2 wave + eh
+    float old0 = 0.f, old1 = 0.f;
+    float* dst0 = nullptr;
+    float* dst1 = nullptr;
+    {
+      const int s0 = 2 * cg, s1 = 2 * cg + 1;
+      if (s0 < cnt) { dst0 = a.out + (long)sg[s0] * 128 + (2 * wave + eh) * 8 + ej; old0 = *dst0; }
+      if (s1 < cnt) { dst1 = a.out + (long)sg[s1] * 128 + (2 * wave + eh) * 8 + ej; old1 = *dst1; }
+    }
+
+    // ---- 2. cooperative fold: Q~[s][h][2 lane + {0, 1}] for h = 2 wave, 2 wave + 1 and the 8 segments of the trip
+#pragma unroll 2
+    for (int s = 0; s < 8; ++s) {
+      float qv[16];
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const float4 v = *reinterpret_cast<const float4*>(QS + s * 128 + 16 * wave + 4 * k4);    // (wave-uniform address: broadcast)
+        qv[4 * k4] = v.x; qv[4 * k4 + 1] = v.y; qv[4 * k4 + 2] = v.z; qv[4 * k4 + 3] = v.w;
+      }
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        float a0 = qv[8 * hh] * Wk[16 * hh], a1 = qv[8 * hh] * Wk[16 * hh + 1];
+#pragma unroll
+        for (int d = 1; d < 8; ++d) {
+          a0 = fmaf(qv[8 * hh + d], Wk[16 * hh + 2 * d], a0);
+          a1 = fmaf(qv[8 * hh + d], Wk[16 * hh + 2 * d + 1], a1);
+        }
+        *reinterpret_cast<float2*>(XB + s * XSTR + (2 * wave + hh) * WPITCH + 2 * lane) = make_float2(a0, a1);
+      }
+    }
+    DD_STAMP(1);
+    __syncthreads();                                     // barrier C
+    DD_STAMP(2);
+    // ---- 3. Q~ of this wave's segment as the MFMA B operand: lane (h = mm, cg) holds Q~[h][16 nt + 4 cg + r]
+    float Qb[32];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+      const float4 v = *reinterpret_cast<const float4*>(XB + wave * XSTR + mm * WPITCH + 16 * nt + 4 * cg);
+      Qb[4 * nt] = v.x; Qb[4 * nt + 1] = v.y; Qb[4 * nt + 2] = v.z; Qb[4 * nt + 3] = v.w;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                     // barrier D: XB is free for the epilogue's exchange
+    DD_STAMP(3);
+
+    // ---- 4. the segment itself: angle codes, k pass, softmax, v pass (as attn2_body<M_BL>) -----------------------------------
+    const long erow_j = (long)b * Eb + (long)sj * NLm1;   // first bond row of destination j in the dst-major tables
+    auto kj_row = [&](int m) {                           // row of bond (k -> j) for member m (clipped)
+      const int k = third_atom(m < M ? m : M - 1, si, sj);
+      return erow_j + (k - (k > sj ? 1 : 0));
+    };
+    float cod[MAXT][3];
+    f32x4 S[MAXT];
+    float ssum = 0.f;
+    f32x4 Z[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) Z[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (active) {
+      const float ax = tri_j[0] - tri_i[0], ay = tri_j[1] - tri_i[1], az = tri_j[2] - tri_i[2];
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t) {
+        const float bx = tri_k[t][0] - tri_i[0], by = tri_k[t][1] - tri_i[1], bz = tri_k[t][2] - tri_i[2];
+        const float dot = ax * bx + ay * by + az * bz;
+        const float cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+        angle_codes(cx * cx + cy * cy + cz * cz, dot, cg, cod[t]);
+      }
+      DD_STAMP(4);
+      const float* rk_row = a.Rk + (long)seg * 128;
+      // k pass: lane (mm, cg) = member 16 t + mm, channels 16 nt + 4 cg + r
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t) {
+        if (t < T) {
+          float P[32];
+#if DD_COOP_RC
+#pragma unroll
+          for (int k = 0; k < 32; ++k) P[k] = Pf[k] + Rc[k];
+#else
+#pragma unroll
+          for (int k = 0; k < 32; ++k) P[k] = Pf[k];
+          add_row(P, rk_row, cg);
+#endif
+          if (t + 1 < MAXT) load_row(Pf, a.ke + kj_row(16 * (t + 1) + mm) * a.ld_ke, cg);   // next tile's rows (clipped members)
+          if (STAMPS && dbg && t == 0) { asm volatile("" : "+v"(P[0]), "+v"(P[31])); DD_STAMP(13); }      // segment row arrived
+          f32x4 acc[8];
+#pragma unroll
+          for (int nt = 0; nt < 8; ++nt) acc[nt] = f32x4{P[4 * nt], P[4 * nt + 1], P[4 * nt + 2], P[4 * nt + 3]};
+          const float* tb = smem + C::WAO + cg * 128 + mm * 4;
+#pragma unroll
+          for (int s3 = 0; s3 < 3; ++s3) mfma_table_step<false>(acc, tb + s3 * 512, cod[t][s3]);
+#pragma unroll
+          for (int nt = 0; nt < 8; ++nt) { P[4 * nt] = acc[nt][0]; P[4 * nt + 1] = acc[nt][1]; P[4 * nt + 2] = acc[nt][2]; P[4 * nt + 3] = acc[nt][3]; }
+          ln_relu32(P, smem + C::LNP, cg);
+          if (STAMPS && dbg && t == 0) { asm volatile("" : "+v"(P[0]), "+v"(P[31])); DD_STAMP(14); }      // table part + LayerNorm done
+          S[t] = mfma_rows(P, Qb);
+          if (STAMPS && dbg && t == 0) { asm volatile("" : "+v"(S[t])); DD_STAMP(15); }                     // scores of tile 0 done
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (16 * t + 4 * cg + r >= M) S[t][r] = -INFINITY;
+        } else {
+          S[t] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+      }
+      DD_STAMP(5);
+      // v-pass rows (member-major layout: lane (mm, cg) holds members 16 t + 4 cg + r, channels 16 nt + mm), one tile ahead
+      float Tc[8], Tr[32];
+      auto fetch_T = [&](int t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float* rs = a.ve + kj_row(16 * t + 4 * cg + r) * a.ld_ve + mm;
+#pragma unroll
+          for (int nt = 0; nt < 8; ++nt) Tr[4 * nt + r] = rs[16 * nt];
+        }
+      };
+      {
+        const float* rc = a.Rv + (long)seg * 128 + mm;
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) Tc[nt] = rc[16 * nt];
+      }
+      fetch_T(0);
+      // segment softmax per head (scatter_softmax): max-shift, exp, one reciprocal per head
+      float mx = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, S[t][r]);
+      mx = quad_max(mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = (16 * t + 4 * cg + r < M) ? expf(S[t][r] - mx) : 0.f;
+          S[t][r] = e;
+          sum += e;
+        }
+      sum = quad_sum(sum);
+#if defined(DD_EXACT_MATH) && DD_EXACT_MATH
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { S[t][r] = (16 * t + 4 * cg + r < M) ? S[t][r] / sum : 0.f; ssum += S[t][r]; }
+#else
+      const float rsum = 1.0f / sum;
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { S[t][r] = (16 * t + 4 * cg + r < M) ? S[t][r] * rsum : 0.f; ssum += S[t][r]; }
+#endif
+      ssum = quad_sum(ssum);
+      DD_STAMP(6);
+      // v pass + aggregation  Z[nt][r] = Z~[head mm][channel 16 nt + 4 cg + r]
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t) {
+        if (t < T) {
+          float Tz[32];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) Tz[4 * nt + r] = Tc[nt] + Tr[4 * nt + r];
+          if (t + 1 < MAXT) fetch_T(t + 1);
+          f32x4 acc[8];
+#pragma unroll
+          for (int nt = 0; nt < 8; ++nt) acc[nt] = f32x4{Tz[4 * nt], Tz[4 * nt + 1], Tz[4 * nt + 2], Tz[4 * nt + 3]};
+          const float* tb = smem + C::WAO + 12 * 128 + cg * 128 + mm * 4;
+#pragma unroll
+          for (int s3 = 0; s3 < 3; ++s3) mfma_table_step<true>(acc, tb + s3 * 512, cod[t][s3]);
+#pragma unroll
+          for (int nt = 0; nt < 8; ++nt) { Tz[4 * nt] = acc[nt][0]; Tz[4 * nt + 1] = acc[nt][1]; Tz[4 * nt + 2] = acc[nt][2]; Tz[4 * nt + 3] = acc[nt][3]; }
+          ln_relu_T(Tz, smem + C::LNP + 256, mm);
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt)
+              Z[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Tz[4 * nt + ks], S[t][ks], Z[nt], 0, 0, 0);
+        }
+      }
+    }
+    DD_STAMP(7);
+
+    // ---- 5. the next trip's prologue: its loads fly during the epilogue, barrier A and the next fold ---------------------------
+    fetch(__builtin_amdgcn_readfirstlane(sb[(it + 1) & 1]), lane);
+#if DD_COOP_WK_RELOAD
+    load_wk(lane);
+#endif
+    DD_STAMP(8);
+
+    // ---- 6. cooperative epilogue ------------------------------------------------------------------------------------------------
+    if (active) {
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt)
+        *reinterpret_cast<float4*>(XB + wave * XSTR + mm * WPITCH + 16 * nt + 4 * cg) = make_float4(Z[nt][0], Z[nt][1], Z[nt][2], Z[nt][3]);
+      if (cg == 0) SS[wave * 16 + mm] = ssum;
+    }
+    DD_STAMP(9);
+    __syncthreads();                                     // barrier E
+    DD_STAMP(10);
+    {
+      // rows i = 2 s + h' (i = lane & 15), k = channel 16 nt + 4 (lane >> 4) + r4;  columns = outputs 16 wave + (lane & 15)
+      const float* ar = XB + (mm >> 1) * XSTR + (2 * wave + (mm & 1)) * WPITCH + 4 * cg;
+      const float* br = WV + (16 * wave + mm) * WPITCH + 4 * cg;
+      f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int nt = 0; nt < 8; nt += 2) {
+        const float4 a0 = *reinterpret_cast<const float4*>(ar + 16 * nt), b0 = *reinterpret_cast<const float4*>(br + 16 * nt);
+        const float4 a1 = *reinterpret_cast<const float4*>(ar + 16 * nt + 16), b1 = *reinterpret_cast<const float4*>(br + 16 * nt + 16);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, d1, 0, 0, 0);
+      }
+      const f32x4 d = d0 + d1;                           // rows 4 cg + r <-> (s = 2 cg + (r >> 1), h' = r & 1); useful: h' == eh
+      DD_STAMP(11);
+      const float bias = ep_bias;
+      if (dst0) *dst0 = old0 + fmaf(bias, SS[(2 * cg) * 16 + 2 * wave + eh], eh ? d[1] : d[0]);
+      if (dst1) *dst1 = old1 + fmaf(bias, SS[(2 * cg + 1) * 16 + 2 * wave + eh], eh ? d[3] : d[2]);
+    }
+    DD_STAMP(12);
+  }
+#undef DD_STAMP
+}
+
+// stand-alone launch of the cooperative bond-layer workgroups (one launch per sub-layer: dd_debug_set_fusion(0), phase stamps)
+template <int MAXT, bool RAG>
+__global__ __launch_bounds__(512) void k_attn2_bl_coop(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[CoopLds::TOTAL];
+  bl_coop_body<MAXT, RAG, true>(a, smem);
+}
+
 template <int MODE, int MAXT, int NW, bool RAG = false>
 __global__ __launch_bounds__(NW * 64) void k_attn2(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[Lds<MODE>::TOTAL + ((MODE == M_PE || MODE == M_PB) ? NW * 256 : 0)];
@@ -959,7 +1511,7 @@ constexpr int imax(int a, int b) { return a > b ? a : b; }
 template <int MAXT, int NW, bool RAG = false>
 __global__ __launch_bounds__(NW * 64) void k_attn2_node(const AttnArgs ne, const AttnArgs nb, const AttnArgs bl, int n_ne, int n_nb,
                                                         int persist, int n_bl_first, const int32_t* wflags, int widx, int wn) {
-  constexpr int SZ = imax(imax(Lds<M_NE>::TOTAL, Lds<M_NB>::TOTAL), Lds<M_BL>::TOTAL) + 4;
+  constexpr int SZ = imax(imax(imax(Lds<M_NE>::TOTAL, Lds<M_NB>::TOTAL), Lds<M_BL>::TOTAL) + 4, DD_COOP && NW == 8 && MAXT == 2 ? CoopLds::TOTAL : 0);
   __shared__ __attribute__((aligned(16))) float smem[SZ];
   int blk = blockIdx.x;
   // this layer's projection / query rows come from the previous layer's tail queue on the other stream (no graph edge)
@@ -979,7 +1531,11 @@ __global__ __launch_bounds__(NW * 64) void k_attn2_node(const AttnArgs ne, const
   // n_bl_first > 0: the persistent bond-layer workgroups come first in dispatch order and keep their CUs for the whole
   // launch, the node blocks cycle through the remaining CUs -- both parts then end together (see launch_node_nw)
   if (n_bl_first > 0) {
-    if (blk < n_bl_first) { attn2_body<M_BL, MAXT, NW, true, RAG, false, false>(args(2), blk, smem); return; }
+    if (blk < n_bl_first) {
+      if constexpr (DD_COOP && NW == 8 && MAXT == 2) bl_coop_body<MAXT, RAG, false>(args(2), smem);
+      else attn2_body<M_BL, MAXT, NW, true, RAG, false, false>(args(2), blk, smem);
+      return;
+    }
     blk -= n_bl_first;
     if (blk < n_ne) attn2_body<M_NE, 2, NW, false, RAG, false, false>(args(0), blk, smem);
     else attn2_body<M_NB, MAXT, NW, false, RAG, false, false>(args(1), blk - n_ne, smem);
@@ -987,7 +1543,10 @@ __global__ __launch_bounds__(NW * 64) void k_attn2_node(const AttnArgs ne, const
   }
   if (blk < n_ne) attn2_body<M_NE, 2, NW, false, RAG, false, false>(args(0), blk, smem);
   else if (blk < n_ne + n_nb) attn2_body<M_NB, MAXT, NW, false, RAG, false, false>(args(1), blk - n_ne, smem);
-  else if (persist) attn2_body<M_BL, MAXT, NW, true, RAG, false, false>(args(2), blk - n_ne - n_nb, smem);
+  else if (persist) {
+    if constexpr (DD_COOP && NW == 8 && MAXT == 2) bl_coop_body<MAXT, RAG, false>(args(2), smem);
+    else attn2_body<M_BL, MAXT, NW, true, RAG, false, false>(args(2), blk - n_ne - n_nb, smem);
+  }
   else attn2_body<M_BL, MAXT, NW, false, RAG, false, false>(args(2), blk - n_ne - n_nb, smem);
 }
 // Same for the two coordinate sub-layers (both write their own delta buffer; x is updated afterwards).
@@ -1090,6 +1649,13 @@ __global__ __launch_bounds__(NW * 128) void k_attn2_pos_g(const AttnArgs pe, con
 
 #endif
 
+#ifdef DD_ASM_ONLY      // (hipcc -S -DDD_ASM_ONLY: only the shipped small-ligand kernels, for instruction censuses -- 20 s instead of 2 min)
+template __global__ void k_attn2_node<2, 8, false>(const AttnArgs, const AttnArgs, const AttnArgs, int, int, int, int, const int32_t*, int, int);
+template __global__ void k_attn2_pos<2, 4, false>(const AttnArgs, const AttnArgs, int);
+template __global__ void k_attn2_bl_coop<2, false>(const AttnArgs);
+}  // namespace v2
+}  // namespace dd
+#else
 template <int MODE, int MAXT, int NW>
 static int launch_mode(const AttnArgs& a, int nseg, hipStream_t st) {
   if (nseg <= 0) return DD_OK;
@@ -1100,6 +1666,11 @@ static int launch_mode(const AttnArgs& a, int nseg, hipStream_t st) {
 }
 
 }  // namespace v2
+
+}  // namespace dd
+// Which form of the packed attention MLPs these kernels expect: 0 canonical (reference values), 1 packing.kernel_form_layer
+extern "C" int dd_weights_form(void) { return DD_LN_FOLD ? 1 : 0; }
+namespace dd {
 
 int g_attn_waves = 8;        // waves (= segments) per workgroup of the fused node launch
 int g_attn_persist = 1;      // bond_layer workgroups of the fused launch are persistent (global batch counter)
@@ -1140,9 +1711,29 @@ int launch_attn2(int mode, const AttnArgs& a, hipStream_t st) {
                             : (big ? launch_mode<M_NB, 8, 8>(a, a.B * a.NL, st) : launch_mode<M_NB, 4, 8>(a, a.B * a.NL, st));
     case M_PB: return small ? launch_mode<M_PB, 2, 8>(a, a.B * a.NL, st)
                             : (big ? launch_mode<M_PB, 8, 8>(a, a.B * a.NL, st) : launch_mode<M_PB, 4, 8>(a, a.B * a.NL, st));
-    case M_BL: return small ? launch_mode<M_BL, 2, 8>(a, a.B * a.NL * (a.NL - 1), st)
-                            : (big ? launch_mode<M_BL, 8, 8>(a, a.B * a.NL * (a.NL - 1), st)
-                                   : launch_mode<M_BL, 4, 8>(a, a.B * a.NL * (a.NL - 1), st));
+    case M_BL:
+#if DD_COOP
+      if (a.work_counter != nullptr && small) {        // the fused launch's persistent cooperative workgroups, on their own
+                                                       // (2-tile body only: the longer bodies spill with the carried prefetch state)
+        const int n_trips = (a.B * a.NL * (a.NL - 1) + 7) / 8;
+        if (n_trips <= 0) return DD_OK;
+        const int n_wg = n_trips < 256 ? n_trips : 256;
+        AttnArgs c = a;
+        c.trip_full = 1 << 27; c.trip_q = 0;
+#define DD_LAUNCH_COOP(MAXT)                                                                                                  \
+        do {                                                                                                                  \
+          if (a.nl_real != nullptr) hipLaunchKernelGGL((k_attn2_bl_coop<MAXT, true>), dim3(n_wg), dim3(512), 0, st, c);       \
+          else hipLaunchKernelGGL((k_attn2_bl_coop<MAXT, false>), dim3(n_wg), dim3(512), 0, st, c);                           \
+        } while (0)
+        DD_LAUNCH_COOP(2);
+#undef DD_LAUNCH_COOP
+        DD_CHECK_LAUNCH();
+        return DD_OK;
+      }
+#endif
+      return small ? launch_mode<M_BL, 2, 8>(a, a.B * a.NL * (a.NL - 1), st)
+                   : (big ? launch_mode<M_BL, 8, 8>(a, a.B * a.NL * (a.NL - 1), st)
+                          : launch_mode<M_BL, 4, 8>(a, a.B * a.NL * (a.NL - 1), st));
   }
   return DD_ERR_BAD_ARG;
 }
@@ -1288,3 +1879,4 @@ int launch_attn2_pos(const AttnArgs& pe, const AttnArgs& pb, hipStream_t st) {
 }
 
 }  // namespace dd
+#endif  // DD_ASM_ONLY

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("DD_HIP_LIB") or os.path.join(_HERE, "lib", "libdecomp
 
 # the drop-in boundary: include/decompdiff_hip.h
 EXPORTED_SYMBOLS = [
-    "dd_status_string", "dd_abi_version", "dd_build_flags", "dd_workspace_floats", "dd_knn", "dd_knn_masked", "dd_edge_weights", "dd_gemm128",
+    "dd_status_string", "dd_abi_version", "dd_weights_form", "dd_build_flags", "dd_workspace_floats", "dd_knn", "dd_knn_masked", "dd_edge_weights", "dd_gemm128",
     "dd_gemm128_tn", "dd_gemm128_tn_bias", "dd_gemm128_tn_scratch_floats",
     "dd_ln_relu_scratch_floats", "dd_ln_relu_forward", "dd_ln_relu_backward",
     "dd_embed_protein", "dd_forward", "dd_sample_steps", "dd_sample_steps_graph", "dd_sample_steps_graph_multi",
@@ -74,7 +74,7 @@ class DDWsView(ctypes.Structure):
 PROF_CATS = ["misc", "gemm", "assemble", "attn_NE", "attn_NB", "attn_BL", "attn_PE", "attn_PB", "step", "event_pair"]
 
 
-ABI_VERSION = 8          # include/decompdiff_hip.h: layout of struct dd_sampler and of the tables it points to
+ABI_VERSION = 9          # include/decompdiff_hip.h: layout of struct dd_sampler and of the tables it points to
 
 
 class HipLibraryError(RuntimeError):
@@ -107,6 +107,7 @@ def load():
     # name -> argtypes (restype c_int = status code unless listed in `restypes`)
     protos = {
         "dd_build_flags": [],
+        "dd_weights_form": [],
         "dd_workspace_floats": [c_int, c_int, c_int, c_int],
         "dd_knn": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
         "dd_knn_masked": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
@@ -190,6 +191,13 @@ def require_gpu(t: torch.Tensor, name: str):
     if not t.is_cuda:
         raise HipLibraryError(f"{name} must live on a HIP device (got {t.device}); the sampling hot path has no "
                               "CPU implementation in this package")
+
+
+def weights_form() -> int:
+    """Form of the packed attention MLPs the loaded library expects (include/decompdiff_hip.h: dd_weights_form; 0 for builds
+    older than ABI 9, loaded with DD_IGNORE_ABI=1 by the A/B tools)."""
+    lib = load()
+    return int(lib.dd_weights_form()) if hasattr(lib, "dd_weights_form") else 0
 
 
 def is_measurement_build() -> bool:

@@ -219,7 +219,7 @@ class DecompScorePosNet3D(nn.Module):
             if self._packed is not None:
                 self._evict_chain_cache(0)                                  # cached chains point into the old arena
             sd = {k: v for k, v in self.state_dict().items()}
-            arena, offsets, _ = packing.pack_model(sd, self.config)
+            arena, offsets, _ = packing.pack_model(sd, self.config, kernel_form=hip_lib.weights_form() == 1)
             tab_pos = torch.stack([self.posterior_mean_c0_coef, self.posterior_mean_ct_coef,
                                    self.posterior_logvar]).detach().float().contiguous()
             tv = self.atom_type_trans

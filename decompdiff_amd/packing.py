@@ -189,6 +189,72 @@ def pack_layer(sd: Dict[str, torch.Tensor], prefix: str) -> "OrderedDict[str, to
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Kernel form of the attention MLPs (round 6).  Every key / value MLP of the five attention sub-layers is
+#     z = relu(LayerNorm(P) * gamma + beta),  P = sum of first-Linear parts (projection rows, Gaussian / angle tables, bias),
+# followed by a second Linear that is linear in z (W2k inside the folded query, W2v after the aggregation).  Three exact
+# identities move work from the kernels' VALU stream to the host:
+#   1. LayerNorm ignores a per-row constant, so the channel mean of every additive part is removed here
+#      (W1 <- (I - 11^T/128) W1): the rows the kernels sum are mean-free and the variance is E[P^2] -- no mean pass.
+#   2. relu(g * xh + b) = |g| * relu(sign(g) * xh + b / |g|): the sign goes into the first-Linear rows, |g| into the COLUMNS of
+#      the second Linear, and the kernels evaluate max(fma(P, rstd, beta'), 0) -- one FMA + one max per element.
+#      (gamma == 0 is carried as |g| = 1e-30: beta' = beta * 1e30 stays finite for |beta| < 3e8 and |g| * relu(.) gives relu(beta).)
+#   3. The softmax scale 1/sqrt(8) of the folded query goes into W2k.
+# The slots keep their shapes and order; the canonical (reference-valued) form is what pack_layer returns and what
+# tests/dense_spec.py consumes.  libdecompdiff_hip.so reports which form its kernels expect (dd_weights_form()).
+_SCALE = 0.35355339059327373       # 1 / sqrt(head dim 8)
+_GAMMA_FLOOR = 1e-30
+
+# per MLP: first-Linear row blocks [(W slot, b slot, first row)], channel-last tables, the LayerNorm slot, second Linears
+# [(slot, channel axis, extra factor)], derived MFMA operand slots are rebuilt afterwards
+_KERNEL_FORM_MLPS = [
+    dict(rows=[("W_n1", "b_n1", 0), ("W_n1", "b_n1", 128)], tabs=["NE_Ak"], ln="NE_lnk", w2=[("NE_W2k", 1, _SCALE)]),
+    dict(rows=[("W_n1", "b_n1", 256), ("W_n1", "b_n1", 384)], tabs=["NE_Av"], ln="NE_lnv", w2=[("NE_W2v", 1, 1.0), ("NE_W2vT", 0, 1.0)]),
+    dict(rows=[("W_l1", "b_l1", 0), ("W_l1", "b_l1", 128), ("W_b1", "b_b1", 0)], tabs=[], ln="NB_lnk", w2=[("NB_W2k", 1, _SCALE)]),
+    dict(rows=[("W_l1", "b_l1", 256), ("W_l1", "b_l1", 384), ("W_b1", "b_b1", 128)], tabs=[], ln="NB_lnv",
+         w2=[("NB_W2v", 1, 1.0), ("NB_W2vT", 0, 1.0)]),
+    dict(rows=[("W_l1", "b_l1", 640), ("W_l1", "b_l1", 768), ("W_b1", "b_b1", 256)], tabs=["BL_Wg1k", "BL_Wg2k", "BL_Wak"],
+         ln="BL_lnk", w2=[("BL_W2k", 1, _SCALE)]),
+    dict(rows=[("W_l1", "b_l1", 896), ("W_l1", "b_l1", 1024), ("W_b1", "b_b1", 384)], tabs=["BL_Wg1v", "BL_Wg2v", "BL_Wav"],
+         ln="BL_lnv", w2=[("BL_W2v", 1, 1.0), ("BL_W2vT", 0, 1.0)]),
+    dict(rows=[("W_n2", "b_n2", 0), ("W_l2", "b_l2", 0)], tabs=["PE_Ak"], ln="PE_lnk", w2=[("PE_W2k", 1, _SCALE)]),
+    dict(rows=[("W_n2", "b_n2", 128), ("W_l2", "b_l2", 128)], tabs=["PE_Av"], ln="PE_lnv", w2=[("PE_W2v", 1, 1.0)]),
+    dict(rows=[("W_l2", "b_l2", 384), ("W_l2", "b_l2", 512), ("W_b2", "b_b2", 0)], tabs=[], ln="PB_lnk", w2=[("PB_W2k", 1, _SCALE)]),
+    dict(rows=[("W_l2", "b_l2", 640), ("W_l2", "b_l2", 768), ("W_b2", "b_b2", 128)], tabs=[], ln="PB_lnv", w2=[("PB_W2v", 1, 1.0)]),
+]
+
+
+def kernel_form_layer(out: "OrderedDict[str, torch.Tensor]") -> "OrderedDict[str, torch.Tensor]":
+    """Canonical packed layer (pack_layer) -> the form the round-6 attention kernels consume (see above).  Returns a new dict;
+    arithmetic in float64, rounded once to fp32."""
+    o = OrderedDict((k, v.clone().double()) for k, v in out.items())
+    for m in _KERNEL_FORM_MLPS:
+        g, be = o[m["ln"]][0].clone(), o[m["ln"]][1].clone()
+        s = torch.where(g < 0, -torch.ones_like(g), torch.ones_like(g))
+        a = g.abs().clamp_min(_GAMMA_FLOOR)
+        for (wn, bn, r0) in m["rows"]:
+            W, b = o[wn], o[bn]
+            blk = W[r0:r0 + H]
+            W[r0:r0 + H] = (blk - blk.mean(0, keepdim=True)) * s[:, None]
+            bb = b[r0:r0 + H]
+            b[r0:r0 + H] = (bb - bb.mean()) * s
+        for tn in m["tabs"]:
+            t = o[tn]
+            o[tn] = (t - t.mean(-1, keepdim=True)) * s
+        o[m["ln"]] = torch.stack([torch.ones_like(g), be / a], 0)
+        for (w2n, axis, fac) in m["w2"]:
+            shape = [1, H] if axis == 1 else [H, 1]
+            o[w2n] = o[w2n] * (a * fac).reshape(shape)
+    res = OrderedDict((k, v.float()) for k, v in o.items())
+    # derived MFMA-operand images of the transformed tables
+    res["NE_Akp"], res["NE_Avp"] = _mfma_rows(res["NE_Ak"], 24), _mfma_rows(res["NE_Av"], 24)
+    res["PE_Akp"], res["PE_Avp"] = _mfma_rows(res["PE_Ak"], 24), _mfma_rows(res["PE_Av"], 24)
+    res["BL_Wgp"] = torch.stack([_mfma_rows(res[k], 20) for k in ("BL_Wg1k", "BL_Wg1v", "BL_Wg2k", "BL_Wg2v")], 0)
+    res["BL_Wakp"], res["BL_Wavp"] = _angle_rows(res["BL_Wak"]), _angle_rows(res["BL_Wav"])
+    assert list(res.keys()) == LAYER_SLOTS
+    return res
+
+
 def pack_global(sd, cfg) -> "OrderedDict[str, torch.Tensor]":
     out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     assert cfg.node_indicator and cfg.hidden_dim == H
@@ -214,12 +280,17 @@ def pack_global(sd, cfg) -> "OrderedDict[str, torch.Tensor]":
     return out
 
 
-def pack_model(sd: Dict[str, torch.Tensor], cfg):
-    """Return (arena fp32 [n], offsets int64 [n_layers*len(LAYER_SLOTS)+len(GLOBAL_SLOTS)], named views)."""
+def pack_model(sd: Dict[str, torch.Tensor], cfg, kernel_form: bool = False):
+    """Return (arena fp32 [n], offsets int64 [n_layers*len(LAYER_SLOTS)+len(GLOBAL_SLOTS)], named views).
+    kernel_form: the attention MLPs in the form the kernels consume (kernel_form_layer) instead of the canonical,
+    reference-valued one (what tests/dense_spec.py reads); same slots, shapes and offsets."""
     sd = {k: v.detach().float().cpu() for k, v in sd.items()}
     named: "OrderedDict[Tuple[int, str], torch.Tensor]" = OrderedDict()
     for l in range(cfg.num_layers):
-        for k, v in pack_layer(sd, f"refine_net.base_block.{l}").items():
+        layer = pack_layer(sd, f"refine_net.base_block.{l}")
+        if kernel_form:
+            layer = kernel_form_layer(layer)
+        for k, v in layer.items():
             named[(l, k)] = v.contiguous()
     for k, v in pack_global(sd, cfg).items():
         named[(-1, k)] = v.contiguous()

@@ -167,6 +167,14 @@ int dd_layer0_prepare(const dd_sampler* s, void* stream);
 
 const char* dd_status_string(int status);
 int dd_abi_version(void);
+/* ABI 9: form of the attention MLPs in the packed arena that the kernels of this build expect.
+ *   0 = canonical: the reference's values in the slot layout of decompdiff_amd/packing.py::pack_layer;
+ *   1 = kernel form (packing.py::kernel_form_layer, exact algebra): every key / value MLP of the five attention sub-layers
+ *       (models/encoders/uni_transformer_edge.py:42-74,125-167,188-210; MLP = models/common.py:85-105) has the channel mean of
+ *       each additive first-Linear part removed (LayerNorm ignores it), sign(gamma) folded into those parts, |gamma| into the
+ *       columns of the second Linear (W2k, W2v), beta / |gamma| in the LayerNorm slot's second row and the softmax scale
+ *       1 / sqrt(8) inside W2k.  Same slots, shapes and offsets. */
+int dd_weights_form(void);
 
 /* (Re)start a chain: step_counter[0..3] = {0, s->t_start, s->seed}.  Must be enqueued on `stream` before the first
  * dd_sample_steps* / dd_graph_launch / dd_reverse_step of a chain. */

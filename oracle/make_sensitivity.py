@@ -30,7 +30,9 @@ import golden_utils as GU                                       # noqa: E402
 from decompdiff_amd import synth                                # noqa: E402
 from oracle import diffusion as OD                              # noqa: E402
 
-POCKET_SEED = {"traj1000_plain": 3, "traj1000_drift": 5}
+POCKET_SEED = {"traj1000_plain": 3, "traj1000_drift": 5, "traj1000_b8_plain": 8, "traj1000_b8_drift": 8}
+# the batches of 8 at the bench shape (configs[1] / configs[2], make_golden.py --only b8long / b8long_drift): per-sample prior scales
+STD_SCALE = {"traj1000_b8_drift": [1.0, 0.9, 0.8, 1.1, 1.0, 0.95, 1.05, 0.85]}
 
 
 def ulp_nudge(pos, gen):
@@ -47,6 +49,9 @@ def main():
     ap.add_argument("--runs", type=int, default=8)
     ap.add_argument("--threads", type=int, default=4)
     ap.add_argument("--name", default="traj1000_drift")
+    ap.add_argument("--first-seed", type=int, default=9000, help="seed of the first replay (parallel processes: distinct ranges)")
+    ap.add_argument("--out", default=None, help="output file (default tests/golden/sens_<name>.npz)")
+    ap.add_argument("--steps", type=int, default=0, help="(timing probe) stop after this many steps; nothing is written")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     name = args.name
@@ -56,14 +61,21 @@ def main():
     n_steps, every = int(g["num_steps"]), int(g["every"])
     n_data = int(b["batch_ligand"].max()) + 1
     torch.manual_seed(int(g["seed"]))
-    synth.build_sampling_batch(synth.make_pocket_small(POCKET_SEED[name]), n_data)     # advances the generator as make_golden did
+    synth.build_sampling_batch(synth.make_pocket_small(POCKET_SEED[name]), n_data,
+                               per_sample_std_scale=STD_SCALE.get(name))              # advances the generator as make_golden did
     noise = synth.draw_step_noise(n_steps, b["init_ligand_pos"].size(0), b["init_ligand_fc_bond_type"].size(0))
     assert np.allclose(GU.checksum(noise), g["noise_checksum"])
     drift = json.loads(str(g["drift"]))
-    out_path = os.path.join(GU.GOLDEN, f"sens_{name}.npz")
-    errs, mvs, mbs = [], [], []
+    out_path = args.out or os.path.join(GU.GOLDEN, f"sens_{name}.npz")
+    if args.steps:
+        import time
+        t0 = time.time()
+        OD.sample_diffusion(sd, cfg, num_steps=args.steps, energy_drift_opt=drift, noise=noise, **b)
+        print(f"{args.steps} steps: {(time.time() - t0) / args.steps:.2f} s / step at {args.threads} threads")
+        return
+    errs, errs_s, mvs, mbs = [], [], [], []
     for run in range(args.runs):
-        gen = torch.Generator().manual_seed(9000 + run)
+        gen = torch.Generator().manual_seed(args.first_seed + run)
 
         def hook(step, t, pos, v, bond, preds):
             ulp_nudge(pos, gen)
@@ -71,14 +83,15 @@ def main():
         r = OD.sample_diffusion(sd, cfg, num_steps=n_steps, energy_drift_opt=drift, noise=noise, step_hook=hook, **b)
         tp = torch.stack(r["pos_traj"]).numpy()[every - 1::every]
         errs.append(np.abs(tp.astype(np.float64) - g["traj_pos"]).reshape(len(tp), -1).max(1))
+        errs_s.append(np.abs(tp.astype(np.float64) - g["traj_pos"]).reshape(len(tp), n_data, -1).max(2))     # [checkpoint, sample]
         mvs.append((torch.stack(r["v_traj"]).numpy()[every - 1::every] != g["traj_v"]).reshape(len(tp), -1).sum(1))
         mbs.append((torch.stack(r["bond_traj"]).numpy()[every - 1::every] != g["traj_bond"]).reshape(len(tp), -1).sum(1))
         print(f"[sens {name}] run {run}: " + " ".join(f"{e:.2g}" for e in errs[-1]) + f"; type mismatches v={int(mvs[-1].sum())} "
               f"bond={int(mbs[-1].sum())}", flush=True)
         E = np.stack(errs)
         np.savez_compressed(out_path, fixture=np.array(name), perturbation=np.array("-1/0/+1 ulp per coordinate per step, p=1/3 each"),
-                            seeds=np.arange(9000, 9000 + len(errs)), every=np.array(every), num_steps=np.array(n_steps),
-                            pos_err=E, v_mismatch=np.stack(mvs), bond_mismatch=np.stack(mbs),
+                            seeds=np.arange(args.first_seed, args.first_seed + len(errs)), every=np.array(every), num_steps=np.array(n_steps),
+                            pos_err=E, pos_err_sample=np.stack(errs_s), v_mismatch=np.stack(mvs), bond_mismatch=np.stack(mbs),
                             pos_err_min=E.min(0), pos_err_median=np.median(E, 0), pos_err_max=E.max(0))
 
 

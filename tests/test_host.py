@@ -302,3 +302,48 @@ def test_sample_time_methods_match_reference():
     assert not np.array_equal(g["importance_filled/7/time_step"], g["importance_empty/7/time_step"])
     with pytest.raises(ValueError):
         training.sample_time(m, 4, "cpu", "uniform")
+
+
+def test_kernel_form_of_the_attention_mlps_is_exact_algebra():
+    """packing.kernel_form_layer (mean-free first-Linear parts, sign / |gamma| of the LayerNorm moved into the neighbouring
+    Linears, softmax scale inside W2k): for every key / value MLP of the five attention sub-layers the kernels' evaluation
+    max(fma(P', rstd, beta'), 0) followed by the scaled second Linear equals relu(LayerNorm(P)) followed by the reference's --
+    including negative and exactly-zero gammas."""
+    cfg, sd = GU.weights(0)
+    sd = {k: v.clone() for k, v in sd.items()}
+    gen = torch.Generator().manual_seed(5)
+    for k in sd:
+        if k.endswith(".net.1.weight") and "base_block.0." in k:
+            g = sd[k]
+            g[torch.randperm(128, generator=gen)[:40]] *= -1.0          # negative gammas
+            g[torch.randperm(128, generator=gen)[:5]] = 0.0             # and a few exact zeros
+    can = packing.pack_layer({k: v.float() for k, v in sd.items()}, "refine_net.base_block.0")
+    ker = packing.kernel_form_layer(can)
+    assert list(ker.keys()) == packing.LAYER_SLOTS and all(ker[k].shape == can[k].shape for k in can)
+    worst = 0.0
+    for m in packing._KERNEL_FORM_MLPS:
+        rows = 64
+        xs = [torch.randn(rows, 128, generator=gen, dtype=torch.float64) for _ in m["rows"]]
+        cs = [torch.randn(rows, can[t].reshape(-1, 128).shape[0], generator=gen, dtype=torch.float64) for t in m["tabs"]]
+
+        def pre(slots):
+            P = torch.zeros(rows, 128, dtype=torch.float64)
+            for x, (wn, bn, r0) in zip(xs, m["rows"]):
+                P = P + x @ slots[wn][r0:r0 + 128].double().t() + slots[bn][r0:r0 + 128].double()
+            for c, t in zip(cs, m["tabs"]):
+                P = P + c @ slots[t].reshape(-1, 128).double()
+            return P
+        P, Pk = pre(can), pre(ker)
+        ln = can[m["ln"]].double()
+        z = torch.relu(torch.nn.functional.layer_norm(P, (128,), ln[0], ln[1], 1e-5))
+        # mean-free up to the signs: E[P'^2] is the variance of the reference's row
+        assert float(((Pk * Pk).mean(-1) - P.var(-1, unbiased=False)).abs().max()) < 1e-5
+        zk = torch.relu(Pk * torch.rsqrt((Pk * Pk).mean(-1, keepdim=True) + 1e-5) + ker[m["ln"]][1].double())
+        for (w2n, axis, fac) in m["w2"]:
+            W, Wk = can[w2n].double(), ker[w2n].double()
+            y = fac * (z @ (W.t() if axis == 1 else W))
+            yk = zk @ (Wk.t() if axis == 1 else Wk)
+            err = float((y - yk).abs().max()) / max(1.0, float(y.abs().max()))
+            worst = max(worst, err)
+            assert err < 2e-6, (m["ln"], w2n, err)
+    print(f"kernel form vs canonical: worst relative difference {worst:.2g}")

@@ -18,6 +18,16 @@ for mode, nm in enumerate(["NE", "NB", "BL", "PE", "PB"]):
     lib.dd_debug_set_clock_buffer(None, -1)
     c = buf.cpu().numpy()
     c = c[c[:, 0] != 0]
+    if nm == "BL" and len(c) and c[:, 12].all():            # cooperative persistent workgroups (bl_coop_body): 13 stamps per TRIP
+        cn = ["coop fold", "barrier C", "Q~ read + barrier D", "angle codes", "k pass", "softmax", "v pass", "next trip's loads issued",
+              "Z~ written", "barrier E", "epilogue MFMAs", "stores"]
+        d = np.diff(c[:, :13], axis=1).astype(np.float64)
+        tot = (c[:, 12] - c[:, 0]).astype(np.float64)
+        print(f"BL (cooperative trips): {len(c)} trips x 6 layers (last layer's stamps), median trip {np.median(tot):.0f} ticks -> {np.median(tot)/2400:.1f} us")
+        print("   " + " | ".join(f"{n} {np.median(d[:, i]):.0f}" for i, n in enumerate(cn)))
+        f = np.stack([c[:, 4], c[:, 13], c[:, 14], c[:, 15], c[:, 5]], 1).astype(np.float64)
+        print("   k pass: segment row arrives %.0f | tile 0 table MFMAs + LayerNorm %.0f | tile 0 scores %.0f | tile 1 %.0f" % tuple(np.median(np.diff(f, axis=1), axis=0)))
+        continue
     last = 10
     d = np.diff(c[:, :last + 1], axis=1).astype(np.float64)
     tot = (c[:, last] - c[:, 0]).astype(np.float64)
