@@ -74,6 +74,9 @@ def parse():
                     "device and CPU slice per rank) as one JSON line and exit; needs no GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rooflines", action="store_true")
+    ap.add_argument("--no-steady", action="store_true", help="skip the long call behind the timed region (steady_ms_per_step, per_call_overhead_ms)")
+    ap.add_argument("--cold", action="store_true", help="config 3: no warm-up -- every pocket timed from first touch (per-shape launch "
+                    "measurement or split-cache lookup, graph capture, then the steps): cold_seconds_per_unit / per_shape_setup_ms")
     ap.add_argument("--cpu-steps", type=int, default=5, help="steps of the CPU baseline's timed sample (~5.5 s each at B=8)")
     ap.add_argument("--cpu-warmup", type=int, default=1)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default 0: picked by a one-step probe of 16 / 64)")
@@ -94,12 +97,14 @@ def respawn_under_torchrun(args):
 
 
 # ---------------------------------------------------------------------------------------------------------- FLOP counts
-def node_launch_mfma_count(nbr, B, NP, NL, K):
+def node_launch_mfma_count(nbr, B, NP, NL, K, lin_in_node=False):
     """Exact number of v_mfma_f32_16x16x4_f32 wave-instructions of one fused node launch (dd_attention2.hip): per
     16-member tile the scores and the aggregation take 32 each; the first-Linear table contraction takes 40 per pass and
     source kind present in the tile (kNN modes: 20 Gaussians = 5 k-steps x 8 channel tiles -- the per-type constant row is added
     on the VALU since round 5, bit-identically; a tile mixing protein and ligand sources runs both tables) or 24 per pass
-    (triplets: 12 merged angle codes); node_layer_with_bond has no table.  `nbr` [B,N,K] is the kNN graph of the step."""
+    (triplets: 12 merged angle codes); node_layer_with_bond has no table.  `nbr` [B,N,K] is the kNN graph of the step.
+    `lin_in_node` (round 6): lin_node runs inside the NE / NB blocks as one 16 x 16 x 128 chain per wave -- 32 instructions per
+    wave, 8 waves per block of 8 segments; half of the 16 rows repeat the 8 segments (counted separately as "lin")."""
     N = NP + NL
     tiles_e = (K + 15) // 16
     kinds = 0
@@ -111,7 +116,11 @@ def node_launch_mfma_count(nbr, B, NP, NL, K):
     ne = 2 * 40 * kinds + 64 * B * N * tiles_e
     nb = 64 * B * NL * ((NL - 1 + 15) // 16)
     bl = (2 * 24 + 64) * B * NL * (NL - 1) * ((NL - 2 + 15) // 16)
-    return ne + nb + bl, {"NE": ne, "NB": nb, "BL": bl}
+    lin = 0
+    if lin_in_node:
+        blocks = B * ((NP + 7) // 8 + (NL + 7) // 8) + (B * NL + 7) // 8
+        lin = blocks * 8 * 32
+    return ne + nb + bl + lin, {"NE": ne, "NB": nb, "BL": bl, "lin": lin}
 
 
 def algorithmic_flops_node_launch(B, NP, NL, K):
@@ -123,7 +132,7 @@ def algorithmic_flops_node_launch(B, NP, NL, K):
     return 2.0 * (e * 2 * (21 * 128 + 128 * 128) + eb * 2 * (128 * 128) + e3 * 2 * (13 * 128 + 128 * 128))
 
 
-def gemm_work_per_step(B, NP, NL, num_layers, layer0_tables=True, p2_in_pos=False):
+def gemm_work_per_step(B, NP, NL, num_layers, layer0_tables=True, p2_in_pos=False, lin_in_node=False):
     """(useful FLOPs, 64x64 output tiles) of the dense GEMM launches of one step (dd_api.hip forward_impl).  With the
     layer-0 tables (dd_sampler.l0_tables) the first layer's projection and query launches do not run; with `p2_in_pos`
     (dd_debug_schedule() & 1) the projections of the new h and the heads' first Linear run inside the coordinate launch and are
@@ -132,6 +141,8 @@ def gemm_work_per_step(B, NP, NL, num_layers, layer0_tables=True, p2_in_pos=Fals
     first = [(B * N, 640), (B * NL, 1280), (B * Eb, 640),                     # projections of the old h / h_bond
              (B * Eb, 128), (B * N, 128), (B * NL, 128)]                      # query MLPs, second Linear
     rest = [(B * N, 128), (B * Eb, 256)]                                      # lin_node, bond projections (coordinates)
+    if lin_in_node:
+        rest = rest[1:]                                                       # (lin_node runs inside the node launch)
     heads = [(B * Eb, 128), (B * NL, 128)]
     if not p2_in_pos:
         rest += [(B * N, 256), (B * NL, 1024)]                                # projections of the new h
@@ -224,6 +235,39 @@ def main():
         return model.sample_diffusion(num_steps=n_steps, center_pos_mode="protein", energy_drift_opt=drift, seed=seed,
                                       keep_traj=True, use_graph=not args.eager, **batch)
 
+    if args.cold:
+        # configs[3] with the per-pocket costs INSIDE: a 100-pocket job meets ~100 distinct shapes, each sampled
+        # once, so the per-shape set-up (CU-split lookup or measurement, graph capture, buffer allocation) is a per-pocket cost.
+        # Pass 0 times every unit from first touch, pass 1 the same units again (everything cached): the difference is the set-up.
+        if world != 1:
+            raise SystemExit("bench.py --cold: single rank only")
+        mine = ddist.units_of_rank(units, args.config, 0, 1)
+        states = [prepare(u) for u in mine]
+        secs = [[], []]
+        for p_ in (0, 1):
+            for u, st_ in zip(mine, states):
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                sample(st_, args.steps, u.noise_seed)
+                torch.cuda.synchronize(dev)
+                secs[p_].append(time.perf_counter() - t1)
+        lib = hip_lib.load()
+        import ctypes as _ct
+        buf = _ct.create_string_buffer(1024)
+        cache_path = buf.value.decode() if lib.dd_debug_node_split_cache_path(buf, 1024) == 0 else "?"
+        cache_path = buf.value.decode()
+        setup = [c - w_ for c, w_ in zip(*secs)]
+        print(json.dumps({
+            "metric": "denoising steps/sec (1000-step reverse) per pocket, every pocket from first touch", "unit": "denoising steps/s",
+            "value": round(len(mine) * args.steps / sum(secs[0]), 3), "value_warm": round(len(mine) * args.steps / sum(secs[1]), 3),
+            "n_gpus": 1, "steps": args.steps, "units": len(mine), "higher_is_better": True, "data": "synthetic", "dtype": "f32",
+            "cold_seconds_per_unit": round(sum(secs[0]) / len(mine), 5), "warm_seconds_per_unit": round(sum(secs[1]) / len(mine), 5),
+            "per_shape_setup_ms": round(1e3 * sum(setup) / len(mine), 3), "per_shape_setup_ms_max": round(1e3 * max(setup), 3),
+            "setup_fraction_of_cold": round(sum(setup) / sum(secs[0]), 4),
+            "node_split_cache_file": cache_path, "node_split_cache_env": os.environ.get("DD_NODE_SPLIT_CACHE", "1"),
+            "config": {"workload": f"configs[3] --cold: {len(mine)} pockets (NP in [250,350], NL in [20,40]), batch={mine[0].n_samples}, "
+                                   f"{args.steps} steps each, no warm-up; pass 0 from first touch, pass 1 cached"}}), flush=True)
+        return
     job = ddist.run_job(units, args.config, rank, world, prepare, sample, args.steps, args.warmup, dev)
     out = job["last_out"]
     if out is not None:
@@ -238,6 +282,21 @@ def main():
         B, NP, NL = u0.n_samples, u0.num_protein, sum(u0.arm_atoms) + u0.scaffold_atoms
         K = min(cfg.knn, NP + NL - 1)
         roofline = roofline_gemm = op_roofline = None
+        # steady-state figure beside the per-call one (the timed region and `value` are untouched): one long call of the same
+        # unit after the timed region -- ms per step once the fixed cost of a call (set-up, trajectory drain, checksum, two syncs) is
+        # amortised -- and what that fixed cost is for the timed call
+        steady = None
+        if args.config in (1, 2) and not args.no_steady:
+            st0 = prepare(u0)
+            n_long = max(200, 10 * args.steps)
+            sample(st0, min(20, n_long), u0.noise_seed + 101)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            sample(st0, n_long, u0.noise_seed + 102)
+            torch.cuda.synchronize(dev)
+            steady_ms = 1e3 * (time.perf_counter() - t1) / n_long
+            steady = {"steady_ms_per_step": round(steady_ms, 4), "steady_steps": n_long,
+                      "per_call_overhead_ms": round(1e3 * elapsed / max(1, job["n_local_units"]) - args.steps * steady_ms, 3)}
         if not args.no_rooflines:
             roofline, roofline_gemm = measure_step_rooflines(torch, model, hip_lib, lib, prepare(u0), cfg, B, NP, NL, K, dev,
                                                              args.config, args.workload)
@@ -272,6 +331,9 @@ def main():
                        "launch": "eager" if args.eager else "hipGraph replay", "noise": "device Philox",
                        "warmup_calls": job["warmup_calls"],    # the W warm-up steps were issued as this many calls
                        "node_launch_split_cus": int(lib.dd_debug_node_split(B, NP, NL, K))},
+            "steady_ms_per_step": steady["steady_ms_per_step"] if steady else None,
+            "per_call_overhead_ms": steady["per_call_overhead_ms"] if steady else None,
+            "steady_steps": steady["steady_steps"] if steady else None,
             "roofline": roofline, "roofline_gemm": roofline_gemm, "roofline_op_level": op_roofline, "cpu_baseline": cpu,
             "per_rank": job["per_rank"], "per_unit": job["per_unit"] if len(units) <= 16 else job["per_unit"][:16],
         }
@@ -304,7 +366,8 @@ def measure_step_rooflines(torch, model, hip_lib, lib, state, cfg, B, NP, NL, K,
     ws = bufs2["workspace"]
     off = (view.nbr - ws.data_ptr()) // 4
     nbr = ws[off:off + B * (NP + NL) * K].view(torch.int32).view(B, NP + NL, K).cpu()
-    n_mfma, by_mode = node_launch_mfma_count(nbr, B, NP, NL, K)
+    lin_in_node = bool(view.lin_in_node)
+    n_mfma, by_mode = node_launch_mfma_count(nbr, B, NP, NL, K, lin_in_node)
     hip_lib.check(lib.dd_sampler_reset(ctypes.byref(s2), hip_lib.stream_ptr(dev)), "dd_sampler_reset")
     # 4 rounds of 5 profiled steps (the first is a warm-up); per launch class the MEAN of the three round means (the minimum
     # of the rounds, kept as launch_ms_min, flattered the fraction by ~4 % against rocprofv3's average: VERDICT r3)
@@ -365,7 +428,7 @@ def measure_step_rooflines(torch, model, hip_lib, lib, state, cfg, B, NP, NL, K,
         "ms_per_step_by_launch_class": {k: round(v, 4) for k, v in per_cat.items()},
     }
     p2_in_pos = bool(lib.dd_debug_schedule() & 1) and NL <= 65
-    g_flops, g_tiles = gemm_work_per_step(B, NP, NL, L, layer0_tables=bool(s2.l0_tables), p2_in_pos=p2_in_pos)
+    g_flops, g_tiles = gemm_work_per_step(B, NP, NL, L, layer0_tables=bool(s2.l0_tables), p2_in_pos=p2_in_pos, lin_in_node=lin_in_node)
     g_ms = per_cat["gemm"]
     roofline_gemm = {"bound": "mfma", "kernel": "dd::k_gemm128_batch (projection / query / lin_node / head GEMMs, serialised)",
                      "flops_per_step": g_flops, "tiles_64x64_per_step": g_tiles, "ms_per_step": round(g_ms, 4),

@@ -181,6 +181,8 @@ DD_OPT g_head_fused = 1;                   // dd_debug_set_option(24, v): head o
 DD_OPT g_side_lin = DD_SIDE_LIN_DEFAULT;   // dd_debug_set_option(27, v): ONE fork per layer -- the side stream forms the new h itself
                                                // (a second, identical lin_node launch into its own buffer) instead of waiting for the
                                                // main stream's lin_node, whose launch then has no cross-queue successor
+DD_OPT g_lin_in_node = 1;                  // dd_debug_set_option(32, v): lin_node (h += W_lin . A + b) inside the NE / NB blocks of the node launch
+                                               // (round 6): no lin_node launch on the layer's critical chain, one fork per layer instead of two
 DD_OPT g_head_rows_first = 0;              // dd_debug_set_option(29, v): see the head of forward_impl
 DD_OPT g_heads_early = 1;                  // dd_debug_set_option(28, v): heads' first Linear in the last layer's projection launch
 DD_OPT g_q_in_pos = 1;                     // dd_debug_set_option(9, v): coordinate query MLPs' second layer inside attn_pos
@@ -232,7 +234,9 @@ struct StepFold {
 
 // First-Linear projections of layer `ll` from h / h_bond (one launch) and the query MLPs' second layer (one launch):
 // the forward's own launches, also run by dd_layer0_tables on its 16-atom problem.
-static int launch_projections1(const dd_sampler* s, const Workspace& w, int ll, const float* h, float* P, hipStream_t sx) {
+// (anb != NULL: the previous layer's W_lin . A_nb is still pending on the ligand rows of h -- lin_node inside the node launch)
+static int launch_projections1(const dd_sampler* s, const Workspace& w, int ll, const float* h, float* P, hipStream_t sx,
+                               const float* anb = nullptr) {
   const int B = s->B, NP = s->NP, NL = s->NL, N = NP + NL;
   const int nE = B * NL * (NL - 1);
   const long hN = (long)N * 128;
@@ -242,6 +246,10 @@ static int launch_projections1(const dd_sampler* s, const Workspace& w, int ll, 
       gemm_args(h, B * N, 0, 128, B * N, LW(ll, DD_W_n1), LW(ll, DD_b_n1), nullptr, P, B * N, 0, 640, 640, 0),
       gemm_args(h + (long)NP * 128, NL, hN, 128, B * NL, LW(ll, DD_W_l1), LW(ll, DD_b_l1), nullptr, w.PL, B * NL, 0, 1280, 1280, 0),
       gemm_args(w.hb, nE, 0, 128, nE, LW(ll, DD_W_b1), LW(ll, DD_b_b1), nullptr, w.PB, nE, 0, 640, 640, 0)};
+  if (anb) {
+    j[0].X2 = anb; j[0].x2_N = N; j[0].x2_NP = NP;       // all-node rows: ligand rows n >= NP take row n - NP of their sample
+    j[1].X2 = anb; j[1].x2_N = NL; j[1].x2_NP = 0;       // ligand rows only
+  }
   return launch_gemm128_batch(j, 3, sx);
 }
 static int launch_queries_q1(const dd_sampler* s, const Workspace& w, int ll, const float* P, float* qn, hipStream_t sx) {
@@ -564,7 +572,16 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     // ---- projections of the old h / h_bond: one launch (the q blocks are the last columns: skipped when fused above).
     //      With the projection-ahead schedule this launch was already issued on the side stream right after the
     //      previous layer's lin_node (it needs h and h_bond only) and is joined before its first consumer.
-    auto launch_batch1 = [&](int ll, hipStream_t sx) -> int { return launch_projections1(s, w, ll, hcur, w.P, sx); };
+    // lin_node inside the node launch (g_lin_in_node): the NE blocks update h in place, the NB blocks leave W_lin . A_nb of this
+    // layer in anb_cur (ping-pong between w.Anb and w.A, which no longer holds the attention output); every consumer of the new h
+    // adds it to the ligand rows (GemmArgs::X2) and the next layer's NE blocks fold it into h
+    const bool lin_in_node = g_lin_in_node && g_lin_with_pb2 && !g_side_lin && g_heads_early;
+    float* const anb_cur = (l & 1) ? w.A : w.Anb;
+    const float* const anb_prev = (lin_in_node && l > 0) ? ((l & 1) ? w.Anb : w.A) : nullptr;
+    auto add_anb = [&](GemmArgs& g, bool all_nodes) {     // X rows of g: all nodes of the batch / the ligand rows only
+      g.X2 = anb_cur; g.x2_N = all_nodes ? N : NL; g.x2_NP = all_nodes ? NP : 0;
+    };
+    auto launch_batch1 = [&](int ll, hipStream_t sx) -> int { return launch_projections1(s, w, ll, hcur, w.P, sx, anb_prev); };
     // (schedule 2) the same projections in two launches: the bond part only needs h_bond, final once the node
     // attention is done; the node parts need h (lin_node)
     // (hsrc: the h the node parts read; lin_dup: the lin_node job that forms it first, one-fork schedule)
@@ -578,13 +595,14 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
       GemmArgs j[2] = {
           gemm_args(hsrc, B * N, 0, 128, B * N, LW(ll, DD_W_n1), LW(ll, DD_b_n1), nullptr, w.P, B * N, 0, 640, 640, 0),
           gemm_args(hsrc + (long)NP * 128, NL, hN, 128, B * NL, LW(ll, DD_W_l1), LW(ll, DD_b_l1), nullptr, w.PL, B * NL, 0, 1280, 1280, 0)};
+      if (lin_in_node) { add_anb(j[0], true); add_anb(j[1], false); }   // (called for the NEXT layer: this layer's W_lin . A_nb is pending)
       return launch_gemm128_batch(j, 2, sx);
     };
     const bool ahead = overlap && g_sched >= 1;
     const bool ahead_split = overlap && g_sched >= 2;
     const bool ahead_b2 = overlap && g_sched >= 3 && g_q1_in_gemm && g_gemm_ksplit_on();
     const bool two_joins = ahead_b2 && g_sched >= 4;     // g_ev_qb_fork[l]: layer l's projections done (side stream)
-    const bool pb_early = g_pb_early && g_lin_with_pb2 && !ahead;   // next layer's bond projections ride with lin_node
+    const bool pb_early = g_pb_early && g_lin_with_pb2 && !ahead && !lin_in_node;   // next layer's bond projections ride with lin_node
     const bool l0_here = l0 && l == 0;                  // this layer's projection / query rows came from the tables
     if (pb_early && l > 0) DD_TRYP(DD_PROF_GEMM, launch_batch1_part(l, 1, st, hcur, nullptr));
     else if (!(ahead && l > 0) && !l0_here) DD_TRYP(DD_PROF_GEMM, launch_batch1(l, st));
@@ -645,6 +663,10 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
       nb.ke = w.PB; nb.ve = w.PB + 128; nb.ld_ke = nb.ld_ve = 640;
       nb.q = w.qlnb; nb.lnk = LW(l, DD_NB_lnk); nb.lnv = LW(l, DD_NB_lnv);
       nb.W2k = LW(l, DD_NB_W2k); nb.W2v = LW(l, DD_NB_W2v); nb.b2v = LW(l, DD_NB_b2v); nb.out = w.Anb; nb.out_assign = 1;
+      if (lin_in_node) {
+        ne.out = hcur; ne.lin_W = LW(l, DD_W_lin); ne.lin_b = LW(l, DD_b_lin); ne.lin_add = anb_prev;
+        nb.out = anb_cur; nb.lin_W = LW(l, DD_W_lin);
+      }
       bl.B = B; bl.NP = NP; bl.NL = NL; bl.K = K; bl.x = xcur;
       bl.ke = w.Ek; bl.ve = w.Ev; bl.ld_ke = bl.ld_ve = 128;
       bl.q = w.qb; bl.Wakp = LW(l, DD_BL_Wakp); bl.Wavp = LW(l, DD_BL_Wavp);
@@ -662,7 +684,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     const bool side_lin = g_side_lin && ahead_split && ahead_b2 && l + 1 < s->num_layers;
     float* const hold = hcur;
     GemmArgs lin_dup;
-    {
+    if (!lin_in_node) {
       GemmArgs g = gemm_args(w.A, B * N, 0, 128, B * N, LW(l, DD_W_lin), LW(l, DD_b_lin), nullptr, hcur, B * N, 0, 128, 128, 1);
       g.X2 = w.Anb; g.x2_N = N; g.x2_NP = NP;
       if (side_lin) {
@@ -697,17 +719,26 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
         gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b2), LW(l, DD_b_b2), nullptr, w.PB2, nE, 0, 256, 256, 0),
         gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b2), LW(l, DD_b_b2), nullptr, w.PB2, nE, 0, 256, 256, 0)};
     int p2n = g_lin_with_pb2 ? 2 : 3;
+    GemmArgs p2x[6];                                     // (lin_in_node: + the coordinate sub-layer's bond projections, which rode with lin_node)
     if (g_heads_early && g_lin_with_pb2 && l + 1 == s->num_layers) {
       p2j[2] = gemm_args(w.hb, nE, 0, 128, nE, GW(DD_G_BH_W1), GW(DD_G_BH_b1), nullptr, w.qb, nE, 0, 128, 128, 0);
       p2j[3] = gemm_args(hcur + (long)NP * 128, NL, hN, 128, B * NL, GW(DD_G_VH_W1), GW(DD_G_VH_b1), nullptr, w.qn, B * NL, 0, 128, 128, 0);
       p2n = 4;
       heads_done = true;
     }
+    int p2xn = 0;
+    if (lin_in_node) {
+      p2x[p2xn++] = p2j[0]; add_anb(p2x[0], true);
+      p2x[p2xn++] = p2j[1]; add_anb(p2x[1], false);
+      p2x[p2xn++] = gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b2), LW(l, DD_b_b2), nullptr, w.PB2, nE, 0, 256, 256, 0);
+      if (p2n == 4) { p2x[p2xn++] = p2j[2]; p2x[p2xn] = p2j[3]; add_anb(p2x[p2xn], false); ++p2xn; }
+    }
     // (round 5) these jobs ride INSIDE the coordinate launch below when it can take them (launch_attn2_pos_g): the attention
     // workgroups wait for the first two, the heads' tiles trail behind them
     bool p2_in_pos = g_p2_in_pos && g_lin_with_pb2 && g_q_in_pos && !g_xup_in_pos && g_pos_waves == 4 && NL <= 65 && l < 64 &&
                      !(overlap && !ahead);
-    if (!p2_in_pos) DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(p2j, p2n, st));
+    if (lin_in_node) { p2_in_pos = false; DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(p2x, p2xn, st)); }
+    else if (!p2_in_pos) DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(p2j, p2n, st));
     const bool q_in_pos = g_q_in_pos;           // second layer of the coordinate query MLPs inside attn_pos
     if (!q_in_pos) {
       GemmArgs j[2] = {
@@ -763,7 +794,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
       if (ahead_split) {
         if (hipStreamWaitEvent(g_side, g_ev_qa_fork[l + 1], 0) != hipSuccess) return DD_ERR_HIP;
         DD_TRY(launch_batch1_part(l + 1, 0, g_side, nullptr, side_lin ? &lin_dup : nullptr));
-        if (!side_lin && hipStreamWaitEvent(g_side, g_ev_fork[l + 1], 0) != hipSuccess) return DD_ERR_HIP;
+        if (!side_lin && !lin_in_node && hipStreamWaitEvent(g_side, g_ev_fork[l + 1], 0) != hipSuccess) return DD_ERR_HIP;   // (lin_in_node: h is final with h_bond)
         DD_TRY(launch_batch1_part(l + 1, 1, g_side, side_lin ? w.hs : hcur, nullptr));
         if (two_joins && hipEventRecord(g_ev_qb_fork[l + 1], g_side) != hipSuccess) return DD_ERR_HIP;
         if (ahead_b2) DD_TRY(launch_b2(l + 1, g_side));
@@ -860,6 +891,9 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     GemmArgs j[2] = {
         gemm_args(w.hb, (int)(B * Eb), 0, 128, (int)(B * Eb), GW(DD_G_BH_W1), GW(DD_G_BH_b1), nullptr, w.qb, (int)(B * Eb), 0, 128, 128, 0),
         gemm_args(hcur + (long)NP * 128, NL, hN, 128, B * NL, GW(DD_G_VH_W1), GW(DD_G_VH_b1), nullptr, w.qn, B * NL, 0, 128, 128, 0)};
+    if (fused && g_lin_in_node && g_lin_with_pb2 && !g_side_lin && g_heads_early) {   // (lin_in_node: the last layer's W_lin . A_nb is pending)
+      j[1].X2 = ((s->num_layers - 1) & 1) ? w.A : w.Anb; j[1].x2_N = NL; j[1].x2_NP = 0;
+    }
     DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, 2, st));   // (v-head hidden -> qn: ql may still be read by the overlapped pos sub-layer)
   }
   {
@@ -1100,6 +1134,13 @@ extern "C" int dd_workspace_view(const dd_sampler* s, dd_ws_view* out) {
   out->x = (s->num_layers & 1) ? w.xb : w.xa;
   out->h = w.h; out->hb = w.hb; out->ew = w.ew; out->A = w.A; out->nbr = w.nbr;
   out->Anb = (dd::g_fuse && s->NL <= dd::g_fused_max_nl) ? w.Anb : nullptr;
+  out->lin_in_node = 0;
+  if (out->Anb && dd::g_lin_in_node && dd::g_lin_with_pb2 && !dd::g_side_lin && dd::g_heads_early) {
+    // lin_node inside the node launch: `h` lacks the last layer's W_lin . A_nb on the ligand rows -- it is in `Anb`; `A` is not formed
+    out->lin_in_node = 1;
+    out->Anb = ((s->num_layers - 1) & 1) ? w.A : w.Anb;
+    out->A = nullptr;
+  }
   return DD_OK;
 }
 
@@ -1587,6 +1628,7 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 30) { dd::g_p2_in_pos = value ? 1 : 0; return DD_OK; }
   if (key == 31) { dd::g_pos_g_mode = value & 3; return DD_OK; }
   if (key == 28) { dd::g_heads_early = value ? 1 : 0; return DD_OK; }
+  if (key == 32) { dd::g_lin_in_node = value ? 1 : 0; return DD_OK; }
   if (key == 29) { dd::g_head_rows_first = value ? 1 : 0; return DD_OK; }
   if (key == 7) { dd::g_step_fused = value ? 1 : 0; return DD_OK; }
   if (key == 5) { if (value != 2 && value != 4 && value != 8) return DD_ERR_BAD_ARG; dd::g_pos_waves = value; return DD_OK; }

@@ -1051,6 +1051,17 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
       qn1 = *reinterpret_cast<const float4*>(a.q + (long)nseg2 * 128 + mm * 8 + 4);
     }
   }
+  // lin_node inside the node launch (a.lin_W != NULL; NE / NB blocks of the fused launch, round 6): this wave's 16 rows of W_lin
+  // as the MFMA B operand, requested ahead of the epilogue (see below)
+  constexpr bool LIN = (MODE == M_NE || MODE == M_NB) && !PERSIST;
+  const bool lin = LIN && a.lin_W != nullptr;            // (block-uniform)
+  float4 Bw[8];
+  if (lin) {
+    const float* bw = a.lin_W + (16 * wave + mm) * 128 + 4 * cg;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) Bw[nt] = *reinterpret_cast<const float4*>(bw + 16 * nt);
+  }
+  float* const lin_rows = smem + L::TOTAL + 16;          // [NW][WPITCH]: the attention outputs of the block's NW segments
   if (active) {
     // lane (h = mm, cg): partial dot products over its 32 channels for the 8 outputs of head h
     float o[8];
@@ -1077,13 +1088,67 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
     q0 = fmaf(a.b2v[mm * 8 + cg], ssum, q0);
     q1 = fmaf(a.b2v[mm * 8 + 4 + cg], ssum, q1);
     const bool nb_assign = (MODE == M_NB) && a.out_assign;
-    float* dst;
-    if (MODE == M_NB && !nb_assign) dst = a.out + ((long)b * N + node) * 128 + mm * 8 + cg;
-    else dst = a.out + (long)seg * 128 + mm * 8 + cg;
-    if (MODE == M_NE || nb_assign) {
-      dst[0] = q0; dst[4] = q1;
+    if (lin) {
+      lin_rows[wave * WPITCH + mm * 8 + cg] = q0;
+      lin_rows[wave * WPITCH + mm * 8 + 4 + cg] = q1;
     } else {
-      dst[0] += q0; dst[4] += q1;
+      float* dst;
+      if (MODE == M_NB && !nb_assign) dst = a.out + ((long)b * N + node) * 128 + mm * 8 + cg;
+      else dst = a.out + (long)seg * 128 + mm * 8 + cg;
+      if (MODE == M_NE || nb_assign) {
+        dst[0] = q0; dst[4] = q1;
+      } else {
+        dst[0] += q0; dst[4] += q1;
+      }
+    }
+  }
+  if constexpr (LIN) {
+    if (lin) {
+      // h' = h + W_lin . A + b_lin (uni_transformer_edge.py:276-277) for the block's NW nodes as ONE 16 x 16 x 128 MFMA chain per
+      // wave: rows = the block's segments (rows 8-15 repeat 0-7), columns = outputs 16 wave .. 16 wave + 15.  NE blocks update
+      // their rows of h in place (no launch reads h while the node launch runs); NB blocks store W_lin . A_nb to their own
+      // buffer (a.out), which the consumers of the new h add to the ligand rows (GemmArgs::X2) and the next layer's NE blocks
+      // fold into h (a.lin_add) -- one writer per row, a fixed order of the sums: deterministic.
+      __syncthreads();
+      const float* ar = lin_rows + (mm & 7) * WPITCH + 4 * cg;
+      f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int nt = 0; nt < 8; nt += 2) {
+        const float4 a0 = *reinterpret_cast<const float4*>(ar + 16 * nt), a1 = *reinterpret_cast<const float4*>(ar + 16 * nt + 16);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, Bw[nt].x, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, Bw[nt + 1].x, d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, Bw[nt].y, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, Bw[nt + 1].y, d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, Bw[nt].z, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, Bw[nt + 1].z, d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, Bw[nt].w, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, Bw[nt + 1].w, d1, 0, 0, 0);
+      }
+      const f32x4 d = d0 + d1;                           // lane (column mm, cg): rows 4 cg + r
+      if (cg < 2) {
+        const int col = 16 * wave + mm;
+        const float bias = (MODE == M_NE) ? a.lin_b[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 4 * cg + r;                      // segment of the block
+          if (MODE == M_NE) {
+            const int nd = wg_protein ? ne_rb * NW + i : a.NP + (ne_rb - ne_nbp) * NW + i;
+            bool ok = nd < (wg_protein ? a.NP : N) && ne_b < a.B;
+            if (RAG && ok) ok = nd < a.NP ? nd < (a.np_real ? a.np_real[ne_b] : a.NP) : nd - a.NP < a.nl_real[ne_b];
+            if (ok) {
+              float* hp = a.out + ((long)ne_b * N + nd) * 128 + col;
+              float v = *hp;
+              if (nd >= a.NP && a.lin_add != nullptr) v += a.lin_add[((long)ne_b * a.NL + nd - a.NP) * 128 + col];
+              *hp = v + (d[r] + bias);
+            }
+          } else {
+            const int sg = block * NW + i;
+            bool ok = sg < a.B * a.NL;
+            if (RAG && ok) ok = sg % a.NL < a.nl_real[sg / a.NL];
+            if (ok) a.out[(long)sg * 128 + col] = d[r];
+          }
+        }
+      }
     }
   }
   DD_STAMP(10);
@@ -1498,7 +1563,8 @@ __global__ __launch_bounds__(512) void k_attn2_bl_coop(const AttnArgs a) {
 
 template <int MODE, int MAXT, int NW, bool RAG = false>
 __global__ __launch_bounds__(NW * 64) void k_attn2(const AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[Lds<MODE>::TOTAL + ((MODE == M_PE || MODE == M_PB) ? NW * 256 : 0)];
+  __shared__ __attribute__((aligned(16))) float smem[Lds<MODE>::TOTAL + ((MODE == M_PE || MODE == M_PB) ? NW * 256 : 0) +
+                                                     ((MODE == M_NE || MODE == M_NB) ? NW * WPITCH + 16 : 0)];
   attn2_body<MODE, MAXT, NW, false, RAG>(a, blockIdx.x, smem);
 }
 

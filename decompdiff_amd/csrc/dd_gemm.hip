@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void k_gemm128_ks(GemmArgs a) {
   gemm_tile_ksplit<true>(a, blockIdx.x, blockIdx.y, sm);
 }
 
-struct GemmBatch { GemmArgs job[4]; int end[4]; int nbx[4]; int big[4]; int njobs; };
+constexpr int DD_GEMM_BATCH_MAX = 6;
+struct GemmBatch { GemmArgs job[DD_GEMM_BATCH_MAX]; int end[DD_GEMM_BATCH_MAX]; int nbx[DD_GEMM_BATCH_MAX]; int big[DD_GEMM_BATCH_MAX]; int njobs; };
 // `nby` > 0 selects the XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so
 // with the plain order (row block fastest) the 64 x 128 input block of a row block is pulled into every L2 once per
 // column tile.  Here a job's block range starts at a multiple of 8, XCD x = lb % 8 owns the row blocks x, x + 8, ...
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void k_gemm128_batch(GemmBatch gb) {
   int j = 0, base = 0;
   const int blk = blockIdx.x;
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < DD_GEMM_BATCH_MAX - 1; ++i)
     if (j == i && blk >= gb.end[i] && i + 1 < gb.njobs) { base = gb.end[i]; j = i + 1; }
   const int lb = blk - base;
   // block-uniform job selection through a uniform index into the kernel arguments (scalar loads): ONE copy of the tile
@@ -255,11 +256,11 @@ int g_gemm_ksplit = 1;   // dd_debug_set_option(1, v): K-split tiles for jobs wi
 int g_gemm_xcd = 1;      // dd_debug_set_option(21, v): XCD-aware tile order in the batched projection launches
 
 int launch_gemm128_batch(const GemmArgs* jobs, int njobs, hipStream_t st) {
-  if (njobs <= 0 || njobs > 4) return DD_ERR_BAD_ARG;
+  if (njobs <= 0 || njobs > DD_GEMM_BATCH_MAX) return DD_ERR_BAD_ARG;
   GemmBatch gb;
   gb.njobs = njobs;
   int total = 0;
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < DD_GEMM_BATCH_MAX; ++i) {
     if (i < njobs) {
       gb.job[i] = jobs[i];
       const int t = GT;

@@ -64,7 +64,7 @@ inline TailJob tail_job(const GemmArgs& g, int wait0 = -1, int wait0_n = 0, int 
 inline int gemm_tiles(int rows, int cols) { return ((rows + 63) / 64) * ((cols + 63) / 64); }
 int launch_gemm_tail(TailArgs& ta, hipStream_t st);
 int launch_gemm128(const GemmArgs& a, hipStream_t st);
-// up to 4 independent projections in one launch (small ones ride along with the big ones)
+// up to 6 independent projections in one launch (small ones ride along with the big ones)
 int launch_gemm128_batch(const GemmArgs* jobs, int njobs, hipStream_t st);
 
 int launch_embed_all(const float* protein_h, const float* protein_pos, const float* lig_pos, const int32_t* lig_v,
@@ -135,6 +135,10 @@ struct AttnArgs {
   // covers trip_q (< NW) segments, so that the last round runs one wave per SIMD on every CU instead of full trips on some CUs
   // beside idle ones.  Set by launch_attn2_node (trip_q = 0 and trip_full = 1 << 27: plain NW-segment trips).
   int trip_full, trip_q;
+  // lin_node inside the node launch (NE / NB blocks, fused launch only; NULL: the attention output goes to `out` as before):
+  //   NE: out[row] += W_lin . A[row] + lin_b (+ lin_add[ligand row]: the previous layer's W_lin . A_nb, still pending) -- `out` = h;
+  //   NB: out[ligand row] = W_lin . A_nb[row]   (W_lin [128 o][128 c], models/encoders/uni_transformer_edge.py:276-277)
+  const float *lin_W, *lin_b, *lin_add;
 };
 
 int launch_attn2(int mode, const AttnArgs& a, hipStream_t st);   // one sub-layer: 16-member tiles, scores/aggregation on MFMA

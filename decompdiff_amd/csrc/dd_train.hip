@@ -162,7 +162,9 @@ inline int ln_grid(long rows) {
 extern "C" size_t dd_ln_relu_scratch_floats(long rows) { return rows > 0 ? (size_t)dd::ln_grid(rows) * 256 : 0; }
 
 extern "C" int dd_ln_relu_forward(const float* x, const float* gamma, const float* beta, float* y, float* stats, long rows, void* stream) {
-  if (!x || !gamma || !beta || !y || !stats || rows < 0 || (reinterpret_cast<size_t>(x) & 7) || (reinterpret_cast<size_t>(y) & 7))
+  // (the kernels read x / y / gamma / beta as float4 and stats as float2)
+  auto mis = [](const void* p, size_t m) { return (reinterpret_cast<size_t>(p) & m) != 0; };
+  if (!x || !gamma || !beta || !y || !stats || rows < 0 || mis(x, 15) || mis(y, 15) || mis(gamma, 15) || mis(beta, 15) || mis(stats, 7))
     return DD_ERR_BAD_ARG;
   if (rows == 0) return DD_OK;
   hipLaunchKernelGGL(dd::k_ln_relu_fwd, dim3(dd::ln_grid(rows)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, stats, rows);
@@ -172,9 +174,11 @@ extern "C" int dd_ln_relu_forward(const float* x, const float* gamma, const floa
 
 extern "C" int dd_ln_relu_backward(const float* x, const float* stats, const float* gamma, const float* beta, const float* dy, float* dx,
                                    float* scratch, float* dgamma, float* dbeta, long rows, void* stream) {
-  if (!x || !stats || !gamma || !beta || !dy || !dx || !scratch || !dgamma || !dbeta || rows <= 0 ||
-      (reinterpret_cast<size_t>(x) & 7) || (reinterpret_cast<size_t>(dy) & 7) || (reinterpret_cast<size_t>(dx) & 7))
+  auto mis = [](const void* p, size_t m) { return (reinterpret_cast<size_t>(p) & m) != 0; };
+  if (!x || !stats || !gamma || !beta || !dy || !dx || !scratch || !dgamma || !dbeta || rows < 0 || mis(x, 15) || mis(dy, 15) ||
+      mis(dx, 15) || mis(gamma, 15) || mis(beta, 15) || mis(stats, 7))
     return DD_ERR_BAD_ARG;
+  if (rows == 0) return DD_OK;                           // (as the forward: nothing to do; dgamma / dbeta are left untouched)
   const int grid = dd::ln_grid(rows);
   hipLaunchKernelGGL(dd::k_ln_relu_bwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, stats, gamma, beta, dy, dx, scratch, rows);
   DD_CHECK_LAUNCH();

@@ -68,7 +68,7 @@ L0_TABLE_FLOATS = 16 * 640 + 16 * 1280 + 5 * 640 + 16 * 128 + 16 * 128 + 80 * 12
 
 class DDWsView(ctypes.Structure):
     _fields_ = [("x", c_void_p), ("h", c_void_p), ("hb", c_void_p), ("ew", c_void_p), ("A", c_void_p),
-                ("nbr", c_void_p), ("Anb", c_void_p)]
+                ("nbr", c_void_p), ("Anb", c_void_p), ("lin_in_node", ctypes.c_int32)]
 
 
 PROF_CATS = ["misc", "gemm", "assemble", "attn_NE", "attn_NB", "attn_BL", "attn_PE", "attn_PB", "step", "event_pair"]

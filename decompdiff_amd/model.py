@@ -186,6 +186,13 @@ class DecompScorePosNet3D(nn.Module):
     def _device(self):
         return self.betas.device
 
+    def invalidate_pocket_uploads(self):
+        """Forget what the cached chains hold of the pocket side (protein coordinates / features / layer-0 rows): the next call of
+        every cached shape uploads again.  Needed only after an in-place write that does not bump tensor version counters."""
+        for ent in list(DecompScorePosNet3D._chain_cache.values()):
+            if isinstance(ent, dict):
+                ent["uploaded"] = None
+
     def invalidate_packed_weights(self):
         """Forget the packed weight arena (and with it the cached chain resources that point into it).  Called by
         load_state_dict / .to() / train(); call it by hand after modifying parameters in place."""
@@ -697,7 +704,11 @@ class DecompScorePosNet3D(nn.Module):
         # layer-0 protein rows) is uploaded once per cached entry and pocket: a later call that passes the SAME tensor objects
         # with unchanged version counters (the next batch of the pocket, the sampling script's loop) finds them in place --
         # five launches less in front of the first graph replay.
-        src = d.get("upload_src") if cacheable else None
+        # CONTRACT of the skip: it keys on the identity of the caller's tensors AND their version counters.  Writes that do not bump
+        # the counter (t.data.copy_, set_, another library writing through data_ptr) are invisible to it: after such a write call
+        # model.invalidate_pocket_uploads() or set DD_POCKET_UPLOAD_SKIP=0 (every call then uploads).  The cache entry holds
+        # references to those tensors for as long as it lives (evicted with the chain cache).
+        src = d.get("upload_src") if (cacheable and os.environ.get("DD_POCKET_UPLOAD_SKIP", "1") != "0") else None
         pocket_in_place = (src is not None and ent.get("uploaded") is not None and ent.get("uploaded_pw") is pw
                            and ent.get("uploaded_mode") == d.get("upload_mode") and len(src) == len(ent["uploaded"])
                            and all(t is u and (t is None or t._version == ver) for t, (u, ver) in zip(src, ent["uploaded"])))

@@ -443,6 +443,17 @@ def network_padded(model, protein_pos, protein_v, ligand_pos, ligand_v, ligand_v
             "pred_bond": out["pred_bond"].index_select(0, rows_b)}
 
 
+# While a step is being CAPTURED every cached object the capture reads (index structures, segment plans) is appended here:
+# the graph bakes in their device addresses, so the graph entry keeps them alive whatever the caches evict later
+_PIN = None
+
+
+def _pin(obj):
+    if _PIN is not None:
+        _PIN.append(obj)
+    return obj
+
+
 _STRUCT: Dict = {}
 _STRUCT_MAX_BYTES = int(os.environ.get("DD_TRAIN_STRUCT_CACHE_MB", "512")) << 20     # device memory the cached index structures may hold
 _STRUCT_MAX_ENTRIES = 16
@@ -466,7 +477,7 @@ def _structure(B, NP, NL, K, dev):
     S = _STRUCT.pop(key, None)
     if S is not None:
         _STRUCT[key] = S                                   # re-inserted: most recently used last
-        return S
+        return _pin(S)
     N = NP + NL
     is_lig = torch.cat([torch.zeros(NP, dtype=torch.bool), torch.ones(NL, dtype=torch.bool)]).repeat(B).to(dev)
     lig_rows = is_lig.nonzero().squeeze(1)
@@ -508,7 +519,7 @@ def _structure(B, NP, NL, K, dev):
         _STRUCT[key] = S
         while len(_STRUCT) > _STRUCT_MAX_ENTRIES or sum(v["_bytes"] for v in _STRUCT.values()) > _STRUCT_MAX_BYTES:
             _STRUCT.pop(next(iter(_STRUCT)))               # least recently used first
-    return S
+    return _pin(S)
 
 
 def _knn_src(x, B, N, K, base, NP=None, pad=None):
@@ -715,7 +726,7 @@ def _static_plan(batch, B, n_l, bonds):
         if len(_PLANS) > 64:
             _PLANS.clear()
         plan = _PLANS[key] = seg_plan(batch.clone(), B)
-    return plan
+    return _pin(plan)
 
 
 def FN_mean(per_row, batch, n):
@@ -875,8 +886,10 @@ def pad_prepared(model, prep: Dict, bucket=(32, 4)) -> Optional[Dict]:
                w_l=torch.zeros(B * NLm, device=dev).index_fill(0, rows_l, 1.0),
                w_b=torch.zeros(B * Ebm, device=dev).index_fill(0, rows_b, 1.0),
                np_real=torch.tensor(n_p, dtype=torch.int32, device=dev), nl_real=torch.tensor(n_l, dtype=torch.int32, device=dev))
-    out["cnt_p"], out["cnt_l"] = out["np_real"].float(), out["nl_real"].float()
-    out["cnt_b"] = out["cnt_l"] * (out["cnt_l"] - 1.0)
+    # (counts clamped to 1 like torch_scatter's scatter_mean: a one-atom ligand has no bonds and an empty pocket no atoms -- 0 / 0
+    #  would poison the step, the ragged path and the reference give 0)
+    out["cnt_p"], out["cnt_l"] = out["np_real"].float().clamp(min=1.0), out["nl_real"].float().clamp(min=1.0)
+    out["cnt_b"] = (out["nl_real"].float() * (out["nl_real"].float() - 1.0)).clamp(min=1.0)
     out["rows_l"], out["rows_b"] = rows_l, rows_b           # (for callers that want the real rows back; not used by the objective)
     return out
 
@@ -973,9 +986,17 @@ class GraphedTrainStep:
     (optimizer steps, ``load_state_dict``) are seen by the next replay, but anything that gives the parameters new storage
     (``model.to(...)``, re-creating the optimizer) needs a new ``GraphedTrainStep``.  At most ``max_graphs`` graphs are kept (least
     recently used first out); each holds the activations of one iteration of its shape (~5 GB at B = 4, 300 + 30 atoms).
-    ``step(**kw)`` takes get_diffusion_loss's keyword arguments and returns {"loss", "losses": {pos, v, bond}} (detached)."""
+    ``step(**kw)`` takes get_diffusion_loss's keyword arguments and returns {"loss", "losses": {pos, v, bond}} (detached).
 
-    def __init__(self, model, optimizer, loss_weights=(1.0, 100.0, 100.0), warmup: int = 3, max_graphs: int = 4, bucket=(32, 4)):
+    ``max_grad_norm`` (the reference clips: ``clip_grad_norm_(model.parameters(), config.train.max_grad_norm)`` between backward and
+    ``optimizer.step()``, scripts/train_diffusion_decomp.py:195; configs/training.yml: 8.0): the same call (foreach, no host
+    sync) inside the captured region and the eager steps.  Learning rate: with ``capturable=True`` a Python-float ``lr`` is baked
+    into the graph at capture time -- pass ``lr=torch.tensor(...)`` (a scheduler then updates it in place and replays see it); if
+    a float ``lr`` of a param group changes (ReduceLROnPlateau), the graphs captured with the old value are dropped and re-captured.
+    Everything a capture read from the module-level caches (index structures, segment plans) is pinned in its graph entry."""
+
+    def __init__(self, model, optimizer, loss_weights=(1.0, 100.0, 100.0), warmup: int = 3, max_graphs: int = 4, bucket=(32, 4),
+                 max_grad_norm=None):
         if not optimizer.defaults.get("capturable", False):
             raise ValueError("GraphedTrainStep needs an optimizer built with capturable=True (its state must live on the device)")
         self.model, self.opt, self.w = model, optimizer, tuple(float(x) for x in loss_weights)
@@ -984,6 +1005,15 @@ class GraphedTrainStep:
         self._graphs: Dict = {}
         self._side = None
         self.replays = self.eager_steps = 0
+        self.max_grad_norm = None if max_grad_norm is None else float(max_grad_norm)
+        self._params = [p for g in optimizer.param_groups for p in g["params"]]
+
+    def _clip(self):
+        if self.max_grad_norm is not None:
+            torch.nn.utils.clip_grad_norm_(self._params, self.max_grad_norm, foreach=True)
+
+    def _float_lrs(self):
+        return tuple(g["lr"] if not torch.is_tensor(g["lr"]) else None for g in self.opt.param_groups)
 
     def _total(self, res):
         lo = res["losses"]
@@ -994,6 +1024,7 @@ class GraphedTrainStep:
         res = (fn or objective)(self.model, prep)
         loss = self._total(res)
         loss.backward()
+        self._clip()
         self.opt.step()
         self.eager_steps += 1
         return {"loss": loss.detach(), "losses": {k: v.detach() for k, v in res["losses"].items()}}
@@ -1023,6 +1054,9 @@ class GraphedTrainStep:
             key = ("padded", data["B"], data["NPm"], data["NLm"], str(dev))
             names, fn = PAD_TENSORS, objective_padded
         ent = self._graphs.get(key)
+        if ent is not None and ent["lrs"] != self._float_lrs():   # a float lr changed since the capture: it is baked into the graph
+            self._graphs.pop(key)
+            ent = None
         if ent is None:
             n = self._seen.get(key, 0)
             self._seen[key] = n + 1
@@ -1042,13 +1076,20 @@ class GraphedTrainStep:
                 static[k] = data[k].clone()
             self.opt.zero_grad(set_to_none=True)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=self._side):
-                res = fn(model, static)
-                loss = self._total(res)
-                loss.backward()
-                self.opt.step()
+            global _PIN
+            pins, _PIN = [], []
+            try:
+                with torch.cuda.graph(graph, stream=self._side):
+                    res = fn(model, static)
+                    loss = self._total(res)
+                    loss.backward()
+                    self._clip()
+                    self.opt.step()
+                pins = _PIN
+            finally:
+                _PIN = None
             cur.wait_stream(self._side)
-            ent = self._graphs[key] = dict(graph=graph, static=static, names=names, loss=loss.detach(),
+            ent = self._graphs[key] = dict(graph=graph, static=static, names=names, loss=loss.detach(), keep=pins, lrs=self._float_lrs(),
                                            losses={k: v.detach() for k, v in res["losses"].items()})
             # (the capture itself computed nothing: this iteration's update happens in the replay below)
         else:

@@ -224,7 +224,8 @@ int dd_gemm128_tn_bias(const float* A, int lda, int M, const float* X, int ldx, 
  *   forward : y[r] = relu(LN(x[r]) * gamma + beta) (eps 1e-5), stats[r] = (mean, 1/std) kept for the backward;
  *   backward: dx from dy (the ReLU mask is recomputed from x), dgamma[128] / dbeta[128] summed over the rows in a fixed order
  *             (no atomics); scratch: dd_ln_relu_scratch_floats(rows) floats.
- * Rows are contiguous ([rows,128] fp32, 8-byte aligned).  (Round 5; new entry points, ABI unchanged.) */
+ * Rows are contiguous [rows,128] fp32; x / y / dy / dx / gamma / beta 16-byte aligned (read as float4), stats 8-byte aligned
+ * (checked: DD_ERR_BAD_ARG otherwise); rows == 0 is DD_OK both ways.  (Round 5; new entry points, ABI unchanged.) */
 size_t dd_ln_relu_scratch_floats(long rows);
 int dd_ln_relu_forward(const float* x, const float* gamma, const float* beta, float* y, float* stats, long rows, void* stream);
 int dd_ln_relu_backward(const float* x, const float* stats, const float* gamma, const float* beta, const float* dy, float* dx,

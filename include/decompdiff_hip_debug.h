@@ -70,6 +70,8 @@ typedef struct dd_ws_view {
   float *x, *h, *hb, *ew, *A;
   int32_t* nbr;
   float* Anb;   /* [B,NL,128] node_layer_with_bond output of the last layer when the fused launch is used, else NULL */
+  int32_t lin_in_node;   /* 1: lin_node ran inside the node launch -- `h` is the final h WITHOUT W_lin . A_nb of the last layer on the
+                            ligand rows, `Anb` holds exactly that pending term (add it to h[:, NP:]), `A` is NULL (never materialised) */
 } dd_ws_view;
 int dd_workspace_view(const dd_sampler* s, dd_ws_view* out);
 
