@@ -191,9 +191,11 @@ def sample_diffusion(sd, cfg, *, protein_pos, protein_v, batch_protein, init_lig
     lowered: time_seq = reversed(range(num_timesteps - num_steps, num_timesteps)), :575).
     """
     assert cfg.model_mean_type == "C0"
-    pt = position_tables(cfg)
-    vt = categorical_tables(cfg, num_classes, prior_atom_types)          # (decompdiff.py:137-144)
-    bt = categorical_tables(cfg, cfg.num_bond_classes, prior_bond_types)
+    dev = protein_pos.device                              # (the tables follow the inputs: a no-op on the CPU, where the oracle is pinned;
+    on_dev = lambda d: {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in d.items()}    # make_sensitivity --device cuda runs it on ATen's HIP kernels)
+    pt = on_dev(position_tables(cfg))
+    vt = on_dev(categorical_tables(cfg, num_classes, prior_atom_types))          # (decompdiff.py:137-144)
+    bt = on_dev(categorical_tables(cfg, cfg.num_bond_classes, prior_bond_types))
     T = cfg.num_diffusion_timesteps
     if num_steps is None:
         num_steps = T
@@ -208,7 +210,7 @@ def sample_diffusion(sd, cfg, *, protein_pos, protein_v, batch_protein, init_lig
     if t_start is not None:
         T = t_start + 1
     for step, i in enumerate(reversed(range(T - num_steps, T))):
-        t = torch.full((num_graphs,), i, dtype=torch.long)
+        t = torch.full((num_graphs,), i, dtype=torch.long, device=dev)
         with torch.no_grad():
             preds = M.forward(sd, cfg, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, ligand_v_aux,
                               batch_ligand, ligand_fc_bond_index, ligand_bond, ligand_atom_mask, num_classes)

@@ -37,6 +37,11 @@ STD_SCALE = {"traj1000_b8_drift": [1.0, 0.9, 0.8, 1.1, 1.0, 0.95, 1.05, 0.85]}
 
 def ulp_nudge(pos, gen):
     """In place: every element to its lower neighbour, itself or its upper neighbour in fp32 (1/3 each)."""
+    if pos.device.type != "cpu":
+        s = torch.randint(0, 3, pos.shape, generator=gen).to(pos.device)
+        inf = torch.full_like(pos, float("inf"))
+        pos.copy_(torch.where(s == 0, torch.nextafter(pos, -inf), torch.where(s == 2, torch.nextafter(pos, inf), pos)))
+        return
     a = pos.numpy()
     s = torch.randint(0, 3, pos.shape, generator=gen).numpy()
     lo = np.nextafter(a, np.float32(-np.inf))
@@ -52,6 +57,9 @@ def main():
     ap.add_argument("--first-seed", type=int, default=9000, help="seed of the first replay (parallel processes: distinct ranges)")
     ap.add_argument("--out", default=None, help="output file (default tests/golden/sens_<name>.npz)")
     ap.add_argument("--steps", type=int, default=0, help="(timing probe) stop after this many steps; nothing is written")
+    ap.add_argument("--device", default="cpu", help="cpu (the pinned oracle) or cuda: the SAME oracle code on ATen's HIP kernels -- a third, "
+                    "independent fp32 implementation of the step (rocBLAS GEMMs, ATen reductions), ~100 x faster; the un-nudged run is then "
+                    "itself a chain that differs from the reference at the ulp level (stored as run -1: seed -1)")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     name = args.name
@@ -66,6 +74,11 @@ def main():
     noise = synth.draw_step_noise(n_steps, b["init_ligand_pos"].size(0), b["init_ligand_fc_bond_type"].size(0))
     assert np.allclose(GU.checksum(noise), g["noise_checksum"])
     drift = json.loads(str(g["drift"]))
+    dev = torch.device(args.device)
+    if dev.type != "cpu":
+        sd = {k: v.to(dev) for k, v in sd.items()}
+        b = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
+        noise = {k: v.to(dev) for k, v in noise.items()}
     out_path = args.out or os.path.join(GU.GOLDEN, f"sens_{name}.npz")
     if args.steps:
         import time
@@ -74,13 +87,19 @@ def main():
         print(f"{args.steps} steps: {(time.time() - t0) / args.steps:.2f} s / step at {args.threads} threads")
         return
     errs, errs_s, mvs, mbs = [], [], [], []
-    for run in range(args.runs):
-        gen = torch.Generator().manual_seed(args.first_seed + run)
+    seeds = list(range(args.first_seed, args.first_seed + args.runs))
+    if dev.type != "cpu":
+        seeds = [-1] + seeds                                  # the plain (un-nudged) chain of this implementation first
+    for seed in seeds:
+        gen = torch.Generator().manual_seed(max(seed, 0))
 
-        def hook(step, t, pos, v, bond, preds):
-            ulp_nudge(pos, gen)
+        def hook(step, t, pos, v, bond, preds, seed=seed):
+            if seed >= 0:
+                ulp_nudge(pos, gen)
 
         r = OD.sample_diffusion(sd, cfg, num_steps=n_steps, energy_drift_opt=drift, noise=noise, step_hook=hook, **b)
+        r = {k: ([t.cpu() for t in v] if isinstance(v, list) else v.cpu()) for k, v in r.items()}
+        run = seed
         tp = torch.stack(r["pos_traj"]).numpy()[every - 1::every]
         errs.append(np.abs(tp.astype(np.float64) - g["traj_pos"]).reshape(len(tp), -1).max(1))
         errs_s.append(np.abs(tp.astype(np.float64) - g["traj_pos"]).reshape(len(tp), n_data, -1).max(2))     # [checkpoint, sample]
@@ -90,7 +109,7 @@ def main():
               f"bond={int(mbs[-1].sum())}", flush=True)
         E = np.stack(errs)
         np.savez_compressed(out_path, fixture=np.array(name), perturbation=np.array("-1/0/+1 ulp per coordinate per step, p=1/3 each"),
-                            seeds=np.arange(args.first_seed, args.first_seed + len(errs)), every=np.array(every), num_steps=np.array(n_steps),
+                            seeds=np.array(seeds[:len(errs)]), device=np.array(str(dev)), every=np.array(every), num_steps=np.array(n_steps),
                             pos_err=E, pos_err_sample=np.stack(errs_s), v_mismatch=np.stack(mvs), bond_mismatch=np.stack(mbs),
                             pos_err_min=E.min(0), pos_err_median=np.median(E, 0), pos_err_max=E.max(0))
 
