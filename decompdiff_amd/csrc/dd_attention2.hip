@@ -355,14 +355,18 @@ __host__ __device__ inline int ne_blocks_per_sample(int NP, int NL, int NW) { re
 // workgroups), and its two halves only meet at the very end: wave 0 of a pair runs the query MLP, the fold, the k pass and
 // the softmax, wave 1 meanwhile the v pass (activations and the 16 per-head values of every member); the attention
 // weights cross through LDS behind one workgroup barrier and wave 1 forms the coordinate update.
-template <int MODE, int MAXT, int NW, bool PERSIST = false, bool RAG = false, bool PAIR = false, bool STAMPS = true, typename ARGS = AttnArgs>
+// PAIR = 2 (QUAD, round 6): four waves per segment -- the two 16-member tiles of a kNN segment (odd / even tiles of a longer bond
+// segment) go to different waves on both sides; the softmax's max and sum and the two halves of the coordinate update cross through
+// LDS (3 more workgroup barriers).  With NW = 2 segments per workgroup the launch has 240 workgroups instead of 120.
+template <int MODE, int MAXT, int NW, bool PERSIST = false, bool RAG = false, int PAIR = 0, bool STAMPS = true, typename ARGS = AttnArgs>
 __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float* smem) {
   constexpr bool KNN = (MODE == M_NE || MODE == M_PE);
   constexpr bool POS = (MODE == M_PE || MODE == M_PB);
   constexpr bool TRIP = (MODE == M_BL);
   constexpr bool BOND = (MODE == M_NB || MODE == M_PB);
   static_assert(!PAIR || (POS && !PERSIST), "wave pairs: coordinate modes");
-  constexpr int NT = (PAIR ? 2 : 1) * NW * 64;
+  constexpr bool QUAD = PAIR == 2;
+  constexpr int NT = (QUAD ? 4 : (PAIR ? 2 : 1)) * NW * 64;
   using L = Lds<MODE>;
   constexpr int LNP = L::LNP, WAO = L::WAO;
   constexpr bool RES = L::RES;
@@ -372,7 +376,9 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
   // (pairs: waves p and p + NW -- one k-side and one v-side wave on every SIMD, which want different units at a time)
   const int wave = PAIR ? ((threadIdx.x >> 6) % NW) : (threadIdx.x >> 6), lane0 = threadIdx.x & 63;
   const int role = PAIR ? ((threadIdx.x >> 6) / NW) : 0;  // 0: query / k pass / softmax, 1: v pass / coordinate update
-  const bool kside = !PAIR || role == 0, vside = !PAIR || role == 1;
+  const bool kside = !PAIR || (QUAD ? role < 2 : role == 0), vside = !PAIR || (QUAD ? role >= 2 : role == 1);   // (QUAD: roles 0, 1 / 2, 3)
+  const int tsel = role & 1;                              // QUAD: this wave's tiles are t = tsel, tsel + 2, ...
+  auto mine = [&](int t) { return !QUAD || (t & 1) == tsel; };
 
   const int N = a.NP + a.NL, NLm1 = a.NL - 1, Eb = a.NL * NLm1;
   // Padded heterogeneous batch (a.nl_real != NULL): sample b's real atoms are the first np_real[b] / nl_real[b] rows of
@@ -545,7 +551,7 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
   } else if (POS && a.W2q != nullptr && kside) {
     // coordinate modes: the query MLP's second layer runs here (q = W2q . relu(LN(hidden)) + b2q, one 128x128
     // mat-vec per segment) instead of as a 16-tile GEMM launch on the critical chain.  Lane l owns outputs 2l, 2l+1.
-    float* sc = smem + L::TOTAL + wave * 256;
+    float* sc = smem + L::TOTAL + (QUAD ? wave + NW * tsel : wave) * 256;   // (QUAD: both k waves of a segment form the query, each in its own scratch)
     if (active) {
       float2 hv = *reinterpret_cast<const float2*>(a.qhid + drow * a.ld_qhid + 2 * lane);
       ln_relu2(hv.x, hv.y, a.lnq[2 * lane], a.lnq[2 * lane + 1], a.lnq[128 + 2 * lane], a.lnq[128 + 2 * lane + 1]);
@@ -604,7 +610,7 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
   const float* rc_row = TRIP ? a.Rk + (long)seg * 128 : a.kd + drow * a.ld_kd;
   if (active && kside) {
     if (!REREAD) load_row(Rc, rc_row, cg);
-    fetch_k_rows(0);
+    fetch_k_rows(QUAD ? tsel : 0);
     if (TRIP) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) { tri_i[c] = xl[3 * si + c]; tri_j[c] = xl[3 * sj + c]; }
@@ -750,7 +756,8 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
           if (BOND) P[k] += Pf2[k];
         }
       }
-      if (t + 1 < MAXT && (DD_UNCOND_FETCH || t + 1 < T)) fetch_k_rows(t + 1);   // next tile's rows fly during this tile's arithmetic
+      if (QUAD) { if (t + 2 < MAXT) fetch_k_rows(t + 2); }
+      else if (t + 1 < MAXT && (DD_UNCOND_FETCH || t + 1 < T)) fetch_k_rows(t + 1);   // next tile's rows fly during this tile's arithmetic
                                                               // (unconditional: members are clipped, a tile beyond T re-reads row M - 1)
     } else if (KNN) {
       load_row(P, tab_d + drow * ld_d, cg);
@@ -853,7 +860,7 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
   if (active && kside) {
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
-      if (t < T) {
+      if (t < T && mine(t)) {
         float P[32];
         build_pre(t, 0, P);
         S[t] = mfma_rows(P, Qb);
@@ -867,6 +874,7 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
     }
     DD_STAMP(5);
     if (!POS) fetch_T(0);                              // v-pass rows of tile 0 arrive during the softmax
+    if constexpr (!QUAD) {
     // segment softmax per head: max-shift, exp, / sum  (scatter_softmax), then * e_w
     float mx = -INFINITY;
 #pragma unroll
@@ -901,9 +909,53 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
         ssum += aw;
       }
     ssum = quad_sum(ssum);
+    }
   } else {
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) S[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // QUAD: the two k-side waves of a segment hold the scores of different tiles -- the per-head max and sum cross through LDS
+  float* const exq = smem + L::TOTAL + 2 * NW * 256 + NW * MAXT * 256;   // [NW][2][16] max, [NW][2][16] sum, [NW][2][4] dx partials
+  if constexpr (QUAD) {
+    const bool ks = active && kside;
+    float mx = -INFINITY;
+    if (ks) {
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, S[t][r]);
+      mx = quad_max(mx);
+      if (cg == 0) exq[(wave * 2 + tsel) * 16 + mm] = mx;
+    }
+    __syncthreads();
+    float sum = 0.f;
+    if (ks) {
+      mx = fmaxf(exq[(wave * 2) * 16 + mm], exq[(wave * 2 + 1) * 16 + mm]);
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = (16 * t + 4 * cg + r < M && mine(t)) ? expf(S[t][r] - mx) : 0.f;
+          S[t][r] = e;
+          sum += e;
+        }
+      sum = quad_sum(sum);
+      if (cg == 0) exq[NW * 32 + (wave * 2 + tsel) * 16 + mm] = sum;
+    }
+    __syncthreads();
+    if (ks) {
+      sum = exq[NW * 32 + (wave * 2) * 16 + mm] + exq[NW * 32 + (wave * 2 + 1) * 16 + mm];   // (the same order in both waves)
+      const float rsum = 1.0f / sum;
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = 16 * t + 4 * cg + r;
+          float w = 1.0f;
+          if (KNN) w = ewm[t][r];
+          S[t][r] = (m < M && mine(t)) ? (S[t][r] * rsum) * w : 0.f;
+        }
+    }
   }
   DD_STAMP(6);
   DD_STAMP(7);
@@ -911,7 +963,7 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
   // ---- pass 2 -----------------------------------------------------------------------------------------------
   if (POS) {
     // wave pairs: the weights go from the k side to the v side through LDS, [tile][r][lane] per pair, behind one barrier
-    float* xw = smem + L::TOTAL + NW * 256 + wave * (MAXT * 4 * 64);
+    float* xw = smem + L::TOTAL + (QUAD ? 2 : 1) * NW * 256 + wave * (MAXT * 4 * 64);
     f32x4 Vt[MAXT];                                    // V[r] = v16[member 16t+4cg+r][head mm] - bias
     if (active && vside) {
       float Wv[32];
@@ -922,7 +974,7 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
       }
 #pragma unroll
       for (int t = 0; t < MAXT; ++t) {
-        if (t < T) {
+        if (t < T && mine(t)) {
           float P[32];
           build_pre(t, 1, P);
           Vt[t] = mfma_rows(P, Wv);
@@ -930,27 +982,31 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
       }
     }
     if (PAIR) {
-      if (active && role == 0) {
+      if (active && kside) {
 #pragma unroll
         for (int t = 0; t < MAXT; ++t)
+          if (mine(t)) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) xw[(t * 4 + r) * 64 + lane] = S[t][r];
+            for (int r = 0; r < 4; ++r) xw[(t * 4 + r) * 64 + lane] = S[t][r];
+          }
       }
       __syncthreads();
-      if (role == 0) { DD_STAMP(10); return; }
-      if (active) {
+      if (!QUAD && role == 0) { DD_STAMP(10); return; }
+      if (active && vside) {
 #pragma unroll
         for (int t = 0; t < MAXT; ++t)
+          if (mine(t)) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) S[t][r] = xw[(t * 4 + r) * 64 + lane];
+            for (int r = 0; r < 4; ++r) S[t][r] = xw[(t * 4 + r) * 64 + lane];
+          }
       }
     }
-    if (active) {
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (active && vside) {
       const float bv = a.b2v16[mm];
-      float dx = 0.f, dy = 0.f, dz = 0.f;
 #pragma unroll
       for (int t = 0; t < MAXT; ++t) {
-        if (t < T) {
+        if (t < T && mine(t)) {
           const f32x4 V = Vt[t];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -971,6 +1027,15 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
       dx = wave_sum(dx) * (1.0f / 16.0f);
       dy = wave_sum(dy) * (1.0f / 16.0f);
       dz = wave_sum(dz) * (1.0f / 16.0f);
+      if (QUAD && lane < 3) exq[NW * 64 + (wave * 2 + tsel) * 4 + lane] = lane == 0 ? dx : (lane == 1 ? dy : dz);
+    }
+    if (QUAD) __syncthreads();                         // (the two halves of the update; every wave of the workgroup arrives here)
+    if (active && vside && (!QUAD || tsel == 0)) {
+      if (QUAD) {                                      // even tiles + odd tiles, in this order
+        dx = exq[NW * 64 + (wave * 2) * 4 + 0] + exq[NW * 64 + (wave * 2 + 1) * 4 + 0];
+        dy = exq[NW * 64 + (wave * 2) * 4 + 1] + exq[NW * 64 + (wave * 2 + 1) * 4 + 1];
+        dz = exq[NW * 64 + (wave * 2) * 4 + 2] + exq[NW * 64 + (wave * 2 + 1) * 4 + 2];
+      }
       if (lane < 3) {
         const float v = lane == 0 ? dx : (lane == 1 ? dy : dz);
         if (MODE == M_PE || a.x_next == nullptr) {
@@ -1651,6 +1716,17 @@ __global__ __launch_bounds__(NW * 128) void k_attn2_pos(const AttnArgs pe, const
   }
 }
 
+// QUAD variant (four waves per segment, NW = 2 segments per workgroup: attn2_body's PAIR = 2)
+template <int MAXT, int NW, bool RAG = false>
+__global__ __launch_bounds__(NW * 256) void k_attn2_pos_q(const AttnArgs pe, const AttnArgs pb, int n_pe) {
+  // + two query-MLP scratch rows per segment + the weights' hand-over + the max / sum / update exchange
+  constexpr int SZ = imax(Lds<M_PE>::TOTAL, Lds<M_PB>::TOTAL) + 2 * NW * 256 + NW * MAXT * 256 + NW * 64 + NW * 8 + 16;
+  __shared__ __attribute__((aligned(16))) float smem[SZ];
+  const int blk = blockIdx.x;
+  if (blk < n_pe) attn2_body<M_PE, 2, NW, false, RAG, 2, false>(pe, blk, smem);
+  else attn2_body<M_PB, MAXT, NW, false, RAG, 2, false>(pb, blk - n_pe, smem);
+}
+
 #if defined(DD_DEBUG_OPTIONS) && DD_DEBUG_OPTIONS
 // ---- coordinate launch with the projections of the new h inside (k_attn2_pos_g) -------------------------------------------
 // MEASUREMENT BUILD ONLY (dd_debug_set_option(30, 1)): bit-identical, but the launch takes 40 us where the two launches it
@@ -1719,6 +1795,7 @@ __global__ __launch_bounds__(NW * 128) void k_attn2_pos_g(const AttnArgs pe, con
 template __global__ void k_attn2_node<2, 8, false>(const AttnArgs, const AttnArgs, const AttnArgs, int, int, int, int, const int32_t*, int, int);
 template __global__ void k_attn2_pos<2, 4, false>(const AttnArgs, const AttnArgs, int);
 template __global__ void k_attn2_bl_coop<2, false>(const AttnArgs);
+template __global__ void k_attn2_pos_q<2, 2, false>(const AttnArgs, const AttnArgs, int);
 }  // namespace v2
 }  // namespace dd
 #else
@@ -1936,8 +2013,28 @@ int launch_attn2_pos_g(const AttnArgs& pe_in, const AttnArgs& pb_in, const GemmA
 }
 
 int g_pos_waves = 4;         // waves per workgroup of the fused coordinate launch: 2, 4 or 8
+#ifndef DD_POS_QUAD
+#define DD_POS_QUAD 1
+#endif
+int g_pos_quad = DD_POS_QUAD;   // four waves per segment, two segments per workgroup (k_attn2_pos_q); no in-launch x update in this form
+static int launch_pos_quad(const AttnArgs& pe, const AttnArgs& pb, hipStream_t st) {
+  using namespace v2;
+  constexpr int NW = 2;
+  const int n = (pe.B * pe.NL + NW - 1) / NW;
+  const dim3 grid(2 * n), block(NW * 256);
+  if (pe.nl_real != nullptr) {
+    if (pe.NL > 65) hipLaunchKernelGGL((k_attn2_pos_q<8, NW, true>), grid, block, 0, st, pe, pb, n);
+    else if (pe.NL > 33) hipLaunchKernelGGL((k_attn2_pos_q<4, NW, true>), grid, block, 0, st, pe, pb, n);
+    else hipLaunchKernelGGL((k_attn2_pos_q<2, NW, true>), grid, block, 0, st, pe, pb, n);
+  } else if (pe.NL > 65) hipLaunchKernelGGL((k_attn2_pos_q<8, NW>), grid, block, 0, st, pe, pb, n);
+  else if (pe.NL > 33) hipLaunchKernelGGL((k_attn2_pos_q<4, NW>), grid, block, 0, st, pe, pb, n);
+  else hipLaunchKernelGGL((k_attn2_pos_q<2, NW>), grid, block, 0, st, pe, pb, n);
+  DD_CHECK_LAUNCH();
+  return DD_OK;
+}
 int launch_attn2_pos(const AttnArgs& pe, const AttnArgs& pb, hipStream_t st) {
   if (pe.NL > 129) return DD_ERR_UNSUPPORTED_SHAPE;
+  if (g_pos_quad && pe.work_counter == nullptr) return launch_pos_quad(pe, pb, st);
   if (pe.NL > 65 && g_pos_waves > 4) return launch_pos_nw<4>(pe, pb, st);
   if (g_pos_waves == 2) return launch_pos_nw<2>(pe, pb, st);
   if (g_pos_waves == 4) return launch_pos_nw<4>(pe, pb, st);

@@ -113,7 +113,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.dd_workspace_floats.restype is ctypes.c_size_t and lib.dd_gemm128_tn_scratch_floats.restype is ctypes.c_size_t
     assert not any(n.startswith("dd_debug") or n.startswith("dd_profile") for n in hip_lib.EXPORTED_SYMBOLS)
     assert lib.dd_build_flags() == 0                         # the default library: no measurement variants compiled in
-    assert lib.dd_abi_version() == hip_lib.ABI_VERSION == 8
+    assert lib.dd_abi_version() == hip_lib.ABI_VERSION == 9 and lib.dd_weights_form() == 1   # (ABI 9: the attention MLPs in kernel form)
     assert lib.dd_status_string(0) == b"ok" and b"workspace" in lib.dd_status_string(-3)
     # pure host helper: workspace size grows with the batch and is non-zero
     w1, w8 = lib.dd_workspace_floats(1, 300, 30, 32), lib.dd_workspace_floats(8, 300, 30, 32)
