@@ -7,6 +7,9 @@
 
 namespace dd {
 
+#ifndef DD_GEMM_EARLY_HALF
+#define DD_GEMM_EARLY_HALF 1
+#endif
 constexpr int GT = 64;        // tile rows / cols
 constexpr int GP = 130;       // LDS row pitch (floats)
 
@@ -37,9 +40,11 @@ __device__ __forceinline__ void st4_sc1(float* base, long off, const float4& v) 
   const u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
   __builtin_amdgcn_raw_buffer_store_b128(u, rs, (int)(off * 4), 0, 16);
 }
+// (bias_pre: the thread's four bias values -- columns col0 + 4 (tid & 15) .. + 3, the same for its four output rows -- requested
+//  by the caller ahead of the MFMAs instead of behind the LDS round trip here; NULL: loaded here)
 template <bool SC1 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, float* sm /*>= 64*EP floats, free*/, const f32x16& acc,
-                                              int row0, int col0) {
+                                              int row0, int col0, const float4* bias_pre = nullptr) {
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, li = lane & 31, hh = lane >> 5;
 #pragma unroll
@@ -61,7 +66,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, float* sm /*>= 
     const long yoff = row_offset(gr, a.y_rows_per_b, a.y_stride_b, a.ldy, plain) + gc;
     float* dst = a.Y + yoff;
     if (vec_ok && gc + 3 < a.ncols) {
-      if (a.bias) { const float4 bb = *reinterpret_cast<const float4*>(a.bias + gc); o[0] += bb.x; o[1] += bb.y; o[2] += bb.z; o[3] += bb.w; }
+      if (a.bias) {
+        const float4 bb = bias_pre ? *bias_pre : *reinterpret_cast<const float4*>(a.bias + gc);
+        o[0] += bb.x; o[1] += bb.y; o[2] += bb.z; o[3] += bb.w;
+      }
       if (a.accumulate) {
         const float* ab = a.acc_src ? a.acc_src : a.Y;
         const float4 old = SC1 ? ld4_sc1(ab, yoff) : *reinterpret_cast<const float4*>(ab + yoff);
@@ -158,6 +166,13 @@ __device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx
   long long* dbg = (STAMPS && a.dbg) ? a.dbg + ((long)by * gridDim.x + bx) * 8 : nullptr;
 #define GSTAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
   GSTAMP(0);
+#if DD_GEMM_EARLY_HALF
+  // the epilogue's bias values, requested now (they used to be a dependent global load behind the output's LDS round trip)
+  const int bias_gc = col0 + (tid & 15) * 4;
+  const bool bias_ok = a.bias != nullptr && bias_gc + 3 < a.ncols;
+  float4 bias_pre = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias_ok) bias_pre = *reinterpret_cast<const float4*>(a.bias + bias_gc);
+#endif
   if (a.ln != nullptr) {
     // LayerNorm+ReLU prologue (MLP hidden activation): both K-halves of the rows are fetched first; a row's 128 channels
     // sit in one 16-lane DPP row (4 + 4 channels per lane), so mean / variance are 4-step row reductions
@@ -198,11 +213,26 @@ __device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx
     for (int k = 0; k < 4; ++k) xv[k] = x1[k];
     fetch_w(1, wv);
   } else {
+#if DD_GEMM_EARLY_HALF
+    // both K halves are requested before the first barrier (round 6): the second half's rows used to be requested behind the first
+    // half's LDS commit and barrier, ~0.6 us of their latency exposed after the first half's 32 MFMAs in the single-tile launches
+    // on the layer's critical chain; 16 more registers per thread, the 33 KB LDS image is unchanged
+    float4 x1[4], w1[4];
+    fetch(0);
+    fetch_x(1, x1);
+    fetch_w(1, w1);
+    commit();
+    __syncthreads();
+    GSTAMP(1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { xv[k] = x1[k]; wv[k] = w1[k]; }
+#else
     fetch(0);
     commit();
     __syncthreads();
     GSTAMP(1);
     fetch(1);
+#endif
   }
 #pragma unroll
   for (int kk = 0; kk < 16; ++kk) {
@@ -229,7 +259,11 @@ __device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx
   asm volatile("" : "+v"(acc));
   GSTAMP(4);
   __syncthreads();                                     // operands dead: the tile buffer becomes the output stage
+#if DD_GEMM_EARLY_HALF
+  gemm_epilogue<SC1>(a, smh, acc, row0, col0, bias_ok ? &bias_pre : nullptr);
+#else
   gemm_epilogue<SC1>(a, smh, acc, row0, col0);
+#endif
   if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); GSTAMP(5); }
 #undef GSTAMP
 }
