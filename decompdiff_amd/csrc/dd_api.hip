@@ -181,12 +181,23 @@ DD_OPT g_head_fused = 1;                   // dd_debug_set_option(24, v): head o
 DD_OPT g_side_lin = DD_SIDE_LIN_DEFAULT;   // dd_debug_set_option(27, v): ONE fork per layer -- the side stream forms the new h itself
                                                // (a second, identical lin_node launch into its own buffer) instead of waiting for the
                                                // main stream's lin_node, whose launch then has no cross-queue successor
-DD_OPT g_lin_in_node = 1;                  // dd_debug_set_option(32, v): lin_node (h += W_lin . A + b) inside the NE / NB blocks of the node launch
-                                               // (round 6): no lin_node launch on the layer's critical chain, one fork per layer instead of two
+// lin_node (h += W_lin . A + b) inside the NE / NB blocks of the node launch (round 6): no lin_node launch on the layer's critical
+// chain, one fork per layer instead of two.  -1 = by shape (lin_in_node_for): measured -7 % step time at B = 1 and +4 % at B = 8, where
+// the side stream's GEMM chain is the longer branch either way and the node launch pays ~9 us for the extra phase (EXPERIMENTS.md
+// R6-3); DD_LIN_IN_NODE=0/1 or dd_debug_set_option(32, v) force it.
+static int g_lin_in_node = [] { const char* e = getenv("DD_LIN_IN_NODE"); return e ? (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : -1)) : -1; }();
+// ... and with it the next layer's node projections ride in the main stream's projection launch (the side stream keeps the bond
+// projections and the query GEMMs): DD_LIN_PROJ_MAIN=0/1
+static int g_lin_proj_main = [] { const char* e = getenv("DD_LIN_PROJ_MAIN"); return e ? (e[0] == '1' ? 1 : 0) : 0; }();
+static bool lin_in_node_for(int B, int NL) {
+  if (g_lin_in_node >= 0) return g_lin_in_node != 0;
+  return (long)B * NL * (NL - 1) < 8L * 256 * 2;        // fewer than two bond-layer trips per CU: the launch chain, not the node launch, bounds the step
+}
 DD_OPT g_head_rows_first = 0;              // dd_debug_set_option(29, v): see the head of forward_impl
 DD_OPT g_heads_early = 1;                  // dd_debug_set_option(28, v): heads' first Linear in the last layer's projection launch
 DD_OPT g_q_in_pos = 1;                     // dd_debug_set_option(9, v): coordinate query MLPs' second layer inside attn_pos
 extern int g_pos_waves;                     // dd_attention2.hip: waves per workgroup of the coordinate launch
+extern int g_pos_quad;                      // dd_attention2.hip: four waves per segment in the coordinate launch (dd_debug_set_option(33, v))
 DD_OPT g_p2_in_pos = 0;                    // dd_debug_set_option(30, v): the projections of the new h ({P2, PL2}; in the last layer the
                                                // heads' first Linear too) run in the leading / trailing workgroups of the coordinate
                                                // launch instead of a launch of their own on the critical chain (round 5: bit-identical,
@@ -575,13 +586,16 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     // lin_node inside the node launch (g_lin_in_node): the NE blocks update h in place, the NB blocks leave W_lin . A_nb of this
     // layer in anb_cur (ping-pong between w.Anb and w.A, which no longer holds the attention output); every consumer of the new h
     // adds it to the ligand rows (GemmArgs::X2) and the next layer's NE blocks fold it into h
-    const bool lin_in_node = g_lin_in_node && g_lin_with_pb2 && !g_side_lin && g_heads_early;
+    const bool lin_in_node = lin_in_node_for(B, NL) && g_lin_with_pb2 && !g_side_lin && g_heads_early;
     float* const anb_cur = (l & 1) ? w.A : w.Anb;
     const float* const anb_prev = (lin_in_node && l > 0) ? ((l & 1) ? w.Anb : w.A) : nullptr;
     auto add_anb = [&](GemmArgs& g, bool all_nodes) {     // X rows of g: all nodes of the batch / the ligand rows only
       g.X2 = anb_cur; g.x2_N = all_nodes ? N : NL; g.x2_NP = all_nodes ? NP : 0;
     };
-    auto launch_batch1 = [&](int ll, hipStream_t sx) -> int { return launch_projections1(s, w, ll, hcur, w.P, sx, anb_prev); };
+    // (called for THIS layer at its head -- the previous layer's W_lin . A_nb is pending -- or for the NEXT one behind the node launch)
+    auto launch_batch1 = [&](int ll, hipStream_t sx) -> int {
+      return launch_projections1(s, w, ll, hcur, w.P, sx, ll == l ? anb_prev : (lin_in_node ? anb_cur : nullptr));
+    };
     // (schedule 2) the same projections in two launches: the bond part only needs h_bond, final once the node
     // attention is done; the node parts need h (lin_node)
     // (hsrc: the h the node parts read; lin_dup: the lin_node job that forms it first, one-fork schedule)
@@ -602,6 +616,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     const bool ahead_split = overlap && g_sched >= 2;
     const bool ahead_b2 = overlap && g_sched >= 3 && g_q1_in_gemm && g_gemm_ksplit_on();
     const bool two_joins = ahead_b2 && g_sched >= 4;     // g_ev_qb_fork[l]: layer l's projections done (side stream)
+    const bool proj_main = lin_in_node && g_lin_proj_main && two_joins && ahead_split;   // next layer's node projections in the main launch
     const bool pb_early = g_pb_early && g_lin_with_pb2 && !ahead && !lin_in_node;   // next layer's bond projections ride with lin_node
     const bool l0_here = l0 && l == 0;                  // this layer's projection / query rows came from the tables
     if (pb_early && l > 0) DD_TRYP(DD_PROF_GEMM, launch_batch1_part(l, 1, st, hcur, nullptr));
@@ -709,7 +724,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
         DD_TRYP(DD_PROF_GEMM, launch_gemm128(g, st));
       }
     }
-    if (ahead && !side_lin && l + 1 < s->num_layers && hipEventRecord(g_ev_fork[l + 1], st) != hipSuccess) return DD_ERR_HIP;   // h, h_bond final
+    if (ahead && !side_lin && !proj_main && l + 1 < s->num_layers && hipEventRecord(g_ev_fork[l + 1], st) != hipSuccess) return DD_ERR_HIP;   // h, h_bond final
     // ---- projections of the new h / h_bond: one launch.  In the LAST layer the heads' first Linear (decompdiff.py:194-211:
     //      bond head on the final h_bond, v head on the ligand rows of the final h) rides along: it needs nothing the coordinate
     //      sub-layers produce, and as a launch of its own behind them it sat on the step's critical chain (8 us per step)
@@ -732,12 +747,22 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
       p2x[p2xn++] = p2j[1]; add_anb(p2x[1], false);
       p2x[p2xn++] = gemm_args(w.hb, nE, 0, 128, nE, LW(l, DD_W_b2), LW(l, DD_b_b2), nullptr, w.PB2, nE, 0, 256, 256, 0);
       if (p2n == 4) { p2x[p2xn++] = p2j[2]; p2x[p2xn] = p2j[3]; add_anb(p2x[p2xn], false); ++p2xn; }
+      if (proj_main && l + 1 < s->num_layers) {           // the next layer's node projections (the side stream is the longer branch otherwise)
+        p2x[p2xn] = gemm_args(hcur, B * N, 0, 128, B * N, LW(l + 1, DD_W_n1), LW(l + 1, DD_b_n1), nullptr, w.P, B * N, 0, 640, 640, 0);
+        add_anb(p2x[p2xn], true); ++p2xn;
+        p2x[p2xn] = gemm_args(hcur + (long)NP * 128, NL, hN, 128, B * NL, LW(l + 1, DD_W_l1), LW(l + 1, DD_b_l1), nullptr, w.PL, B * NL, 0, 1280, 1280, 0);
+        add_anb(p2x[p2xn], false); ++p2xn;
+      }
     }
     // (round 5) these jobs ride INSIDE the coordinate launch below when it can take them (launch_attn2_pos_g): the attention
     // workgroups wait for the first two, the heads' tiles trail behind them
     bool p2_in_pos = g_p2_in_pos && g_lin_with_pb2 && g_q_in_pos && !g_xup_in_pos && g_pos_waves == 4 && NL <= 65 && l < 64 &&
                      !(overlap && !ahead);
-    if (lin_in_node) { p2_in_pos = false; DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(p2x, p2xn, st)); }
+    if (lin_in_node) {
+      p2_in_pos = false;
+      DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(p2x, p2xn, st));
+      if (proj_main && l + 1 < s->num_layers && hipEventRecord(g_ev_fork[l + 1], st) != hipSuccess) return DD_ERR_HIP;   // P, PL of the next layer
+    }
     else if (!p2_in_pos) DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(p2j, p2n, st));
     const bool q_in_pos = g_q_in_pos;           // second layer of the coordinate query MLPs inside attn_pos
     if (!q_in_pos) {
@@ -795,8 +820,9 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
         if (hipStreamWaitEvent(g_side, g_ev_qa_fork[l + 1], 0) != hipSuccess) return DD_ERR_HIP;
         DD_TRY(launch_batch1_part(l + 1, 0, g_side, nullptr, side_lin ? &lin_dup : nullptr));
         if (!side_lin && !lin_in_node && hipStreamWaitEvent(g_side, g_ev_fork[l + 1], 0) != hipSuccess) return DD_ERR_HIP;   // (lin_in_node: h is final with h_bond)
-        DD_TRY(launch_batch1_part(l + 1, 1, g_side, side_lin ? w.hs : hcur, nullptr));
+        if (!proj_main) DD_TRY(launch_batch1_part(l + 1, 1, g_side, side_lin ? w.hs : hcur, nullptr));
         if (two_joins && hipEventRecord(g_ev_qb_fork[l + 1], g_side) != hipSuccess) return DD_ERR_HIP;
+        if (proj_main && hipStreamWaitEvent(g_side, g_ev_fork[l + 1], 0) != hipSuccess) return DD_ERR_HIP;   // the main stream's P, PL
         if (ahead_b2) DD_TRY(launch_b2(l + 1, g_side));
       } else {
         if (hipStreamWaitEvent(g_side, g_ev_fork[l + 1], 0) != hipSuccess) return DD_ERR_HIP;
@@ -891,7 +917,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
     GemmArgs j[2] = {
         gemm_args(w.hb, (int)(B * Eb), 0, 128, (int)(B * Eb), GW(DD_G_BH_W1), GW(DD_G_BH_b1), nullptr, w.qb, (int)(B * Eb), 0, 128, 128, 0),
         gemm_args(hcur + (long)NP * 128, NL, hN, 128, B * NL, GW(DD_G_VH_W1), GW(DD_G_VH_b1), nullptr, w.qn, B * NL, 0, 128, 128, 0)};
-    if (fused && g_lin_in_node && g_lin_with_pb2 && !g_side_lin && g_heads_early) {   // (lin_in_node: the last layer's W_lin . A_nb is pending)
+    if (fused && lin_in_node_for(B, NL) && g_lin_with_pb2 && !g_side_lin && g_heads_early) {   // (lin_in_node: the last layer's W_lin . A_nb is pending)
       j[1].X2 = ((s->num_layers - 1) & 1) ? w.A : w.Anb; j[1].x2_N = NL; j[1].x2_NP = 0;
     }
     DD_TRYP(DD_PROF_GEMM, launch_gemm128_batch(j, 2, st));   // (v-head hidden -> qn: ql may still be read by the overlapped pos sub-layer)
@@ -1135,7 +1161,7 @@ extern "C" int dd_workspace_view(const dd_sampler* s, dd_ws_view* out) {
   out->h = w.h; out->hb = w.hb; out->ew = w.ew; out->A = w.A; out->nbr = w.nbr;
   out->Anb = (dd::g_fuse && s->NL <= dd::g_fused_max_nl) ? w.Anb : nullptr;
   out->lin_in_node = 0;
-  if (out->Anb && dd::g_lin_in_node && dd::g_lin_with_pb2 && !dd::g_side_lin && dd::g_heads_early) {
+  if (out->Anb && dd::lin_in_node_for(s->B, s->NL) && dd::g_lin_with_pb2 && !dd::g_side_lin && dd::g_heads_early) {
     // lin_node inside the node launch: `h` lacks the last layer's W_lin . A_nb on the ligand rows -- it is in `Anb`; `A` is not formed
     out->lin_in_node = 1;
     out->Anb = ((s->num_layers - 1) & 1) ? w.A : w.Anb;
@@ -1628,7 +1654,8 @@ extern "C" int dd_debug_set_option(int key, int value) {
   if (key == 30) { dd::g_p2_in_pos = value ? 1 : 0; return DD_OK; }
   if (key == 31) { dd::g_pos_g_mode = value & 3; return DD_OK; }
   if (key == 28) { dd::g_heads_early = value ? 1 : 0; return DD_OK; }
-  if (key == 32) { dd::g_lin_in_node = value ? 1 : 0; return DD_OK; }
+  if (key == 32) { dd::g_lin_in_node = value < 0 ? -1 : (value ? 1 : 0); return DD_OK; }
+  if (key == 33) { dd::g_pos_quad = value ? 1 : 0; return DD_OK; }
   if (key == 29) { dd::g_head_rows_first = value ? 1 : 0; return DD_OK; }
   if (key == 7) { dd::g_step_fused = value ? 1 : 0; return DD_OK; }
   if (key == 5) { if (value != 2 && value != 4 && value != 8) return DD_ERR_BAD_ARG; dd::g_pos_waves = value; return DD_OK; }

@@ -1121,10 +1121,36 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
   constexpr bool LIN = (MODE == M_NE || MODE == M_NB) && !PERSIST;
   const bool lin = LIN && a.lin_W != nullptr;            // (block-uniform)
   float4 Bw[8];
+  float lin_old[4] = {0.f, 0.f, 0.f, 0.f};              // rows 4 cg + r of the block, column 16 wave + mm: h (+ the pending W_lin . A_nb) + bias
+  long lin_off[4] = {-1, -1, -1, -1};
   if (lin) {
     const float* bw = a.lin_W + (16 * wave + mm) * 128 + 4 * cg;
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) Bw[nt] = *reinterpret_cast<const float4*>(bw + 16 * nt);
+    if (cg < 2) {                                        // (requested here, ahead of the epilogue: no dependent load behind the barrier)
+      const int col = 16 * wave + mm;
+      const float bias = (MODE == M_NE) ? a.lin_b[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 4 * cg + r;                        // segment of the block
+        if (MODE == M_NE) {
+          const int nd = wg_protein ? ne_rb * NW + i : a.NP + (ne_rb - ne_nbp) * NW + i;
+          bool ok = nd < (wg_protein ? a.NP : N) && ne_b < a.B;
+          if (RAG && ok) ok = nd < a.NP ? nd < (a.np_real ? a.np_real[ne_b] : a.NP) : nd - a.NP < a.nl_real[ne_b];
+          if (ok) {
+            lin_off[r] = ((long)ne_b * N + nd) * 128 + col;
+            float v = a.out[lin_off[r]];
+            if (nd >= a.NP && a.lin_add != nullptr) v += a.lin_add[((long)ne_b * a.NL + nd - a.NP) * 128 + col];
+            lin_old[r] = v + bias;
+          }
+        } else {
+          const int sg = block * NW + i;
+          bool ok = sg < a.B * a.NL;
+          if (RAG && ok) ok = sg % a.NL < a.nl_real[sg / a.NL];
+          if (ok) lin_off[r] = (long)sg * 128 + col;
+        }
+      }
+    }
   }
   float* const lin_rows = smem + L::TOTAL + 16;          // [NW][WPITCH]: the attention outputs of the block's NW segments
   if (active) {
@@ -1191,28 +1217,9 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
       }
       const f32x4 d = d0 + d1;                           // lane (column mm, cg): rows 4 cg + r
       if (cg < 2) {
-        const int col = 16 * wave + mm;
-        const float bias = (MODE == M_NE) ? a.lin_b[col] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = 4 * cg + r;                      // segment of the block
-          if (MODE == M_NE) {
-            const int nd = wg_protein ? ne_rb * NW + i : a.NP + (ne_rb - ne_nbp) * NW + i;
-            bool ok = nd < (wg_protein ? a.NP : N) && ne_b < a.B;
-            if (RAG && ok) ok = nd < a.NP ? nd < (a.np_real ? a.np_real[ne_b] : a.NP) : nd - a.NP < a.nl_real[ne_b];
-            if (ok) {
-              float* hp = a.out + ((long)ne_b * N + nd) * 128 + col;
-              float v = *hp;
-              if (nd >= a.NP && a.lin_add != nullptr) v += a.lin_add[((long)ne_b * a.NL + nd - a.NP) * 128 + col];
-              *hp = v + (d[r] + bias);
-            }
-          } else {
-            const int sg = block * NW + i;
-            bool ok = sg < a.B * a.NL;
-            if (RAG && ok) ok = sg % a.NL < a.nl_real[sg / a.NL];
-            if (ok) a.out[(long)sg * 128 + col] = d[r];
-          }
-        }
+        for (int r = 0; r < 4; ++r)
+          if (lin_off[r] >= 0) a.out[lin_off[r]] = (MODE == M_NE) ? lin_old[r] + d[r] : d[r];
       }
     }
   }
@@ -2014,7 +2021,7 @@ int launch_attn2_pos_g(const AttnArgs& pe_in, const AttnArgs& pb_in, const GemmA
 
 int g_pos_waves = 4;         // waves per workgroup of the fused coordinate launch: 2, 4 or 8
 #ifndef DD_POS_QUAD
-#define DD_POS_QUAD 1
+#define DD_POS_QUAD 0       // measured SLOWER (EXPERIMENTS.md R6-5): 240 workgroups of 130 KB LDS leave no CU for the side stream's GEMMs
 #endif
 int g_pos_quad = DD_POS_QUAD;   // four waves per segment, two segments per workgroup (k_attn2_pos_q); no in-launch x update in this form
 static int launch_pos_quad(const AttnArgs& pe, const AttnArgs& pb, hipStream_t st) {

@@ -8,8 +8,8 @@
 namespace dd {
 
 #ifndef DD_GEMM_EARLY_HALF
-#define DD_GEMM_EARLY_HALF 1
-#endif
+#define DD_GEMM_EARLY_HALF 0  // both K halves + the bias requested before the first barrier: measured 1.8 % SLOWER at B = 8 (120 instead of
+#endif                        // 104 registers per thread, EXPERIMENTS.md R6-5)
 constexpr int GT = 64;        // tile rows / cols
 constexpr int GP = 130;       // LDS row pitch (floats)
 
