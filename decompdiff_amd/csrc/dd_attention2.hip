@@ -52,6 +52,12 @@
 #ifndef DD_COOP_RC
 #define DD_COOP_RC 0          // bl_coop_body: the segment's own row (Rk) requested with the next trip's prologue instead of at its first tile
 #endif
+#ifndef DD_NE_COOP_EPI
+#define DD_NE_COOP_EPI 1   // node_layer_with_edge blocks: no W2v image -- the epilogue as one MFMA chain per wave (W2v rows from L2, Z~ through LDS)
+#endif
+#ifndef DD_GAUSS_CACHE
+#define DD_GAUSS_CACHE 1   // node_layer_with_edge: the tile's Gaussian features kept from the k pass for the v pass
+#endif
 #ifndef DD_UNCOND_FETCH
 #define DD_UNCOND_FETCH 1  // next tile's rows requested unconditionally (clipped members): no register copies at the tile joins
 #endif
@@ -316,9 +322,10 @@ struct Lds {
   static constexpr bool KNN = (MODE == M_NE || MODE == M_PE);
   static constexpr bool RES = (MODE == M_NB || MODE == M_BL);  // no Gaussian tables: W2k and W2v images both resident
   static constexpr int WV = RES ? WB_FLOATS : 0;              // W2v image (aliases the W2k buffer unless RES)
-  static constexpr int TAB = WB_FLOATS;                       // kNN modes: [k lo, k hi, v lo, v hi] tables of the two
+  static constexpr int XPAD = KNN ? 128 : 0;                  // (node mode: the W2k image's place later holds the 8 x (16 x WPITCH + 16) exchange buffer)
+  static constexpr int TAB = WB_FLOATS + XPAD;                // kNN modes: [k lo, k hi, v lo, v hi] tables of the two
                                                               // source types a workgroup meets (4 x 24 x 128)
-  static constexpr int LNP = WB_FLOATS * (RES ? 2 : 1) + (KNN ? 4 * TABP : 0);   // [4][128] gamma_k, beta_k, gamma_v, beta_v
+  static constexpr int LNP = WB_FLOATS * (RES ? 2 : 1) + XPAD + (KNN ? 4 * TABP : 0);   // [4][128] gamma_k, beta_k, gamma_v, beta_v
   static constexpr int WAO = LNP + 512;                       // [2][12][128] angle weights (BL), MFMA operand layout
   static constexpr int TOTAL = WAO + (TRIP ? 2 * 12 * 128 : 0);
 };
@@ -689,6 +696,10 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
   DD_STAMP(3);
 
   // first-layer table part of tile t (features of member 16t + mm), either orientation
+  // (DD_GAUSS_CACHE, node mode: the Gaussians of a tile are formed in the k pass and kept for the v pass -- 5 registers per tile
+  //  instead of 5 more expf per tile)
+  constexpr bool GCACHE = DD_GAUSS_CACHE && KNN && !POS;
+  float Fg[GCACHE ? MAXT : 1][5];
   auto table_part = [&](int t, int pass, f32x4 (&acc)[8], auto tr) {
     constexpr bool TR = decltype(tr)::value;
     if (KNN) {
@@ -699,8 +710,17 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
       // on the VALU after the Gaussian steps gives the same bits: 8 (16 in a mixed tile) MFMAs less per tile pass.
       constexpr int KS = DD_KNN_CONST_ADD ? 5 : 6;
       float F[6];
+      if (GCACHE) {
+        if (pass == 0) {
 #pragma unroll
-      for (int s = 0; s < 5; ++s) F[s] = gauss_feat(dm[t], 4 * s + cg);
+          for (int s = 0; s < 5; ++s) Fg[t][s] = gauss_feat(dm[t], 4 * s + cg);
+        }
+#pragma unroll
+        for (int s = 0; s < 5; ++s) F[s] = Fg[GCACHE ? t : 0][s];
+      } else {
+#pragma unroll
+        for (int s = 0; s < 5; ++s) F[s] = gauss_feat(dm[t], 4 * s + cg);
+      }
       F[5] = cg == 0 ? 1.0f : 0.0f;
       const bool hi = jm[t] < a.NP;
       const float* tab = smem + L::TAB + pass * 2 * TABP + cg * 128 + mm * 4;   // [lo, hi] tables of this pass
@@ -847,10 +867,13 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
   // ---- kNN node mode: the W2k image is dead once every wave has folded its query; W2v takes its place now.  The
   //      second barrier follows at once (the waves are still aligned here; one in front of the epilogue would make
   //      every wave wait for the slowest); the Gaussian tables of both passes are resident.
+  constexpr bool NECO = DD_NE_COOP_EPI && MODE == M_NE && !PERSIST && NW == 8;   // cooperative epilogue, no W2v image (see below)
   if (KNN && !POS) {
-    __syncthreads();
-    stage_w2k_permuted<NT>(WV, a.W2v);                 // row o = h*8 + j  ->  LDS row j*16 + h
-    __syncthreads();
+    __syncthreads();                                   // (NECO: every wave has folded its query -- the image's place becomes the exchange buffer)
+    if (!NECO) {
+      stage_w2k_permuted<NT>(WV, a.W2v);               // row o = h*8 + j  ->  LDS row j*16 + h
+      __syncthreads();
+    }
   }
   DD_STAMP(4);
 
@@ -1153,6 +1176,56 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
     }
   }
   float* const lin_rows = smem + L::TOTAL + 16;          // [NW][WPITCH]: the attention outputs of the block's NW segments
+  if constexpr (NECO) {
+    // Cooperative epilogue of a node block (as bl_coop_body's): every wave leaves its Z~ [16 heads][128] in the exchange buffer that
+    // took the W2k image's place; wave w then forms out[s][16 w .. 16 w + 15] for the block's 8 segments as ONE 16 x 16 x 128 MFMA
+    // chain -- rows i = 2 s + h' (the two heads 2w, 2w + 1 of segment s), columns = the 16 outputs of those heads, the two diagonal
+    // 8-column blocks are the results -- with its 16 rows of W2v as the B operand straight from L2 (requested before the barrier).
+    // No W2v image: one barrier instead of a 64 KB re-staging between two, and 8 KB instead of 64 KB of LDS reads per wave.
+    constexpr int XSTR = 16 * WPITCH + 16;
+    float* const XB = smem;
+    float* const SS = lin_rows + NW * WPITCH;            // [8][16] sums of the attention weights
+    float4 Bv[8];
+    {
+      const float* bv = a.W2v + (16 * wave + mm) * 128 + 4 * cg;
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) Bv[nt] = *reinterpret_cast<const float4*>(bv + 16 * nt);
+    }
+    const int eh = mm >> 3;
+    const float bias2 = a.b2v[16 * wave + mm];
+    if (active) {
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt)
+        *reinterpret_cast<float4*>(XB + wave * XSTR + mm * WPITCH + 16 * nt + 4 * cg) = make_float4(Z[nt][0], Z[nt][1], Z[nt][2], Z[nt][3]);
+      if (cg == 0) SS[wave * 16 + mm] = ssum;
+    }
+    __syncthreads();
+    const float* ar = XB + (mm >> 1) * XSTR + (2 * wave + (mm & 1)) * WPITCH + 4 * cg;
+    f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < 8; nt += 2) {
+      const float4 a0 = *reinterpret_cast<const float4*>(ar + 16 * nt), a1 = *reinterpret_cast<const float4*>(ar + 16 * nt + 16);
+      d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, Bv[nt].x, d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, Bv[nt + 1].x, d1, 0, 0, 0);
+      d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, Bv[nt].y, d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, Bv[nt + 1].y, d1, 0, 0, 0);
+      d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, Bv[nt].z, d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, Bv[nt + 1].z, d1, 0, 0, 0);
+      d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, Bv[nt].w, d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, Bv[nt + 1].w, d1, 0, 0, 0);
+    }
+    const f32x4 d = d0 + d1;                             // rows 4 cg + r <-> (s = 2 cg + (r >> 1), h' = r & 1); useful: h' == eh
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int sI = 2 * cg + u;                         // segment of the block
+      const int nd = wg_protein ? ne_rb * NW + sI : a.NP + (ne_rb - ne_nbp) * NW + sI;
+      bool ok = nd < (wg_protein ? a.NP : N) && ne_b < a.B;
+      if (RAG && ok) ok = nd < a.NP ? nd < (a.np_real ? a.np_real[ne_b] : a.NP) : nd - a.NP < a.nl_real[ne_b];
+      const float val = fmaf(bias2, SS[sI * 16 + 2 * wave + eh], eh ? d[2 * u + 1] : d[2 * u]);
+      if (lin) lin_rows[sI * WPITCH + 16 * wave + mm] = val;       // (rows of idle segments: finite garbage, never stored)
+      else if (ok) a.out[((long)ne_b * N + nd) * 128 + 16 * wave + mm] = val;
+    }
+  } else
   if (active) {
     // lane (h = mm, cg): partial dot products over its 32 channels for the 8 outputs of head h
     float o[8];
@@ -1636,7 +1709,7 @@ __global__ __launch_bounds__(512) void k_attn2_bl_coop(const AttnArgs a) {
 template <int MODE, int MAXT, int NW, bool RAG = false>
 __global__ __launch_bounds__(NW * 64) void k_attn2(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[Lds<MODE>::TOTAL + ((MODE == M_PE || MODE == M_PB) ? NW * 256 : 0) +
-                                                     ((MODE == M_NE || MODE == M_NB) ? NW * WPITCH + 16 : 0)];
+                                                     ((MODE == M_NE || MODE == M_NB) ? NW * WPITCH + 16 + 128 : 0)];
   attn2_body<MODE, MAXT, NW, false, RAG>(a, blockIdx.x, smem);
 }
 
