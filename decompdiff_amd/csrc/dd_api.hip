@@ -226,6 +226,7 @@ static int ensure_side_stream() {
 
 static int g_fuse = 1;                       // dd_debug_set_fusion: 0 = one launch per sub-layer (per-kernel timing)
 extern long long* g_gemm_dbg;              // dd_gemm.hip
+extern long long* g_node_trace;            // dd_attention2.hip
 static long long* g_dbg_clock = nullptr;   // set by dd_debug_set_clock_buffer (profiling aid)
 static int g_dbg_mode = -1;
 
@@ -1585,6 +1586,7 @@ static int g_options_epoch = 0;
 extern "C" int dd_debug_set_clock_buffer(long long* buf, int mode) {
   ++g_options_epoch;
   if (mode == 100) { dd::g_gemm_dbg = buf; return DD_OK; }      // dd_gemm128 phase stamps
+  if (mode == 200) { dd::g_node_trace = buf; return DD_OK; }    // per-workgroup clocks of the fused node launch (-DDD_NODE_TRACE=1 builds)
   dd::g_gemm_dbg = nullptr;
   dd::g_dbg_clock = buf;
   dd::g_dbg_mode = buf ? mode : -1;

@@ -55,6 +55,9 @@
 #ifndef DD_NE_COOP_EPI
 #define DD_NE_COOP_EPI 1   // node_layer_with_edge blocks: no W2v image -- the epilogue as one MFMA chain per wave (W2v rows from L2, Z~ through LDS)
 #endif
+#ifndef DD_NODE_TRACE
+#define DD_NODE_TRACE 0    // measurement variant (tools/build_variant.sh trace -DDD_NODE_TRACE=1): per-workgroup clocks of the fused node launch
+#endif
 #ifndef DD_GAUSS_CACHE
 #define DD_GAUSS_CACHE 1   // node_layer_with_edge: the tile's Gaussian features kept from the k pass for the v pass
 #endif
@@ -1726,7 +1729,9 @@ __global__ __launch_bounds__(NW * 64) void k_attn2_node(const AttnArgs ne, const
   __shared__ __attribute__((aligned(16))) float smem[SZ];
   int blk = blockIdx.x;
   // this layer's projection / query rows come from the previous layer's tail queue on the other stream (no graph edge)
+#if !DD_NODE_TRACE
   dd_wait_flags(wflags, widx, wn, -1, 0, DD_FLAG_ERR, 500);
+#endif
   // Each body reads ITS argument block through the kernarg pointer with an offset the compiler cannot see through: with
   // the three by-value structs used directly, their scalar loads are hoisted in front of the branch below and stay live
   // across all bodies (104 SGPRs + 80 spilled to VGPR lanes, which in turn pushed the 256-register node body into
@@ -1741,15 +1746,29 @@ __global__ __launch_bounds__(NW * 64) void k_attn2_node(const AttnArgs ne, const
   (void)ne; (void)nb; (void)bl;
   // n_bl_first > 0: the persistent bond-layer workgroups come first in dispatch order and keep their CUs for the whole
   // launch, the node blocks cycle through the remaining CUs -- both parts then end together (see launch_node_nw)
+#if DD_NODE_TRACE   // (measurement variant: start / end shader clock, kind and hardware id of every workgroup -> tools/node_trace.py)
+  long long* const trace = (wn == -12345) ? reinterpret_cast<long long*>(const_cast<int32_t*>(wflags)) + (long)blockIdx.x * 16 : nullptr;   // (a 128-byte line per workgroup: lines shared across XCDs lose updates)
+  // (system-scope stores: a dirty line left in one XCD's L2 by an earlier launch would otherwise be written back over a later launch's entry)
+#define DD_TRACE_ST(i, v) __hip_atomic_store(trace + (i), (long long)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+  if (trace && threadIdx.x == 0) {
+    DD_TRACE_ST(0, __builtin_amdgcn_s_memrealtime());   // (the 100 MHz real-time counter: one time base for all XCDs)
+    DD_TRACE_ST(3, (long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4 /* HW_REG_HW_ID */) |
+                       ((long long)(unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20 /* HW_REG_XCC_ID */) << 32));
+  }
+#define DD_TRACE_END(kind) do { if (trace && threadIdx.x == 0) { DD_TRACE_ST(1, __builtin_amdgcn_s_memrealtime()); DD_TRACE_ST(2, kind); } } while (0)
+#else
+#define DD_TRACE_END(kind) do { } while (0)
+#endif
   if (n_bl_first > 0) {
     if (blk < n_bl_first) {
       if constexpr (DD_COOP && NW == 8 && MAXT == 2) bl_coop_body<MAXT, RAG, false>(args(2), smem);
       else attn2_body<M_BL, MAXT, NW, true, RAG, false, false>(args(2), blk, smem);
+      DD_TRACE_END(2);
       return;
     }
     blk -= n_bl_first;
-    if (blk < n_ne) attn2_body<M_NE, 2, NW, false, RAG, false, false>(args(0), blk, smem);
-    else attn2_body<M_NB, MAXT, NW, false, RAG, false, false>(args(1), blk - n_ne, smem);
+    if (blk < n_ne) { attn2_body<M_NE, 2, NW, false, RAG, false, false>(args(0), blk, smem); DD_TRACE_END(0); }
+    else { attn2_body<M_NB, MAXT, NW, false, RAG, false, false>(args(1), blk - n_ne, smem); DD_TRACE_END(1); }
     return;
   }
   if (blk < n_ne) attn2_body<M_NE, 2, NW, false, RAG, false, false>(args(0), blk, smem);
@@ -1903,6 +1922,7 @@ int g_attn_persist = 1;      // bond_layer workgroups of the fused launch are pe
 int g_bl_tail = DD_BL_TAIL;  // the last (partial) round of bond-layer trips spread evenly over the persistent workgroups
 int g_bl_first = 1;          // bond-layer workgroups first in the node launch: 0 off, 1 measured split per shape, n>1 that many
 int g_node_split_trial = -1; // >= 0 while autotune_node_split is timing a candidate (0 = node blocks first)
+long long* g_node_trace = nullptr;   // DD_NODE_TRACE builds: [workgroups][16] clocks of the next fused node launches (dd_debug_set_clock_buffer(buf, 200))
 namespace {
 struct NodeSplit { int B, NP, NL, K, n_bl; };
 std::vector<NodeSplit> g_node_splits;
@@ -1970,6 +1990,8 @@ static int launch_node_nw(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs
   const int n_ne = ne.B * ne_blocks_per_sample(ne.NP, ne.NL, NW), n_nb = (ne.B * ne.NL + NW - 1) / NW;
   int n_bl = (ne.B * ne.NL * (ne.NL - 1) + NW - 1) / NW;
   const int persist = (g_attn_persist && bl.work_counter != nullptr) ? 1 : 0;
+  const int32_t* const wf = g_node_trace ? reinterpret_cast<const int32_t*>(g_node_trace) : ne.wait_flags;   // (DD_NODE_TRACE builds)
+  const int wfn = g_node_trace ? -12345 : ne.wait_n;
   AttnArgs blt = bl;                                   // + the trip plan of the persistent workgroups (set_trips below)
   blt.trip_full = 1 << 27; blt.trip_q = 0;
   auto set_trips = [&](int n_wg) {
@@ -1993,15 +2015,18 @@ static int launch_node_nw(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs
       // parts run in whole "rounds" (a node block ~23 us, a bond-layer trip ~17 us at NL = 30), so the best share is a
       // step function of the shape -- it is measured once per shape (dd_api.hip::autotune_node_split), not modelled.
       int want = g_bl_first > 1 ? g_bl_first : (g_node_split_trial >= 0 ? g_node_split_trial : node_split_lookup(ne.B, ne.NP, ne.NL, ne.K));
+#if DD_NODE_TRACE
+      { static const int env_bl = [] { const char* e = getenv("DD_BL_FIRST"); return e ? atoi(e) : 0; }(); if (env_bl > 0 && g_node_split_trial < 0) want = env_bl; }
+#endif
       if (want > 0) {
         n_bl = want < 16 ? 16 : (want > n_cu - 16 ? n_cu - 16 : want);
         set_trips(n_bl);
         if (ne.nl_real != nullptr)
           hipLaunchKernelGGL((k_attn2_node<MAXT, NW, true>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, blt, n_ne, n_nb,
-                             persist, n_bl, ne.wait_flags, ne.wait_idx, ne.wait_n);
+                             persist, n_bl, wf, ne.wait_idx, wfn);
         else
           hipLaunchKernelGGL((k_attn2_node<MAXT, NW>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, blt, n_ne, n_nb, persist,
-                             n_bl, ne.wait_flags, ne.wait_idx, ne.wait_n);
+                             n_bl, wf, ne.wait_idx, wfn);
         DD_CHECK_LAUNCH();
         return DD_OK;
       }
@@ -2009,9 +2034,9 @@ static int launch_node_nw(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs
   }
   if (persist) set_trips(n_bl);
   if (ne.nl_real != nullptr)
-    hipLaunchKernelGGL((k_attn2_node<MAXT, NW, true>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, blt, n_ne, n_nb, persist, 0, ne.wait_flags, ne.wait_idx, ne.wait_n);
+    hipLaunchKernelGGL((k_attn2_node<MAXT, NW, true>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, blt, n_ne, n_nb, persist, 0, wf, ne.wait_idx, wfn);
   else
-    hipLaunchKernelGGL((k_attn2_node<MAXT, NW>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, blt, n_ne, n_nb, persist, 0, ne.wait_flags, ne.wait_idx, ne.wait_n);
+    hipLaunchKernelGGL((k_attn2_node<MAXT, NW>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, blt, n_ne, n_nb, persist, 0, wf, ne.wait_idx, wfn);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }
