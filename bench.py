@@ -288,7 +288,7 @@ def main():
         steady = None
         if args.config in (1, 2) and not args.no_steady:
             st0 = prepare(u0)
-            n_long = max(200, 10 * args.steps)
+            n_long = min(max(200, 10 * args.steps), int(model.num_timesteps))
             sample(st0, min(20, n_long), u0.noise_seed + 101)
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()

@@ -55,6 +55,10 @@
 #ifndef DD_NE_COOP_EPI
 #define DD_NE_COOP_EPI 1   // node_layer_with_edge blocks: no W2v image -- the epilogue as one MFMA chain per wave (W2v rows from L2, Z~ through LDS)
 #endif
+#ifndef DD_TRIP_SYNC
+#define DD_TRIP_SYNC 6     // persistent bond-layer workgroups: a workgroup barrier every n-th trip (1 <= n <= 7).  Round 2 kept the waves in
+                           // lock-step (free-running waves measured 6 % slower then); round 6: n = 3 ... 6 -1.7 % at B = 8, -3.5 % at C-large, bit-identical (R6-7)
+#endif
 #ifndef DD_NODE_TRACE
 #define DD_NODE_TRACE 0    // measurement variant (tools/build_variant.sh trace -DDD_NODE_TRACE=1): per-workgroup clocks of the fused node launch
 #endif
@@ -455,8 +459,8 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
     }
     __syncthreads();
   };
-  // persistent batches: bases of the current / next batch in sb[0..1] (thread 0 draws the next one while the current is
-  // processed; sb[2] = number of bases published so far, release/acquire), next batch's query prefetched over the epilogue
+  // persistent batches: trip indices in sb[it & 7] (thread 0 draws the next one while the current is processed; sb[8] = number of
+  // indices published so far, release/acquire), next batch's query prefetched over the epilogue
   int* sb = reinterpret_cast<int*>(smem + L::TOTAL);
   int it = 0;
   float4 qn0 = make_float4(0.f, 0.f, 0.f, 0.f), qn1 = qn0;
@@ -467,7 +471,7 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
     cnt = nseg - base < cnt ? nseg - base : cnt;         // <= 0: no work left
   };
   if (PERSIST) {
-    if (threadIdx.x == 0) { sb[0] = atomicAdd(a.work_counter, 1); sb[2] = 0; }
+    if (threadIdx.x == 0) { sb[0] = atomicAdd(a.work_counter, 1); sb[8] = 0; }
     stage_all();                                       // (ends with the barrier that also publishes sb[0])
   }
 
@@ -479,15 +483,17 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
   const int mm = lane & 15, cg = lane >> 4;            // member slot / channel group; also (head, row-group)
   int seg;
   if (PERSIST) {
-    // workgroup-synchronous: NW consecutive segments per trip (letting every wave pull segments on its own was measured
-    // 6 % slower: the waves drift out of phase and thrash the instruction cache)
-    if (it > 0) __syncthreads();                       // one barrier per trip keeps the waves in phase
+    // NW consecutive segments per trip (round 2: letting every wave pull segments on its own was measured 6 % slower; round 6: the
+    // waves of a workgroup still take the segments of a trip together, but only meet at a barrier every DD_TRIP_SYNC trips)
+    // (DD_TRIP_SYNC = n: a barrier every n-th trip only -- a wave's trip index then leads another's by at most n - 1, the eight trip
+    //  slots sb[0..7] and the published count sb[8] cover n <= 7; every wave has waited for sb[8] >= it in the previous trip's epilogue)
+    if (it > 0 && it % DD_TRIP_SYNC == 0) __syncthreads();   // a barrier per trip keeps the waves in phase
     int base, cnt;
-    trip_range(__builtin_amdgcn_readfirstlane(sb[it & 1]), base, cnt);
+    trip_range(__builtin_amdgcn_readfirstlane(sb[it & 7]), base, cnt);
     if (cnt <= 0) break;
     if (threadIdx.x == 0) {
-      sb[(it + 1) & 1] = atomicAdd(a.work_counter, 1);
-      __hip_atomic_store(&sb[2], it + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      sb[(it + 1) & 7] = atomicAdd(a.work_counter, 1);
+      __hip_atomic_store(&sb[8], it + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     seg = wave < cnt ? bl_dense_seg(base + wave) : a.B * Eb;
   } else if (MODE == M_NE) {
@@ -1133,9 +1139,9 @@ __device__ __forceinline__ void attn2_body(const ARGS& a, const int block, float
   // ---- epilogue: out[o] = W2v[o,:] . Z~[head(o),:] + b2v[o] * sum_m alpha*w ----------------------------------
   DD_STAMP(9);
   if (PERSIST) {                                       // next trip's query
-    while (__hip_atomic_load(&sb[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < it + 1) {}
+    while (__hip_atomic_load(&sb[8], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < it + 1) {}
     int base2, cnt2;
-    trip_range(sb[(it + 1) & 1], base2, cnt2);
+    trip_range(sb[(it + 1) & 7], base2, cnt2);
     if (wave < cnt2) {
       const int nseg2 = bl_dense_seg(base2 + wave);
       qn0 = *reinterpret_cast<const float4*>(a.q + (long)nseg2 * 128 + mm * 8);
@@ -1725,7 +1731,7 @@ constexpr int imax(int a, int b) { return a > b ? a : b; }
 template <int MAXT, int NW, bool RAG = false>
 __global__ __launch_bounds__(NW * 64) void k_attn2_node(const AttnArgs ne, const AttnArgs nb, const AttnArgs bl, int n_ne, int n_nb,
                                                         int persist, int n_bl_first, const int32_t* wflags, int widx, int wn) {
-  constexpr int SZ = imax(imax(imax(Lds<M_NE>::TOTAL, Lds<M_NB>::TOTAL), Lds<M_BL>::TOTAL) + 4, DD_COOP && NW == 8 && MAXT == 2 ? CoopLds::TOTAL : 0);
+  constexpr int SZ = imax(imax(imax(Lds<M_NE>::TOTAL, Lds<M_NB>::TOTAL), Lds<M_BL>::TOTAL) + 12, DD_COOP && NW == 8 && MAXT == 2 ? CoopLds::TOTAL : 0);
   __shared__ __attribute__((aligned(16))) float smem[SZ];
   int blk = blockIdx.x;
   // this layer's projection / query rows come from the previous layer's tail queue on the other stream (no graph edge)
