@@ -116,11 +116,14 @@ def node_launch_mfma_count(nbr, B, NP, NL, K, lin_in_node=False):
     ne = 2 * 40 * kinds + 64 * B * N * tiles_e
     nb = 64 * B * NL * ((NL - 1 + 15) // 16)
     bl = (2 * 24 + 64) * B * NL * (NL - 1) * ((NL - 2 + 15) // 16)
+    # round 6: the node_layer_with_edge blocks (8 segments each) run their epilogue W2v . Z~ as one 16 x 16 x 128 chain per wave
+    # (32 instructions x 8 waves per block; the two diagonal 8 x 8 blocks of the 16 x 16 result are the outputs)
+    ne_blocks = B * ((NP + 7) // 8 + (NL + 7) // 8)
+    ne_epi = ne_blocks * 8 * 32
     lin = 0
     if lin_in_node:
-        blocks = B * ((NP + 7) // 8 + (NL + 7) // 8) + (B * NL + 7) // 8
-        lin = blocks * 8 * 32
-    return ne + nb + bl + lin, {"NE": ne, "NB": nb, "BL": bl, "lin": lin}
+        lin = (ne_blocks + (B * NL + 7) // 8) * 8 * 32
+    return ne + ne_epi + nb + bl + lin, {"NE": ne, "NE_epilogue": ne_epi, "NB": nb, "BL": bl, "lin": lin}
 
 
 def algorithmic_flops_node_launch(B, NP, NL, K):
@@ -296,7 +299,9 @@ def main():
             torch.cuda.synchronize(dev)
             steady_ms = 1e3 * (time.perf_counter() - t1) / n_long
             steady = {"steady_ms_per_step": round(steady_ms, 4), "steady_steps": n_long,
-                      "per_call_overhead_ms": round(1e3 * elapsed / max(1, job["n_local_units"]) - args.steps * steady_ms, 3)}
+                      # (only meaningful when the long call is longer than the timed one)
+                      "per_call_overhead_ms": round(1e3 * elapsed / max(1, job["n_local_units"]) - args.steps * steady_ms, 3)
+                      if n_long >= 4 * args.steps else None}
         if not args.no_rooflines:
             roofline, roofline_gemm = measure_step_rooflines(torch, model, hip_lib, lib, prepare(u0), cfg, B, NP, NL, K, dev,
                                                              args.config, args.workload)
@@ -405,7 +410,7 @@ def measure_step_rooflines(torch, model, hip_lib, lib, state, cfg, B, NP, NL, K,
             traffic_source = f"committed PMC pass {ent.get('measured_at_commit', '?')} ({ent.get('source', 'profiles/')}); kernel source {src_sha}"
         elif ent:
             traffic_note = (f"stale: the committed PMC pass was taken on dd_attention2.hip {ent.get('kernel_source_sha256_16')}, this "
-                            f"run's source is {src_sha} -- re-run the PMC passes (tools/gpu_round5_evidence.sh)")
+                            f"run's source is {src_sha} -- re-run the PMC passes (tools/gpu_round6_evidence.sh)")
     except (OSError, KeyError, ValueError):
         pass
     roofline = {
@@ -417,8 +422,8 @@ def measure_step_rooflines(torch, model, hip_lib, lib, state, cfg, B, NP, NL, K,
         "mfma_instructions_per_launch": n_mfma, "mfma_instructions_by_sublayer": by_mode,
         "algorithmic_tflops": round(algorithmic, 2),
         "note": "achieved = FLOPs EXECUTED on the matrix cores (exact count of v_mfma_f32_16x16x4_f32 wave-instructions of this "
-                "launch from the step's kNN graph x 2048; cross-checked against SQ_INSTS_VALU_MFMA_MOPS/SQ_INSTS_MFMA in "
-                "profiles/) / mean duration of the shipped fused launch from HIP events on its stream; VALU work (LayerNorm, "
+                "launch from the step's kNN graph x 2048; cross-checked against SQ_INSTS_MFMA in "
+                "profiles/ (round 6: 2 596 176 counted, 2 594 760 measured)) / mean duration of the shipped fused launch from HIP events on its stream; VALU work (LayerNorm, "
                 "softmax, query fold, epilogue) is not counted.  algorithmic_tflops = SURVEY.md 8d factored FLOPs of the same "
                 "three sub-layers / the same time: work the exact restructurings of DESIGN.md 3 remove, not a utilisation.  "
                 "The kernel is fused: q / k / v never touch HBM, so it is priced against the fp32 MFMA peak, not HBM.  "

@@ -252,6 +252,65 @@ def test_graphed_train_step_follows_the_eager_steps():
         training.GraphedTrainStep(m_e, opt_e)
 
 
+def test_graph_entries_pin_the_cached_structures_they_captured():
+    """a captured step bakes in the device addresses of the cached index structures / segment plans it read.  The
+    module-level caches evict (16 structures, 64 plans); the graph entry must keep what its capture used alive.  Capture a graph, churn
+    more than 16 other structures and more than 64 plans, replay: the replayed steps must follow an eager twin step for step -- and with
+    gradient clipping (max_grad_norm, the reference's train loop) in both."""
+    from decompdiff_amd import training
+    torch.manual_seed(5)
+    b1 = synth.build_sampling_batch(synth.make_pocket(41, 72, (4, 3), 5, num_full_protein=0), 2)
+    d = lambda t: t.to(dev()) if torch.is_tensor(t) else t
+    kw = dict(
+        protein_pos=d(b1["protein_pos"]), protein_v=d(b1["protein_v"]), batch_protein=d(b1["batch_protein"]),
+        protein_group_idx=d(b1["protein_group_idx"]), ligand_pos=d(b1["init_ligand_pos"]), ligand_v=d(b1["init_ligand_v"]),
+        ligand_v_aux=d(b1["ligand_v_aux"]), batch_ligand=d(b1["batch_ligand"]), ligand_group_idx=d(b1["ligand_group_idx"]),
+        prior_centers=d(b1["prior_centers"]), prior_stds=d(b1["prior_stds"]), prior_num_atoms=d(b1["prior_num_atoms"]),
+        batch_prior=d(b1["batch_prior"]), prior_group_idx=d(b1["prior_group_idx"]), ligand_decomp_batch=d(b1["ligand_decomp_batch"]),
+        ligand_decomp_index=d(b1["ligand_decomp_index"]), ligand_fc_bond_index=d(b1["ligand_fc_bond_index"]),
+        ligand_fc_bond_type=d(b1["init_ligand_fc_bond_type"]), batch_ligand_bond=d(b1["batch_ligand_bond"]))
+
+    def fresh(capturable):
+        m = DecompScorePosNet3D(shipped_config(), 29, 10, 8)
+        sd = m.state_dict(); sd.update(synth.synthetic_state_dict(shipped_config(), 2)); m.load_state_dict(sd)
+        m = m.to(dev()).train()
+        return m, torch.optim.Adam(m.parameters(), lr=1e-4, capturable=capturable)
+
+    n_steps = 7
+    m_e, opt_e = fresh(False)
+    torch.manual_seed(21)
+    eager = []
+    for _ in range(n_steps):
+        opt_e.zero_grad(set_to_none=True)
+        r = m_e.get_diffusion_loss(**kw)
+        loss = r["losses"]["pos"] + 100.0 * r["losses"]["v"] + 100.0 * r["losses"]["bond"]
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m_e.parameters(), 8.0)
+        opt_e.step()
+        eager.append(float(loss))
+    m_g, opt_g = fresh(True)
+    gs = training.GraphedTrainStep(m_g, opt_g, loss_weights=(1.0, 100.0, 100.0), warmup=2, max_grad_norm=8.0)
+    torch.manual_seed(21)
+    graphed = [float(gs.step(**kw)["loss"]) for _ in range(3)]            # 2 eager + the capture's replay
+    ent = next(iter(gs._graphs.values()))
+    assert len(ent["keep"]) > 0                                            # the structures / plans the capture read
+    held = {id(o) for o in ent["keep"]}
+    # churn the caches past their limits
+    for i in range(training._STRUCT_MAX_ENTRIES + 3):
+        training._structure(1, 40 + i, 6, 8, dev())
+    for i in range(70):
+        nl = [5 + (i % 7), 6 + (i // 7)]
+        training._static_plan(torch.arange(2, device=dev()).repeat_interleave(torch.tensor(nl, device=dev())), 2, nl, False)
+    assert not any(id(v) in held for v in training._STRUCT.values())       # evicted from the cache ...
+    torch.cuda.empty_cache()
+    junk = [torch.full((1 << 20,), -7, dtype=torch.int64, device=dev()) for _ in range(8)]   # ... and their memory would be reused by now
+    graphed += [float(gs.step(**kw)["loss"]) for _ in range(n_steps - 3)]
+    del junk
+    assert gs.replays == n_steps - 2
+    for a, c in zip(eager, graphed):
+        assert np.isfinite(c) and abs(a - c) <= 2e-4 * max(1.0, abs(a)), (eager, graphed)
+
+
 def test_gemm128_tn_bias_matches_torch():
     """dd_gemm128_tn_bias: dW = dY^T X and db = column sums of dY from one launch pair, against torch in float64, for the three
     tile heights (M <= 32 / 64 / 128) and row counts that are not multiples of the 32-row trips."""

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""profiles/pmc_traffic.json <- the FETCH_SIZE / WRITE_SIZE passes of tools/gpu_round5_evidence.sh (CPU; run in the builder's
+"""profiles/pmc_traffic.json <- the FETCH_SIZE / WRITE_SIZE passes of tools/gpu_round6_evidence.sh (CPU; run in the builder's
 tree after gpurun merged gpurun_out/ back).  Every node-launch entry names the dd_attention2.hip it was measured on
 (kernel_source_sha256_16, written by the evidence script on the GPU box) and the commit: bench.py refuses an entry whose hash
 is not the current source's.   usage: python tools/pmc_traffic_update.py gpurun_out/r4fin <commit> profiles/round4_pmc_node"""
@@ -26,7 +26,7 @@ def pair(f_md, w_md, key, label):
                  "fetch_kib_per_launch": round(f[1], 1), "write_kib_per_launch": round(w[1], 1),
                  "kernel_source_sha256_16": sha, "measured_at_commit": commit, "source": src_note,
                  "note": f"FETCH_SIZE + WRITE_SIZE per launch, rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes "
-                         f"(tools/gpu_round5_evidence.sh), averages over the {f[0]} / {w[0]} launches of the grid each process settled "
+                         f"(tools/gpu_round6_evidence.sh), averages over the {f[0]} / {w[0]} launches of the grid each process settled "
                          "on; KiB as reported; the gfx950 FETCH_SIZE under-count of wide coalesced reads (guide: up to 2x) is not "
                          "applied because the kernel mixes 16-byte and 4-byte gathers"}
 
