@@ -360,6 +360,7 @@ static int forward_tail(const dd_sampler* s, hipStream_t st, StepFold* fold, boo
       ne.kd = Pn; ne.ks = Pn + 128; ne.vd = Pn + 256; ne.vs = Pn + 384; ne.ld_kd = ne.ld_ks = ne.ld_vd = ne.ld_vs = 640;
       ne.q = l0_here ? s->l0_qn : w.qn; ne.Akp = LW(l, DD_NE_Akp); ne.Avp = LW(l, DD_NE_Avp); ne.lnk = LW(l, DD_NE_lnk); ne.lnv = LW(l, DD_NE_lnv);
       ne.W2k = LW(l, DD_NE_W2k); ne.W2v = LW(l, DD_NE_W2v); ne.b2v = LW(l, DD_NE_b2v); ne.out = w.A;
+      ne.work_counter = (l < 32) ? w.counters + 128 + 2 * l : nullptr;   // persistent node_layer_with_edge workgroups (two block counters)
       nb.B = B; nb.NP = NP; nb.NL = NL; nb.K = K; nb.x = xcur;
       nb.kd = w.PL; nb.ks = w.PL + 128; nb.vd = w.PL + 256; nb.vs = w.PL + 384; nb.ld_kd = nb.ld_ks = nb.ld_vd = nb.ld_vs = 1280;
       nb.ke = w.PB; nb.ve = w.PB + 128; nb.ld_ke = nb.ld_ve = 640;
@@ -674,6 +675,7 @@ static int forward_impl(const dd_sampler* s, hipStream_t st, StepFold* fold = nu
       ne.kd = Pn; ne.ks = Pn + 128; ne.vd = Pn + 256; ne.vs = Pn + 384; ne.ld_kd = ne.ld_ks = ne.ld_vd = ne.ld_vs = 640;
       ne.q = l0_here ? s->l0_qn : w.qn; ne.Akp = LW(l, DD_NE_Akp); ne.Avp = LW(l, DD_NE_Avp); ne.lnk = LW(l, DD_NE_lnk); ne.lnv = LW(l, DD_NE_lnv);
       ne.W2k = LW(l, DD_NE_W2k); ne.W2v = LW(l, DD_NE_W2v); ne.b2v = LW(l, DD_NE_b2v); ne.out = w.A;
+      ne.work_counter = (l < 32) ? w.counters + 128 + 2 * l : nullptr;   // persistent node_layer_with_edge workgroups (two block counters)
       nb.B = B; nb.NP = NP; nb.NL = NL; nb.K = K; nb.x = xcur;
       nb.kd = w.PL; nb.ks = w.PL + 128; nb.vd = w.PL + 256; nb.vs = w.PL + 384; nb.ld_kd = nb.ld_ks = nb.ld_vd = nb.ld_vs = 1280;
       nb.ke = w.PB; nb.ve = w.PB + 128; nb.ld_ke = nb.ld_ve = 640;

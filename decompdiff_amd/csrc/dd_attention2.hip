@@ -55,6 +55,10 @@
 #ifndef DD_NE_COOP_EPI
 #define DD_NE_COOP_EPI 1   // node_layer_with_edge blocks: no W2v image -- the epilogue as one MFMA chain per wave (W2v rows from L2, Z~ through LDS)
 #endif
+#ifndef DD_NE_PERSIST
+#define DD_NE_PERSIST 0    // node_layer_with_edge as persistent workgroups (ne_persist_body) beside the persistent bond-layer ones: bit-identical,
+                           // measured 10 % SLOWER (EXPERIMENTS.md R6-8); compiled with -DDD_NE_PERSIST=1 for the A/B only
+#endif
 #ifndef DD_TRIP_SYNC
 #define DD_TRIP_SYNC 6     // persistent bond-layer workgroups: a workgroup barrier every n-th trip (1 <= n <= 7).  Round 2 kept the waves in
                            // lock-step (free-running waves measured 6 % slower then); round 6: n = 3 ... 6 -1.7 % at B = 8, -3.5 % at C-large, bit-identical (R6-7)
@@ -1708,6 +1712,328 @@ __device__ __forceinline__ void bl_coop_body(const ARGS& a, float* smem) {
 #undef DD_STAMP
 }
 
+// ---- persistent node_layer_with_edge workgroups (round 6, EXPERIMENTS.md R6-8) ------------------------------------------------------
+// The NE blocks of attn2_body stage 112 KB of weight images for every 8 nodes (18 % of a block's time) and start and end as workgroups of
+// their own.  Here a workgroup stages ONLY the Gaussian tables of its centre kind (protein or ligand) and the LayerNorm rows, once, and
+// then pulls blocks of 8 nodes of that kind from a counter:
+//   * no W2k image: the query fold is split by head over the 8 waves (as bl_coop_body: wave w keeps the 16 W2k rows of heads 2w, 2w + 1
+//     in registers, the block's 8 queries are published in LDS, the products cross through the exchange buffer);
+//   * no W2v image: the epilogue is one MFMA chain per wave with its 16 W2v rows straight from L2 (as the NE blocks' NECO form), Z~
+//     through the same exchange buffer.  (Launches that carry lin_node, a.lin_W, keep the block form: launch_node_nw.)
+// LDS: exchange buffer 70 KB + tables 48 KB + small = 127 KB.  Same arithmetic in the same order as the block form: bit-identical.
+struct NepLds {
+  static constexpr int XSTR = 16 * WPITCH + 16;
+  static constexpr int XB = 0;
+  static constexpr int TAB = 8 * XSTR;                  // [k lo, k hi, v lo, v hi] tables of this centre kind (4 x 24 x 128)
+  static constexpr int LNP = TAB + 4 * TABP;            // [4][128]
+  static constexpr int QS = LNP + 512;                  // [8][128] queries of the block
+  static constexpr int ROWS = QS + 8 * 128;             // [8][WPITCH] attention outputs of the block (lin_node)
+  static constexpr int SS = ROWS + 8 * WPITCH;          // [8][16]
+  static constexpr int SB = SS + 128;                   // ints: block indices (current, next)
+  static constexpr int TOTAL = SB + 16;
+};
+
+template <bool RAG, typename ARGS>
+__device__ __forceinline__ void ne_persist_body(const ARGS& a, float* smem, const bool wg_protein, int32_t* counter) {
+  constexpr int NW = 8, NT = NW * 64, MAXT = 2;
+  using C = NepLds;
+  constexpr int XSTR = C::XSTR;
+  const int wave = threadIdx.x >> 6, lane0 = threadIdx.x & 63;
+  const int N = a.NP + a.NL;
+  const int nb_kind = wg_protein ? (a.NP + NW - 1) / NW : (a.NL + NW - 1) / NW;     // blocks of this kind per sample
+  const int n_blocks = a.B * nb_kind;
+  float* const XB = smem + C::XB;
+  float* const QS = smem + C::QS;
+  float* const SS = smem + C::SS;
+  int* const sb = reinterpret_cast<int*>(smem + C::SB);
+  const int M = a.K, T = (M + 15) >> 4;
+
+  // ---- once per workgroup: tables of this centre kind, LayerNorm rows; this wave's W2k rows in registers
+  {
+    const int tyl = wg_protein ? 1 : 0;                  // edge type = 2 * (source is protein) + (centre is protein)
+    constexpr int PER = (4 * 768) / NT;
+    float4 tmp[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = threadIdx.x + k * NT, q = i / 768, w = i - q * 768;
+      const float* src = (q < 2 ? a.Akp : a.Avp) + (tyl + 2 * (q & 1)) * TABP;
+      tmp[k] = reinterpret_cast<const float4*>(src)[w];
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) reinterpret_cast<float4*>(smem + C::TAB)[threadIdx.x + k * NT] = tmp[k];
+    if (threadIdx.x < 64) {
+      reinterpret_cast<float4*>(smem + C::LNP)[threadIdx.x] = reinterpret_cast<const float4*>(a.lnk)[threadIdx.x];
+      reinterpret_cast<float4*>(smem + C::LNP + 256)[threadIdx.x] = reinterpret_cast<const float4*>(a.lnv)[threadIdx.x];
+    }
+  }
+  if (threadIdx.x == 0) sb[0] = atomicAdd(counter, 1);
+  __syncthreads();
+
+  for (int it = 0;; ++it) {
+    int lane = lane0;
+    asm volatile("" : "+v"(lane) :: "memory");
+    const int mm = lane & 15, cg = lane >> 4;
+    const int blk = __builtin_amdgcn_readfirstlane(sb[it & 1]);
+    if (blk >= n_blocks) break;
+    const int ne_b = blk / nb_kind, rb = blk % nb_kind;
+    const int node = wg_protein ? rb * NW + wave : a.NP + rb * NW + wave;
+    bool active = node < (wg_protein ? a.NP : N);
+    if (RAG && active) active = wg_protein ? node < (a.np_real ? a.np_real[ne_b] : a.NP) : node - a.NP < a.nl_real[ne_b];
+    const long seg = (long)ne_b * N + node;
+    const float* xb = a.x + (long)ne_b * N * 3;
+    const long src_base = (long)ne_b * N;
+
+    // neighbours, edge weights, distances (two dependent round trips: first), the query, the rows of the first k-pass tile
+    int jm[MAXT], jT[MAXT][4];
+    float dm[MAXT], ewm[MAXT][4];
+    float2 q2 = make_float2(0.f, 0.f);
+    float Rc[32], Pf[32];
+    if (active) {
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t) {
+        const int m = 16 * t + mm;
+        jm[t] = a.nbr[seg * a.K + (m < M ? m : M - 1)];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int mr = 16 * t + 4 * cg + r;
+          ewm[t][r] = a.ew[seg * a.K + (mr < M ? mr : 0)];
+          jT[t][r] = a.nbr[seg * a.K + (mr < M ? mr : M - 1)];
+        }
+      }
+      q2 = *reinterpret_cast<const float2*>(a.q + seg * 128 + 2 * lane);
+      const float cx = xb[3 * node], cy = xb[3 * node + 1], cz = xb[3 * node + 2];
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t) {
+        const float rx = cx - xb[3 * jm[t]], ry = cy - xb[3 * jm[t] + 1], rz = cz - xb[3 * jm[t] + 2];
+        dm[t] = sqrtf(rx * rx + ry * ry + rz * rz);
+      }
+      load_row(Rc, a.kd + seg * a.ld_kd, cg);
+      load_row(Pf, a.ks + (src_base + jm[0]) * a.ld_ks, cg);
+      *reinterpret_cast<float2*>(QS + wave * 128 + 2 * lane) = q2;
+    }
+    // this wave's 16 rows of W2k (heads 2 wave, 2 wave + 1), channels 2 lane, 2 lane + 1: 8 KB per wave and block from L2 (held in
+    // registers for the whole workgroup they cost the k / v passes 32 registers: 442 spilled)
+    float Wk[32];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float2 w = *reinterpret_cast<const float2*>(a.W2k + (16 * wave + r) * 128 + 2 * lane);
+#if DD_LN_FOLD
+      Wk[2 * r] = w.x; Wk[2 * r + 1] = w.y;
+#else
+      Wk[2 * r] = w.x * 0.35355339059327373f; Wk[2 * r + 1] = w.y * 0.35355339059327373f;
+#endif
+    }
+    __syncthreads();                                     // barrier 1: queries published; the previous block's exchange reads are done
+    if (threadIdx.x == 0) sb[(it + 1) & 1] = atomicAdd(counter, 1);
+
+    // ---- cooperative fold: Q~[s][h][2 lane + {0, 1}] for h = 2 wave, 2 wave + 1 and the 8 segments of the block
+#pragma unroll 2
+    for (int s = 0; s < 8; ++s) {
+      float qv[16];
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const float4 v = *reinterpret_cast<const float4*>(QS + s * 128 + 16 * wave + 4 * k4);
+        qv[4 * k4] = v.x; qv[4 * k4 + 1] = v.y; qv[4 * k4 + 2] = v.z; qv[4 * k4 + 3] = v.w;
+      }
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        // (the same chain as attn2_body's fold: fma(q_d, w_d, acc) from acc = 0, d ascending)
+        float a0 = fmaf(qv[8 * hh], Wk[16 * hh], 0.f), a1 = fmaf(qv[8 * hh], Wk[16 * hh + 1], 0.f);
+#pragma unroll
+        for (int d = 1; d < 8; ++d) {
+          a0 = fmaf(qv[8 * hh + d], Wk[16 * hh + 2 * d], a0);
+          a1 = fmaf(qv[8 * hh + d], Wk[16 * hh + 2 * d + 1], a1);
+        }
+        *reinterpret_cast<float2*>(XB + s * XSTR + (2 * wave + hh) * WPITCH + 2 * lane) = make_float2(a0, a1);
+      }
+    }
+    __syncthreads();                                     // barrier 2
+    float Qb[32];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+      const float4 v = *reinterpret_cast<const float4*>(XB + wave * XSTR + mm * WPITCH + 16 * nt + 4 * cg);
+      Qb[4 * nt] = v.x; Qb[4 * nt + 1] = v.y; Qb[4 * nt + 2] = v.z; Qb[4 * nt + 3] = v.w;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                     // barrier 3: the exchange buffer is free for the epilogue
+
+    // first-Linear table part (type (x) Gaussian) of tile t on the matrix cores, either orientation (see attn2_body::table_part)
+    float Fg[MAXT][5];
+    auto table_part = [&](int t, int pass, f32x4 (&acc)[8], auto tr) {
+      constexpr bool TR = decltype(tr)::value;
+      if (pass == 0) {
+#pragma unroll
+        for (int s = 0; s < 5; ++s) Fg[t][s] = gauss_feat(dm[t], 4 * s + cg);
+      }
+      const bool hi = jm[t] < a.NP;
+      const float* tab = smem + C::TAB + pass * 2 * TABP + cg * 128 + mm * 4;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const bool want = half ? hi : !hi;
+        if (__builtin_amdgcn_ballot_w64(want) != 0ull) {
+#pragma unroll
+          for (int s = 0; s < 5; ++s) mfma_table_step<TR>(acc, tab + half * TABP + s * 512, want ? Fg[t][s] : 0.0f);
+        }
+      }
+      const float* row20 = smem + C::TAB + pass * 2 * TABP + 20 * 128;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool hi_r = TR ? (jT[t][r] < a.NP) : hi;
+        const float* p = row20 + (hi_r ? TABP : 0) + (TR ? mm : 4 * cg + r) * 4;
+        const float4 c0 = *reinterpret_cast<const float4*>(p);
+        const float4 c1 = *reinterpret_cast<const float4*>(p + 64);
+        acc[0][r] += c0.x; acc[1][r] += c0.y; acc[2][r] += c0.z; acc[3][r] += c0.w;
+        acc[4][r] += c1.x; acc[5][r] += c1.y; acc[6][r] += c1.z; acc[7][r] += c1.w;
+      }
+    };
+
+    f32x4 S[MAXT];
+    float ssum = 0.f;
+    f32x4 Z[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) Z[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (active) {
+      // ---- k pass
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t) {
+        if (t < T) {
+          float P[32];
+#pragma unroll
+          for (int k = 0; k < 32; ++k) P[k] = Rc[k] + Pf[k];
+          if (t + 1 < MAXT) load_row(Pf, a.ks + (src_base + jm[t + 1]) * a.ld_ks, cg);
+          f32x4 acc[8];
+#pragma unroll
+          for (int nt = 0; nt < 8; ++nt) acc[nt] = f32x4{P[4 * nt], P[4 * nt + 1], P[4 * nt + 2], P[4 * nt + 3]};
+          table_part(t, 0, acc, std::false_type{});
+#pragma unroll
+          for (int nt = 0; nt < 8; ++nt) { P[4 * nt] = acc[nt][0]; P[4 * nt + 1] = acc[nt][1]; P[4 * nt + 2] = acc[nt][2]; P[4 * nt + 3] = acc[nt][3]; }
+          ln_relu32(P, smem + C::LNP, cg);
+          S[t] = mfma_rows(P, Qb);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (16 * t + 4 * cg + r >= M) S[t][r] = -INFINITY;
+        } else {
+          S[t] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+      }
+      // ---- v-pass rows of tile 0 (member-major layout), then the softmax
+      float Tc[8], Tr[32];
+      auto fetch_T = [&](int t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float* rs = a.vs + (src_base + jT[t][r]) * a.ld_vs + mm;
+#pragma unroll
+          for (int nt = 0; nt < 8; ++nt) Tr[4 * nt + r] = rs[16 * nt];
+        }
+      };
+      {
+        const float* rc = a.vd + seg * a.ld_vd + mm;
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) Tc[nt] = rc[16 * nt];
+      }
+      fetch_T(0);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, S[t][r]);
+      mx = quad_max(mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = (16 * t + 4 * cg + r < M) ? expf(S[t][r] - mx) : 0.f;
+          S[t][r] = e;
+          sum += e;
+        }
+      sum = quad_sum(sum);
+      const float rsum = 1.0f / sum;
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = 16 * t + 4 * cg + r;
+#if defined(DD_EXACT_MATH) && DD_EXACT_MATH
+          const float aw = (m < M) ? (S[t][r] / sum) * ewm[t][r] : 0.f;
+#else
+          const float aw = (m < M) ? (S[t][r] * rsum) * ewm[t][r] : 0.f;
+#endif
+          S[t][r] = aw;
+          ssum += aw;
+        }
+      ssum = quad_sum(ssum);
+      // ---- v pass + aggregation
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t) {
+        if (t < T) {
+          float Tz[32];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) Tz[4 * nt + r] = Tc[nt] + Tr[4 * nt + r];
+          if (t + 1 < MAXT) fetch_T(t + 1);
+          f32x4 acc[8];
+#pragma unroll
+          for (int nt = 0; nt < 8; ++nt) acc[nt] = f32x4{Tz[4 * nt], Tz[4 * nt + 1], Tz[4 * nt + 2], Tz[4 * nt + 3]};
+          table_part(t, 1, acc, std::true_type{});
+#pragma unroll
+          for (int nt = 0; nt < 8; ++nt) { Tz[4 * nt] = acc[nt][0]; Tz[4 * nt + 1] = acc[nt][1]; Tz[4 * nt + 2] = acc[nt][2]; Tz[4 * nt + 3] = acc[nt][3]; }
+          ln_relu_T(Tz, smem + C::LNP + 256, mm);
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt)
+              Z[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Tz[4 * nt + ks], S[t][ks], Z[nt], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- cooperative epilogue (as the NE blocks' NECO form)
+    float4 Bv[8];
+    {
+      const float* bv = a.W2v + (16 * wave + mm) * 128 + 4 * cg;
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) Bv[nt] = *reinterpret_cast<const float4*>(bv + 16 * nt);
+    }
+    const int eh = mm >> 3;
+    const float bias2 = a.b2v[16 * wave + mm];
+    if (active) {
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt)
+        *reinterpret_cast<float4*>(XB + wave * XSTR + mm * WPITCH + 16 * nt + 4 * cg) = make_float4(Z[nt][0], Z[nt][1], Z[nt][2], Z[nt][3]);
+      if (cg == 0) SS[wave * 16 + mm] = ssum;
+    }
+    __syncthreads();                                     // barrier 4
+    {
+      const float* ar = XB + (mm >> 1) * XSTR + (2 * wave + (mm & 1)) * WPITCH + 4 * cg;
+      f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int nt = 0; nt < 8; nt += 2) {
+        const float4 a0 = *reinterpret_cast<const float4*>(ar + 16 * nt), a1 = *reinterpret_cast<const float4*>(ar + 16 * nt + 16);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, Bv[nt].x, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, Bv[nt + 1].x, d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, Bv[nt].y, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, Bv[nt + 1].y, d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, Bv[nt].z, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, Bv[nt + 1].z, d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, Bv[nt].w, d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, Bv[nt + 1].w, d1, 0, 0, 0);
+      }
+      const f32x4 d = d0 + d1;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int sI = 2 * cg + u;
+        const int nd = (wg_protein ? rb * NW : a.NP + rb * NW) + sI;
+        bool ok = nd < (wg_protein ? a.NP : N);
+        if (RAG && ok) ok = wg_protein ? nd < (a.np_real ? a.np_real[ne_b] : a.NP) : nd - a.NP < a.nl_real[ne_b];
+        const float val = fmaf(bias2, SS[sI * 16 + 2 * wave + eh], eh ? d[2 * u + 1] : d[2 * u]);
+        if (ok) a.out[((long)ne_b * N + nd) * 128 + 16 * wave + mm] = val;
+      }
+    }
+  }
+}
+
 // stand-alone launch of the cooperative bond-layer workgroups (one launch per sub-layer: dd_debug_set_fusion(0), phase stamps)
 template <int MAXT, bool RAG>
 __global__ __launch_bounds__(512) void k_attn2_bl_coop(const AttnArgs a) {
@@ -1730,8 +2056,8 @@ constexpr int imax(int a, int b) { return a > b ? a : b; }
 // within one segment of each other.
 template <int MAXT, int NW, bool RAG = false>
 __global__ __launch_bounds__(NW * 64) void k_attn2_node(const AttnArgs ne, const AttnArgs nb, const AttnArgs bl, int n_ne, int n_nb,
-                                                        int persist, int n_bl_first, const int32_t* wflags, int widx, int wn) {
-  constexpr int SZ = imax(imax(imax(Lds<M_NE>::TOTAL, Lds<M_NB>::TOTAL), Lds<M_BL>::TOTAL) + 12, DD_COOP && NW == 8 && MAXT == 2 ? CoopLds::TOTAL : 0);
+                                                        int persist, int n_bl_first, const int32_t* wflags, int widx, int wn, int nep) {
+  constexpr int SZ = imax(imax(imax(Lds<M_NE>::TOTAL, Lds<M_NB>::TOTAL), Lds<M_BL>::TOTAL) + 12, imax(DD_COOP && NW == 8 && MAXT == 2 ? CoopLds::TOTAL : 0, DD_NE_PERSIST && NW == 8 ? NepLds::TOTAL : 0));
   __shared__ __attribute__((aligned(16))) float smem[SZ];
   int blk = blockIdx.x;
   // this layer's projection / query rows come from the previous layer's tail queue on the other stream (no graph edge)
@@ -1773,6 +2099,20 @@ __global__ __launch_bounds__(NW * 64) void k_attn2_node(const AttnArgs ne, const
       return;
     }
     blk -= n_bl_first;
+    if constexpr (DD_NE_PERSIST && NW == 8) {
+      if (nep != 0) {
+        // persistent node_layer_with_edge workgroups (nep = protein-kind count << 16 | ligand-kind count): the NB blocks come FIRST in
+        // dispatch order, the persistent workgroups their CUs cannot hold yet start when they end and pull what is left
+        const int np_p = nep >> 16, np_l = nep & 0xffff;
+        if (blk < n_nb) { attn2_body<M_NB, MAXT, NW, false, RAG, false, false>(args(1), blk, smem); DD_TRACE_END(1); return; }
+        blk -= n_nb;
+        KArgs& na = args(0);
+        if (blk < np_p) ne_persist_body<RAG>(na, smem, true, na.work_counter);
+        else if (blk < np_p + np_l) ne_persist_body<RAG>(na, smem, false, na.work_counter + 1);
+        DD_TRACE_END(0);
+        return;
+      }
+    }
     if (blk < n_ne) { attn2_body<M_NE, 2, NW, false, RAG, false, false>(args(0), blk, smem); DD_TRACE_END(0); }
     else { attn2_body<M_NB, MAXT, NW, false, RAG, false, false>(args(1), blk - n_ne, smem); DD_TRACE_END(1); }
     return;
@@ -1897,7 +2237,7 @@ __global__ __launch_bounds__(NW * 128) void k_attn2_pos_g(const AttnArgs pe, con
 #endif
 
 #ifdef DD_ASM_ONLY      // (hipcc -S -DDD_ASM_ONLY: only the shipped small-ligand kernels, for instruction censuses -- 20 s instead of 2 min)
-template __global__ void k_attn2_node<2, 8, false>(const AttnArgs, const AttnArgs, const AttnArgs, int, int, int, int, const int32_t*, int, int);
+template __global__ void k_attn2_node<2, 8, false>(const AttnArgs, const AttnArgs, const AttnArgs, int, int, int, int, const int32_t*, int, int, int);
 template __global__ void k_attn2_pos<2, 4, false>(const AttnArgs, const AttnArgs, int);
 template __global__ void k_attn2_bl_coop<2, false>(const AttnArgs);
 template __global__ void k_attn2_pos_q<2, 2, false>(const AttnArgs, const AttnArgs, int);
@@ -1927,6 +2267,7 @@ int g_attn_persist = 1;      // bond_layer workgroups of the fused launch are pe
 #endif
 int g_bl_tail = DD_BL_TAIL;  // the last (partial) round of bond-layer trips spread evenly over the persistent workgroups
 int g_bl_first = 1;          // bond-layer workgroups first in the node launch: 0 off, 1 measured split per shape, n>1 that many
+int g_ne_persist = [] { const char* e = getenv("DD_NE_PERSIST"); return e ? (e[0] != '0') : 1; }();   // (A/B: DD_NE_PERSIST=0 keeps the block form)
 int g_node_split_trial = -1; // >= 0 while autotune_node_split is timing a candidate (0 = node blocks first)
 long long* g_node_trace = nullptr;   // DD_NODE_TRACE builds: [workgroups][16] clocks of the next fused node launches (dd_debug_set_clock_buffer(buf, 200))
 namespace {
@@ -2027,12 +2368,23 @@ static int launch_node_nw(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs
       if (want > 0) {
         n_bl = want < 16 ? 16 : (want > n_cu - 16 ? n_cu - 16 : want);
         set_trips(n_bl);
+        // persistent node_layer_with_edge workgroups on the other CUs, split by centre kind in proportion to the blocks of each kind
+        int nep = 0, n_grid = n_ne + n_nb + n_bl;
+        if (DD_NE_PERSIST && NW == 8 && g_ne_persist && ne.work_counter != nullptr && ne.lin_W == nullptr) {
+          const int nbp = ne.B * ((ne.NP + NW - 1) / NW), nbl = ne.B * ((ne.NL + NW - 1) / NW), n_rest = n_cu - n_bl;
+          int np_l = nbl > 0 ? (int)((long)n_rest * nbl / (nbp + nbl > 0 ? nbp + nbl : 1) + 0.5) : 0;
+          if (nbl > 0 && np_l < 1) np_l = 1;
+          if (np_l > nbl) np_l = nbl;
+          int np_p = n_rest - np_l;
+          if (np_p > nbp) np_p = nbp;
+          if (np_p > 0 || np_l > 0) { nep = (np_p << 16) | np_l; n_grid = n_bl + n_nb + np_p + np_l; }
+        }
         if (ne.nl_real != nullptr)
-          hipLaunchKernelGGL((k_attn2_node<MAXT, NW, true>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, blt, n_ne, n_nb,
-                             persist, n_bl, wf, ne.wait_idx, wfn);
+          hipLaunchKernelGGL((k_attn2_node<MAXT, NW, true>), dim3(n_grid), dim3(NW * 64), 0, st, ne, nb, blt, n_ne, n_nb,
+                             persist, n_bl, wf, ne.wait_idx, wfn, nep);
         else
-          hipLaunchKernelGGL((k_attn2_node<MAXT, NW>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, blt, n_ne, n_nb, persist,
-                             n_bl, wf, ne.wait_idx, wfn);
+          hipLaunchKernelGGL((k_attn2_node<MAXT, NW>), dim3(n_grid), dim3(NW * 64), 0, st, ne, nb, blt, n_ne, n_nb, persist,
+                             n_bl, wf, ne.wait_idx, wfn, nep);
         DD_CHECK_LAUNCH();
         return DD_OK;
       }
@@ -2040,9 +2392,9 @@ static int launch_node_nw(const AttnArgs& ne, const AttnArgs& nb, const AttnArgs
   }
   if (persist) set_trips(n_bl);
   if (ne.nl_real != nullptr)
-    hipLaunchKernelGGL((k_attn2_node<MAXT, NW, true>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, blt, n_ne, n_nb, persist, 0, wf, ne.wait_idx, wfn);
+    hipLaunchKernelGGL((k_attn2_node<MAXT, NW, true>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, blt, n_ne, n_nb, persist, 0, wf, ne.wait_idx, wfn, 0);
   else
-    hipLaunchKernelGGL((k_attn2_node<MAXT, NW>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, blt, n_ne, n_nb, persist, 0, wf, ne.wait_idx, wfn);
+    hipLaunchKernelGGL((k_attn2_node<MAXT, NW>), dim3(n_ne + n_nb + n_bl), dim3(NW * 64), 0, st, ne, nb, blt, n_ne, n_nb, persist, 0, wf, ne.wait_idx, wfn, 0);
   DD_CHECK_LAUNCH();
   return DD_OK;
 }

@@ -41,8 +41,9 @@ constexpr int DD_NUM_FLAGS = DD_FLAG_ERR + DD_FLAG_STRIDE;
 #else
 constexpr int DD_NUM_FLAGS = 0;                                         // the default library's workspace carries no flag words
 #endif
-constexpr int DD_NUM_COUNTERS = 128;                                    // [0, 64): work counters of the persistent attention workgroups (per
-                                                                        // layer), [64, 128): tile counters of the coordinate launches (k_attn2_pos_g)
+constexpr int DD_NUM_COUNTERS = 192;                                    // [0, 64): work counters of the persistent attention workgroups (per
+                                                                        // layer), [64, 128): tile counters of the coordinate launches (k_attn2_pos_g), [128, 192): block counters of the persistent
+                                                                        // node_layer_with_edge workgroups (two per layer: protein / ligand centres)
 constexpr int DD_TAIL_CHUNK = 2;                                        // consecutive tiles drawn per ticket
 constexpr int DD_TAIL_MAX_JOBS = 14;
 struct TailJob {
