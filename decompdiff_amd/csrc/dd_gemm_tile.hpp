@@ -7,6 +7,9 @@
 
 namespace dd {
 
+#ifndef DD_GEMM_EARLY_BIAS
+#define DD_GEMM_EARLY_BIAS 1  // the bias (one float4 per thread) requested ahead of the MFMAs: -0.4 % (B = 8), -1.0 % (B = 1), 0 (B = 16); R6-5
+#endif
 #ifndef DD_GEMM_EARLY_HALF
 #define DD_GEMM_EARLY_HALF 0  // both K halves + the bias requested before the first barrier: measured 1.8 % SLOWER at B = 8 (120 instead of
 #endif                        // 104 registers per thread, EXPERIMENTS.md R6-5)
@@ -41,10 +44,11 @@ __device__ __forceinline__ void st4_sc1(float* base, long off, const float4& v) 
   __builtin_amdgcn_raw_buffer_store_b128(u, rs, (int)(off * 4), 0, 16);
 }
 // (bias_pre: the thread's four bias values -- columns col0 + 4 (tid & 15) .. + 3, the same for its four output rows -- requested
-//  by the caller ahead of the MFMAs instead of behind the LDS round trip here; NULL: loaded here)
+//  by the caller ahead of the MFMAs instead of behind the LDS round trip here; !have_pre: loaded here)
 template <bool SC1 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, float* sm /*>= 64*EP floats, free*/, const f32x16& acc,
-                                              int row0, int col0, const float4* bias_pre = nullptr) {
+                                              int row0, int col0, const bool have_pre = false,
+                                              const float4 bias_pre = float4{0.f, 0.f, 0.f, 0.f}) {
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, li = lane & 31, hh = lane >> 5;
 #pragma unroll
@@ -67,7 +71,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, float* sm /*>= 
     float* dst = a.Y + yoff;
     if (vec_ok && gc + 3 < a.ncols) {
       if (a.bias) {
-        const float4 bb = bias_pre ? *bias_pre : *reinterpret_cast<const float4*>(a.bias + gc);
+        const float4 bb = have_pre ? bias_pre : *reinterpret_cast<const float4*>(a.bias + gc);
         o[0] += bb.x; o[1] += bb.y; o[2] += bb.z; o[3] += bb.w;
       }
       if (a.accumulate) {
@@ -166,7 +170,7 @@ __device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx
   long long* dbg = (STAMPS && a.dbg) ? a.dbg + ((long)by * gridDim.x + bx) * 8 : nullptr;
 #define GSTAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
   GSTAMP(0);
-#if DD_GEMM_EARLY_HALF
+#if DD_GEMM_EARLY_HALF || DD_GEMM_EARLY_BIAS
   // the epilogue's bias values, requested now (they used to be a dependent global load behind the output's LDS round trip)
   const int bias_gc = col0 + (tid & 15) * 4;
   const bool bias_ok = a.bias != nullptr && bias_gc + 3 < a.ncols;
@@ -259,8 +263,8 @@ __device__ __forceinline__ void gemm_tile_ksplit(const GemmArgs& a, const int bx
   asm volatile("" : "+v"(acc));
   GSTAMP(4);
   __syncthreads();                                     // operands dead: the tile buffer becomes the output stage
-#if DD_GEMM_EARLY_HALF
-  gemm_epilogue<SC1>(a, smh, acc, row0, col0, bias_ok ? &bias_pre : nullptr);
+#if DD_GEMM_EARLY_HALF || DD_GEMM_EARLY_BIAS
+  gemm_epilogue<SC1>(a, smh, acc, row0, col0, bias_ok, bias_pre);
 #else
   gemm_epilogue<SC1>(a, smh, acc, row0, col0);
 #endif

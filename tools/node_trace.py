@@ -26,7 +26,7 @@ span = float(t1 - t0)          # ticks of the 100 MHz real-time counter (10 ns)
 cu = ((hw >> 8) & 15) | (((hw >> 13) & 7) << 4) | (((hw >> 12) & 1) << 7)                 # CU | SE | SH
 print(f"B = {B}: {len(c)} workgroups, launch span {span:.0f} ticks of 10 ns ({span / 100:.1f} us); "
       f"{len(set(zip(xcc.tolist(), cu.tolist())))} distinct (XCD, CU) slots")
-for k, name in ((2, "bond-layer (persistent)"), (0, "node blocks NE"), (1, "node blocks NB")):
+for k, name in ((2, "bond-layer (persistent)"), (0, "node blocks NE"), (4, "node half blocks NE"), (1, "node blocks NB")):
     s = c[kind == k]
     if len(s):
         life = (s[:, 1] - s[:, 0]).astype(float)
