@@ -203,13 +203,17 @@ DD_OPT g_p2_in_pos = 0;                    // dd_debug_set_option(30, v): the pr
                                                // launch instead of a launch of their own on the critical chain (round 5: bit-identical,
                                                // measured 2.6 % SLOWER -- 40 us where the two launches take 11 + 23; EXPERIMENTS.md R5-2)
 // (ev_fork / ev_join: [0..7] per layer, [8] graph construction at the head of a forward)
-// DD_SIDE_PRIO: 1 (default) lowest priority for the side stream, 0 default priority, 2 highest
-static int g_side_low_priority = [] { const char* e = getenv("DD_SIDE_PRIO"); return (e && e[0] == '0') ? 0 : ((e && e[0] == '2') ? 2 : 1); }();
+// DD_SIDE_PRIO: 0 (default since round 6) default priority for the side stream, 1 lowest (rounds 3-6), 2 highest.  A stream of another
+// priority takes its hardware queue from a pool of its own (ROCm keeps GPU_MAX_HW_QUEUES = 4 queues PER PRIORITY); with it the process
+// could reach a fifth active queue as soon as a second step graph was instantiated, and every graph from then on ran 14 % (B = 8) to 42 %
+// (B = 1) slower -- the same slowdown GPU_MAX_HW_QUEUES >= 5 causes for the first graph.  At the default priority all of the process's
+// streams share the four queues (EXPERIMENTS.md R6-11; tools/two_lengths.py).
+static int g_side_low_priority = [] { const char* e = getenv("DD_SIDE_PRIO"); return (e && e[0] == '1') ? 1 : ((e && e[0] == '2') ? 2 : 0); }();
 static int g_overlap = 1;                     // measured in-process A/B: -3.5 % step time
 static int ensure_side_stream() {
   if (g_side) return DD_OK;
   {
-    int lo = 0, hi = 0;                                  // lowest priority: side work fills CUs the main chain leaves idle
+    int lo = 0, hi = 0;                                  // (DD_SIDE_PRIO=1: lowest priority -- side work fills CUs the main chain leaves idle)
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; (void)hipGetLastError(); }
     if (hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, g_side_low_priority == 1 ? lo : (g_side_low_priority == 2 ? hi : 0)) != hipSuccess) return DD_ERR_HIP;
   }

@@ -650,6 +650,36 @@ def test_measured_node_split_is_kept_across_processes(tmp_path):
     # (DD_NODE_SPLIT_CACHE=0 -> dd_debug_node_split_cache_path() == "": covered by the host-side getenv, not worth a third process)
 
 
+_TWO_LENGTHS_PROBE = r"""
+import json, sys, time, torch
+sys.path.insert(0, ".")
+from decompdiff_amd import DecompScorePosNet3D, shipped_config, synth
+dev = torch.device("cuda:0"); cfg = shipped_config()
+m = DecompScorePosNet3D(cfg, 29, 10, 8); sd = m.state_dict(); sd.update(synth.synthetic_state_dict(cfg, seed=0)); m.load_state_dict(sd); m = m.to(dev)
+torch.manual_seed(3)
+b = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synth.build_sampling_batch(synth.make_pocket_small(0), 1).items()}
+ms = {}
+for n in (20, 100, 100, 100, 200, 200, 200):
+    torch.cuda.synchronize(); t = time.perf_counter()
+    m.sample_diffusion(num_steps=n, center_pos_mode="protein", seed=5, **b)
+    torch.cuda.synchronize()
+    ms.setdefault(n, []).append(1e3 * (time.perf_counter() - t) / n)
+print(json.dumps({str(k): v for k, v in ms.items()}))
+"""
+
+
+def test_a_second_chain_length_runs_as_fast_as_the_first():
+    """Round 6 (EXPERIMENTS.md R6-11): with the library's side stream at a priority of its own, the SECOND step graph of a process (here:
+    the same pocket sampled with another num_steps, i.e. another cached chain entry) ran 42 % slower at B = 1 (14 % at B = 8) -- a fifth
+    hardware queue in use.  Own process (stream set-up is per process); the later calls of each length are compared."""
+    out = subprocess.run([sys.executable, "-c", _TWO_LENGTHS_PROBE], cwd=ROOT, env=_bench_env(), capture_output=True, text=True, timeout=600,
+                         check=True).stdout.strip().splitlines()[-1]
+    ms = json.loads(out)
+    first, second = min(ms["100"][1:]), min(ms["200"][1:])
+    print(f"\n  B = 1: {first:.4f} ms/step in 100-step calls, {second:.4f} in 200-step calls of the same process")
+    assert second < 1.15 * first, ms                           # (the slow regime: 1.42 x)
+
+
 def to_dev_local(batch):
     return {k: (v.to(dev()) if torch.is_tensor(v) else v) for k, v in batch.items()}
 
