@@ -455,6 +455,17 @@ def test_chain_cache_reuses_buffers_and_graph_without_changing_results(monkeypat
     _sample_hip(m, b1, 5, None, None, seed=1)
     _sample_hip(m, b1, 20, None, None, seed=2)                       # 5 and 20 steps share one entry (capacity 32)
     assert len(m._chain_cache) == 1
+    _sample_hip(m, b1, 40, None, None, seed=2)                       # 40 steps: another capacity, a second entry ...
+    assert len(m._chain_cache) == 2
+    m._evict_chain_cache(0)
+    m.traj_capacity_hint = 40                                        # ... unless the caller announced the length (bench.py does)
+    try:
+        short = _sample_hip(m, b1, 5, None, None, seed=1)
+        _sample_hip(m, b1, 40, None, None, seed=2)
+        assert len(m._chain_cache) == 1 and len(short["pos_traj"]) == 5
+    finally:
+        m.traj_capacity_hint = 0
+        m._evict_chain_cache(0)
 
 
 def _hetero_batch(sizes, n_protein, seed=0):
